@@ -1,0 +1,117 @@
+"""Pins the travelling oracle (oracle/block_ref.py + oracle/mssvt_oracle.c) against the
+outputs of the reference's own Python (tests/golden/*.npz, made by oracle/gen_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import block_ref, cref
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    sd = {k[3:]: v for k, v in d.items() if k.startswith("sd.")}
+    return d, sd
+
+
+def test_attention_block_mode(golden_dir):
+    d, sd = load(golden_dir, "attention_block")
+    out = block_ref.mixed_scale_attention(sd, "", 32, [2, 2], d["query"], d["keys"],
+                                          query_mask=d["query_mask"], key_masks=d["key_masks"],
+                                          batch_first=True)
+    np.testing.assert_allclose(out, d["out"], **TOL)
+
+
+def test_attention_compress_mode(golden_dir):
+    d, sd = load(golden_dir, "attention_compress")
+    out = block_ref.mixed_scale_attention(sd, "", 32, [4], d["query"], d["keys"], key_masks=d["key_masks"])
+    np.testing.assert_allclose(out, d["out"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["w335_777", "w222_444", "w557_bbb", "w115", "w3316"])
+def test_query_tables_match_reference_up_to_tie_order(golden_dir, name):
+    d, _ = load(golden_dir, "query_tables")
+    ws = d[name + ".window_size"].tolist()
+    tabs, n_odd, n_even = block_ref.vox_query_table(ws[0], ws[1] if len(ws) == 2 else None)
+    for k, mine in tabs.items():
+        ref = d["%s.%s" % (name, k)]
+        assert mine.shape == ref.shape
+        # identical multiset per Chebyshev shell, identical shell sequence
+        cheb = lambda a: np.abs(a).max(1)  # noqa: E731
+        np.testing.assert_array_equal(cheb(mine), cheb(ref))
+        for s in np.unique(cheb(ref)):
+            a = sorted(map(tuple, mine[cheb(mine) == s]))
+            b = sorted(map(tuple, ref[cheb(ref) == s]))
+            assert a == b
+    if n_odd is not None:
+        assert n_odd == int(d[name + ".max_num_odd"]) and n_even == int(d[name + ".max_num_even"])
+
+
+def _tables(d):
+    return {k[3:]: v for k, v in d.items() if k.startswith("qt.")}
+
+
+def _state(d):
+    return block_ref.SparseState(d["voxel_features"], d["voxel_coords"], d["grid_size"].tolist(),
+                                 d["voxel_size"].tolist(), d["point_cloud_range"].tolist(),
+                                 int(d["batch_size"]), int(d["hash_size"]))
+
+
+BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc"]
+
+
+@pytest.mark.parametrize("name", BLOCKS)
+def test_block_forward_matches_reference(golden_dir, name):
+    d, sd = load(golden_dir, name)
+    sp = _state(d)
+    np.testing.assert_array_equal(sp.map_table, d["map_table"])
+    rec = {}
+    m1, m2 = int(d["max_num_win1"]), int(d["max_num_win2"])
+    sp = block_ref.block_forward(sd, "", sp, d["window_size"].tolist(), d["num_heads"].tolist(),
+                                 m1, m2, int(d["cbs_pattern"]), int(d["key_num_sample"]),
+                                 bool(d["use_feature_interpolation"]), tables=_tables(d), record=rec)
+    np.testing.assert_array_equal(rec["win_ind"], d["rec.get_non_empty_window_center.0.win_ind"])
+    for k in ("ind_odd", "ind_even", "ind_win1", "ind_win2", "coord_odd", "coord_even", "coord_win1", "coord_win2"):
+        np.testing.assert_array_equal(rec[k], d["rec.gather_two_window_voxels.0." + k])
+    np.testing.assert_array_equal(rec["fps1"], d["rec.farthest_point_sample.0.fps_ind"])
+    np.testing.assert_array_equal(rec["fps2"], d["rec.farthest_point_sample.1.fps_ind"])
+    if bool(d["use_feature_interpolation"]):
+        np.testing.assert_array_equal(rec["nn_idx"], d["rec.three_nn.0.idx"])
+    np.testing.assert_allclose(sp.features, d["out_features"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5"])
+def test_compress_forward_matches_reference(golden_dir, name):
+    d, sd = load(golden_dir, name)
+    sp = _state(d)
+    rec = {}
+    sp = block_ref.compress_forward(sd, "", sp, d["window_size"].tolist(), d["num_heads"].tolist(),
+                                    int(d["max_num_win1"]), tables=_tables(d), record=rec)
+    np.testing.assert_array_equal(rec["ind_win1"], d["rec.gather_one_window_voxels.0.ind_win1"])
+    np.testing.assert_array_equal(sp.indices, d["out_indices"])
+    np.testing.assert_array_equal(sp.map_table, d["out_map_table"])
+    assert sp.spatial_shape == d["out_spatial_shape"].tolist()
+    np.testing.assert_allclose(sp.voxel_size, d["out_voxel_size"], rtol=1e-12)
+    np.testing.assert_allclose(sp.features, d["out_features"], **TOL)
+
+
+def test_backbone_forward_matches_reference(golden_dir):
+    d, sd = load(golden_dir, "backbone")
+    params = json.loads(str(d["params_json"]))
+    # the reference built its tables with torch.sort on CPU; the oracle's stable order must give
+    # the same features here because no list in this fixture is truncated (order-invariant sets),
+    # except through FPS/3-NN index ties -- so feed nothing and compare loosely first, then exactly
+    sp = block_ref.backbone_forward(sd, params, d["voxel_features"], d["voxel_coords"], int(d["batch_size"]),
+                                    d["grid_size"].tolist(), d["voxel_size"].tolist(),
+                                    d["point_cloud_range"].tolist(), int(d["hash_size"]))
+    np.testing.assert_array_equal(sp.indices, d["out_indices"])
+    assert sp.spatial_shape == d["out_spatial_shape"].tolist()
+    dense = sp.dense()
+    assert list(dense.shape) == d["dense_shape"].tolist()
+    np.testing.assert_allclose(sp.features, d["out_features"], **TOL)
+    np.testing.assert_allclose(dense[0, :, 0], d["dense_b0_z0"], **TOL)
+    np.testing.assert_allclose(dense.sum(), float(d["dense_sum"]), rtol=1e-4)
