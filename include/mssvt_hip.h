@@ -1,0 +1,167 @@
+/*
+ * mssvt_hip.h -- C ABI of libmssvt_hip.so: the MI355X (gfx950) implementation of
+ * MsSVT's mixed-scale sparse-voxel attention hot path.
+ *
+ * This is the drop-in boundary.  Every entry point in
+ * part 1 replaces one pybind wrapper of the reference's two CUDA extensions,
+ * with the same argument order and meaning, except that
+ *   - at::Tensor arguments become raw DEVICE pointers (caller-owned buffers,
+ *     C-contiguous, pre-allocated and pre-filled exactly as the reference's
+ *     Python callers pre-fill them);
+ *   - a trailing `void *stream` (a hipStream_t; NULL = default stream) is added:
+ *     the reference launches on the legacy default stream;
+ *   - a few calls take a caller-provided `int *workspace` (sizes below) -- the
+ *     library never allocates, keeps no global state and never exit()s;
+ *   - the return value is 0 on success, a positive hipError_t if a launch
+ *     failed, or a negative MSSVT_E_* code for argument errors (the reference
+ *     returns the constant 1 and exit(-1)s on error).
+ * All pointers are device pointers unless stated otherwise.  All kernels are
+ * asynchronous with respect to the host.
+ *
+ * "ref:" citations are relative to /root/reference/pcdet/ops/.
+ */
+#ifndef MSSVT_HIP_H
+#define MSSVT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSSVT_OK 0
+#define MSSVT_E_BADARG (-1)   /* null pointer / non-positive size            */
+#define MSSVT_E_TOOLARGE (-2) /* a size exceeds what the kernel supports     */
+
+/* Library / build identification.  Returns e.g. 100 for 1.0.0. */
+int mssvt_hip_abi_version(void);
+/* Static string for a status code returned by any function below. */
+const char *mssvt_hip_status_string(int status);
+
+/* ======================================================================== *
+ * Part 1a -- replacements for pybind module `mssvt_ops_cuda`
+ *            (ref: mssvt/src/ms_api.cpp:7-14)
+ * ======================================================================== */
+
+/* Number of int32 words of workspace the two hash builders need for
+ * `num_voxels` voxels (flags, ranks and scan partials). */
+long long mssvt_hash_workspace_ints(int num_voxels, int batch_size);
+
+/* ref: build_mapping_with_hash_wrapper, mssvt/src/ms_sparse_attention.cpp:23-35
+ *      (kernel ms_sparse_attention_gpu.cu:66-97).
+ * v_indices (N,4) int32 [b,z,y,x], batch-contiguous; v_bs_cnt (B) int32;
+ * xyz_to_vidx (B,H,2) int32 pre-filled with -1 by the caller.
+ * The table layout produced equals SEQUENTIAL insertion in voxel-index order
+ * (one legal outcome of the reference's racing atomicCAS insertions); for
+ * duplicate keys the highest voxel index owns the value.
+ * Extra vs the reference: batch_size (to bound b), workspace, stream.        */
+int mssvt_build_mapping_with_hash(int x_max, int y_max, int z_max, int num_voxels, int hash_size,
+                                  int batch_size, const int *v_indices, const int *v_bs_cnt,
+                                  int *xyz_to_vidx, int *workspace, void *stream);
+
+/* ref: window_with_hash_wrapper, ms_sparse_attention.cpp:37-59 (kernel :117-168).
+ * w_indices (B,num_windows,3) int32 pre-filled -1 -> rows [wz,wy,wx];
+ * xyz_to_vidx (B,H,2) pre-filled -1; vcount (B) zeroed.
+ * Windows are numbered by FIRST OCCURRENCE in voxel-index order within each
+ * sample and the table equals sequential insertion in that order.  Windows
+ * beyond num_windows are counted in vcount but not written (the reference
+ * writes out of bounds there).                                               */
+int mssvt_window_with_hash(int x_wgs, int y_wgs, int z_wgs, int x_ws, int y_ws, int z_ws,
+                           int num_voxels, int num_windows, int hash_size, int batch_size,
+                           const int *v_indices, int *w_indices, int *xyz_to_vidx, int *vcount,
+                           int *workspace, void *stream);
+
+/* ref: gather_two_window_voxels_with_hash_wrapper, ms_sparse_attention.cpp:61-120
+ *      (kernel :193-350).  vox_ind_* (nw,max_num_*) pre-filled -1, vox_coord_*
+ * (nw,max_num_*,3) pre-filled 0; vox_query_* (num_*,3) int32 offset tables;
+ * win_indices (nw,4) [b,wz,wy,wx]; xyz_to_vidx (B,H,2).                      */
+int mssvt_gather_two_window_voxels_with_hash(
+    int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd,
+    int max_num_even, int max_num_win1, int max_num_win2, int num_wins, int hash_size, int num_odd,
+    int num_even, int num_win1, int num_win2, int *vox_ind_odd, int *vox_ind_even,
+    int *vox_ind_win1, int *vox_ind_win2, int *vox_coord_odd, int *vox_coord_even,
+    int *vox_coord_win1, int *vox_coord_win2, const int *vox_query_odd, const int *vox_query_even,
+    const int *vox_query_win1, const int *vox_query_win2, const int *win_indices,
+    const int *xyz_to_vidx, void *stream);
+
+/* ref: gather_one_window_voxels_with_hash_wrapper, ms_sparse_attention.cpp:122-150
+ *      (kernel :383-433).                                                    */
+int mssvt_gather_one_window_voxels_with_hash(int x_max, int y_max, int z_max, int x_ws, int y_ws,
+                                             int z_ws, int max_num_win1, int num_wins,
+                                             int hash_size, int num_win1, int *vox_ind_win1,
+                                             int *vox_coord_win1, const int *vox_query_win1,
+                                             const int *win_indices, const int *xyz_to_vidx,
+                                             void *stream);
+
+/* ref: group_features_wrapper_stack, mssvt/src/group_features.cpp:50-68
+ *      (kernel group_features_gpu.cu:73-106).  features (N,C) f32, idx (M,nsample)
+ * int32 (index within the sample, <0 = skip), out (M,C,nsample) f32 pre-zeroed. */
+int mssvt_group_features(int B, int M, int C, int nsample, const float *features,
+                         const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt,
+                         float *out, void *stream);
+
+/* ref: group_features_grad_wrapper_stack, group_features.cpp:29-47
+ *      (kernel group_features_gpu.cu:15-47).  grad_features (N,C) pre-zeroed.  */
+int mssvt_group_features_grad(int B, int M, int C, int N, int nsample, const float *grad_out,
+                              const int *idx, const int *idx_batch_cnt,
+                              const int *features_batch_cnt, float *grad_features, void *stream);
+
+/* ======================================================================== *
+ * Part 1b -- replacements for the four forward ops (and two grads) of pybind
+ *            module `pointnet2_batch_cuda` that the path uses
+ *            (ref: pointnet2/pointnet2_batch/src/pointnet2_api.cpp:10-24)
+ * ======================================================================== */
+
+/* ref: farthest_point_sampling_wrapper, pointnet2/pointnet2_batch/src/sampling.cpp:41-50
+ *      (kernel sampling_gpu.cu:100-216).  dataset (B,N,3) f32, temp (B,N) f32
+ * pre-filled 1e10 (scratch, overwritten), idxs (B,m) int32.  Ties resolve
+ * exactly as the reference block of opt_n_threads(N) threads resolves them.   */
+int mssvt_farthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                  int *idxs, void *stream);
+
+/* ref: gather_points_wrapper_fast, sampling.cpp:18-27 (kernel sampling_gpu.cu:15-31).
+ * points (B,C,N), idx (B,npoints) -> out (B,C,npoints).                       */
+int mssvt_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                        float *out, void *stream);
+/* ref: gather_points_grad_wrapper_fast, sampling.cpp:29-39 (kernel :53-90).   */
+int mssvt_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                             const int *idx, float *grad_points, void *stream);
+
+/* ref: three_nn_wrapper_fast, pointnet2/pointnet2_batch/src/interpolate.cpp:21-30
+ *      (kernel interpolate_gpu.cu:16-59).  unknown (B,N,3), known (B,M,3) ->
+ * dist2 (B,N,3) squared distances, idx (B,N,3).                               */
+int mssvt_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                   int *idx, void *stream);
+
+/* ref: group_points_wrapper_fast, pointnet2/pointnet2_batch/src/group_points.cpp:30-40
+ *      (kernel group_points_gpu.cu:53-72).  points (B,C,N), idx (B,npoints,nsample)
+ * -> out (B,C,npoints,nsample).                                               */
+int mssvt_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                       const int *idx, float *out, void *stream);
+/* ref: group_points_grad_wrapper_fast, group_points.cpp:18-28 (kernel :14-50). */
+int mssvt_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                            const int *idx, float *grad_points, void *stream);
+
+/* ======================================================================== *
+ * Part 2 -- device-resident variants used by the module fast path.  They
+ *           compute exactly what the reference's Python glue computes around
+ *           the wrappers above, without host round trips.
+ * ======================================================================== */
+
+/* workspace[0] = status bits after any hash builder call (host-readable after a
+ * stream sync): */
+#define MSSVT_ST_DUPLICATE_KEY 1   /* duplicate voxel coordinates were present   */
+#define MSSVT_ST_TABLE_OVERFLOW 2  /* a sample has more distinct keys than H     */
+#define MSSVT_ST_WINDOW_OVERFLOW 4 /* a sample has more than max_num_wins windows */
+
+/* K2 + the per-sample compaction of ref mssvt/mssvt_ops.py:45-53 on the device:
+ * win_ind receives the (nw,4) rows [b,wz,wy,wx] in sample order, then window
+ * number order (capacity: num_voxels rows); vcount (B) = windows per sample
+ * (= k_bs_cnt of ref mssvt_backbone.py:218); workspace[1] = nw.              */
+int mssvt_window_partition_compact(int x_wgs, int y_wgs, int z_wgs, int x_ws, int y_ws, int z_ws,
+                                   int num_voxels, int max_num_wins, int hash_size, int batch_size,
+                                   const int *v_indices, int *win_ind, int *xyz_to_vidx,
+                                   int *vcount, int *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSSVT_HIP_H */

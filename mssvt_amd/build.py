@@ -1,0 +1,67 @@
+"""Build libmssvt_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m mssvt_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build
+container.  The .so is git-ignored but travels to the GPU box with the snapshot.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmssvt_hip.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: every fused multiply-add in the library is written explicitly
+# (fmaf / MFMA), so results do not depend on the compiler's contraction choices.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+        glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared library; returns its path."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed for %s:\n%s\n" % (src, out.decode()))
+        elif verbose and out:
+            print(out.decode())
+    if failed:
+        raise RuntimeError("hipcc compilation failed")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,133 @@
+// common.hip.h -- shared device helpers for libmssvt_hip (gfx950 / CDNA4 only).
+//
+// Wavefront = 64 lanes everywhere in this library.  No CUDA compatibility
+// layer, no multi-backend macros: this code is written for MI355X directly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mssvt_hip.h"
+
+#define MSSVT_WAVE 64
+#define MSSVT_EMPTY (-1)  // ref: mssvt/src/ms_cuda_utils.h:9 (EMPTY_KEY)
+
+// workspace header words (int32) written by the hash builders
+#define WS_STATUS 0       // bit0: duplicate key seen, bit1: table overflow, bit2: window overflow
+#define WS_HDR_INTS 4
+#define ST_DUP 1
+#define ST_TABLE_OVERFLOW 2
+#define ST_WIN_OVERFLOW 4
+
+static inline int mssvt_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSSVT_OK : (int)e;
+}
+
+static inline int divup(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (MSSVT_WAVE - 1); }
+
+// Ordering point for LDS traffic between lanes of ONE wave (LDS operations of a
+// wave complete in order; this only stops the compiler from moving them).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------
+// Hash table slots: (key, value) int32 pairs, ref layout (B, H, 2).  A slot is
+// manipulated as one 64-bit word: low half = key, high half = value.
+// ---------------------------------------------------------------------------
+typedef unsigned long long slot_t;
+#define SLOT_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ slot_t slot_pack(int key, int value) {
+    return (slot_t)(uint32_t)key | ((slot_t)(uint32_t)value << 32);
+}
+__device__ __forceinline__ int slot_key(slot_t s) { return (int)(uint32_t)(s & 0xFFFFFFFFull); }
+__device__ __forceinline__ int slot_val(slot_t s) { return (int)(uint32_t)(s >> 32); }
+
+__device__ __forceinline__ slot_t slot_load(const slot_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Lookup.  ref: hash_table_find, mssvt/src/ms_sparse_attention_gpu.cu:43-64.
+// Returns the value or MSSVT_EMPTY; *slot_out (optional) = slot index or -1.
+__device__ __forceinline__ int table_find(int key, int hash_size, const slot_t *tab,
+                                          int *slot_out = nullptr) {
+    int h = key % hash_size;
+    int prob = 0;
+    for (;;) {
+        slot_t s = tab[h];
+        int k = slot_key(s);
+        if (k == key) {
+            if (slot_out) *slot_out = h;
+            return slot_val(s);
+        }
+        if (k == MSSVT_EMPTY) break;
+        h = h + 1 == hash_size ? 0 : h + 1;
+        if (++prob >= hash_size) break;
+    }
+    if (slot_out) *slot_out = -1;
+    return MSSVT_EMPTY;
+}
+
+// Deterministic insertion: the final layout equals SEQUENTIAL linear-probing
+// insertion (ref: hash_table_insert, ms_sparse_attention_gpu.cu:22-41) of the
+// keys in increasing `value` order, whatever order the lanes actually run in.
+// Rule: a slot always ends up holding the highest-priority (= lowest value)
+// entry that probed it; the displaced entry carries on probing.  Slot contents
+// only ever move towards higher priority, so a stale read can only cause a
+// retry, never a wrong decision.  REQUIRES: keys inserted through this function
+// into one table are pairwise distinct (duplicates are resolved by the
+// callers first); returns bit flags ST_DUP / ST_TABLE_OVERFLOW it observed.
+__device__ __forceinline__ int table_insert_ordered(int key, int value, int hash_size,
+                                                    slot_t *tab) {
+    slot_t cur = slot_pack(key, value);
+    int i = key % hash_size;
+    int dist = 0;
+    for (;;) {
+        slot_t c = slot_load(tab + i);
+        for (;;) {  // settle this slot
+            if (c == SLOT_EMPTY) {
+                slot_t prev = atomicCAS(tab + i, c, cur);
+                if (prev == c) return 0;
+                c = prev;
+                continue;
+            }
+            if (slot_key(c) == slot_key(cur)) return ST_DUP;
+            if ((uint32_t)slot_val(c) > (uint32_t)slot_val(cur)) {  // cur outranks the resident
+                slot_t prev = atomicCAS(tab + i, c, cur);
+                if (prev == c) {
+                    cur = c;  // carry the displaced entry onwards
+                    int home = slot_key(cur) % hash_size;
+                    dist = i - home;
+                    if (dist < 0) dist += hash_size;
+                    break;
+                }
+                c = prev;
+                continue;
+            }
+            break;  // resident outranks cur: move on
+        }
+        i = i + 1 == hash_size ? 0 : i + 1;
+        if (++dist >= hash_size) return ST_TABLE_OVERFLOW;  // ref :39 silent drop
+    }
+}
+
+// Order-agnostic insertion keeping, per key, the MINIMUM value seen (used to
+// find first occurrences).  Returns the slot index or -1 when the table is full.
+__device__ __forceinline__ int table_insert_min(int key, int value, int hash_size, slot_t *tab) {
+    int *words = reinterpret_cast<int *>(tab);
+    int h = key % hash_size;
+    int prob = 0;
+    for (;;) {
+        int prev = atomicCAS(words + 2 * h, MSSVT_EMPTY, key);
+        if (prev == MSSVT_EMPTY || prev == key) {
+            atomicMin(reinterpret_cast<unsigned int *>(words + 2 * h + 1), (unsigned int)value);
+            return h;
+        }
+        h = h + 1 == hash_size ? 0 : h + 1;
+        if (++prob >= hash_size) return -1;
+    }
+}

@@ -1,0 +1,189 @@
+"""Operator surface of the MsSVT window ops on MI355X.
+
+Same entry-point names, argument order, shapes, dtypes and padding conventions as
+the reference's ``pcdet/ops/mssvt/mssvt_ops.py`` (``build_hash_table`` :26,
+``get_non_empty_window_center`` :60, ``gather_two_window_voxels`` :102,
+``gather_one_window_voxels`` :133, ``grouping_operation`` :192), so the
+reference's call sites work unchanged -- but every buffer is allocated directly
+in HBM (the reference fills its tables on the CPU and copies them over each
+call), the window list is compacted on the device, and the only host
+synchronisation left is the one the data-dependent output shape forces
+(``get_non_empty_window_center`` must know ``nw`` to size its result).
+
+All work happens in libmssvt_hip.so (hand-written HIP, include/mssvt_hip.h);
+there is no CPU fallback.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+
+ST_DUPLICATE_KEY, ST_TABLE_OVERFLOW, ST_WINDOW_OVERFLOW = 1, 2, 4
+
+# The reference asserts ``features.shape[0] == features_batch_cnt.sum()`` (mssvt_ops.py:157-160),
+# which costs two host syncs per call; here those checks are opt-in.
+CHECK_COUNTS = os.environ.get("MSSVT_CHECK_COUNTS", "0") == "1"
+
+_i = ctypes.c_int
+
+
+def _ints(xs):
+    return [int(v) for v in xs]
+
+
+def hash_workspace(num_voxels, batch_size, device):
+    n = int(_lib.lib().mssvt_hash_workspace_ints(_i(int(num_voxels)), _i(int(batch_size))))
+    return torch.empty(n, dtype=torch.int32, device=device)
+
+
+def _check_int32(t, name):
+    assert t.dtype == torch.int32, "%s must be int32" % name
+    assert t.is_contiguous(), "%s must be contiguous" % name
+
+
+def build_hash_table(batch_size, hash_size, spatial_shape, voxel_indices, v_bs_cnt, workspace=None):
+    """(B, H, 2) int32 table key -> voxel index within its sample.
+
+    ref: BuildHashTable.forward, mssvt_ops.py:10-20.  Layout = sequential insertion
+    in voxel-index order (deterministic; see include/mssvt_hip.h)."""
+    x_max, y_max, z_max = _ints(spatial_shape)
+    _check_int32(voxel_indices, "voxel_indices")
+    v_bs_cnt = v_bs_cnt.to(device=voxel_indices.device, dtype=torch.int32).contiguous()
+    n = voxel_indices.shape[0]
+    table = torch.full((batch_size, hash_size, 2), -1, dtype=torch.int32, device=voxel_indices.device)
+    ws = workspace if workspace is not None else hash_workspace(n, batch_size, voxel_indices.device)
+    _lib.call("mssvt_build_mapping_with_hash", _i(x_max), _i(y_max), _i(z_max), _i(n),
+              _i(int(hash_size)), _i(int(batch_size)), _lib.ptr(voxel_indices), _lib.ptr(v_bs_cnt),
+              _lib.ptr(table), _lib.ptr(ws), _lib.stream())
+    return table
+
+
+def window_partition_device(win_size, max_num_wins, batch_size, hash_size, spatial_shape,
+                            voxel_indices, workspace=None):
+    """Device-resident window discovery: returns (win_ind_padded (N,4), table (B,H,2),
+    k_bs_cnt (B), workspace) without synchronising; ``workspace[1]`` holds nw and
+    ``workspace[0]`` the status bits."""
+    x_ws, y_ws, z_ws = _ints(win_size)
+    x_wgs, y_wgs, z_wgs = _ints(spatial_shape)
+    _check_int32(voxel_indices, "voxel_indices")
+    dev = voxel_indices.device
+    n = voxel_indices.shape[0]
+    table = torch.full((batch_size, hash_size, 2), -1, dtype=torch.int32, device=dev)
+    win = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
+    vcount = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+    ws = workspace if workspace is not None else hash_workspace(n, batch_size, dev)
+    _lib.call("mssvt_window_partition_compact", _i(x_wgs), _i(y_wgs), _i(z_wgs), _i(x_ws), _i(y_ws),
+              _i(z_ws), _i(n), _i(int(max_num_wins)), _i(int(hash_size)), _i(int(batch_size)),
+              _lib.ptr(voxel_indices), _lib.ptr(win), _lib.ptr(table), _lib.ptr(vcount), _lib.ptr(ws),
+              _lib.stream())
+    return win, table, vcount, ws
+
+
+def get_non_empty_window_center(win_size, max_num_wins, batch_size, hash_size, spatial_shape,
+                                voxel_indices):
+    """-> (win_ind (nw,4) int32 [b,wz,wy,wx], window table (B,H,2) int32).
+
+    ref: WindowPartition.forward, mssvt_ops.py:31-54.  ``spatial_shape`` is the window
+    grid (``spatial_shape // win_size``).  Windows are numbered by first occurrence in
+    voxel-index order per sample (the reference's order depends on thread timing)."""
+    win, table, _, ws = window_partition_device(win_size, max_num_wins, batch_size, hash_size,
+                                                spatial_shape, voxel_indices)
+    status, nw = ws[:2].tolist()  # the one sync the output shape needs
+    if status & ST_WINDOW_OVERFLOW:
+        raise _lib.MssvtHipError("a sample has more than max_num_wins=%d non-empty windows "
+                                 "(the reference writes out of bounds here)" % max_num_wins)
+    if status & ST_TABLE_OVERFLOW:
+        raise _lib.MssvtHipError("window hash table overflow: more windows than hash_size=%d" % hash_size)
+    return win[:nw].contiguous(), table
+
+
+def gather_two_window_voxels(spatial_shape, win_size, max_num_odd, max_num_even, max_num_win1,
+                             max_num_win2, vox_query_odd, vox_query_even, vox_query_win1,
+                             vox_query_win2, win_indices, dense_map):
+    """-> 4 index tensors (nw, max_num_*) int32 (-1 padded) + 4 offset tensors
+    (nw, max_num_*, 3) int32 (0 padded), for the odd / even / win1 / win2 lists.
+
+    ref: GatherTwoWindowVoxels.forward, mssvt_ops.py:66-96."""
+    x_max, y_max, z_max = _ints(spatial_shape)
+    x_ws, y_ws, z_ws = _ints(win_size)
+    _, hash_size, _ = dense_map.shape
+    _check_int32(win_indices, "win_indices")
+    dev = win_indices.device
+    nw = win_indices.shape[0]
+    tabs = [t.to(device=dev, dtype=torch.int32).contiguous()
+            for t in (vox_query_odd, vox_query_even, vox_query_win1, vox_query_win2)]
+    maxes = _ints((max_num_odd, max_num_even, max_num_win1, max_num_win2))
+    inds = [torch.full((nw, m), -1, dtype=torch.int32, device=dev) for m in maxes]
+    coords = [torch.zeros((nw, m, 3), dtype=torch.int32, device=dev) for m in maxes]
+    _lib.call("mssvt_gather_two_window_voxels_with_hash", _i(x_max), _i(y_max), _i(z_max), _i(x_ws),
+              _i(y_ws), _i(z_ws), *[_i(m) for m in maxes], _i(nw), _i(int(hash_size)),
+              *[_i(t.shape[0]) for t in tabs], *[_lib.ptr(t) for t in inds],
+              *[_lib.ptr(t) for t in coords], *[_lib.ptr(t) for t in tabs], _lib.ptr(win_indices),
+              _lib.ptr(dense_map), _lib.stream())
+    return (*inds, *coords)
+
+
+def gather_one_window_voxels(spatial_shape, win_size, max_num_win1, vox_query_win1, win_indices,
+                             dense_map):
+    """-> (vox_ind_win1 (nw,max_num_win1), vox_coord_win1 (nw,max_num_win1,3)).
+
+    ref: GatherOneWindowVoxels.forward, mssvt_ops.py:108-127."""
+    x_max, y_max, z_max = _ints(spatial_shape)
+    x_ws, y_ws, z_ws = _ints(win_size)
+    _, hash_size, _ = dense_map.shape
+    _check_int32(win_indices, "win_indices")
+    dev = win_indices.device
+    nw = win_indices.shape[0]
+    tab = vox_query_win1.to(device=dev, dtype=torch.int32).contiguous()
+    ind = torch.full((nw, int(max_num_win1)), -1, dtype=torch.int32, device=dev)
+    coord = torch.zeros((nw, int(max_num_win1), 3), dtype=torch.int32, device=dev)
+    _lib.call("mssvt_gather_one_window_voxels_with_hash", _i(x_max), _i(y_max), _i(z_max), _i(x_ws),
+              _i(y_ws), _i(z_ws), _i(int(max_num_win1)), _i(nw), _i(int(hash_size)), _i(tab.shape[0]),
+              _lib.ptr(ind), _lib.ptr(coord), _lib.ptr(tab), _lib.ptr(win_indices), _lib.ptr(dense_map),
+              _lib.stream())
+    return ind, coord
+
+
+class _GroupFeatures(torch.autograd.Function):
+    """Stacked-batch row gather, differentiable w.r.t. ``features``.
+
+    ref: GroupingOperation, mssvt_ops.py:136-190 (forward K5, backward K6)."""
+
+    @staticmethod
+    def forward(ctx, features, features_batch_cnt, idx, idx_batch_cnt):
+        assert features.is_contiguous() and idx.is_contiguous()
+        assert features.dtype == torch.float32
+        _check_int32(idx, "idx")
+        features_batch_cnt = features_batch_cnt.to(torch.int32).contiguous()
+        idx_batch_cnt = idx_batch_cnt.to(torch.int32).contiguous()
+        M, nsample = idx.shape
+        N, C = features.shape
+        B = idx_batch_cnt.shape[0]
+        if CHECK_COUNTS:
+            assert N == int(features_batch_cnt.sum()), (features.shape, features_batch_cnt)
+            assert M == int(idx_batch_cnt.sum()), (idx.shape, idx_batch_cnt)
+        out = torch.zeros((M, C, nsample), dtype=torch.float32, device=features.device)
+        _lib.call("mssvt_group_features", _i(B), _i(M), _i(C), _i(nsample), _lib.ptr(features),
+                  _lib.ptr(features_batch_cnt), _lib.ptr(idx), _lib.ptr(idx_batch_cnt), _lib.ptr(out),
+                  _lib.stream())
+        ctx.for_backwards = (B, N, idx, features_batch_cnt, idx_batch_cnt)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        B, N, idx, features_batch_cnt, idx_batch_cnt = ctx.for_backwards
+        M, C, nsample = grad_out.shape
+        grad_out = grad_out.contiguous()
+        grad = torch.zeros((N, C), dtype=torch.float32, device=grad_out.device)
+        _lib.call("mssvt_group_features_grad", _i(B), _i(M), _i(C), _i(N), _i(nsample),
+                  _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(idx_batch_cnt),
+                  _lib.ptr(features_batch_cnt), _lib.ptr(grad), _lib.stream())
+        return grad, None, None, None
+
+
+def grouping_operation(features, features_batch_cnt, idx, idx_batch_cnt):
+    """features (N1+N2.., C), idx (M1+M2.., nsample) with per-sample indices (<0 = empty
+    slot) -> (M, C, nsample); empty slots stay 0.  ref: mssvt_ops.py:139-170."""
+    return _GroupFeatures.apply(features, features_batch_cnt, idx, idx_batch_cnt)

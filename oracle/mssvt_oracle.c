@@ -347,11 +347,11 @@ int orc_farthest_point_sampling(int b, int n, int m, const float *dataset,
                 float best = -1;
                 for (int k = tid; k < n; k += bs) {
                     float x2 = d[k * 3 + 0], y2 = d[k * 3 + 1], z2 = d[k * 3 + 2];
-                    /* nvcc default -fmad=true contracts this into an fma chain;
-                     * on the path the inputs are small integers so every
-                     * evaluation order is exact.                              */
-                    float dd = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) +
-                               (z2 - z1) * (z2 - z1);
+                    /* written as the fma chain nvcc's default -fmad=true emits
+                     * (see orc_three_nn); on the path the inputs are small
+                     * integers so every evaluation order is exact anyway.     */
+                    float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+                    float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     float d2 = dd < tmp[k] ? dd : tmp[k]; /* min(d, temp[k]) */
                     tmp[k] = d2;
                     besti = d2 > best ? k : besti;
