@@ -68,52 +68,42 @@ __global__ void __launch_bounds__(TPB) k_vox_insert_all(VoxKey kf, int n, int ha
     if (st) atomicOr(ws + WS_STATUS, st);
 }
 
-// ---- K1 slow path (duplicate voxel coordinates: invalid input for every VFE,
-// but defined by the oracle): one workgroup redoes the build in phases ---------
+// ---- K1 slow path: duplicate voxel coordinates.  No VFE produces them, but the
+// oracle defines the outcome (first inserter owns the slot, last writer owns the
+// value, also when the table overflows), so it is reproduced literally: the
+// tables are cleared and ONE THREAD PER SAMPLE replays the reference's insertion
+// loop (ref :22-41) in voxel-index order.  Slow (sequential per sample) by design:
+// it only runs for invalid input, and it exits immediately otherwise. ------------
 __global__ void __launch_bounds__(1024) k_vox_dup_fallback(VoxKey kf, int n, int hash_size,
                                                            int batch_size, const int *v_indices,
                                                            const int *v_bs_cnt, slot_t *table,
                                                            int *ws) {
     if (!(ws[WS_STATUS] & ST_DUP)) return;
-    int *first = ws + WS_HDR_INTS;
     const long long cells = (long long)batch_size * hash_size;
     for (long long c = threadIdx.x; c < cells; c += 1024) table[c] = SLOT_EMPTY;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {  // phase A: min index per key
-        int b, key;
-        first[i] = 0;
-        if (!kf(v_indices, i, b, key) || b < 0 || b >= batch_size) continue;
-        int v_idx = i - sample_start(v_bs_cnt, b);
-        if (table_insert_min(key, v_idx, hash_size, table + (size_t)b * hash_size) < 0)
-            atomicOr(ws + WS_STATUS, ST_TABLE_OVERFLOW);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        int b, key;
-        if (!kf(v_indices, i, b, key) || b < 0 || b >= batch_size) continue;
-        int v_idx = i - sample_start(v_bs_cnt, b);
-        first[i] = table_find(key, hash_size, table + (size_t)b * hash_size) == v_idx;
-    }
-    __syncthreads();
-    for (long long c = threadIdx.x; c < cells; c += 1024) table[c] = SLOT_EMPTY;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {  // phase B: ordered insert of first occurrences
-        if (!first[i]) continue;
-        int b, key;
-        kf(v_indices, i, b, key);
-        int v_idx = i - sample_start(v_bs_cnt, b);
-        int st = table_insert_ordered(key, v_idx, hash_size, table + (size_t)b * hash_size);
-        if (st & ST_TABLE_OVERFLOW) atomicOr(ws + WS_STATUS, ST_TABLE_OVERFLOW);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {  // phase C: last writer owns the value
-        int b, key;
-        if (!kf(v_indices, i, b, key) || b < 0 || b >= batch_size) continue;
-        int v_idx = i - sample_start(v_bs_cnt, b);
-        int slot;
-        slot_t *tab = table + (size_t)b * hash_size;
-        table_find(key, hash_size, tab, &slot);
-        if (slot >= 0) atomicMax(reinterpret_cast<int *>(tab + slot) + 1, v_idx);
+    for (int bs = threadIdx.x; bs < batch_size; bs += 1024) {
+        int *tab = reinterpret_cast<int *>(table + (size_t)bs * hash_size);
+        const int start = sample_start(v_bs_cnt, bs);
+        const int end = min(n, start + v_bs_cnt[bs]);
+        for (int i = start; i < end; ++i) {
+            int b, key;
+            if (!kf(v_indices, i, b, key) || b != bs) continue;
+            int h = key % hash_size, prob = 0;
+            for (;;) {
+                const int prev = tab[2 * h];
+                if (prev == MSSVT_EMPTY) tab[2 * h] = key;
+                if (prev == MSSVT_EMPTY || prev == key) {
+                    tab[2 * h + 1] = i - start;
+                    break;
+                }
+                h = h + 1 == hash_size ? 0 : h + 1;
+                if (++prob >= hash_size) {
+                    atomicOr(ws + WS_STATUS, ST_TABLE_OVERFLOW);
+                    break;
+                }
+            }
+        }
     }
 }
 
