@@ -1,0 +1,347 @@
+"""``MixedScaleSparseTransformer`` -- the MsSVT 3-D backbone on MI355X.
+
+Drop-in for the reference's ``pcdet/models/backbones_3d/mssvt_backbone.py``: the
+registry name ``MixedScaleSparseTransformer`` (:401), its constructor
+``(model_cfg, input_channels, grid_size, voxel_size, point_cloud_range)``,
+``num_point_features``, ``forward(batch_dict)`` reading ``voxel_features``,
+``voxel_coords``, ``batch_size`` and writing ``encoded_spconv_tensor`` (+ stride 1),
+the block classes ``MixedScaleSparseTransformerBlock`` (:11) /
+``MixedScaleSparseTransformerCompressBlock`` (:349) with their constructor
+arguments, and every state-dict key (``backbone.{i}.{ms_attn.to_qs.{g}, ms_attn.to_kvs.{g},
+ms_attn.projs.{g}, linear1, linear2, out_linear, norm1, norm2, pos_proj.{0,2}}``).
+
+Two execution paths compute the same function:
+
+* ``impl="fused"`` (default): window plan + fused HIP block kernels
+  (mssvt_amd/fused.py); index work is done once per window configuration and shared
+  by consecutive blocks, nothing padded is materialised, no host synchronisation
+  inside the blocks.
+* ``impl="ops"``: operator-level composition through the reference-shaped ops of
+  ``mssvt_ops`` / ``pointnet2_utils`` (HIP kernels) and torch dense math -- the
+  structure of the reference's forward, kept as the mid-level parity surface.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import mssvt_ops, pointnet2_utils, query_table
+from .mssvt_utils import MixedScaleAttention, SparseTensor, batch_counts
+
+MAX_NUM_WINS = 90000  # ref: mssvt_backbone.py:56
+DEFAULT_IMPL = "ops"  # switched to "fused" once mssvt_amd/fused.py lands
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per row (the ``timm.models.layers.DropPath`` the reference imports,
+    mssvt_backbone.py:4); identity in eval mode."""
+
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
+
+
+def metric_centres(indices, point_cloud_range, cell_size):
+    """Cell centres in metres, (n,3) [x,y,z]: ``(idx[:, [3,2,1]] + 0.5) * cell + min``, three
+    separately rounded fp32 ops.  ref: with_coords, mssvt_backbone.py:132-137."""
+    cell = torch.tensor(list(cell_size), dtype=torch.float32, device=indices.device).unsqueeze(0)
+    lo = torch.tensor(list(point_cloud_range[0:3]), dtype=torch.float32, device=indices.device).unsqueeze(0)
+    return (indices[:, [3, 2, 1]].float() + 0.5) * cell + lo
+
+
+class WindowPlan(object):
+    """Index-only products of one window configuration on one voxel set (R2, R4, R7 of
+    SURVEY.md section 8a).  They depend on ``indices`` and the window sizes but not on the
+    features, so consecutive blocks with the same configuration share one plan."""
+    pass
+
+
+class MixedScaleSparseTransformerBlock(nn.Module):
+    def __init__(self, cfg, in_channels, ff_channels, out_channels, num_heads, dropout=0.,
+                 drop_path=None, window_size=None, max_num_win1=None, max_num_win2=None,
+                 cbs_mode='odd_even', cbs_pattern=1, key_num_sample=32,
+                 use_feature_interpolation=True):
+        super().__init__()
+        self.cfg = cfg
+        self.in_channels, self.ff_channels, self.out_channels = in_channels, ff_channels, out_channels
+        self.ms_attn = MixedScaleAttention(embed_dim=in_channels, num_heads=num_heads, dropout=dropout)
+        self.linear1 = nn.Linear(in_channels, ff_channels)
+        self.linear2 = nn.Linear(ff_channels, in_channels)
+        if out_channels != in_channels:
+            self.out_linear = nn.Linear(in_channels, out_channels)
+        self.norm1 = nn.LayerNorm(in_channels)
+        self.norm2 = nn.LayerNorm(in_channels)
+        self.activation = nn.ReLU()
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.drop_path = DropPath(drop_path) if drop_path and drop_path > 0. else nn.Identity()
+        assert len(window_size) <= 2
+        pos = [nn.Conv1d(6, in_channels, 1), nn.ReLU()]
+        if len(window_size) != 2:  # single-window blocks get a second layer (ref :48-54)
+            pos += [nn.Conv1d(in_channels, in_channels, 1), nn.ReLU()]
+        self.pos_proj = nn.Sequential(*pos)
+        self.key_num_sample = key_num_sample
+        self.max_num_wins = MAX_NUM_WINS
+        self.use_feature_interpolation = use_feature_interpolation
+        self.cbs_mode, self.cbs_pattern = cbs_mode, cbs_pattern
+        self.window_size = [list(w) for w in window_size]
+        self.win1_size = self.window_size[0]
+        self.win2_size = self.window_size[1] if len(self.window_size) == 2 else None
+        self.max_num_win1 = int(np.prod(self.win1_size)) if max_num_win1 is None else max_num_win1
+        self.max_num_win2 = None
+        if self.win2_size is not None:
+            self.max_num_win2 = int(np.prod(self.win2_size)) if max_num_win2 is None else max_num_win2
+        tables, self.max_num_odd, self.max_num_even = self.get_vox_query_table(
+            self.win1_size, self.win2_size, self.cbs_mode)
+        self.set_vox_query_table(tables)
+        self.impl = DEFAULT_IMPL
+
+    # -- query tables -------------------------------------------------------
+    def get_vox_query_table(self, win1_size, win2_size=None, cbs_mode=None):
+        tabs, n_odd, n_even = query_table.vox_query_table(win1_size, win2_size, cbs_mode or 'odd_even')
+        return {k: torch.from_numpy(v) for k, v in tabs.items()}, n_odd, n_even
+
+    def set_vox_query_table(self, tables):
+        """Install explicit offset tables (dict of (n,3) int tensors/arrays), e.g. tables
+        exported from a reference run whose tie order differs."""
+        self.vox_query_table = {k: torch.as_tensor(v).to(torch.int32).contiguous() for k, v in tables.items()}
+        if 'odd' in self.vox_query_table:
+            self.max_num_odd = self.vox_query_table['odd'].shape[0]
+            self.max_num_even = self.vox_query_table['even'].shape[0]
+        self._table_sig = hash(tuple(v.cpu().numpy().tobytes() for v in self.vox_query_table.values()))
+
+    def _tables_on(self, device):
+        t = self.vox_query_table
+        if next(iter(t.values())).device != device:
+            self.vox_query_table = t = {k: v.to(device) for k, v in t.items()}
+        return t
+
+    def plan_key(self):
+        return (tuple(map(tuple, self.window_size)), self.max_num_odd, self.max_num_even,
+                self.max_num_win1, self.max_num_win2, self.key_num_sample, self._table_sig)
+
+    # -- helpers shared with the reference's API ------------------------------
+    @torch.no_grad()
+    def with_bs_cnt(self, indices, batch_size):
+        return batch_counts(indices, batch_size)
+
+    @torch.no_grad()
+    def with_coords(self, indices, point_cloud_range, voxel_size):
+        return metric_centres(indices, point_cloud_range, voxel_size)
+
+    def window_partition(self, sp_tensor):
+        new_shape = [sp_tensor.spatial_shape[i] // self.win1_size[i] for i in range(3)]
+        win_ind, win_table = mssvt_ops.get_non_empty_window_center(
+            self.win1_size, self.max_num_wins, sp_tensor.batch_size, sp_tensor.hash_size, new_shape,
+            sp_tensor.indices)
+        return new_shape, win_ind, win_table
+
+    def mixed_scale_vox_sample(self, sp_tensor, win_ind):
+        t = self._tables_on(win_ind.device)
+        if self.win2_size is None:
+            ind, coord = mssvt_ops.gather_one_window_voxels(
+                sp_tensor.spatial_shape, self.win1_size, self.max_num_win1, t['win1'], win_ind,
+                sp_tensor.map_table)
+            return {'vox_ind_win1': ind, 'vox_mask_win1': ind < 0, 'vox_coord_win1': coord}
+        outs = mssvt_ops.gather_two_window_voxels(
+            sp_tensor.spatial_shape, self.win1_size, self.max_num_odd, self.max_num_even,
+            self.max_num_win1, self.max_num_win2, t['odd'], t['even'], t['win1'], t['win2'], win_ind,
+            sp_tensor.map_table)
+        names = ('win1_odd', 'win1_even', 'win1', 'win2')
+        d = {}
+        for n, ind, coord in zip(names, outs[:4], outs[4:]):
+            d['vox_ind_' + n], d['vox_mask_' + n], d['vox_coord_' + n] = ind, ind < 0, coord
+        return d
+
+    # -- operator-level plan ---------------------------------------------------
+    @torch.no_grad()
+    def _ops_plan(self, sp):
+        cache = getattr(sp, '_ops_plans', None)
+        if cache is None:
+            cache = sp._ops_plans = {}
+        key = self.plan_key()
+        if key in cache:
+            return cache[key]
+        p = WindowPlan()
+        p.new_spatial_shape, p.win_ind, p.win_table = self.window_partition(sp)
+        p.win_size_m = [sp.voxel_size[i] * self.win1_size[i] for i in range(3)]
+        p.lists = self.mixed_scale_vox_sample(sp, p.win_ind)
+        p.v_bs_cnt = batch_counts(sp.indices, sp.batch_size)
+        p.k_bs_cnt = batch_counts(p.win_ind, sp.batch_size)
+        if self.win2_size is not None:
+            for tag in ('win1', 'win2'):
+                ind, coord = p.lists['vox_ind_' + tag], p.lists['vox_coord_' + tag]
+                fps = pointnet2_utils.farthest_point_sample(coord.float().contiguous(), self.key_num_sample)
+                mask = fps == 0  # repeated picks of slot 0 ...
+                mask[:, 0] = False  # ... except the seed itself (ref :248-252)
+                # ref :253-256: indices go through fp32 and come back with (x + 0.1).int(); .int()
+                # truncates toward zero, so a picked EMPTY slot (-1) turns into voxel 0 of the sample
+                k_ind = (torch.gather(ind, 1, fps.long()).float() + 0.1).int()
+                setattr(p, 'k_ind_' + tag, k_ind.contiguous())
+                setattr(p, 'k_mask_' + tag, mask | (k_ind < 0))
+                setattr(p, 'fps_' + tag, fps)
+        # first voxel row of the sample each window belongs to (per-sample -> global indices)
+        v_start = torch.cumsum(p.v_bs_cnt, 0) - p.v_bs_cnt
+        p.win_v_start = v_start[p.win_ind[:, 0].long()].long()
+        cache[key] = p
+        return p
+
+    def _query_lists(self, p):
+        tag = {0: 'win1_even', 1: 'win1_odd', 2: 'win1'}[self.cbs_pattern]  # ref :220-232
+        return p.lists['vox_ind_' + tag], p.lists['vox_mask_' + tag]
+
+    def _ffn(self, x):
+        return self.linear2(self.dropout1(self.activation(self.linear1(self.norm2(x)))))
+
+    # -- forward ---------------------------------------------------------------
+    def forward(self, sp_tensor, block_idx=None, recycle_dict=None):
+        if self.impl == "fused":
+            from . import fused
+            return fused.block_forward(self, sp_tensor)
+        return self.forward_ops(sp_tensor)
+
+    def forward_ops(self, sp):
+        """Operator-level forward (ref: mssvt_backbone.py:201-346)."""
+        x_in = sp.features
+        C = x_in.shape[1]
+        x = self.norm1(x_in)
+        p = self._ops_plan(sp)
+        grp = lambda f, idx: mssvt_ops.grouping_operation(f, p.v_bs_cnt, idx, p.k_bs_cnt)  # noqa: E731
+        q_ind, q_mask = self._query_lists(p)
+        win1_ind = p.lists['vox_ind_win1']
+        k_mask1, k_mask2 = p.k_mask_win1, p.k_mask_win2
+
+        vox_xyz = metric_centres(sp.indices, sp.point_cloud_range, sp.voxel_size)
+        centre = metric_centres(p.win_ind, sp.point_cloud_range, p.win_size_m).unsqueeze(-1)  # (nw,3,1)
+        q_xyz = grp(vox_xyz, q_ind)  # (nw,3,nq); empty slots stay at the origin
+        rel_q = (q_xyz - centre) * (~q_mask).unsqueeze(1)
+        rel_k = torch.cat([(grp(vox_xyz, p.k_ind_win1) - centre) * (~k_mask1).unsqueeze(1),
+                           (grp(vox_xyz, p.k_ind_win2) - centre) * (~k_mask2).unsqueeze(1)], dim=-1)
+        q_tok = grp(x, q_ind) + self.pos_proj(torch.cat([rel_q, centre.expand_as(rel_q)], dim=1))
+        k_tok = torch.cat([grp(x, p.k_ind_win1), grp(x, p.k_ind_win2)], dim=-1) + \
+            self.pos_proj(torch.cat([rel_k, centre.expand_as(rel_k)], dim=1))
+        attn = self.ms_attn(query=q_tok.transpose(1, 2).contiguous(), keys=k_tok.transpose(1, 2).contiguous(),
+                            query_mask=q_mask, key_masks=torch.cat([k_mask1, k_mask2], dim=-1),
+                            batch_first=True)  # (nw,nq,C)
+
+        if self.use_feature_interpolation:  # ref :300-310
+            unknown = grp(vox_xyz, win1_ind).transpose(1, 2).contiguous()  # (nw,n1,3)
+            dist, nn_idx = pointnet2_utils.three_nn(unknown, q_xyz.transpose(1, 2).contiguous())
+            w = 1.0 / torch.clamp(dist, min=1e-10)
+            w = w / w.sum(-1, keepdim=True)
+            picked = pointnet2_utils.grouping_operation(attn.transpose(1, 2).contiguous(), nn_idx)
+            upd = (picked * w.unsqueeze(1)).sum(-1).transpose(1, 2).reshape(-1, C)  # (nw*n1,C)
+            upd_ind = win1_ind
+        else:
+            upd, upd_ind = attn.reshape(-1, C), q_ind
+        # scatter (ref :313-334): per-sample index -> global row; empty slots are dropped
+        rows = (upd_ind.long() + p.win_v_start.unsqueeze(1)).reshape(-1)
+        valid = (upd_ind >= 0).reshape(-1)
+        feats = x_in.clone()
+        feats[rows[valid]] = upd[valid]
+        new = self.drop_path(feats) + x_in  # untouched voxels end up as 2 * x_in (ref quirk, R12)
+        new = new + self.drop_path(self.dropout1(self._ffn(new)))
+        if hasattr(self, 'out_linear'):
+            new = self.out_linear(new)
+        sp.features = new
+        sp.gather_dict = None
+        return sp
+
+
+class MixedScaleSparseTransformerCompressBlock(MixedScaleSparseTransformerBlock):
+
+    def forward(self, sp_tensor, block_idx=None, recycle_dict=None):
+        if self.impl == "fused":
+            from . import fused
+            return fused.compress_forward(self, sp_tensor)
+        return self.forward_ops(sp_tensor)
+
+    def forward_ops(self, sp):
+        """Operator-level forward (ref: mssvt_backbone.py:351-398): window pooling."""
+        x = self.norm1(sp.features)
+        p = self._ops_plan(sp)
+        k_ind, k_mask = p.lists['vox_ind_win1'], p.lists['vox_mask_win1']
+        grp = lambda f, idx: mssvt_ops.grouping_operation(f, p.v_bs_cnt, idx, p.k_bs_cnt)  # noqa: E731
+        k_fea = grp(x, k_ind)  # (nw,C,ns), zeros in empty slots
+        vox_xyz = metric_centres(sp.indices, sp.point_cloud_range, sp.voxel_size)
+        centre = metric_centres(p.win_ind, sp.point_cloud_range, p.win_size_m).unsqueeze(-1)
+        rel_k = grp(vox_xyz, k_ind) - centre  # NOT masked (ref :372): empty slots sit at -centre
+        q_tok = k_fea.max(dim=-1)[0].unsqueeze(0)  # (1,nw,C); the zero padding takes part (ref :370)
+        k_tok = (k_fea + self.pos_proj(torch.cat([rel_k, centre.expand_as(rel_k)], dim=1))).permute(2, 0, 1)
+        new = self.ms_attn(query=q_tok, keys=k_tok.contiguous(), key_masks=k_mask).squeeze(0)
+        new = new + self.dropout1(self._ffn(new))  # no residual to the block input (ref :383-385)
+        if hasattr(self, 'out_linear'):
+            new = self.out_linear(new)
+        sp.features = new
+        sp.indices = p.win_ind
+        sp.spatial_shape = p.new_spatial_shape
+        sp.voxel_size = p.win_size_m
+        sp.map_table = p.win_table
+        sp.gather_dict = None
+        sp._ops_plans = None
+        sp._plans = None
+        return sp
+
+
+class MixedScaleSparseTransformer(nn.Module):
+
+    def __init__(self, model_cfg, input_channels, grid_size, voxel_size, point_cloud_range):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.input_channels = input_channels
+        self.grid_size = [int(v) for v in grid_size]
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.hash_size = model_cfg.get('HASH_SIZE', None)
+        params = model_cfg.PARAMS if hasattr(model_cfg, 'PARAMS') else model_cfg['PARAMS']
+        get = lambda p, k, d=None: (p.get(k, d) if hasattr(p, 'get') else getattr(p, k, d))  # noqa: E731
+        # stochastic-depth schedule: len(PARAMS)-1 rates, so the last PARAM must be a CompressBlock
+        dpr = [x.item() for x in torch.linspace(0, 0.3, len(params) - 1)]
+        self.backbone = nn.ModuleList()
+        for i, p in enumerate(params):
+            c_in, c_ff, c_out = get(p, 'channels')
+            name = get(p, 'name')
+            if name == 'MixedScaleSparseTransformerBlock':
+                blk = MixedScaleSparseTransformerBlock(
+                    cfg=p, in_channels=c_in, ff_channels=c_ff, out_channels=c_out,
+                    num_heads=get(p, 'num_heads'), drop_path=dpr[i], window_size=get(p, 'window_size'),
+                    max_num_win1=get(p, 'max_num_win1'), max_num_win2=get(p, 'max_num_win2'),
+                    cbs_mode=get(p, 'cbs_mode'), cbs_pattern=get(p, 'cbs_pattern'),
+                    key_num_sample=get(p, 'key_num_sample'),
+                    use_feature_interpolation=get(p, 'use_feature_interpolation'))
+            elif name == 'MixedScaleSparseTransformerCompressBlock':
+                blk = MixedScaleSparseTransformerCompressBlock(
+                    cfg=p, in_channels=c_in, ff_channels=c_ff, out_channels=c_out,
+                    num_heads=get(p, 'num_heads'), drop_path=0., window_size=get(p, 'window_size'),
+                    max_num_win1=get(p, 'max_num_win1'))
+            else:
+                raise NotImplementedError(name)
+            self.backbone.append(blk)
+        self.num_point_features = model_cfg.get('NUM_OUTPUT_FEATURES') if hasattr(model_cfg, 'get') \
+            else model_cfg.NUM_OUTPUT_FEATURES
+
+    def set_impl(self, impl):
+        assert impl in ("fused", "ops")
+        for blk in self.backbone:
+            blk.impl = impl
+        return self
+
+    def forward(self, batch_dict):
+        feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+        sp = SparseTensor(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
+                          voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
+                          batch_size=batch_dict['batch_size'], hash_size=self.hash_size,
+                          map_table=None, gather_dict=None)
+        for i, blk in enumerate(self.backbone):
+            sp = blk(sp, block_idx=i)
+        batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
+        return batch_dict

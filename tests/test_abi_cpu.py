@@ -1,0 +1,58 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports every symbol that
+include/mssvt_hip.h declares (no compute calls here: there is no GPU in this container)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mssvt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mssvt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_declared_abi():
+    from mssvt_amd import build
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libmssvt_hip.so does not export %s" % n
+    lib.mssvt_hip_status_string.restype = ctypes.c_char_p
+    assert lib.mssvt_hip_abi_version() >= 100
+    assert lib.mssvt_hip_status_string(0) == b"ok"
+    assert b"bad argument" in lib.mssvt_hip_status_string(-1)
+    lib.mssvt_hash_workspace_ints.restype = ctypes.c_longlong
+    assert lib.mssvt_hash_workspace_ints(1000, 2) >= 1000
+
+
+def test_argument_errors_are_status_codes_not_exits():
+    from mssvt_amd import build
+    lib = ctypes.CDLL(build.build())
+    null = ctypes.c_void_p(0)
+    i = ctypes.c_int
+    # null pointers / bad sizes are rejected before any HIP call
+    assert lib.mssvt_build_mapping_with_hash(i(8), i(8), i(8), i(10), i(0), i(1), null, null, null, null, null) == -1
+    assert lib.mssvt_group_features(i(0), i(1), i(1), i(1), null, null, null, null, null, null) == -1
+    assert lib.mssvt_three_nn(i(1), i(0), i(1), null, null, null, null, null) == -1
+
+
+def test_product_has_no_oracle_import_and_fails_loudly_without_library(monkeypatch):
+    import mssvt_amd
+    pkg = os.path.dirname(mssvt_amd.__file__)
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in txt and "from oracle" not in txt, fn
+    from mssvt_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmssvt_hip.so")
+    try:
+        _lib.lib()
+    except _lib.MssvtHipError as e:
+        assert "no CPU fallback" in str(e).replace("\n", " ") or "not built" in str(e)
+    else:
+        raise AssertionError("missing library must raise")
