@@ -161,6 +161,52 @@ int mssvt_window_partition_compact(int x_wgs, int y_wgs, int z_wgs, int x_ws, in
                                    const int *v_indices, int *win_ind, int *xyz_to_vidx,
                                    int *vcount, int *workspace, void *stream);
 
+/* Fused window plan of a two-scale Block: K3 + 2 x K7 + 2 x K8 + the key-mask logic
+ * of ref mssvt_backbone.py:247-258 in one launch, one wavefront per window, hit lists
+ * kept in LDS.  num_wins_dev: DEVICE scalar (e.g. workspace+1 of
+ * mssvt_window_partition_compact); win_capacity: rows allocated in the per-window
+ * outputs.  Outputs: ind_odd/ind_even/ind_win1 (cap,max_num_*) as K3 writes them (-1
+ * padded); k_ind1/k_ind2 (cap,K) sampled key voxels of the win1 / win2 list (an EMPTY
+ * slot picked by FPS becomes voxel 0, as in the reference); k_mask1/k_mask2 (cap,K)
+ * bytes, 1 = masked; win_vstart (cap) first feature row of the window's sample;
+ * owner_* (N) pre-filled -1: highest flat list slot (w*max_num + s) holding the voxel. */
+int mssvt_window_plan_two(
+    int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
+    int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
+    int num_win1, int num_win2, const int *vox_query_odd, const int *vox_query_even,
+    const int *vox_query_win1, const int *vox_query_win2, int key_num_sample, const int *win_indices,
+    const int *num_wins_dev, int win_capacity, const int *xyz_to_vidx, const int *v_bs_cnt,
+    int *ind_odd, int *ind_even, int *ind_win1, int *k_ind1, int *k_ind2, unsigned char *k_mask1,
+    unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
+    void *stream);
+
+/* Fused attention of ONE head group of a Block (channels [c0, c0+Cg), Cg = heads*head_dim
+ * <= 64): gathers + positional MLP + MixedScaleAttention (ref mssvt_backbone.py:260-295,
+ * mssvt_utils.py:112-150) for every valid query of every window.  xhat (N,C) = norm1
+ * output; q_ind (cap,nq); k_ind/k_mask (cap,K) of the scale this group attends to; Wq
+ * (Cg,Cg), Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) + biases = the module's parameters;
+ * attn (cap,nq,C): rows of valid query slots, columns [c0,c0+Cg) are written.
+ * host_*3: HOST pointers to 3 floats [x,y,z].                                        */
+int mssvt_block_attention_group(
+    int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
+    const float *xhat, const int *indices, const int *win_ind, const int *num_wins_dev,
+    const int *win_vstart, const int *q_ind, const int *k_ind, const unsigned char *k_mask,
+    const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3,
+    const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo,
+    const float *bo, const float *Wpos, const float *bpos, float *attn, void *stream);
+
+/* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
+ * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):
+ * x_new[v] = interp(v) + x_in[v] for every voxel v owned by a list slot; rows of other
+ * voxels are left untouched (the caller pre-fills x_new = 2*x_in, ref quirk R12).
+ * use_interpolation = 0: x_new[v] = attn[slot] + x_in[v] for the query voxels only.   */
+int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_interpolation, const float *attn,
+                               const float *x_in, float *x_new, const int *indices,
+                               const int *win_ind, const int *num_wins_dev, int win_capacity,
+                               const int *win_vstart, const int *q_ind, const int *upd_ind,
+                               const int *owner, const float *host_voxel_size3,
+                               const float *host_range_min3, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

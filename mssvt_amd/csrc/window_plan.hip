@@ -1,0 +1,288 @@
+// window_plan.hip -- fused, device-resident "window plan" for the module fast path.
+//
+// One launch does, for every non-empty window, what the reference does with
+// K3 (gather_two_window_voxels, ref: mssvt/src/ms_sparse_attention_gpu.cu:193-350),
+// two K7 launches (farthest point sampling of 32 keys from the win1 and win2 lists,
+// ref: pointnet2/pointnet2_batch/src/sampling_gpu.cu:100-216), two K8 launches plus
+// the mask logic of mssvt_backbone.py:247-258 -- without ever writing the padded
+// (nw,343) index / (nw,343,3) offset arrays to HBM (~130 MB per call at 160k
+// points in the reference): the hit lists live in LDS, FPS runs on them in place,
+// and only what the attention stage consumes is stored:
+//     ind_odd / ind_even / ind_win1   (-1 padded, identical to K3's outputs)
+//     k_ind1 / k_ind2                 the 32 sampled key voxels per scale
+//     k_mask1 / k_mask2               1 = masked key slot
+//     win_vstart                      first feature row of the window's sample
+//     owner_*                         per voxel, the flat list slot that updates it
+// One WAVEFRONT per window; lanes probe 64 offsets at a time (ballot + prefix
+// popcount keeps the reference's append order), then replay the reference's FPS
+// block tree so that ties resolve identically (see fps_nn.hip).
+//
+// The number of windows is read from DEVICE memory (no host round trip); the grid
+// is sized for the capacity and surplus waves exit.
+#include "common.hip.h"
+
+#define PLAN_MAX_WPB 4
+
+struct PlanArgs {
+    int x_max, y_max, z_max, x_ws, y_ws, z_ws;
+    int max_odd, max_even, max_win1, max_win2;
+    int hash_size, batch_size;
+    int n_odd, n_even, n_win1, n_win2;
+    const int *q_odd, *q_even, *q_win1, *q_win2;
+    int key_num_sample, bs1, bs2;  // FPS picks, reference block sizes for n = max_win1 / max_win2
+    const int *win_indices;
+    const int *num_wins;  // device scalar
+    const slot_t *table;
+    const int *v_bs_cnt;
+    int *ind_odd, *ind_even, *ind_win1, *k_ind1, *k_ind2;
+    unsigned char *k_mask1, *k_mask2;
+    int *win_vstart;
+    int *owner_win1, *owner_odd, *owner_even;
+    int lds_words_per_wave;
+};
+
+#define PACK0 (64 | (64 << 8) | (64 << 16))
+__device__ __forceinline__ int pack_off(int ox, int oy, int oz) {
+    return (ox + 64) | ((oy + 64) << 8) | ((oz + 64) << 16);
+}
+
+// Farthest point sampling over an LDS list of packed integer offsets (padding = offset 0),
+// replaying a reference block of `bs` threads (ref sampling_gpu.cu:100-216).  Writes the m
+// picked slot numbers to fps_out[0..m).
+__device__ __forceinline__ void fps_on_list(const int *packed, int n, int m, int bs, float *temp,
+                                            float *bv, int *bidx, int *fps_out, int lane) {
+    for (int k = lane; k < n; k += MSSVT_WAVE) temp[k] = 1e10f;
+    if (lane == 0) fps_out[0] = 0;
+    wave_lds_sync();
+    int old = 0;
+    const int top = bs < MSSVT_WAVE ? bs : MSSVT_WAVE;
+    for (int j = 1; j < m; ++j) {
+        const int po = packed[old];
+        const float x1 = (float)((po & 255) - 64), y1 = (float)(((po >> 8) & 255) - 64),
+                    z1 = (float)(((po >> 16) & 255) - 64);
+        float best = -1.0f;
+        int besti = 0;
+        for (int vt = lane; vt < bs; vt += MSSVT_WAVE) {
+            best = -1.0f;
+            besti = 0;
+            for (int k = vt; k < n; k += bs) {
+                const int p = packed[k];
+                const float dx = (float)((p & 255) - 64) - x1, dy = (float)(((p >> 8) & 255) - 64) - y1,
+                            dz = (float)(((p >> 16) & 255) - 64) - z1;
+                const float d2 = fminf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), temp[k]);
+                temp[k] = d2;
+                besti = d2 > best ? k : besti;
+                best = d2 > best ? d2 : best;
+            }
+            if (bs > MSSVT_WAVE) {
+                bv[vt] = best;
+                bidx[vt] = besti;
+            }
+        }
+        for (int s = bs >> 1; s >= MSSVT_WAVE; s >>= 1) {
+            wave_lds_sync();
+            for (int t = lane; t < s; t += MSSVT_WAVE) {
+                const float v1 = bv[t], v2 = bv[t + s];
+                const int i1 = bidx[t], i2 = bidx[t + s];
+                bv[t] = fmaxf(v1, v2);
+                bidx[t] = v2 > v1 ? i2 : i1;
+            }
+        }
+        if (bs > MSSVT_WAVE) {
+            wave_lds_sync();
+            best = bv[lane];
+            besti = bidx[lane];
+        }
+        for (int s = top >> 1; s >= 1; s >>= 1) {
+            const float v2 = __shfl_down(best, s);
+            const int i2 = __shfl_down(besti, s);
+            besti = v2 > best ? i2 : besti;
+            best = fmaxf(best, v2);
+        }
+        old = __builtin_amdgcn_readfirstlane(besti);
+        if (lane == 0) fps_out[j] = old;
+        wave_lds_sync();
+    }
+}
+
+__global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanArgs a) {
+    extern __shared__ int lds[];
+    const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    const int w = blockIdx.x * (blockDim.x / MSSVT_WAVE) + wv;
+    if (w >= *a.num_wins) return;  // wave-uniform
+    int *base = lds + (size_t)wv * a.lds_words_per_wave;
+    int *l1_ind = base;
+    int *l1_c = l1_ind + a.max_win1;
+    int *l2_ind = l1_c + a.max_win1;
+    int *l2_c = l2_ind + a.max_win2;
+    const int nmax = a.max_win1 > a.max_win2 ? a.max_win1 : a.max_win2;
+    float *temp = reinterpret_cast<float *>(l2_c + a.max_win2);
+    int *fps_out = reinterpret_cast<int *>(temp + nmax);
+    float *bv = reinterpret_cast<float *>(fps_out + a.key_num_sample);
+    const int bsmax = a.bs1 > a.bs2 ? a.bs1 : a.bs2;
+    int *bidx = reinterpret_cast<int *>(bv + bsmax);
+
+    for (int k = lane; k < a.max_win1; k += MSSVT_WAVE) {
+        l1_ind[k] = -1;
+        l1_c[k] = PACK0;
+    }
+    for (int k = lane; k < a.max_win2; k += MSSVT_WAVE) {
+        l2_ind[k] = -1;
+        l2_c[k] = PACK0;
+    }
+    for (int k = lane; k < a.max_odd; k += MSSVT_WAVE) a.ind_odd[(size_t)w * a.max_odd + k] = -1;
+    for (int k = lane; k < a.max_even; k += MSSVT_WAVE) a.ind_even[(size_t)w * a.max_even + k] = -1;
+    wave_lds_sync();
+
+    const int4 wi = reinterpret_cast<const int4 *>(a.win_indices)[w];  // [b,wz,wy,wx]
+    const slot_t *tab = a.table + (size_t)wi.x * a.hash_size;
+    int vstart = 0;
+    for (int k = 0; k < wi.x; ++k) vstart += a.v_bs_cnt[k];
+    if (lane == 0) a.win_vstart[w] = vstart;
+    const int cx = wi.w * a.x_ws + a.x_ws / 2, cy = wi.z * a.y_ws + a.y_ws / 2,
+              cz = wi.y * a.z_ws + a.z_ws / 2;
+    const int e0 = a.n_odd, e1 = e0 + a.n_even, e2 = e1 + a.n_win1, total = e2 + a.n_win2;
+    int cnt_odd = 0, cnt_even = 0, cnt_w1 = 0, cnt_w2 = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // ---- K3: probe all offsets, 64 per step, ordered append ----------------------
+    for (int bq = 0; bq < total; bq += MSSVT_WAVE) {
+        if (cnt_w2 >= a.max_win2 && cnt_w1 >= a.max_win1 && (cnt_even >= a.max_even || bq >= e1) &&
+            (cnt_odd >= a.max_odd || bq >= e0))
+            break;
+        const int q = bq + lane;
+        const int seg = (q >= e0) + (q >= e1) + (q >= e2);
+        int sv = MSSVT_EMPTY, ox = 0, oy = 0, oz = 0;
+        if (q < total) {
+            const int *src = seg == 0 ? a.q_odd + q * 3
+                           : seg == 1 ? a.q_even + (q - e0) * 3
+                           : seg == 2 ? a.q_win1 + (q - e1) * 3
+                                      : a.q_win2 + (q - e2) * 3;
+            ox = src[0];
+            oy = src[1];
+            oz = src[2];
+            const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
+            if (!(sx >= a.x_max || sx < 0 || sy >= a.y_max || sy < 0 || sz >= a.z_max || sz < 0))
+                sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
+        }
+        const bool hit = sv != MSSVT_EMPTY;
+        const unsigned long long m_all = __ballot(hit);
+        if (m_all == 0) continue;
+        const unsigned long long m_odd = __ballot(hit && seg == 0);
+        const unsigned long long m_even = __ballot(hit && seg == 1);
+        const unsigned long long m_w1 = __ballot(hit && seg <= 2);
+        if (hit) {
+            const int pk = pack_off(ox, oy, oz);
+            if (seg == 0) {
+                const int p = cnt_odd + __popcll(m_odd & below);
+                if (p < a.max_odd) {
+                    a.ind_odd[(size_t)w * a.max_odd + p] = sv;
+                    atomicMax(a.owner_odd + vstart + sv, w * a.max_odd + p);
+                }
+            }
+            if (seg == 1) {
+                const int p = cnt_even + __popcll(m_even & below);
+                if (p < a.max_even) {
+                    a.ind_even[(size_t)w * a.max_even + p] = sv;
+                    atomicMax(a.owner_even + vstart + sv, w * a.max_even + p);
+                }
+            }
+            if (seg <= 2) {
+                const int p = cnt_w1 + __popcll(m_w1 & below);
+                if (p < a.max_win1) {
+                    l1_ind[p] = sv;
+                    l1_c[p] = pk;
+                    atomicMax(a.owner_win1 + vstart + sv, w * a.max_win1 + p);
+                }
+            }
+            const int p2 = cnt_w2 + __popcll(m_all & below);
+            if (p2 < a.max_win2) {
+                l2_ind[p2] = sv;
+                l2_c[p2] = pk;
+            }
+        }
+        cnt_odd += __popcll(m_odd);
+        cnt_even += __popcll(m_even);
+        cnt_w1 += __popcll(m_w1);
+        cnt_w2 += __popcll(m_all);
+    }
+    wave_lds_sync();
+    for (int k = lane; k < a.max_win1; k += MSSVT_WAVE) a.ind_win1[(size_t)w * a.max_win1 + k] = l1_ind[k];
+
+    // ---- K7 + K8 + masks for both scales (ref mssvt_backbone.py:247-258) -----------
+    const int K = a.key_num_sample;
+    for (int scale = 0; scale < 2; ++scale) {
+        const int *lind = scale ? l2_ind : l1_ind;
+        const int *lc = scale ? l2_c : l1_c;
+        const int n = scale ? a.max_win2 : a.max_win1;
+        fps_on_list(lc, n, K, scale ? a.bs2 : a.bs1, temp, bv, bidx, fps_out, lane);
+        int *kout = (scale ? a.k_ind2 : a.k_ind1) + (size_t)w * K;
+        unsigned char *mout = (scale ? a.k_mask2 : a.k_mask1) + (size_t)w * K;
+        for (int j = lane; j < K; j += MSSVT_WAVE) {
+            const int f = fps_out[j];
+            // ref :253-256: the index is round-tripped through fp32 and "(x + 0.1).int()"
+            // truncates toward zero -> a picked EMPTY slot (-1) becomes voxel 0 of the sample
+            const int kid = (int)((float)lind[f] + 0.1f);
+            kout[j] = kid;
+            mout[j] = (unsigned char)(((j > 0 && f == 0) || kid < 0) ? 1 : 0);
+        }
+        wave_lds_sync();
+    }
+}
+
+static inline int plan_opt_n_threads(int work_size) {  // ref cuda_utils.h:10-14
+    const int pow_2 = (int)(log((double)work_size) / log(2.0));
+    int v = 1 << pow_2;
+    if (v > 1024) v = 1024;
+    if (v < 1) v = 1;
+    return v;
+}
+
+extern "C" int mssvt_window_plan_two(
+    int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
+    int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
+    int num_win1, int num_win2, const int *vox_query_odd, const int *vox_query_even,
+    const int *vox_query_win1, const int *vox_query_win2, int key_num_sample, const int *win_indices,
+    const int *num_wins_dev, int win_capacity, const int *xyz_to_vidx, const int *v_bs_cnt,
+    int *ind_odd, int *ind_even, int *ind_win1, int *k_ind1, int *k_ind2, unsigned char *k_mask1,
+    unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
+    void *stream) {
+    if (!win_indices || !num_wins_dev || !xyz_to_vidx || !v_bs_cnt || !ind_odd || !ind_even ||
+        !ind_win1 || !k_ind1 || !k_ind2 || !k_mask1 || !k_mask2 || !win_vstart || !owner_win1 ||
+        !owner_odd || !owner_even || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
+        max_num_win2 <= 0 || max_num_odd <= 0 || max_num_even <= 0)
+        return MSSVT_E_BADARG;
+    if (win_capacity <= 0) return MSSVT_OK;
+    // offsets are packed into bytes (|offset| <= 63) -- far beyond any window in use
+    if (x_ws > 60 || y_ws > 60 || z_ws > 60 || key_num_sample > 1024) return MSSVT_E_TOOLARGE;
+    PlanArgs a;
+    a.x_max = x_max; a.y_max = y_max; a.z_max = z_max;
+    a.x_ws = x_ws; a.y_ws = y_ws; a.z_ws = z_ws;
+    a.max_odd = max_num_odd; a.max_even = max_num_even; a.max_win1 = max_num_win1; a.max_win2 = max_num_win2;
+    a.hash_size = hash_size; a.batch_size = batch_size;
+    a.n_odd = num_odd; a.n_even = num_even; a.n_win1 = num_win1; a.n_win2 = num_win2;
+    a.q_odd = vox_query_odd; a.q_even = vox_query_even; a.q_win1 = vox_query_win1; a.q_win2 = vox_query_win2;
+    a.key_num_sample = key_num_sample;
+    a.bs1 = plan_opt_n_threads(max_num_win1);
+    a.bs2 = plan_opt_n_threads(max_num_win2);
+    a.win_indices = win_indices; a.num_wins = num_wins_dev;
+    a.table = reinterpret_cast<const slot_t *>(xyz_to_vidx);
+    a.v_bs_cnt = v_bs_cnt;
+    a.ind_odd = ind_odd; a.ind_even = ind_even; a.ind_win1 = ind_win1;
+    a.k_ind1 = k_ind1; a.k_ind2 = k_ind2; a.k_mask1 = k_mask1; a.k_mask2 = k_mask2;
+    a.win_vstart = win_vstart;
+    a.owner_win1 = owner_win1; a.owner_odd = owner_odd; a.owner_even = owner_even;
+    const int nmax = max_num_win1 > max_num_win2 ? max_num_win1 : max_num_win2;
+    const int bsmax = a.bs1 > a.bs2 ? a.bs1 : a.bs2;
+    a.lds_words_per_wave = 2 * max_num_win1 + 2 * max_num_win2 + nmax + key_num_sample + 2 * bsmax;
+    int wpb = PLAN_MAX_WPB;  // waves (windows) per workgroup: as many as fit in 64 KiB of LDS
+    while (wpb > 1 && (size_t)a.lds_words_per_wave * 4 * wpb > 64 * 1024) wpb >>= 1;
+    const size_t lds_bytes = (size_t)a.lds_words_per_wave * 4 * wpb;
+    if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_plan),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    k_window_plan<<<divup(win_capacity, wpb), wpb * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
+    return mssvt_launch_status();
+}

@@ -1,0 +1,204 @@
+"""Module fast path: window plan + fused HIP block kernels (``impl="fused"``).
+
+What the reference does per Block with ~100 launches and >= 5B+2 host syncs
+ becomes, per forward,
+
+    once per voxel set   K1 hash map (SparseTensor) + per-sample counts
+    once per window cfg  K2 window discovery (device-compacted) + ONE fused plan kernel
+                         (K3 + 2xK7 + 2xK8 + key masks), shared by consecutive Blocks
+    per Block            LayerNorm, one fused attention kernel per head group,
+                         one interpolation/scatter/residual kernel, the FFN
+
+with no host synchronisation: window counts stay in device memory, per-window buffers
+are sized by their capacity (#voxels) and kernels read the live count.  Only the
+CompressBlock's data-dependent output shape costs one sync per forward.
+
+Everything that touches voxels or windows is hand-written HIP behind the C ABI
+(include/mssvt_hip.h, part 2); torch supplies memory, streams, LayerNorm and the
+per-voxel FFN GEMMs.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, mssvt_ops
+from .mssvt_utils import batch_counts
+
+_i, _f = ctypes.c_int, ctypes.c_float
+
+
+def _f3(xs):
+    return (ctypes.c_float * 3)(*[float(v) for v in xs])
+
+
+class _Plan(object):
+    pass
+
+
+def supported(block, sp):
+    """Shapes the v1 fused kernels cover; anything else runs the operator-level path."""
+    if torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters())):
+        return False  # forward-only kernels: training goes through the differentiable ops path
+    if sp.features.dtype != torch.float32 or not sp.features.is_cuda:
+        return False
+    attn = block.ms_attn
+    if max(attn.scale_dims) > 64 or block.key_num_sample > 64:
+        return False
+    if block.win2_size is None or len(attn.num_heads) != 2:
+        return False
+    nq = {0: block.max_num_even, 1: block.max_num_odd, 2: block.max_num_win1}[block.cbs_pattern]
+    return nq <= 256 and max(block.win1_size) <= 60
+
+
+@torch.no_grad()
+def level_state(sp):
+    """Per voxel-set (resolution level) device state shared by all plans on it."""
+    st = getattr(sp, "_level", None)
+    if st is None or st["indices"] is not sp.indices:
+        st = {"indices": sp.indices, "v_bs_cnt": batch_counts(sp.indices, sp.batch_size), "plans": {}}
+        sp._level = st
+    return st
+
+
+@torch.no_grad()
+def two_scale_plan(block, sp):
+    st = level_state(sp)
+    key = block.plan_key()
+    if key in st["plans"]:
+        return st["plans"][key]
+    dev = sp.indices.device
+    N = sp.indices.shape[0]
+    B, H = sp.batch_size, sp.hash_size
+    p = _Plan()
+    p.new_spatial_shape = [sp.spatial_shape[i] // block.win1_size[i] for i in range(3)]
+    p.win_size_m = [sp.voxel_size[i] * block.win1_size[i] for i in range(3)]
+    p.win_ind, p.win_table, p.k_bs_cnt, ws = mssvt_ops.window_partition_device(
+        block.win1_size, block.max_num_wins, B, H, p.new_spatial_shape, sp.indices)
+    p.num_wins = ws[1:2]  # device scalar
+    p.status = ws[0:1]
+    p.cap = cap = max(N, 1)
+    n_o, n_e, n1, n2, K = (block.max_num_odd, block.max_num_even, block.max_num_win1, block.max_num_win2,
+                           block.key_num_sample)
+    p.ind_odd = torch.empty((cap, n_o), dtype=torch.int32, device=dev)
+    p.ind_even = torch.empty((cap, n_e), dtype=torch.int32, device=dev)
+    p.ind_win1 = torch.empty((cap, n1), dtype=torch.int32, device=dev)
+    p.k_ind = [torch.empty((cap, K), dtype=torch.int32, device=dev) for _ in range(2)]
+    p.k_mask = [torch.empty((cap, K), dtype=torch.uint8, device=dev) for _ in range(2)]
+    p.win_vstart = torch.empty(cap, dtype=torch.int32, device=dev)
+    owners = torch.full((3, cap), -1, dtype=torch.int32, device=dev)
+    p.owner_win1, p.owner_odd, p.owner_even = owners[0], owners[1], owners[2]
+    t = block._tables_on(dev)
+    _lib.call("mssvt_window_plan_two", *[_i(int(v)) for v in sp.spatial_shape],
+              *[_i(int(v)) for v in block.win1_size], _i(n_o), _i(n_e), _i(n1), _i(n2), _i(H), _i(B),
+              _i(t['odd'].shape[0]), _i(t['even'].shape[0]), _i(t['win1'].shape[0]), _i(t['win2'].shape[0]),
+              _lib.ptr(t['odd']), _lib.ptr(t['even']), _lib.ptr(t['win1']), _lib.ptr(t['win2']), _i(K),
+              _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(cap), _lib.ptr(sp.map_table),
+              _lib.ptr(st["v_bs_cnt"]), _lib.ptr(p.ind_odd), _lib.ptr(p.ind_even), _lib.ptr(p.ind_win1),
+              _lib.ptr(p.k_ind[0]), _lib.ptr(p.k_ind[1]), _lib.ptr(p.k_mask[0]), _lib.ptr(p.k_mask[1]),
+              _lib.ptr(p.win_vstart), _lib.ptr(p.owner_win1), _lib.ptr(p.owner_odd), _lib.ptr(p.owner_even),
+              _lib.stream())
+    st["plans"][key] = p
+    return p
+
+
+def _query(block, p):
+    if block.cbs_pattern == 0:
+        return p.ind_even, block.max_num_even, p.owner_even
+    if block.cbs_pattern == 1:
+        return p.ind_odd, block.max_num_odd, p.owner_odd
+    return p.ind_win1, block.max_num_win1, p.owner_win1
+
+
+def _ffn_tail(block, new):
+    # TODO(perf): fused LN2 + GEMM1 + ReLU + GEMM2 + residual MFMA kernel
+    new = new + block.linear2(F.relu(block.linear1(block.norm2(new))))
+    if hasattr(block, 'out_linear'):
+        new = block.out_linear(new)
+    return new
+
+
+def block_forward(block, sp):
+    """Fused forward of a MixedScaleSparseTransformerBlock (eval / no-grad)."""
+    if not supported(block, sp):
+        return block.forward_ops(sp)
+    x_in = sp.features.contiguous()
+    N, C = x_in.shape
+    p = two_scale_plan(block, sp)
+    xhat = F.layer_norm(x_in, (C,), block.norm1.weight, block.norm1.bias, block.norm1.eps)
+    q_ind, nq, owner_q = _query(block, p)
+    attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
+    ma = block.ms_attn
+    vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
+    wpos, bpos = block.pos_proj[0].weight, block.pos_proj[0].bias
+    c0 = 0
+    for g, heads in enumerate(ma.num_heads):
+        cg = ma.scale_dims[g]
+        _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(heads), _i(ma.per_head_dim),
+                  _f(ma.scale), _i(nq), _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(sp.indices),
+                  _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _lib.ptr(p.win_vstart), _lib.ptr(q_ind),
+                  _lib.ptr(p.k_ind[g]), _lib.ptr(p.k_mask[g]), vs3, mn3, ws3,
+                  _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
+                  _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
+                  _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(attn), _lib.stream())
+        c0 += cg
+    new = x_in * 2.0  # voxels no list slot owns keep features + shortcut = 2 * x_in (ref quirk R12)
+    interp = 1 if block.use_feature_interpolation else 0
+    upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
+    _lib.call("mssvt_block_interp_scatter", _i(C), _i(nq), _i(n_upd), _i(interp), _lib.ptr(attn),
+              _lib.ptr(x_in), _lib.ptr(new), _lib.ptr(sp.indices), _lib.ptr(p.win_ind), _lib.ptr(p.num_wins),
+              _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind), _lib.ptr(upd_ind), _lib.ptr(owner), vs3, mn3,
+              _lib.stream())
+    sp.features = _ffn_tail(block, new)
+    sp.gather_dict = None
+    return sp
+
+
+def compress_forward(block, sp):
+    """CompressBlock: operator-level path for now (fused variant: see DESIGN.md, next steps)."""
+    return block.forward_ops(sp)
+
+
+def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
+    """Roofline of the fused attention kernel (group 1 = the win2 scale, the larger one) on the
+    bench inputs.  Algorithmic bytes per launch: per window 16 B (window row) + 4 B
+    (vstart) + 4*nq + 5*K B (lists + masks) ; per valid key / query row a 4*Cg-byte feature slice
+    + 16 B of voxel indices ; per valid query 4*Cg bytes written."""
+    from .mssvt_utils import SparseTensor
+    blk = net.backbone[0]
+    with torch.no_grad():
+        sp = SparseTensor(features=feats, indices=vc.int().contiguous(), spatial_shape=net.grid_size,
+                          voxel_size=net.voxel_size, point_cloud_range=net.point_cloud_range,
+                          batch_size=batch, hash_size=net.hash_size)
+        p = two_scale_plan(blk, sp)
+        x_in = sp.features.contiguous()
+        C = x_in.shape[1]
+        xhat = F.layer_norm(x_in, (C,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        q_ind, nq, _ = _query(blk, p)
+        attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
+        ma = blk.ms_attn
+        g = 1
+        cg, c0 = ma.scale_dims[g], ma.scale_dims[0]
+        vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
+
+        def launch():
+            _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(ma.num_heads[g]),
+                      _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(blk.key_num_sample), _lib.ptr(xhat),
+                      _lib.ptr(sp.indices), _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _lib.ptr(p.win_vstart),
+                      _lib.ptr(q_ind), _lib.ptr(p.k_ind[g]), _lib.ptr(p.k_mask[g]), vs3, mn3, ws3,
+                      _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
+                      _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
+                      _lib.ptr(blk.pos_proj[0].weight), _lib.ptr(blk.pos_proj[0].bias), _lib.ptr(attn),
+                      _lib.stream())
+
+        ms = event_time_ms(launch, 20)
+        nw = int(p.num_wins.item())
+        K = blk.key_num_sample
+        n_keys = int((p.k_mask[g][:nw] == 0).sum())
+        n_q = int((q_ind[:nw] >= 0).sum())
+    alg = nw * (16 + 4 + 4 * nq + 5 * K) + (n_keys + n_q) * (4 * cg + 16) + n_q * 4 * cg
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_block_attn (group 1: win2 keys)", "achieved": achieved, "peak": peak_gbs,
+            "unit": "GB/s", "frac": achieved / peak_gbs, "traffic": None, "algorithmic_bytes_per_launch": alg,
+            "avg_launch_us": ms * 1e3,
+            "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q}}

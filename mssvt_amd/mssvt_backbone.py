@@ -28,7 +28,7 @@ from . import mssvt_ops, pointnet2_utils, query_table
 from .mssvt_utils import MixedScaleAttention, SparseTensor, batch_counts
 
 MAX_NUM_WINS = 90000  # ref: mssvt_backbone.py:56
-DEFAULT_IMPL = "ops"  # switched to "fused" once mssvt_amd/fused.py lands
+DEFAULT_IMPL = "fused"
 
 
 class DropPath(nn.Module):

@@ -1,0 +1,67 @@
+"""Fused fast path on the MI355X: the device-resident window plan against the oracle
+(bit-exact index work) -- block-level feature parity is in test_module_gpu.py (impl="fused")."""
+import numpy as np
+import pytest
+import torch
+
+from mssvt_amd import synthetic
+from oracle import block_ref, cref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _block(ws, m1, m2, K, pattern=1, C=32, heads=(2, 2)):
+    from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformerBlock
+    return MixedScaleSparseTransformerBlock(cfg=None, in_channels=C, ff_channels=2 * C, out_channels=C,
+                                            num_heads=list(heads), drop_path=0.0, window_size=ws,
+                                            max_num_win1=m1, max_num_win2=m2, cbs_pattern=pattern,
+                                            key_num_sample=K).to(DEV).eval()
+
+
+@pytest.mark.parametrize("ws,m1,m2,K,B,pts", [([[3, 3, 5], [7, 7, 7]], 45, 343, 32, 2, 20000),
+                                              ([[3, 3, 5], [7, 7, 7]], 6, 20, 8, 3, 30000),
+                                              ([[2, 2, 2], [4, 4, 4]], 8, 64, 16, 1, 20000),
+                                              ([[5, 5, 7], [11, 11, 11]], 175, 1331, 32, 1, 60000)])
+def test_window_plan_matches_oracle(ws, m1, m2, K, B, pts):
+    from mssvt_amd import fused
+    from mssvt_amd.mssvt_utils import SparseTensor
+    H = 200003
+    p_np = synthetic.make_batch_points(pts, B, 11)
+    vc, _, _ = synthetic.voxelize_numpy(p_np)
+    blk = _block(ws, m1, m2, K)
+    sp = SparseTensor(features=torch.zeros(vc.shape[0], 32, device=DEV), indices=torch.from_numpy(vc).to(DEV),
+                      spatial_shape=synthetic.GRID_SIZE, voxel_size=synthetic.VOXEL_SIZE,
+                      point_cloud_range=synthetic.POINT_CLOUD_RANGE, batch_size=B, hash_size=H)
+    p = fused.two_scale_plan(blk, sp)
+    nw = int(p.num_wins.item())
+    # oracle
+    tabs = {k: v.cpu().numpy() for k, v in blk.vox_query_table.items()}
+    cnt = cref.bs_cnt(vc, B)
+    table = cref.build_hash_table(B, H, synthetic.GRID_SIZE, vc, cnt)
+    wgrid = [synthetic.GRID_SIZE[i] // ws[0][i] for i in range(3)]
+    win, _ = cref.get_non_empty_window_center(ws[0], 90000, B, H, wgrid, vc)
+    o = cref.gather_two_window_voxels(synthetic.GRID_SIZE, ws[0], blk.max_num_odd, blk.max_num_even, m1, m2,
+                                      tabs["odd"], tabs["even"], tabs["win1"], tabs["win2"], win, table)
+    assert nw == win.shape[0]
+    np.testing.assert_array_equal(p.win_ind[:nw].cpu().numpy(), win)
+    np.testing.assert_array_equal(p.ind_odd[:nw].cpu().numpy(), o[0])
+    np.testing.assert_array_equal(p.ind_even[:nw].cpu().numpy(), o[1])
+    np.testing.assert_array_equal(p.ind_win1[:nw].cpu().numpy(), o[2])
+    for g, (ind, coord) in enumerate(((o[2], o[6]), (o[3], o[7]))):
+        fps = cref.farthest_point_sample(coord.astype(np.float32), K)
+        k_ind = (np.take_along_axis(ind, fps.astype(np.int64), 1).astype(np.float32) + np.float32(0.1)).astype(np.int32)
+        mask = fps == 0
+        mask[:, 0] = False
+        mask |= k_ind < 0
+        np.testing.assert_array_equal(p.k_ind[g][:nw].cpu().numpy(), k_ind, err_msg="k_ind scale %d" % g)
+        np.testing.assert_array_equal(p.k_mask[g][:nw].cpu().numpy().astype(bool), mask, err_msg="mask %d" % g)
+    v_start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    np.testing.assert_array_equal(p.win_vstart[:nw].cpu().numpy(), v_start[win[:, 0]])
+    # owner: the highest flat slot that holds each voxel; -1 for voxels in no win1 list
+    own = np.full(vc.shape[0], -1, np.int64)
+    rows = (o[2].astype(np.int64) + v_start[win[:, 0]][:, None]).reshape(-1)
+    flat = np.arange(rows.shape[0])
+    ok = o[2].reshape(-1) >= 0
+    np.maximum.at(own, rows[ok], flat[ok])
+    np.testing.assert_array_equal(p.owner_win1.cpu().numpy(), own)
