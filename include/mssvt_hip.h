@@ -207,6 +207,41 @@ int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_interpolation, 
                                const int *owner, const float *host_voxel_size3,
                                const float *host_range_min3, void *stream);
 
+/* ---- CompressBlock fast path (ref mssvt_backbone.py:351-398): ragged pieces ---------
+ * K4 list per window + allocation of one "pair row" per valid (window, slot) (+ one PAD
+ * row per window if with_pad).  k_ind (cap,max_num_win1) as K4 writes it; win_cnt (cap)
+ * valid slots; pair_base (cap); pair_win / pair_vox (row capacity) window id and global
+ * voxel row (-1 = pad) of every pair row; counters[0] = rows handed out.               */
+int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws,
+                          int max_num_win1, int hash_size, int num_win1, const int *vox_query_win1,
+                          const int *win_indices, const int *num_wins_dev, int win_capacity,
+                          const int *xyz_to_vidx, const int *v_bs_cnt, int with_pad, int *k_ind,
+                          int *win_vstart, int *win_cnt, int *pair_base, int *pair_win, int *pair_vox,
+                          int *counters, void *stream);
+/* out (R,C) = relu(W1 [voxel centre - window centre ; window centre] + b1) per pair row
+ * (first layer of pos_proj, ref :49-54, :372-373).                                     */
+int mssvt_compress_pos1(int C, const int *num_rows_dev, int row_capacity, const int *pair_win,
+                        const int *pair_vox, const int *indices, const int *win_indices,
+                        const float *host_voxel_size3, const float *host_range_min3,
+                        const float *host_win_size3, const float *W1, const float *b1, float *out,
+                        void *stream);
+/* rows[r] += xhat[pair_vox[r]] for non-pad rows (key token = feature + positional emb.). */
+int mssvt_compress_add_features(int C, const int *num_rows_dev, int row_capacity, const int *pair_vox,
+                                const float *xhat, float *rows, void *stream);
+/* q_tok (nw,C) = channel-wise max over the window's zero-padded key features (ref :370). */
+int mssvt_compress_pool(int C, int max_num_win1, const int *num_wins_dev, int win_capacity,
+                        const int *k_ind, const int *win_vstart, const int *win_cnt, const float *xhat,
+                        float *q_tok, void *stream);
+/* nq=1 attention of head group `group` (channels [c0,c0+Cg), list slots
+ * [group*keys_per_group, (group+1)*keys_per_group)): qp (nw,C) projected queries,
+ * kv (R,2*Cg) = [K|V] rows of this group's to_kvs for every pair row -> out (nw,C)
+ * columns [c0,c0+Cg) (before the output projection).                                   */
+int mssvt_compress_attention_group(int C, int c0, int Cg, int head_dim, float scale,
+                                   int keys_per_group, int group, int with_pad,
+                                   const int *num_wins_dev, int win_capacity, const int *win_cnt,
+                                   const int *pair_base, const float *qp, const float *kv, float *out,
+                                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,9 +154,113 @@ def block_forward(block, sp):
     return sp
 
 
+def compress_supported(block, sp):
+    if torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters())):
+        return False
+    if sp.features.dtype != torch.float32 or not sp.features.is_cuda:
+        return False
+    hd = block.ms_attn.per_head_dim
+    return hd <= 64 and (hd & (hd - 1)) == 0 and max(block.ms_attn.scale_dims) <= 128
+
+
+@torch.no_grad()
+def one_scale_plan(block, sp):
+    """K2 + K4 + pair-row allocation for a CompressBlock; one host sync (the block's output
+    shape is data dependent anyway)."""
+    st = level_state(sp)
+    dev = sp.indices.device
+    N, B, H = sp.indices.shape[0], sp.batch_size, sp.hash_size
+    p = _Plan()
+    p.new_spatial_shape = [sp.spatial_shape[i] // block.win1_size[i] for i in range(3)]
+    p.win_size_m = [sp.voxel_size[i] * block.win1_size[i] for i in range(3)]
+    p.win_ind, p.win_table, p.k_bs_cnt, ws = mssvt_ops.window_partition_device(
+        block.win1_size, block.max_num_wins, B, H, p.new_spatial_shape, sp.indices)
+    p.num_wins = ws[1:2]
+    cap = max(N, 1)
+    ns = block.max_num_win1
+    p.with_pad = 1 if block.ms_attn.num_head_groups > 1 else 0
+    # a voxel sits in one window per axis for odd sizes, up to two for even ones (ref quirk R3)
+    overlap = 1
+    for w in block.win1_size:
+        overlap *= 2 if w % 2 == 0 else 1
+    row_cap = cap * overlap + (cap if p.with_pad else 0)
+    p.k_ind = torch.empty((cap, ns), dtype=torch.int32, device=dev)
+    p.win_vstart = torch.empty(cap, dtype=torch.int32, device=dev)
+    p.win_cnt = torch.empty(cap, dtype=torch.int32, device=dev)
+    p.pair_base = torch.empty(cap, dtype=torch.int32, device=dev)
+    p.pair_win = torch.empty(row_cap, dtype=torch.int32, device=dev)
+    p.pair_vox = torch.empty(row_cap, dtype=torch.int32, device=dev)
+    p.num_rows = ws[2:3]
+    t = block._tables_on(dev)
+    _lib.call("mssvt_window_plan_one", *[_i(int(v)) for v in sp.spatial_shape],
+              *[_i(int(v)) for v in block.win1_size], _i(ns), _i(H), _i(t['win1'].shape[0]), _lib.ptr(t['win1']),
+              _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(cap), _lib.ptr(sp.map_table),
+              _lib.ptr(st["v_bs_cnt"]), _i(p.with_pad), _lib.ptr(p.k_ind), _lib.ptr(p.win_vstart),
+              _lib.ptr(p.win_cnt), _lib.ptr(p.pair_base), _lib.ptr(p.pair_win), _lib.ptr(p.pair_vox),
+              _lib.ptr(p.num_rows), _lib.stream())
+    status, p.nw, p.R = ws[:3].tolist()  # the forward's single host sync
+    if status & mssvt_ops.ST_WINDOW_OVERFLOW:
+        raise _lib.MssvtHipError("a sample has more than max_num_wins=%d windows" % block.max_num_wins)
+    if status & mssvt_ops.ST_TABLE_OVERFLOW:
+        raise _lib.MssvtHipError("window hash table overflow (hash_size=%d)" % H)
+    return p
+
+
 def compress_forward(block, sp):
-    """CompressBlock: operator-level path for now (fused variant: see DESIGN.md, next steps)."""
-    return block.forward_ops(sp)
+    """Fused forward of a MixedScaleSparseTransformerCompressBlock (eval / no-grad)."""
+    if not compress_supported(block, sp):
+        return block.forward_ops(sp)
+    x_in = sp.features.contiguous()
+    C = x_in.shape[1]
+    dev = x_in.device
+    xhat = F.layer_norm(x_in, (C,), block.norm1.weight, block.norm1.bias, block.norm1.eps)
+    p = one_scale_plan(block, sp)
+    nw, R, ns = p.nw, p.R, block.max_num_win1
+    ma = block.ms_attn
+    vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
+    # key tokens, one row per valid (window, slot) pair: feature + 2-layer positional MLP
+    rows = torch.empty((max(R, 1), C), dtype=torch.float32, device=dev)
+    _lib.call("mssvt_compress_pos1", _i(C), _lib.ptr(p.num_rows), _i(R), _lib.ptr(p.pair_win),
+              _lib.ptr(p.pair_vox), _lib.ptr(sp.indices), _lib.ptr(p.win_ind), vs3, mn3, ws3,
+              _lib.ptr(block.pos_proj[0].weight), _lib.ptr(block.pos_proj[0].bias), _lib.ptr(rows), _lib.stream())
+    k_tok = F.relu(F.linear(rows, block.pos_proj[2].weight.view(C, C), block.pos_proj[2].bias))
+    _lib.call("mssvt_compress_add_features", _i(C), _lib.ptr(p.num_rows), _i(R), _lib.ptr(p.pair_vox),
+              _lib.ptr(xhat), _lib.ptr(k_tok), _lib.stream())
+    q_tok = torch.empty((max(nw, 1), C), dtype=torch.float32, device=dev)
+    _lib.call("mssvt_compress_pool", _i(C), _i(ns), _lib.ptr(p.num_wins), _i(nw), _lib.ptr(p.k_ind),
+              _lib.ptr(p.win_vstart), _lib.ptr(p.win_cnt), _lib.ptr(xhat), _lib.ptr(q_tok), _lib.stream())
+    G = ma.num_head_groups
+    nk = ns // G
+    pre = torch.empty_like(q_tok)
+    qp = torch.empty_like(q_tok)
+    outs = []
+    c0 = 0
+    for g in range(G):
+        cg = ma.scale_dims[g]
+        qp[:, c0:c0 + cg] = ma.to_qs[g](q_tok[:, c0:c0 + cg])
+        kv = ma.to_kvs[g](k_tok[:, c0:c0 + cg]).contiguous()  # (R, 2*cg) = [K | V]
+        _lib.call("mssvt_compress_attention_group", _i(C), _i(c0), _i(cg), _i(ma.per_head_dim), _f(ma.scale),
+                  _i(nk), _i(g), _i(p.with_pad), _lib.ptr(p.num_wins), _i(nw), _lib.ptr(p.win_cnt),
+                  _lib.ptr(p.pair_base), _lib.ptr(qp), _lib.ptr(kv), _lib.ptr(pre), _lib.stream())
+        c0 += cg
+    c0 = 0
+    for g in range(G):
+        cg = ma.scale_dims[g]
+        outs.append(ma.projs[g](pre[:, c0:c0 + cg]))
+        c0 += cg
+    new = (outs[0] if G == 1 else torch.cat(outs, dim=-1))[:nw]
+    new = new + block.linear2(F.relu(block.linear1(block.norm2(new))))  # no residual to the input (ref :383-385)
+    if hasattr(block, 'out_linear'):
+        new = block.out_linear(new)
+    sp.features = new
+    sp.indices = p.win_ind[:nw].contiguous()
+    sp.spatial_shape = p.new_spatial_shape
+    sp.voxel_size = p.win_size_m
+    sp.map_table = p.win_table
+    sp.gather_dict = None
+    sp._level = None
+    sp._ops_plans = None
+    return sp
 
 
 def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
