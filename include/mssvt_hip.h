@@ -186,14 +186,16 @@ int mssvt_window_plan_two(
  * output; q_ind (cap,nq); k_ind/k_mask (cap,K) of the scale this group attends to; Wq
  * (Cg,Cg), Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) + biases = the module's parameters;
  * attn (cap,nq,C): rows of valid query slots, columns [c0,c0+Cg) are written.
- * host_*3: HOST pointers to 3 floats [x,y,z].                                        */
+ * host_*3: HOST pointers to 3 floats [x,y,z].  work_counter: 128 device ints of scratch
+ * (windows are handed to wavefronts through 8 sharded tickets; zeroed by the call).    */
 int mssvt_block_attention_group(
     int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
     const float *xhat, const int *indices, const int *win_ind, const int *num_wins_dev,
     const int *win_vstart, const int *q_ind, const int *k_ind, const unsigned char *k_mask,
     const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3,
     const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo,
-    const float *bo, const float *Wpos, const float *bpos, float *attn, void *stream);
+    const float *bo, const float *Wpos, const float *bpos, float *attn, int *work_counter,
+    void *stream);
 
 /* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
  * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):

@@ -18,8 +18,11 @@ LIB_PATH = os.path.join(LIB_DIR, "libmssvt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every fused multiply-add in the library is written explicitly
 # (fmaf / MFMA), so results do not depend on the compiler's contraction choices.
+# -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar fp32 FMAs into v_pk_fma_f32
+# and pays for it with register shuffles (v_mov): 2x the VALU instructions in the
+# LDS-fed mat-vec loops of block_attn.hip (measured from the ISA).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function"]
+         "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def sources():

@@ -27,14 +27,13 @@
 // Differences to the reference are re-association only (~1e-6 relative).
 //
 // LDS (floats): WqT | Wk | WvT | WoT (Cg^2 each) | bq bv bo | per wave:
-//   keys[K][Cg+1] (row stride Cg+1: conflict-free both by row and by column),
-//   qt[heads][Cg], pb[heads][K], xbar[heads][Cg+1], krow[K].
+//   see k_block_attn below.
 #include "common.hip.h"
 
 #define ATTN_MAX_WAVES 8
 
 struct AttnArgs {
-    int C, c0, Cg, heads, hd;
+    int C, c0, heads, hd;
     float scale;
     int nq, K;
     const float *xhat;
@@ -43,6 +42,7 @@ struct AttnArgs {
     float vsx, vsy, vsz, minx, miny, minz, wsx, wsy, wsz;
     const float *Wq, *bq, *Wkv, *bkv, *Wo, *bo, *Wp, *bp;
     float *attn;
+    int *work_counter;  // 128 device ints (8 counters, one per 64-B line), zeroed per launch
     int wave_floats;
 };
 
@@ -52,39 +52,105 @@ __device__ __forceinline__ float centre_of(int idx, float cell, float lo) {
     return __fadd_rn(__fmul_rn(__fadd_rn((float)idx, 0.5f), cell), lo);
 }
 
-__device__ __forceinline__ float bcast(float v, int src_lane) {  // src_lane wave-uniform
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+
+// all-reduce inside each 16-lane row with DPP (no LDS round trip), then across rows
+#define DPP_MOV(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float row_max16(float v) {
+    v = fmaxf(v, DPP_MOV(v, 0xB1));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, DPP_MOV(v, 0x4E));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, DPP_MOV(v, 0x141));  // row_half_mirror
+    v = fmaxf(v, DPP_MOV(v, 0x140));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += DPP_MOV(v, 0xB1);
+    v += DPP_MOV(v, 0x4E);
+    v += DPP_MOV(v, 0x141);
+    v += DPP_MOV(v, 0x140);
+    return v;
+}
+__device__ __forceinline__ float half_max(float v) { v = row_max16(v); return fmaxf(v, __shfl_xor(v, 16)); }
+__device__ __forceinline__ float half_sum(float v) { v = row_sum16(v); return v + __shfl_xor(v, 16); }
+__device__ __forceinline__ float wave_max(float v) { v = half_max(v); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float wave_sum(float v) { v = half_sum(v); return v + __shfl_xor(v, 32); }
+
+// y[lane] = bias + sum_i W4[i/4][lane][i%4] * x[i]: the matrix is stored so that one
+// ds_read_b128 per lane brings 4 consecutive inputs' weights, x comes as a broadcast
+// ds_read_b128; CG/4 fully unrolled steps keep ~2*CG/4 LDS reads in flight.
+template <int CG>
+__device__ __forceinline__ float matvec4(const float *W4, const float *x, int cl, float bias) {
+    const float4 *w = reinterpret_cast<const float4 *>(W4) + cl;
+    const float4 *xv = reinterpret_cast<const float4 *>(x);
+    float a0 = bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // 8 steps (16 ds_read_b128) are issued back to back, THEN consumed: with <= 2 waves per
+    // SIMD nobody else hides the ~100-cycle LDS latency, and left alone hipcc keeps only
+    // two reads in flight (s_waitcnt lgkmcnt(2) after every pair).
+    constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
+#pragma unroll
+    for (int b = 0; b < CG / 4; b += STEP) {
+        float4 wv[STEP], xx[STEP];
+#pragma unroll
+        for (int i = 0; i < STEP; ++i) {
+            wv[i] = w[(b + i) * CG];
+            xx[i] = xv[b + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < STEP; ++i) {
+            a0 = __builtin_fmaf(wv[i].x, xx[i].x, a0);
+            a1 = __builtin_fmaf(wv[i].y, xx[i].y, a1);
+            a2 = __builtin_fmaf(wv[i].z, xx[i].z, a2);
+            a3 = __builtin_fmaf(wv[i].w, xx[i].w, a3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return (a0 + a1) + (a2 + a3);
 }
 
+// CG = channels of the head group (compile time, multiple of 4, <= 64), HP = padded
+// head count (4 or 8).  LDS (floats): WqT4 | WkT4 | WvT4 | WoT4 (CG^2 each, the
+// [i/4][lane][i%4] layout above) | bq bv bo | per wave: keys[K][CG+4], xq[CG], qp[CG],
+// qt[HP][CG], pb[K][HP], xbar[HP][CG+4], vb[CG], krow[K].
+template <int CG, int HD, int HP>
 __global__ void __launch_bounds__(ATTN_MAX_WAVES *MSSVT_WAVE) k_block_attn(AttnArgs a) {
-    extern __shared__ float lds[];
-    const int Cg = a.Cg, Cg2 = Cg * Cg, ks = Cg + 1;
-    float *WqT = lds, *Wk = WqT + Cg2, *WvT = Wk + Cg2, *WoT = WvT + Cg2;
-    float *bq = WoT + Cg2, *bv = bq + Cg, *bo = bv + Cg;
-    const int nwaves = blockDim.x / MSSVT_WAVE, wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
-    float *wbase = bo + Cg + (size_t)wv * a.wave_floats;
+    extern __shared__ float4 lds4[];
+    float *lds = reinterpret_cast<float *>(lds4);
+    constexpr int CG2 = CG * CG, KS = CG + 4;
+    float *WqT = lds, *WkT = WqT + CG2, *WvT = WkT + CG2, *WoT = WvT + CG2;
+    float *bq = WoT + CG2, *bv = bq + CG, *bo = bv + CG;
+    const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    float *wbase = bo + CG + (size_t)wv * a.wave_floats;
     float *keys = wbase;
-    float *qt = keys + a.K * ks;
-    float *pb = qt + a.heads * Cg;
-    float *xbar = pb + a.heads * a.K;
-    int *krow = reinterpret_cast<int *>(xbar + a.heads * ks);
+    float *xq = keys + a.K * KS;
+    float *qp = xq + CG;
+    float *qt = qp + CG;
+    float *pb = qt + HP * CG;
+    float *xbar = pb + a.K * HP;
+    float *vb = xq;  // xq is dead once q' exists; v lives in the same CG floats
+    float *krel = xbar + HP * KS;  // [K][3] key coordinates relative to the window centre
+    float *qrel = krel + 3 * a.K;  // [nq][3]
+    int *krow = reinterpret_cast<int *>(qrel + 3 * a.nq);
+    int *qrow = krow + a.K;
+    int *qslot = qrow + a.nq;
 
-    // ---- stage this group's weights (once per persistent workgroup) ----------------
-    for (int e = threadIdx.x; e < Cg2; e += blockDim.x) {
-        const int o = e / Cg, i = e % Cg;
-        WqT[i * Cg + o] = a.Wq[e];
-        Wk[e] = a.Wkv[e];                  // rows [0,Cg) of to_kvs: K projection, [o][i]
-        WvT[i * Cg + o] = a.Wkv[Cg2 + e];  // rows [Cg,2Cg): V projection
-        WoT[i * Cg + o] = a.Wo[e];
+    // ---- stage this group's weights once per persistent workgroup ---------------------
+    for (int e = threadIdx.x; e < CG2; e += blockDim.x) {
+        const int o = e / CG, i = e % CG;  // nn.Linear weight [o][i]
+        const int t_io = ((i >> 2) * CG + o) * 4 + (i & 3);  // input index i in the b128, lane = output o
+        const int t_oi = ((o >> 2) * CG + i) * 4 + (o & 3);  // summed index o in the b128, lane = i
+        WqT[t_io] = a.Wq[e];
+        WkT[t_oi] = a.Wkv[e];        // rows [0,CG) of to_kvs = K projection; folded onto the query
+        WvT[t_io] = a.Wkv[CG2 + e];  // rows [CG,2CG) = V projection
+        WoT[t_io] = a.Wo[e];
     }
-    for (int e = threadIdx.x; e < Cg; e += blockDim.x) {
+    for (int e = threadIdx.x; e < CG; e += blockDim.x) {
         bq[e] = a.bq[e];
-        bv[e] = a.bkv[Cg + e];
+        bv[e] = a.bkv[CG + e];
         bo[e] = a.bo[e];
     }
     __syncthreads();
 
-    const bool act = lane < Cg;
+    const bool act = lane < CG;
     const int cl = act ? lane : 0;
     float wp[6], bpv;  // positional MLP row of this lane's channel (ref pos_proj.0: (C,6,1))
 #pragma unroll
@@ -92,98 +158,267 @@ __global__ void __launch_bounds__(ATTN_MAX_WAVES *MSSVT_WAVE) k_block_attn(AttnA
     bpv = a.bp[a.c0 + cl];
     const int nw = *a.num_wins;
     const bool two_heads = a.K <= 32;  // score pass: lane = key + 32 * (head & 1)
-    const int my_h = act ? cl / a.hd : 0;
+    const int my_h = cl / a.hd;
+    const int heads = a.heads;
 
-    for (int w = blockIdx.x * nwaves + wv; w < nw; w += gridDim.x * nwaves) {
+    // Windows are handed out dynamically: their cost varies by >10x (0..20 queries x 1..32
+    // keys) and a static split leaves most waves idle at the end.  One counter would
+    // serialise (~88 tickets/us chip-wide), so there are 8 counters on separate cache
+    // lines; counter c owns the windows w == c (mod 8) and is drawn 2 windows at a time,
+    // first by the workgroups with blockIdx == c (mod 8) (one XCD under round-robin
+    // placement; speed only), then by anybody (work stealing).
+    int shard = blockIdx.x & 7, tries = 0, t_next = 0, t_end = 0;
+    for (;;) {
+        if (t_next >= t_end) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(a.work_counter + 16 * shard, 2);
+            t_next = __builtin_amdgcn_readfirstlane(t);
+            t_end = t_next + 2;
+        }
+        const int w = t_next * 8 + shard;
+        if (w >= nw) {  // this shard is drained: move on to the next one
+            if (++tries >= 8) break;
+            shard = (shard + 1) & 7;
+            t_next = t_end = 0;
+            continue;
+        }
+        ++t_next;
         const int4 wi = reinterpret_cast<const int4 *>(a.win_ind)[w];  // [b,wz,wy,wx]
         const int vstart = a.win_vstart[w];
         const float cxm = centre_of(wi.w, a.wsx, a.minx), cym = centre_of(wi.z, a.wsy, a.miny),
                     czm = centre_of(wi.y, a.wsz, a.minz);
-        // ---- unmasked keys -> compact row list ------------------------------------
-        int nkv = 0;
+        const float posc = bpv + wp[3] * cxm + wp[4] * cym + wp[5] * czm;  // window part of the pos. MLP
+        // ---- metadata, all rows of the window at once (2 dependent memory latencies) --------
+        // unmasked keys -> compact list {row, rel. coordinates}; valid queries likewise
+        int nkv = 0, nqv = 0;
         for (int j0 = 0; j0 < a.K; j0 += MSSVT_WAVE) {
             const int j = j0 + lane;
             const bool ok = j < a.K && a.k_mask[(size_t)w * a.K + j] == 0;
+            int row = 0;
+            int4 vi = make_int4(0, 0, 0, 0);
+            if (ok) {
+                row = vstart + a.k_ind[(size_t)w * a.K + j];
+                vi = reinterpret_cast<const int4 *>(a.indices)[row];
+            }
             const unsigned long long m = __ballot(ok);
-            if (ok) krow[nkv + __popcll(m & ((1ull << lane) - 1ull))] = vstart + a.k_ind[(size_t)w * a.K + j];
+            if (ok) {
+                const int p = nkv + __popcll(m & ((1ull << lane) - 1ull));
+                krow[p] = row;
+                krel[3 * p + 0] = centre_of(vi.w, a.vsx, a.minx) - cxm;
+                krel[3 * p + 1] = centre_of(vi.z, a.vsy, a.miny) - cym;
+                krel[3 * p + 2] = centre_of(vi.y, a.vsz, a.minz) - czm;
+            }
             nkv += __popcll(m);
         }
-        wave_lds_sync();
-        // ---- key tokens: LN'd feature slice + positional embedding -> LDS ------------
-#pragma unroll 4
-        for (int jj = 0; jj < nkv; ++jj) {
-            const int row = krow[jj];
-            const int4 vi = reinterpret_cast<const int4 *>(a.indices)[row];
-            const float rx = centre_of(vi.w, a.vsx, a.minx) - cxm, ry = centre_of(vi.z, a.vsy, a.miny) - cym,
-                        rz = centre_of(vi.y, a.vsz, a.minz) - czm;
-            float pos = bpv + wp[0] * rx + wp[1] * ry + wp[2] * rz + wp[3] * cxm + wp[4] * cym + wp[5] * czm;
-            pos = fmaxf(pos, 0.0f);
-            if (act) keys[jj * ks + lane] = a.xhat[(size_t)row * a.C + a.c0 + lane] + pos;
+        for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {
+            const int qi = q0 + lane;
+            int qid = -1;
+            if (qi < a.nq) qid = a.q_ind[(size_t)w * a.nq + qi];
+            const bool ok = qid >= 0;
+            int4 vi = make_int4(0, 0, 0, 0);
+            if (ok) vi = reinterpret_cast<const int4 *>(a.indices)[vstart + qid];
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int p = nqv + __popcll(m & ((1ull << lane) - 1ull));
+                qrow[p] = vstart + qid;
+                qslot[p] = qi;
+                qrel[3 * p + 0] = centre_of(vi.w, a.vsx, a.minx) - cxm;
+                qrel[3 * p + 1] = centre_of(vi.z, a.vsy, a.miny) - cym;
+                qrel[3 * p + 2] = centre_of(vi.y, a.vsz, a.minz) - czm;
+            }
+            nqv += __popcll(m);
         }
         wave_lds_sync();
-        // ---- queries -------------------------------------------------------------------
-        for (int qi = 0; qi < a.nq; ++qi) {
-            const int qid = a.q_ind[(size_t)w * a.nq + qi];
-            if (qid < 0) continue;  // wave-uniform; K3 lists are front-packed but stay general
-            const int row = vstart + qid;
-            const int4 vi = reinterpret_cast<const int4 *>(a.indices)[row];
-            const float rx = centre_of(vi.w, a.vsx, a.minx) - cxm, ry = centre_of(vi.z, a.vsy, a.miny) - cym,
-                        rz = centre_of(vi.y, a.vsz, a.minz) - czm;
-            float pos = bpv + wp[0] * rx + wp[1] * ry + wp[2] * rz + wp[3] * cxm + wp[4] * cym + wp[5] * czm;
-            const float xq = act ? a.xhat[(size_t)row * a.C + a.c0 + lane] + fmaxf(pos, 0.0f) : 0.0f;
-            // q' = Wq xq + bq        (lane = output channel)
-            float qp = act ? bq[lane] : 0.0f;
-            for (int i = 0; i < Cg; ++i) qp = __builtin_fmaf(WqT[i * Cg + cl], bcast(xq, i), qp);
-            // qt_h = scale * Wk_h^T q'_h   (lane = input channel)
-            for (int h = 0; h < a.heads; ++h) {
-                float acc = 0.0f;
-                for (int d = 0; d < a.hd; ++d) {
-                    const int o = h * a.hd + d;
-                    acc = __builtin_fmaf(Wk[o * Cg + cl], bcast(qp, o), acc);
-                }
-                if (act) qt[h * Cg + lane] = acc * a.scale;
+        if (nqv == 0) continue;  // nothing to update from this window (wave-uniform)
+        // ---- key tokens: LN'd feature slice + positional embedding -> LDS; 16 row loads in
+        //      flight per step (one latency per 16 keys) --------------------------------------
+        for (int jb = 0; jb < nkv; jb += 16) {
+            // unconditional loads (index clamped to the last key): a guarded load makes hipcc
+            // branch around it and wait for each one in turn
+            float val[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int jc = min(jb + u, nkv - 1);
+                val[u] = a.xhat[(size_t)krow[jc] * a.C + a.c0 + cl];
             }
-            wave_lds_sync();
-            // scores + softmax       (lane = key, two heads side by side when K <= 32)
-            const int j = two_heads ? (lane & 31) : lane;
-            const int npass = two_heads ? (a.heads + 1) / 2 : a.heads;
-            for (int p = 0; p < npass; ++p) {
-                const int h = two_heads ? 2 * p + (lane >> 5) : p;
-                const bool on = j < nkv && h < a.heads;
-                float s = -INFINITY;
-                if (on) {
-                    s = 0.0f;
-                    const float *kr = keys + j * ks, *qh = qt + h * Cg;
-                    for (int c = 0; c < Cg; ++c) s = __builtin_fmaf(qh[c], kr[c], s);
-                }
-                float mx = s;
-                for (int off = two_heads ? 16 : 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-                const float e = on ? expf(s - mx) : 0.0f;
-                float sum = e;
-                for (int off = two_heads ? 16 : 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-                if (on) pb[h * a.K + j] = e / sum;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int jj = jb + u, jc = min(jj, nkv - 1);
+                const float pos = fmaxf(posc + wp[0] * krel[3 * jc] + wp[1] * krel[3 * jc + 1] +
+                                        wp[2] * krel[3 * jc + 2], 0.0f);
+                if (jj < nkv && act) keys[jj * KS + lane] = val[u] + pos;
             }
+        }
+        // ---- queries (their rows are fetched 4 at a time) ---------------------------------------
+        for (int qb = 0; qb < nqv; qb += 4) {
+          float qval[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+              qval[u] = a.xhat[(size_t)qrow[min(qb + u, nqv - 1)] * a.C + a.c0 + cl];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int qq = qb + u;
+            if (qq >= nqv) break;
+            const int qi = qslot[qq];
+            const float pos = fmaxf(posc + wp[0] * qrel[3 * qq] + wp[1] * qrel[3 * qq + 1] + wp[2] * qrel[3 * qq + 2], 0.0f);
+            if (act) xq[lane] = qval[u] + pos;
             wave_lds_sync();
-            // xbar_h = sum_k p_hk x_k   (lane = channel)
-            for (int h = 0; h < a.heads; ++h) {
-                float acc = 0.0f;
-                for (int jj = 0; jj < nkv; ++jj) acc = __builtin_fmaf(pb[h * a.K + jj], keys[jj * ks + cl], acc);
-                if (act) xbar[h * ks + lane] = acc;
-            }
+            // q' = Wq xq + bq                       (lane = output channel)
+            // q' = Wq xq + bq                       (lane = output channel)
+            const float qpv = matvec4<CG>(WqT, xq, cl, bq[cl]);
+            if (act) qp[lane] = qpv;
             wave_lds_sync();
-            // v = Wv xbar_h(o) + bv      (lane = output channel o, head of o = o / hd)
-            float vb = act ? bv[lane] : 0.0f;
+            // qt_h = scale * Wk_h^T q'_h            (lane = input channel; all heads, fully unrolled)
             {
-                const float *xb = xbar + my_h * ks;
-                for (int i = 0; i < Cg; ++i) vb = __builtin_fmaf(WvT[i * Cg + cl], xb[i], vb);
+                const float4 *wk = reinterpret_cast<const float4 *>(WkT) + cl;
+                const float4 *qv = reinterpret_cast<const float4 *>(qp);
+                float acc[CG / HD];
+#pragma unroll
+                for (int h = 0; h < CG / HD; ++h) acc[h] = 0.f;
+                constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
+#pragma unroll
+                for (int b = 0; b < CG / 4; b += STEP) {
+                    float4 wv4[STEP], q4[STEP];
+#pragma unroll
+                    for (int i = 0; i < STEP; ++i) {
+                        wv4[i] = wk[(b + i) * CG];
+                        q4[i] = qv[b + i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < STEP; ++i) {
+                        const int h = ((b + i) * 4) / HD;  // compile-time after unrolling
+                        acc[h] = __builtin_fmaf(wv4[i].x, q4[i].x, acc[h]);
+                        acc[h] = __builtin_fmaf(wv4[i].y, q4[i].y, acc[h]);
+                        acc[h] = __builtin_fmaf(wv4[i].z, q4[i].z, acc[h]);
+                        acc[h] = __builtin_fmaf(wv4[i].w, q4[i].w, acc[h]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (act) {
+#pragma unroll
+                    for (int h = 0; h < CG / HD; ++h) qt[h * CG + lane] = acc[h] * a.scale;
+                }
             }
+            wave_lds_sync();
+            // scores + softmax                      (lane = key, two heads side by side when K <= 32)
+            {
+                const int j = two_heads ? (lane & 31) : lane;
+                const int npass = two_heads ? (heads + 1) / 2 : heads;
+                const float4 *kr = reinterpret_cast<const float4 *>(keys + (j < nkv ? j : 0) * KS);
+                for (int p = 0; p < npass; ++p) {
+                    const int h = two_heads ? 2 * p + (lane >> 5) : p;
+                    const bool on = j < nkv && h < heads;
+                    const float4 *qh = reinterpret_cast<const float4 *>(qt + (h < heads ? h : 0) * CG);
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
+#pragma unroll
+                    for (int b = 0; b < CG / 4; b += STEP) {
+                        float4 kk[STEP], qq[STEP];
+#pragma unroll
+                        for (int i = 0; i < STEP; ++i) {
+                            kk[i] = kr[b + i];
+                            qq[i] = qh[b + i];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < STEP; ++i) {
+                            s0 = __builtin_fmaf(kk[i].x, qq[i].x, s0);
+                            s1 = __builtin_fmaf(kk[i].y, qq[i].y, s1);
+                            s2 = __builtin_fmaf(kk[i].z, qq[i].z, s2);
+                            s3 = __builtin_fmaf(kk[i].w, qq[i].w, s3);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const float sc = on ? (s0 + s1) + (s2 + s3) : -INFINITY;
+                    const float mx = two_heads ? half_max(sc) : wave_max(sc);
+                    const float e = on ? __expf(sc - mx) : 0.0f;
+                    const float sum = two_heads ? half_sum(e) : wave_sum(e);
+                    if (j < a.K && h < heads) pb[j * HP + h] = e * __builtin_amdgcn_rcpf(sum);  // 0 for unused rows
+                }
+            }
+            wave_lds_sync();
+            // xbar_h = sum_k p_hk x_k                (lane = channel, all heads at once, 8 keys per step)
+            {
+                float acc[HP];
+#pragma unroll
+                for (int h = 0; h < HP; ++h) acc[h] = 0.f;
+                for (int jb = 0; jb < nkv; jb += 8) {
+                    float kv[8];
+                    float4 pp[8][HP / 4];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int jj = jb + u, jc = jj < nkv ? jj : nkv - 1;  // rows >= nkv: weight 0 (see above)
+                        kv[u] = keys[jc * KS + cl];
+                        const int jp = jj < a.K ? jj : a.K - 1;
+#pragma unroll
+                        for (int h4 = 0; h4 < HP / 4; ++h4) pp[u][h4] = reinterpret_cast<const float4 *>(pb + jp * HP)[h4];
+                        if (jj >= a.K) {
+#pragma unroll
+                            for (int h4 = 0; h4 < HP / 4; ++h4) pp[u][h4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                        for (int h4 = 0; h4 < HP / 4; ++h4) {
+                            acc[4 * h4 + 0] = __builtin_fmaf(pp[u][h4].x, kv[u], acc[4 * h4 + 0]);
+                            acc[4 * h4 + 1] = __builtin_fmaf(pp[u][h4].y, kv[u], acc[4 * h4 + 1]);
+                            acc[4 * h4 + 2] = __builtin_fmaf(pp[u][h4].z, kv[u], acc[4 * h4 + 2]);
+                            acc[4 * h4 + 3] = __builtin_fmaf(pp[u][h4].w, kv[u], acc[4 * h4 + 3]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (act) {
+#pragma unroll
+                    for (int h = 0; h < HP; ++h)
+                        if (h < heads) xbar[h * KS + lane] = acc[h];
+                }
+            }
+            wave_lds_sync();
+            // v = Wv xbar_{head(o)} + bv             (lane = output channel o)
+            const float vbv = matvec4<CG>(WvT, xbar + my_h * KS, cl, bv[cl]);
+            if (act) vb[lane] = vbv;
+            wave_lds_sync();
             // out = Wo v + bo
-            float out = act ? bo[lane] : 0.0f;
-            for (int i = 0; i < Cg; ++i) out = __builtin_fmaf(WoT[i * Cg + cl], bcast(vb, i), out);
+            const float out = matvec4<CG>(WoT, vb, cl, bo[cl]);
             if (act) a.attn[((size_t)w * a.nq + qi) * a.C + a.c0 + lane] = out;
-            wave_lds_sync();  // qt / pb / xbar are reused by the next query
+            wave_lds_sync();  // xq (= vb) is rewritten by the next query
+          }
         }
+        wave_lds_sync();  // keys / lists are rewritten for the next window
     }
+}
+
+template <int CG, int HD, int HP>
+static int launch_block_attn(AttnArgs &a, hipStream_t stream) {
+    constexpr int KS = CG + 4;
+    a.wave_floats = a.K * KS + 2 * CG + HP * CG + a.K * HP + HP * KS + 4 * a.K + 5 * a.nq;
+    a.wave_floats = (a.wave_floats + 3) & ~3;  // keep every wave's region 16-B aligned
+    const size_t fixed = (size_t)4 * CG * CG + 3 * CG;
+    int waves = ATTN_MAX_WAVES;
+    while (waves > 1 && (fixed + (size_t)waves * a.wave_floats) * 4 > 160 * 1024) --waves;
+    const size_t lds_bytes = (fixed + (size_t)waves * a.wave_floats) * 4;
+    if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_attn<CG, HD, HP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    // persistent grid: as many workgroups per CU as the LDS footprint admits (256 CUs on MI355X)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    int per_cu = (int)((160 * 1024) / lds_bytes);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    hipError_t me = hipMemsetAsync(a.work_counter, 0, 128 * sizeof(int), stream);
+    if (me != hipSuccess) return (int)me;
+    k_block_attn<CG, HD, HP><<<cus * per_cu, waves * MSSVT_WAVE, lds_bytes, stream>>>(a);
+    return mssvt_launch_status();
 }
 
 extern "C" int mssvt_block_attention_group(
@@ -192,15 +427,17 @@ extern "C" int mssvt_block_attention_group(
     const int *win_vstart, const int *q_ind, const int *k_ind, const unsigned char *k_mask,
     const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3, const float *Wq,
     const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
-    const float *Wpos, const float *bpos, float *attn, void *stream) {
+    const float *Wpos, const float *bpos, float *attn, int *work_counter, void *stream) {
+    if (!work_counter) return MSSVT_E_BADARG;
     if (!xhat || !indices || !win_ind || !num_wins_dev || !win_vstart || !q_ind || !k_ind || !k_mask ||
         !host_voxel_size3 || !host_range_min3 || !host_win_size3 || !Wq || !bq || !Wkv || !bkv || !Wo || !bo || !Wpos ||
         !bpos || !attn || C <= 0 || Cg <= 0 || heads <= 0 || head_dim <= 0 || nq <= 0 || key_num_sample <= 0)
         return MSSVT_E_BADARG;
     if (Cg != heads * head_dim || c0 < 0 || c0 + Cg > C) return MSSVT_E_BADARG;
-    if (Cg > MSSVT_WAVE || key_num_sample > MSSVT_WAVE) return MSSVT_E_TOOLARGE;  // v1: one channel per lane
+    // one channel per lane, heads aligned to 4-float LDS vectors, <= 8 heads per group
+    if (Cg > MSSVT_WAVE || key_num_sample > MSSVT_WAVE || (head_dim & 3) || heads > 8) return MSSVT_E_TOOLARGE;
     AttnArgs a;
-    a.C = C; a.c0 = c0; a.Cg = Cg; a.heads = heads; a.hd = head_dim; a.scale = scale;
+    a.C = C; a.c0 = c0; a.heads = heads; a.hd = head_dim; a.scale = scale;
     a.nq = nq; a.K = key_num_sample;
     a.xhat = xhat; a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev;
     a.win_vstart = win_vstart; a.q_ind = q_ind; a.k_ind = k_ind; a.k_mask = k_mask;
@@ -209,24 +446,24 @@ extern "C" int mssvt_block_attention_group(
     a.wsx = host_win_size3[0]; a.wsy = host_win_size3[1]; a.wsz = host_win_size3[2];
     a.Wq = Wq; a.bq = bq; a.Wkv = Wkv; a.bkv = bkv; a.Wo = Wo; a.bo = bo; a.Wp = Wpos; a.bp = bpos;
     a.attn = attn;
-    const int ks = Cg + 1;
-    a.wave_floats = key_num_sample * ks + heads * Cg + heads * key_num_sample + heads * ks + key_num_sample;
-    const size_t fixed = (size_t)4 * Cg * Cg + 3 * Cg;
-    int waves = ATTN_MAX_WAVES;
-    while (waves > 1 && (fixed + (size_t)waves * a.wave_floats) * 4 > 160 * 1024) --waves;
-    const size_t lds_bytes = (fixed + (size_t)waves * a.wave_floats) * 4;
-    if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_attn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
-    // persistent grid: one workgroup per CU (LDS-bound residency), 256 CUs on MI355X
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
-    k_block_attn<<<cus * per_cu, waves * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
-    return mssvt_launch_status();
+    a.work_counter = work_counter;
+    hipStream_t st = (hipStream_t)stream;
+#define MSSVT_ATTN_CASE(cg, hd)                                   \
+    if (Cg == cg && head_dim == hd)                               \
+        return launch_block_attn<cg, hd, ((cg / hd + 3) / 4) * 4>(a, st);
+    MSSVT_ATTN_CASE(8, 8)
+    MSSVT_ATTN_CASE(16, 8)
+    MSSVT_ATTN_CASE(16, 16)
+    MSSVT_ATTN_CASE(24, 8)
+    MSSVT_ATTN_CASE(32, 8)
+    MSSVT_ATTN_CASE(32, 16)
+    MSSVT_ATTN_CASE(32, 32)
+    MSSVT_ATTN_CASE(48, 16)
+    MSSVT_ATTN_CASE(64, 8)
+    MSSVT_ATTN_CASE(64, 16)
+    MSSVT_ATTN_CASE(64, 32)
+    return MSSVT_E_TOOLARGE;  // shape not instantiated: the caller falls back to the operator path
+#undef MSSVT_ATTN_CASE
 }
 
 // ---------------------------------------------------------------------------------

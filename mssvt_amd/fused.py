@@ -36,6 +36,11 @@ class _Plan(object):
     pass
 
 
+# (channels per head group, head dim) pairs instantiated in csrc/block_attn.hip
+ATTN_SHAPES = {(8, 8), (16, 8), (16, 16), (24, 8), (32, 8), (32, 16), (32, 32), (48, 16), (64, 8), (64, 16),
+               (64, 32)}
+
+
 def supported(block, sp):
     """Shapes the v1 fused kernels cover; anything else runs the operator-level path."""
     if torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters())):
@@ -43,7 +48,7 @@ def supported(block, sp):
     if sp.features.dtype != torch.float32 or not sp.features.is_cuda:
         return False
     attn = block.ms_attn
-    if max(attn.scale_dims) > 64 or block.key_num_sample > 64:
+    if any((cg, attn.per_head_dim) not in ATTN_SHAPES for cg in attn.scale_dims) or block.key_num_sample > 64:
         return False
     if block.win2_size is None or len(attn.num_heads) != 2:
         return False
@@ -86,6 +91,7 @@ def two_scale_plan(block, sp):
     p.k_ind = [torch.empty((cap, K), dtype=torch.int32, device=dev) for _ in range(2)]
     p.k_mask = [torch.empty((cap, K), dtype=torch.uint8, device=dev) for _ in range(2)]
     p.win_vstart = torch.empty(cap, dtype=torch.int32, device=dev)
+    p.ticket = torch.zeros(128, dtype=torch.int32, device=dev)
     owners = torch.full((3, cap), -1, dtype=torch.int32, device=dev)
     p.owner_win1, p.owner_odd, p.owner_even = owners[0], owners[1], owners[2]
     t = block._tables_on(dev)
@@ -140,7 +146,7 @@ def block_forward(block, sp):
                   _lib.ptr(p.k_ind[g]), _lib.ptr(p.k_mask[g]), vs3, mn3, ws3,
                   _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                   _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
-                  _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(attn), _lib.stream())
+                  _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(attn), _lib.ptr(p.ticket), _lib.stream())
         c0 += cg
     new = x_in * 2.0  # voxels no list slot owns keep features + shortcut = 2 * x_in (ref quirk R12)
     interp = 1 if block.use_feature_interpolation else 0
@@ -293,7 +299,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
                       _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                       _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
                       _lib.ptr(blk.pos_proj[0].weight), _lib.ptr(blk.pos_proj[0].bias), _lib.ptr(attn),
-                      _lib.stream())
+                      _lib.ptr(p.ticket), _lib.stream())
 
         ms = event_time_ms(launch, 20)
         nw = int(p.num_wins.item())
