@@ -244,6 +244,17 @@ int mssvt_compress_attention_group(int C, int c0, int Cg, int head_dim, float sc
                                    const int *pair_base, const float *qp, const float *kv, float *out,
                                    void *stream);
 
+/* Fused feed-forward tail of a block on the fp32 matrix cores (ref mssvt_backbone.py:336-343,
+ * :383-387): x = owner && owner[v] < 0 ? 2*x_in[v] : x_new[v];
+ * y = x + linear2(relu(linear1(norm(x)))); optionally y_norm = next_norm(y) (the next block's
+ * norm1).  x_new/x_in/y/y_norm (N,C) f32; W1 (FF,C), W2 (C,FF) as in nn.Linear.
+ * Instantiated for (C,FF) in {(128,256),(64,128),(32,64)}; MSSVT_E_TOOLARGE otherwise.   */
+int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *x_in, const int *owner,
+                    const float *norm_w, const float *norm_b, float eps, const float *W1,
+                    const float *b1, const float *W2, const float *b2, float *y,
+                    const float *next_norm_w, const float *next_norm_b, float next_eps, float *y_norm,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,27 +53,6 @@ __device__ __forceinline__ float centre_of(int idx, float cell, float lo) {
 }
 
 
-// all-reduce inside each 16-lane row with DPP (no LDS round trip), then across rows
-#define DPP_MOV(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
-__device__ __forceinline__ float row_max16(float v) {
-    v = fmaxf(v, DPP_MOV(v, 0xB1));   // quad_perm [1,0,3,2]
-    v = fmaxf(v, DPP_MOV(v, 0x4E));   // quad_perm [2,3,0,1]
-    v = fmaxf(v, DPP_MOV(v, 0x141));  // row_half_mirror
-    v = fmaxf(v, DPP_MOV(v, 0x140));  // row_mirror
-    return v;
-}
-__device__ __forceinline__ float row_sum16(float v) {
-    v += DPP_MOV(v, 0xB1);
-    v += DPP_MOV(v, 0x4E);
-    v += DPP_MOV(v, 0x141);
-    v += DPP_MOV(v, 0x140);
-    return v;
-}
-__device__ __forceinline__ float half_max(float v) { v = row_max16(v); return fmaxf(v, __shfl_xor(v, 16)); }
-__device__ __forceinline__ float half_sum(float v) { v = row_sum16(v); return v + __shfl_xor(v, 16); }
-__device__ __forceinline__ float wave_max(float v) { v = half_max(v); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float wave_sum(float v) { v = half_sum(v); return v + __shfl_xor(v, 32); }
-
 // y[lane] = bias + sum_i W4[i/4][lane][i%4] * x[i]: the matrix is stored so that one
 // ds_read_b128 per lane brings 4 consecutive inputs' weights, x comes as a broadcast
 // ds_read_b128; CG/4 fully unrolled steps keep ~2*CG/4 LDS reads in flight.

@@ -34,6 +34,28 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// all-reduce inside each 16-lane row with DPP (no LDS round trip), then across rows
+#define DPP_MOV(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float row_max16(float v) {
+    v = fmaxf(v, DPP_MOV(v, 0xB1));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, DPP_MOV(v, 0x4E));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, DPP_MOV(v, 0x141));  // row_half_mirror
+    v = fmaxf(v, DPP_MOV(v, 0x140));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += DPP_MOV(v, 0xB1);
+    v += DPP_MOV(v, 0x4E);
+    v += DPP_MOV(v, 0x141);
+    v += DPP_MOV(v, 0x140);
+    return v;
+}
+__device__ __forceinline__ float half_max(float v) { v = row_max16(v); return fmaxf(v, __shfl_xor(v, 16)); }
+__device__ __forceinline__ float half_sum(float v) { v = row_sum16(v); return v + __shfl_xor(v, 16); }
+__device__ __forceinline__ float wave_max(float v) { v = half_max(v); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float wave_sum(float v) { v = half_sum(v); return v + __shfl_xor(v, 32); }
+
+
 // ---------------------------------------------------------------------------
 // Hash table slots: (key, value) int32 pairs, ref layout (B, H, 2).  A slot is
 // manipulated as one 64-bit word: low half = key, high half = value.

@@ -116,22 +116,56 @@ def _query(block, p):
     return p.ind_win1, block.max_num_win1, p.owner_win1
 
 
-def _ffn_tail(block, new):
-    # TODO(perf): fused LN2 + GEMM1 + ReLU + GEMM2 + residual MFMA kernel
-    new = new + block.linear2(F.relu(block.linear1(block.norm2(new))))
+FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
+
+
+def _ffn_tail(block, sp, x_new, x_in=None, owner=None):
+    """y = x + linear2(relu(linear1(norm2(x)))) (+ out_linear) with x = x_new, or 2*x_in on rows
+    no list slot owns.  One fused MFMA kernel when the shape is instantiated; it also emits the
+    NEXT block's norm1(y) (sp._xhat) so that LayerNorm never runs as a launch of its own."""
+    C, FF = block.linear1.in_features, block.linear1.out_features
+    if (C, FF) not in FFN_SHAPES:
+        x = x_new if owner is None else torch.where((owner >= 0).unsqueeze(1), x_new, x_in * 2.0)
+        y = x + block.linear2(F.relu(block.linear1(block.norm2(x))))
+        sp._xhat = None
+    else:
+        n = x_new.shape[0]
+        y = torch.empty_like(x_new)
+        nxt = getattr(sp, "_next_norm1", None)
+        has_out = hasattr(block, 'out_linear')
+        y_norm = None
+        if nxt is not None and not has_out and nxt.normalized_shape[0] == C:
+            y_norm = torch.empty_like(x_new)
+        _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
+                  _lib.ptr(block.norm2.weight), _lib.ptr(block.norm2.bias), _f(block.norm2.eps),
+                  _lib.ptr(block.linear1.weight), _lib.ptr(block.linear1.bias), _lib.ptr(block.linear2.weight),
+                  _lib.ptr(block.linear2.bias), _lib.ptr(y),
+                  _lib.ptr(nxt.weight if y_norm is not None else None),
+                  _lib.ptr(nxt.bias if y_norm is not None else None),
+                  _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.stream())
+        sp._xhat = (y_norm, nxt, y) if y_norm is not None else None
     if hasattr(block, 'out_linear'):
-        new = block.out_linear(new)
-    return new
+        y = block.out_linear(y)
+    return y
+
+
+def _norm1(block, sp, x_in):
+    """norm1(x_in): taken from the previous block's fused FFN epilogue when it produced it."""
+    pre = getattr(sp, "_xhat", None)
+    if pre is not None and pre[1] is block.norm1 and pre[2] is sp.features:
+        return pre[0]
+    C = x_in.shape[1]
+    return F.layer_norm(x_in, (C,), block.norm1.weight, block.norm1.bias, block.norm1.eps)
 
 
 def block_forward(block, sp):
     """Fused forward of a MixedScaleSparseTransformerBlock (eval / no-grad)."""
     if not supported(block, sp):
         return block.forward_ops(sp)
+    xhat = _norm1(block, sp, sp.features)
     x_in = sp.features.contiguous()
     N, C = x_in.shape
     p = two_scale_plan(block, sp)
-    xhat = F.layer_norm(x_in, (C,), block.norm1.weight, block.norm1.bias, block.norm1.eps)
     q_ind, nq, owner_q = _query(block, p)
     attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
     ma = block.ms_attn
@@ -148,14 +182,16 @@ def block_forward(block, sp):
                   _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
                   _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(attn), _lib.ptr(p.ticket), _lib.stream())
         c0 += cg
-    new = x_in * 2.0  # voxels no list slot owns keep features + shortcut = 2 * x_in (ref quirk R12)
+    # rows no list slot owns are never written here: the FFN reads them as 2 * x_in
+    # (features + shortcut, ref quirk R12) through the owner array
+    new = torch.empty_like(x_in)
     interp = 1 if block.use_feature_interpolation else 0
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
     _lib.call("mssvt_block_interp_scatter", _i(C), _i(nq), _i(n_upd), _i(interp), _lib.ptr(attn),
               _lib.ptr(x_in), _lib.ptr(new), _lib.ptr(sp.indices), _lib.ptr(p.win_ind), _lib.ptr(p.num_wins),
               _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind), _lib.ptr(upd_ind), _lib.ptr(owner), vs3, mn3,
               _lib.stream())
-    sp.features = _ffn_tail(block, new)
+    sp.features = _ffn_tail(block, sp, new, x_in, owner)
     sp.gather_dict = None
     return sp
 
@@ -216,10 +252,10 @@ def compress_forward(block, sp):
     """Fused forward of a MixedScaleSparseTransformerCompressBlock (eval / no-grad)."""
     if not compress_supported(block, sp):
         return block.forward_ops(sp)
+    xhat = _norm1(block, sp, sp.features)
     x_in = sp.features.contiguous()
     C = x_in.shape[1]
     dev = x_in.device
-    xhat = F.layer_norm(x_in, (C,), block.norm1.weight, block.norm1.bias, block.norm1.eps)
     p = one_scale_plan(block, sp)
     nw, R, ns = p.nw, p.R, block.max_num_win1
     ma = block.ms_attn
@@ -254,11 +290,8 @@ def compress_forward(block, sp):
         cg = ma.scale_dims[g]
         outs.append(ma.projs[g](pre[:, c0:c0 + cg]))
         c0 += cg
-    new = (outs[0] if G == 1 else torch.cat(outs, dim=-1))[:nw]
-    new = new + block.linear2(F.relu(block.linear1(block.norm2(new))))  # no residual to the input (ref :383-385)
-    if hasattr(block, 'out_linear'):
-        new = block.out_linear(new)
-    sp.features = new
+    new = (outs[0] if G == 1 else torch.cat(outs, dim=-1))[:nw].contiguous()
+    sp.features = _ffn_tail(block, sp, new)  # no residual to the block input (ref :383-385)
     sp.indices = p.win_ind[:nw].contiguous()
     sp.spatial_shape = p.new_spatial_shape
     sp.voxel_size = p.win_size_m

@@ -342,6 +342,8 @@ class MixedScaleSparseTransformer(nn.Module):
                           batch_size=batch_dict['batch_size'], hash_size=self.hash_size,
                           map_table=None, gather_dict=None)
         for i, blk in enumerate(self.backbone):
+            # lets a fused FFN epilogue also emit the next block's norm1 (mssvt_amd/fused.py)
+            sp._next_norm1 = self.backbone[i + 1].norm1 if i + 1 < len(self.backbone) else None
             sp = blk(sp, block_idx=i)
         batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
         return batch_dict

@@ -65,3 +65,32 @@ def test_window_plan_matches_oracle(ws, m1, m2, K, B, pts):
     ok = o[2].reshape(-1) >= 0
     np.maximum.at(own, rows[ok], flat[ok])
     np.testing.assert_array_equal(p.owner_win1.cpu().numpy(), own)
+
+
+@pytest.mark.parametrize("C,FF,n", [(128, 256, 5000), (64, 128, 1000), (32, 64, 129), (128, 256, 7)])
+def test_fused_ffn_kernel_matches_torch(C, FF, n):
+    """LN2 + linear1 + ReLU + linear2 + residual (+ next block's norm1) on the fp32 matrix cores."""
+    import ctypes
+    from mssvt_amd import _lib
+    torch.manual_seed(C + n)
+    x_new = torch.randn(n, C, device=DEV)
+    x_in = torch.randn(n, C, device=DEV)
+    owner = torch.randint(-1, 3, (n,), device=DEV, dtype=torch.int32)
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    ln2 = torch.nn.LayerNorm(C).to(DEV)
+    l1, l2 = torch.nn.Linear(C, FF).to(DEV), torch.nn.Linear(FF, C).to(DEV)
+    with torch.no_grad():
+        for m in (ln, ln2):
+            m.weight.add_(0.2 * torch.randn_like(m.weight))
+            m.bias.add_(0.2 * torch.randn_like(m.bias))
+        x = torch.where((owner >= 0).unsqueeze(1), x_new, 2.0 * x_in)
+        want = x + l2(torch.relu(l1(ln(x))))
+        want_n = ln2(want)
+    y, yn = torch.empty_like(x_new), torch.empty_like(x_new)
+    i, f = ctypes.c_int, ctypes.c_float
+    _lib.call("mssvt_ffn_fused", i(n), i(C), i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
+              _lib.ptr(ln.weight), _lib.ptr(ln.bias), f(ln.eps), _lib.ptr(l1.weight), _lib.ptr(l1.bias),
+              _lib.ptr(l2.weight), _lib.ptr(l2.bias), _lib.ptr(y), _lib.ptr(ln2.weight), _lib.ptr(ln2.bias),
+              f(ln2.eps), _lib.ptr(yn), _lib.stream())
+    np.testing.assert_allclose(y.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(yn.cpu().numpy(), want_n.cpu().numpy(), rtol=1e-4, atol=1e-4)
