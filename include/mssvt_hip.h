@@ -213,13 +213,16 @@ int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_interpolation, 
  * K4 list per window + allocation of one "pair row" per valid (window, slot) (+ one PAD
  * row per window if with_pad).  k_ind (cap,max_num_win1) as K4 writes it; win_cnt (cap)
  * valid slots; pair_base (cap); pair_win / pair_vox (row capacity) window id and global
- * voxel row (-1 = pad) of every pair row; counters[0] = rows handed out.               */
+ * voxel row (-1 = pad) of every pair row.  disjoint_lists != 0 (no voxel in two lists: odd
+ * window sizes): pair row = the voxel's feature row, pad row of window w = num_voxels + w,
+ * pair_win must be pre-filled with -1, pair_base = -1.  Otherwise rows are reserved through
+ * counters[0] (= rows handed out) and pair_base[w] is the window's first row.            */
 int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws,
                           int max_num_win1, int hash_size, int num_win1, const int *vox_query_win1,
                           const int *win_indices, const int *num_wins_dev, int win_capacity,
-                          const int *xyz_to_vidx, const int *v_bs_cnt, int with_pad, int *k_ind,
-                          int *win_vstart, int *win_cnt, int *pair_base, int *pair_win, int *pair_vox,
-                          int *counters, void *stream);
+                          const int *xyz_to_vidx, const int *v_bs_cnt, int with_pad,
+                          int disjoint_lists, int num_voxels, int *k_ind, int *win_vstart, int *win_cnt,
+                          int *pair_base, int *pair_win, int *pair_vox, int *counters, void *stream);
 /* out (R,C) = relu(W1 [voxel centre - window centre ; window centre] + b1) per pair row
  * (first layer of pos_proj, ref :49-54, :372-373).                                     */
 int mssvt_compress_pos1(int C, const int *num_rows_dev, int row_capacity, const int *pair_win,
@@ -239,9 +242,10 @@ int mssvt_compress_pool(int C, int max_num_win1, const int *num_wins_dev, int wi
  * kv (R,2*Cg) = [K|V] rows of this group's to_kvs for every pair row -> out (nw,C)
  * columns [c0,c0+Cg) (before the output projection).                                   */
 int mssvt_compress_attention_group(int C, int c0, int Cg, int head_dim, float scale,
-                                   int keys_per_group, int group, int with_pad,
-                                   const int *num_wins_dev, int win_capacity, const int *win_cnt,
-                                   const int *pair_base, const float *qp, const float *kv, float *out,
+                                   int keys_per_group, int group, int with_pad, int max_num_win1,
+                                   int num_voxels, const int *num_wins_dev, int win_capacity,
+                                   const int *win_cnt, const int *pair_base, const int *k_ind,
+                                   const int *win_vstart, const float *qp, const float *kv, float *out,
                                    void *stream);
 
 /* Fused feed-forward tail of a block on the fp32 matrix cores (ref mssvt_backbone.py:336-343,

@@ -24,17 +24,19 @@ __device__ __forceinline__ float cell_centre(int idx, float cell, float lo) {
 
 // ---------------------------------------------------------------------------------
 // plan: K4 (ref ms_sparse_attention_gpu.cu:383-433) + pair rows.
-// pair_base[w] = first row of window w in the pair arrays; rows [base, base+cnt) are
-// its valid slots in list order; if with_pad, row base+cnt is the window's PAD token
-// (an empty slot: zero features, coordinates at the world origin; ref :365-373).
-// counters[0] = number of pair rows handed out.
+// Every valid (window, slot) pair gets a row in the pair arrays:
+//   disjoint lists (odd window sizes, the normal case): row = the voxel's own feature
+//     row, pad row of window w = num_voxels + w -- no allocation, no atomics;
+//   overlapping lists (even sizes): rows [pair_base[w], +cnt) (+1 pad) are reserved with
+//     one atomicAdd per window on counters[0].
+// pair_win[row] = window (-1: row unused), pair_vox[row] = voxel feature row (-1: pad).
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(CP_WPB *MSSVT_WAVE)
     k_window_plan_one(int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_win1,
                       int hash_size, int n_win1, const int *q_win1, const int *win_indices,
                       const int *num_wins, const slot_t *table, const int *v_bs_cnt, int with_pad,
-                      int *k_ind, int *win_vstart, int *win_cnt, int *pair_base, int *pair_win,
-                      int *pair_vox, int *counters) {
+                      int disjoint, int num_voxels, int *k_ind, int *win_vstart, int *win_cnt,
+                      int *pair_base, int *pair_win, int *pair_vox, int *counters) {
     const int w = blockIdx.x * CP_WPB + threadIdx.x / MSSVT_WAVE;
     if (w >= *num_wins) return;
     const int lane = lane_id();
@@ -46,16 +48,14 @@ __global__ void __launch_bounds__(CP_WPB *MSSVT_WAVE)
     for (int k = lane; k < max_win1; k += MSSVT_WAVE) k_ind[(size_t)w * max_win1 + k] = -1;
     int cnt = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
-    // pass 1: count (so the pair rows can be reserved with one atomic), pass 2: write
-    for (int pass = 0; pass < 2; ++pass) {
+    // overlapping lists: pass 0 counts (so the rows can be reserved with one atomic), pass 1 writes
+    for (int pass = disjoint ? 1 : 0; pass < 2; ++pass) {
         int base = 0;
-        if (pass == 1) {
+        if (pass == 1 && !disjoint) {
             const int total = (cnt < max_win1 ? cnt : max_win1) + (with_pad ? 1 : 0);
             if (lane == 0) base = atomicAdd(counters, total);
             base = __builtin_amdgcn_readfirstlane(base);
             if (lane == 0) {
-                win_vstart[w] = vstart;
-                win_cnt[w] = cnt < max_win1 ? cnt : max_win1;
                 pair_base[w] = base;
                 if (with_pad) {
                     pair_win[base + total - 1] = w;
@@ -78,11 +78,23 @@ __global__ void __launch_bounds__(CP_WPB *MSSVT_WAVE)
                 const int p = cnt + __popcll(m & below);
                 if (p < max_win1) {
                     k_ind[(size_t)w * max_win1 + p] = sv;
-                    pair_win[base + p] = w;
-                    pair_vox[base + p] = vstart + sv;
+                    const int row = disjoint ? vstart + sv : base + p;
+                    pair_win[row] = w;
+                    pair_vox[row] = vstart + sv;
                 }
             }
             cnt += __popcll(m);
+        }
+    }
+    if (lane == 0) {
+        win_vstart[w] = vstart;
+        win_cnt[w] = cnt < max_win1 ? cnt : max_win1;
+        if (disjoint) {
+            pair_base[w] = -1;  // rows are addressed through the voxel index instead
+            if (with_pad) {
+                pair_win[num_voxels + w] = w;
+                pair_vox[num_voxels + w] = -1;
+            }
         }
     }
 }
@@ -100,7 +112,12 @@ __global__ void __launch_bounds__(CP_WPB *MSSVT_WAVE)
     const int nrows = *num_rows;
     const int lane = lane_id();
     for (int r = blockIdx.x * CP_WPB + threadIdx.x / MSSVT_WAVE; r < nrows; r += gridDim.x * CP_WPB) {
-        const int4 wi = reinterpret_cast<const int4 *>(win_indices)[pair_win[r]];
+        const int pw = pair_win[r];
+        if (pw < 0) {  // voxel in no list (ragged border / truncated list): keep the row finite
+            for (int c = lane; c < C; c += MSSVT_WAVE) out[(size_t)r * C + c] = 0.0f;
+            continue;
+        }
+        const int4 wi = reinterpret_cast<const int4 *>(win_indices)[pw];
         const float cxm = cell_centre(wi.w, wsx, minx), cym = cell_centre(wi.z, wsy, miny),
                     czm = cell_centre(wi.y, wsz, minz);
         const int vox = pair_vox[r];
@@ -160,26 +177,29 @@ __global__ void __launch_bounds__(CP_WPB *MSSVT_WAVE)
 // hd consecutive lanes (hd | 64), scores are reduced with xor-shuffles inside them.
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(CP_WPB *MSSVT_WAVE)
-    k_compress_attn(int C, int c0, int Cg, int hd, float scale, int nk, int g, int with_pad,
-                    const int *num_wins, const int *win_cnt, const int *pair_base, const float *qp,
-                    const float *kv, float *out) {
+    k_compress_attn(int C, int c0, int Cg, int hd, float scale, int nk, int g, int with_pad, int max_win1,
+                    int num_voxels, const int *num_wins, const int *win_cnt, const int *pair_base,
+                    const int *k_ind, const int *win_vstart, const float *qp, const float *kv, float *out) {
     const int nw = *num_wins;
     const int lane = lane_id();
     for (int w = blockIdx.x * CP_WPB + threadIdx.x / MSSVT_WAVE; w < nw; w += gridDim.x * CP_WPB) {
-        const int cnt = win_cnt[w], base = pair_base[w];
+        const int cnt = win_cnt[w], base = pair_base[w], vstart = win_vstart[w];
         const int s_lo = g * nk, s_hi = min((g + 1) * nk, cnt);
+        // pair row of slot s / of the pad token (see k_window_plan_one)
+        const int pad_row = base >= 0 ? base + cnt : num_voxels + w;
         for (int cb = 0; cb < Cg; cb += MSSVT_WAVE) {  // Cg <= 64: one pass
             const int c = cb + lane;
             const bool act = c < Cg;
             const int cc = act ? c : 0;
             float res;
             if (s_hi <= s_lo) {  // every slot of this group is empty
-                res = with_pad ? kv[(size_t)(base + cnt) * 2 * Cg + Cg + cc] : 0.0f;
+                res = with_pad ? kv[(size_t)pad_row * 2 * Cg + Cg + cc] : 0.0f;
             } else {
                 const float q = qp[(size_t)w * C + c0 + cc] * scale;
                 float m = -INFINITY, l = 0.0f, acc = 0.0f;
                 for (int s = s_lo; s < s_hi; ++s) {
-                    const float *row = kv + (size_t)(base + s) * 2 * Cg;
+                    const int prow = base >= 0 ? base + s : vstart + k_ind[(size_t)w * max_win1 + s];
+                    const float *row = kv + (size_t)prow * 2 * Cg;
                     float sc = act ? q * row[cc] : 0.0f;
                     for (int off = 1; off < hd; off <<= 1) sc += __shfl_xor(sc, off);
                     const float mn = fmaxf(m, sc);
@@ -205,9 +225,10 @@ extern "C" int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, 
                                      int max_num_win1, int hash_size, int num_win1,
                                      const int *vox_query_win1, const int *win_indices,
                                      const int *num_wins_dev, int win_capacity, const int *xyz_to_vidx,
-                                     const int *v_bs_cnt, int with_pad, int *k_ind, int *win_vstart,
-                                     int *win_cnt, int *pair_base, int *pair_win, int *pair_vox,
-                                     int *counters, void *stream) {
+                                     const int *v_bs_cnt, int with_pad, int disjoint_lists,
+                                     int num_voxels, int *k_ind, int *win_vstart, int *win_cnt,
+                                     int *pair_base, int *pair_win, int *pair_vox, int *counters,
+                                     void *stream) {
     if (!vox_query_win1 || !win_indices || !num_wins_dev || !xyz_to_vidx || !v_bs_cnt || !k_ind ||
         !win_vstart || !win_cnt || !pair_base || !pair_win || !pair_vox || !counters || hash_size <= 0 ||
         max_num_win1 <= 0)
@@ -217,8 +238,8 @@ extern "C" int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, 
     if (e != hipSuccess) return (int)e;
     k_window_plan_one<<<divup(win_capacity, CP_WPB), CP_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(
         x_max, y_max, z_max, x_ws, y_ws, z_ws, max_num_win1, hash_size, num_win1, vox_query_win1,
-        win_indices, num_wins_dev, reinterpret_cast<const slot_t *>(xyz_to_vidx), v_bs_cnt, with_pad, k_ind,
-        win_vstart, win_cnt, pair_base, pair_win, pair_vox, counters);
+        win_indices, num_wins_dev, reinterpret_cast<const slot_t *>(xyz_to_vidx), v_bs_cnt, with_pad,
+        disjoint_lists, num_voxels, k_ind, win_vstart, win_cnt, pair_base, pair_win, pair_vox, counters);
     return mssvt_launch_status();
 }
 
@@ -261,16 +282,19 @@ extern "C" int mssvt_compress_pool(int C, int max_num_win1, const int *num_wins_
 
 extern "C" int mssvt_compress_attention_group(int C, int c0, int Cg, int head_dim, float scale,
                                               int keys_per_group, int group, int with_pad,
+                                              int max_num_win1, int num_voxels,
                                               const int *num_wins_dev, int win_capacity,
-                                              const int *win_cnt, const int *pair_base, const float *qp,
-                                              const float *kv, float *out, void *stream) {
-    if (!num_wins_dev || !win_cnt || !pair_base || !qp || !kv || !out || C <= 0 || Cg <= 0 || head_dim <= 0)
+                                              const int *win_cnt, const int *pair_base, const int *k_ind,
+                                              const int *win_vstart, const float *qp, const float *kv,
+                                              float *out, void *stream) {
+    if (!num_wins_dev || !win_cnt || !pair_base || !k_ind || !win_vstart || !qp || !kv || !out || C <= 0 ||
+        Cg <= 0 || head_dim <= 0)
         return MSSVT_E_BADARG;
     if (head_dim > MSSVT_WAVE || (MSSVT_WAVE % head_dim) != 0 || (head_dim & (head_dim - 1)) != 0)
         return MSSVT_E_TOOLARGE;  // a head must be a power-of-two run of lanes
     if (win_capacity <= 0) return MSSVT_OK;
     k_compress_attn<<<stride_blocks(win_capacity), CP_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(
-        C, c0, Cg, head_dim, scale, keys_per_group, group, with_pad, num_wins_dev, win_cnt, pair_base, qp, kv,
-        out);
+        C, c0, Cg, head_dim, scale, keys_per_group, group, with_pad, max_num_win1, num_voxels, num_wins_dev,
+        win_cnt, pair_base, k_ind, win_vstart, qp, kv, out);
     return mssvt_launch_status();
 }

@@ -221,26 +221,35 @@ def one_scale_plan(block, sp):
     cap = max(N, 1)
     ns = block.max_num_win1
     p.with_pad = 1 if block.ms_attn.num_head_groups > 1 else 0
-    # a voxel sits in one window per axis for odd sizes, up to two for even ones (ref quirk R3)
-    overlap = 1
-    for w in block.win1_size:
-        overlap *= 2 if w % 2 == 0 else 1
+    # the lists of different windows are disjoint iff every table offset stays inside the window
+    # (true for the tables this package generates; checked so that custom tables stay correct)
+    tw = block.vox_query_table['win1']
+    lo = torch.tensor([-(w // 2) for w in block.win1_size])
+    hi = torch.tensor([w - w // 2 - 1 for w in block.win1_size])
+    tcpu = tw.cpu()
+    p.disjoint = 1 if bool(((tcpu >= lo) & (tcpu <= hi)).all()) else 0
+    overlap = 1 if p.disjoint else 8
     row_cap = cap * overlap + (cap if p.with_pad else 0)
     p.k_ind = torch.empty((cap, ns), dtype=torch.int32, device=dev)
     p.win_vstart = torch.empty(cap, dtype=torch.int32, device=dev)
     p.win_cnt = torch.empty(cap, dtype=torch.int32, device=dev)
     p.pair_base = torch.empty(cap, dtype=torch.int32, device=dev)
-    p.pair_win = torch.empty(row_cap, dtype=torch.int32, device=dev)
-    p.pair_vox = torch.empty(row_cap, dtype=torch.int32, device=dev)
+    p.pair_win = torch.full((row_cap,), -1, dtype=torch.int32, device=dev)
+    p.pair_vox = torch.full((row_cap,), -1, dtype=torch.int32, device=dev)
     p.num_rows = ws[2:3]
     t = block._tables_on(dev)
     _lib.call("mssvt_window_plan_one", *[_i(int(v)) for v in sp.spatial_shape],
               *[_i(int(v)) for v in block.win1_size], _i(ns), _i(H), _i(t['win1'].shape[0]), _lib.ptr(t['win1']),
               _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(cap), _lib.ptr(sp.map_table),
-              _lib.ptr(st["v_bs_cnt"]), _i(p.with_pad), _lib.ptr(p.k_ind), _lib.ptr(p.win_vstart),
+              _lib.ptr(st["v_bs_cnt"]), _i(p.with_pad), _i(p.disjoint), _i(N), _lib.ptr(p.k_ind),
+              _lib.ptr(p.win_vstart),
               _lib.ptr(p.win_cnt), _lib.ptr(p.pair_base), _lib.ptr(p.pair_win), _lib.ptr(p.pair_vox),
               _lib.ptr(p.num_rows), _lib.stream())
     status, p.nw, p.R = ws[:3].tolist()  # the forward's single host sync
+    if p.disjoint:
+        p.R = N + (p.nw if p.with_pad else 0)  # rows = voxel rows (+ one pad row per window)
+        p.num_rows = torch.full((1,), p.R, dtype=torch.int32, device=dev)
+    p.N = N
     if status & mssvt_ops.ST_WINDOW_OVERFLOW:
         raise _lib.MssvtHipError("a sample has more than max_num_wins=%d windows" % block.max_num_wins)
     if status & mssvt_ops.ST_TABLE_OVERFLOW:
@@ -282,8 +291,9 @@ def compress_forward(block, sp):
         qp[:, c0:c0 + cg] = ma.to_qs[g](q_tok[:, c0:c0 + cg])
         kv = ma.to_kvs[g](k_tok[:, c0:c0 + cg]).contiguous()  # (R, 2*cg) = [K | V]
         _lib.call("mssvt_compress_attention_group", _i(C), _i(c0), _i(cg), _i(ma.per_head_dim), _f(ma.scale),
-                  _i(nk), _i(g), _i(p.with_pad), _lib.ptr(p.num_wins), _i(nw), _lib.ptr(p.win_cnt),
-                  _lib.ptr(p.pair_base), _lib.ptr(qp), _lib.ptr(kv), _lib.ptr(pre), _lib.stream())
+                  _i(nk), _i(g), _i(p.with_pad), _i(ns), _i(p.N), _lib.ptr(p.num_wins), _i(nw),
+                  _lib.ptr(p.win_cnt), _lib.ptr(p.pair_base), _lib.ptr(p.k_ind), _lib.ptr(p.win_vstart),
+                  _lib.ptr(qp), _lib.ptr(kv), _lib.ptr(pre), _lib.stream())
         c0 += cg
     c0 = 0
     for g in range(G):
