@@ -259,6 +259,24 @@ int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *
                     const float *next_norm_w, const float *next_norm_b, float next_eps, float *y_norm,
                     void *stream);
 
+/* Table form of mssvt_block_interp_scatter: for every voxel owned by a list slot, tab_row (N,4)
+ * int32 = the three rows of `attn` (row = w*nq + slot; empty slots / zero weights -> zero_row) and
+ * tab_w (N,4) f32 = their inverse-distance weights.  The caller pre-fills tab_row with -1
+ * (= voxel owned by no slot).                                                            */
+int mssvt_block_interp_table(int nq, int n_upd, int use_interpolation, const int *indices,
+                             const int *win_ind, const int *num_wins_dev, int win_capacity,
+                             const int *win_vstart, const int *q_ind, const int *upd_ind,
+                             const int *owner, const float *host_voxel_size3,
+                             const float *host_range_min3, int zero_row, int *tab_row, float *tab_w,
+                             void *stream);
+/* mssvt_ffn_fused fed by that table: x = tab_row[v][0] < 0 ? 2*x_in[v]
+ *                                      : x_in[v] + sum_i tab_w[v][i] * attn[tab_row[v][i]].   */
+int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_in, const int *tab_row,
+                           const float *tab_w, const float *attn, const float *norm_w,
+                           const float *norm_b, float eps, const float *W1, const float *b1,
+                           const float *W2, const float *b2, float *y, const float *next_norm_w,
+                           const float *next_norm_b, float next_eps, float *y_norm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -454,6 +454,11 @@ struct ScatterArgs {
     float *x_new;
     const int *indices, *win_ind, *num_wins, *win_vstart, *q_ind, *upd_ind, *owner;
     float vsx, vsy, vsz, minx, miny, minz;
+    // table mode (tab_row != null): nothing is gathered; per owned voxel the three attention
+    // rows and weights are recorded so that a consumer (the fused FFN) can apply them
+    int4 *tab_row;
+    float4 *tab_w;
+    int zero_row;  // row of `attn` that holds zeros: target of empty slots / zero weights
 };
 
 #define SC_WPB 4
@@ -470,6 +475,13 @@ __global__ void __launch_bounds__(SC_WPB *MSSVT_WAVE) k_block_scatter(ScatterArg
             for (int i = 0; i < a.nq; ++i) {
                 const int v = a.q_ind[(size_t)w * a.nq + i];
                 if (v < 0 || a.owner[vstart + v] != w * a.nq + i) continue;
+                if (a.tab_row) {
+                    if (lane == 0) {
+                        a.tab_row[vstart + v] = make_int4(w * a.nq + i, a.zero_row, a.zero_row, 0);
+                        a.tab_w[vstart + v] = make_float4(1.f, 0.f, 0.f, 0.f);
+                    }
+                    continue;
+                }
                 const float *src = a.attn + ((size_t)w * a.nq + i) * a.C;
                 const size_t row = (size_t)(vstart + v) * a.C;
                 for (int c = lane; c < a.C; c += MSSVT_WAVE) a.x_new[row + c] = src[c] + a.x_in[row + c];
@@ -521,6 +533,15 @@ __global__ void __launch_bounds__(SC_WPB *MSSVT_WAVE) k_block_scatter(ScatterArg
                 if (!kvalid[wv][i2]) w2 = 0.f;
                 if (!kvalid[wv][i3]) w3 = 0.f;
             }
+            if (a.tab_row) {
+                if (v >= 0) {
+                    a.tab_row[vstart + v] = make_int4(w1 != 0.f ? w * a.nq + i1 : a.zero_row,
+                                                      w2 != 0.f ? w * a.nq + i2 : a.zero_row,
+                                                      w3 != 0.f ? w * a.nq + i3 : a.zero_row, 0);
+                    a.tab_w[vstart + v] = make_float4(w1, w2, w3, 0.f);
+                }
+                continue;
+            }
             unsigned long long todo = __ballot(v >= 0);
             while (todo) {  // one covered voxel at a time, lanes sweep its channels
                 const int src = __ffsll((long long)todo) - 1;
@@ -566,8 +587,39 @@ extern "C" int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_inte
     a.q_ind = q_ind; a.upd_ind = upd_ind; a.owner = owner;
     a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
     a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
+    a.tab_row = nullptr; a.tab_w = nullptr; a.zero_row = 0;
     int grid = divup(win_capacity, SC_WPB);
     if (grid > 4096) grid = 4096;  // grid-stride over the windows actually present
+    k_block_scatter<<<grid, SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(a);
+    return mssvt_launch_status();
+}
+
+// Table form of mssvt_block_interp_scatter: records, per voxel owned by a list slot, the
+// (up to) three attention rows and inverse-distance weights instead of applying them.
+extern "C" int mssvt_block_interp_table(int nq, int n_upd, int use_interpolation, const int *indices,
+                                        const int *win_ind, const int *num_wins_dev, int win_capacity,
+                                        const int *win_vstart, const int *q_ind, const int *upd_ind,
+                                        const int *owner, const float *host_voxel_size3,
+                                        const float *host_range_min3, int zero_row, int *tab_row,
+                                        float *tab_w, void *stream) {
+    if (!indices || !win_ind || !num_wins_dev || !win_vstart || !q_ind || !owner || !host_voxel_size3 ||
+        !host_range_min3 || !tab_row || !tab_w || nq <= 0)
+        return MSSVT_E_BADARG;
+    if (use_interpolation && (!upd_ind || n_upd <= 0)) return MSSVT_E_BADARG;
+    if (nq > SC_MAXQ) return MSSVT_E_TOOLARGE;
+    if (win_capacity <= 0) return MSSVT_OK;
+    ScatterArgs a;
+    a.C = 0; a.nq = nq; a.n1 = n_upd; a.interp = use_interpolation;
+    a.attn = nullptr; a.x_in = nullptr; a.x_new = nullptr;
+    a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev; a.win_vstart = win_vstart;
+    a.q_ind = q_ind; a.upd_ind = upd_ind; a.owner = owner;
+    a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
+    a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
+    a.tab_row = reinterpret_cast<int4 *>(tab_row);
+    a.tab_w = reinterpret_cast<float4 *>(tab_w);
+    a.zero_row = zero_row;
+    int grid = divup(win_capacity, SC_WPB);
+    if (grid > 4096) grid = 4096;
     k_block_scatter<<<grid, SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(a);
     return mssvt_launch_status();
 }

@@ -32,6 +32,11 @@ struct FfnArgs {
     int n_rows;
     const float *x_new, *x_in;  // x = owner < 0 ? 2 * x_in : x_new   (x_in/owner may be null)
     const int *owner;
+    // interpolation-table input (tab_row != null; replaces x_new/owner):
+    //   x = tab_row[v].x < 0 ? 2 * x_in[v] : x_in[v] + sum_i tab_w[v][i] * attn[tab_row[v][i]]
+    const int4 *tab_row;
+    const float4 *tab_w;
+    const float *attn;
     const float *ln_w, *ln_b;  // norm2
     float eps;
     const float *W1, *b1, *W2, *b2;  // linear1 (FF,C), linear2 (C,FF)
@@ -97,6 +102,37 @@ __global__ void __launch_bounds__(FFN_WAVES *MSSVT_WAVE) k_ffn(FfnArgs a) {
         const int row = min(r0 + li, a.n_rows - 1);
         float xn[KS];
         {
+            if (a.tab_row) {
+                // residual input built on the fly: x_in + 3-NN interpolated attention rows (the rows of
+                // empty slots point at a zero row, so all three gathers are unconditional)
+                const int4 tr = a.tab_row[row];
+                const float4 tw = a.tab_w[row];
+                const bool unowned = tr.x < 0;
+                const float *sx = a.x_in + (size_t)row * C + lg * KS;
+                // (an unowned voxel gathers its own finite x_in row three times with weight 0: attn rows
+                //  of never-written slots may hold NaNs, and 0 * NaN is NaN)
+                const float *s1 = unowned ? sx : a.attn + (size_t)tr.x * C + lg * KS;
+                const float *s2 = unowned ? sx : a.attn + (size_t)tr.y * C + lg * KS;
+                const float *s3 = unowned ? sx : a.attn + (size_t)tr.z * C + lg * KS;
+                const float w1 = unowned ? 0.f : tw.x, w2 = unowned ? 0.f : tw.y, w3 = unowned ? 0.f : tw.z;
+                const float wx = unowned ? 2.0f : 1.0f;  // untouched voxel: features + shortcut = 2 * x_in
+                float *ys = a.y + (size_t)row * C + lg * KS;
+#pragma unroll
+                for (int s = 0; s < KS; s += 4) {
+                    const float4 vx = *reinterpret_cast<const float4 *>(sx + s);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(s1 + s);
+                    const float4 v2 = *reinterpret_cast<const float4 *>(s2 + s);
+                    const float4 v3 = *reinterpret_cast<const float4 *>(s3 + s);
+                    float4 o;
+                    o.x = ((v1.x * w1 + v2.x * w2) + v3.x * w3) + vx.x * wx;
+                    o.y = ((v1.y * w1 + v2.y * w2) + v3.y * w3) + vx.y * wx;
+                    o.z = ((v1.z * w1 + v2.z * w2) + v3.z * w3) + vx.z * wx;
+                    o.w = ((v1.w * w1 + v2.w * w2) + v3.w * w3) + vx.w * wx;
+                    xn[s] = o.x; xn[s + 1] = o.y; xn[s + 2] = o.z; xn[s + 3] = o.w;
+                    // x is parked in the output buffer; the epilogue re-reads it in its own layout
+                    if (r0 + li < a.n_rows) *reinterpret_cast<float4 *>(ys + s) = o;
+                }
+            } else {
             const bool dbl = a.owner != nullptr && a.owner[row] < 0;  // untouched voxel: 2 * x_in (ref quirk R12)
             const float *src = (dbl ? a.x_in : a.x_new) + (size_t)row * C + lg * KS;
 #pragma unroll
@@ -107,6 +143,7 @@ __global__ void __launch_bounds__(FFN_WAVES *MSSVT_WAVE) k_ffn(FfnArgs a) {
             if (dbl) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) xn[s] *= 2.0f;
+            }
             }
             float sum = 0.f;
 #pragma unroll
@@ -174,16 +211,20 @@ __global__ void __launch_bounds__(FFN_WAVES *MSSVT_WAVE) k_ffn(FfnArgs a) {
             }
         }
         // ---- epilogue: y = x + W2 u + b2   (lane = output channel li of each 16-tile, rows 4*lg+reg) --
+        // (table mode: the parked x rows were stored long ago -- a whole MFMA phase and at least one
+        //  workgroup barrier lie in between; the fence makes the ordering explicit)
+        if (a.tab_row) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int rr = r0 + 4 * lg + reg;
             const int r = min(rr, a.n_rows - 1);
-            const bool dbl = a.owner != nullptr && a.owner[r] < 0;
-            const float *src = (dbl ? a.x_in : a.x_new) + (size_t)r * C + li;
+            const bool dbl = !a.tab_row && a.owner != nullptr && a.owner[r] < 0;
+            const float *src = (a.tab_row ? a.y : (dbl ? a.x_in : a.x_new)) + (size_t)r * C + li;
             float s = 0.f;
 #pragma unroll
             for (int ot = 0; ot < C / 16; ++ot) {
-                float xv = src[ot * 16];
+                // table mode: x was parked in y by other lanes of this wave -> bypass the (stale) L1
+                float xv = a.tab_row ? __builtin_nontemporal_load(src + ot * 16) : src[ot * 16];
                 if (dbl) xv *= 2.0f;
                 const float v = xv + (acc2[ot][reg] + a.b2[ot * 16 + li]);
                 acc2[ot][reg] = v;
@@ -252,9 +293,39 @@ extern "C" int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, co
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
     a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm;
+    a.tab_row = nullptr; a.tab_w = nullptr; a.attn = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (C == 128 && FF == 256) return launch_ffn<128, 256>(a, st);
     if (C == 64 && FF == 128) return launch_ffn<64, 128>(a, st);
     if (C == 32 && FF == 64) return launch_ffn<32, 64>(a, st);
     return MSSVT_E_TOOLARGE;  // shape not instantiated: callers use library GEMMs instead
+}
+
+// Same tail, fed by the interpolation table of mssvt_block_interp_table: the residual input
+// x = x_in + sum_i w_i * attn[row_i] (or 2 * x_in for voxels no list slot owns) is built while the
+// rows are loaded, so neither the scatter kernel nor its (N,C) output exist.
+extern "C" int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_in, const int *tab_row,
+                                      const float *tab_w, const float *attn, const float *norm_w,
+                                      const float *norm_b, float eps, const float *W1, const float *b1,
+                                      const float *W2, const float *b2, float *y,
+                                      const float *next_norm_w, const float *next_norm_b, float next_eps,
+                                      float *y_norm, void *stream) {
+    if (n_rows < 0 || !x_in || !tab_row || !tab_w || !attn || !norm_w || !norm_b || !W1 || !b1 || !W2 ||
+        !b2 || !y)
+        return MSSVT_E_BADARG;
+    if (y_norm && (!next_norm_w || !next_norm_b)) return MSSVT_E_BADARG;
+    if (n_rows == 0) return MSSVT_OK;
+    FfnArgs a;
+    a.n_rows = n_rows; a.x_new = nullptr; a.x_in = x_in; a.owner = nullptr;
+    a.tab_row = reinterpret_cast<const int4 *>(tab_row);
+    a.tab_w = reinterpret_cast<const float4 *>(tab_w);
+    a.attn = attn;
+    a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
+    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 128 && FF == 256) return launch_ffn<128, 256>(a, st);
+    if (C == 64 && FF == 128) return launch_ffn<64, 128>(a, st);
+    if (C == 32 && FF == 64) return launch_ffn<32, 64>(a, st);
+    return MSSVT_E_TOOLARGE;
 }

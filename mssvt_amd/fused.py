@@ -108,6 +108,19 @@ def two_scale_plan(block, sp):
     return p
 
 
+def _attn_buffer(p, nq, C, dev):
+    """(cap*nq + 1, C) rows of attention output, one per (window, query slot), shared by the
+    blocks of a plan; only rows of valid slots are ever written, the last row stays zero."""
+    bufs = getattr(p, "attn_bufs", None)
+    if bufs is None:
+        bufs = p.attn_bufs = {}
+    if (nq, C) not in bufs:
+        b = torch.empty((p.cap * nq + 1, C), dtype=torch.float32, device=dev)
+        b[-1].zero_()
+        bufs[(nq, C)] = b
+    return bufs[(nq, C)]
+
+
 def _query(block, p):
     if block.cbs_pattern == 0:
         return p.ind_even, block.max_num_even, p.owner_even
@@ -119,11 +132,13 @@ def _query(block, p):
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
 
 
-def _ffn_tail(block, sp, x_new, x_in=None, owner=None):
+def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None):
     """y = x + linear2(relu(linear1(norm2(x)))) (+ out_linear) with x = x_new, or 2*x_in on rows
     no list slot owns.  One fused MFMA kernel when the shape is instantiated; it also emits the
     NEXT block's norm1(y) (sp._xhat) so that LayerNorm never runs as a launch of its own."""
     C, FF = block.linear1.in_features, block.linear1.out_features
+    if table is not None:
+        x_new = x_in  # shapes / dtype template only
     if (C, FF) not in FFN_SHAPES:
         x = x_new if owner is None else torch.where((owner >= 0).unsqueeze(1), x_new, x_in * 2.0)
         y = x + block.linear2(F.relu(block.linear1(block.norm2(x))))
@@ -136,13 +151,19 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None):
         y_norm = None
         if nxt is not None and not has_out and nxt.normalized_shape[0] == C:
             y_norm = torch.empty_like(x_new)
-        _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
-                  _lib.ptr(block.norm2.weight), _lib.ptr(block.norm2.bias), _f(block.norm2.eps),
-                  _lib.ptr(block.linear1.weight), _lib.ptr(block.linear1.bias), _lib.ptr(block.linear2.weight),
-                  _lib.ptr(block.linear2.bias), _lib.ptr(y),
-                  _lib.ptr(nxt.weight if y_norm is not None else None),
-                  _lib.ptr(nxt.bias if y_norm is not None else None),
-                  _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.stream())
+        tail = (_lib.ptr(block.norm2.weight), _lib.ptr(block.norm2.bias), _f(block.norm2.eps),
+                _lib.ptr(block.linear1.weight), _lib.ptr(block.linear1.bias), _lib.ptr(block.linear2.weight),
+                _lib.ptr(block.linear2.bias), _lib.ptr(y),
+                _lib.ptr(nxt.weight if y_norm is not None else None),
+                _lib.ptr(nxt.bias if y_norm is not None else None),
+                _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.stream())
+        if table is not None:
+            (tab_row, tab_w), attn = table
+            _lib.call("mssvt_ffn_fused_interp", _i(n), _i(C), _i(FF), _lib.ptr(x_in), _lib.ptr(tab_row),
+                      _lib.ptr(tab_w), _lib.ptr(attn), *tail)
+        else:
+            _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
+                      *tail)
         sp._xhat = (y_norm, nxt, y) if y_norm is not None else None
     if hasattr(block, 'out_linear'):
         y = block.out_linear(y)
@@ -167,7 +188,7 @@ def block_forward(block, sp):
     N, C = x_in.shape
     p = two_scale_plan(block, sp)
     q_ind, nq, owner_q = _query(block, p)
-    attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
+    attn = _attn_buffer(p, nq, C, x_in.device)
     ma = block.ms_attn
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
     wpos, bpos = block.pos_proj[0].weight, block.pos_proj[0].bias
@@ -182,18 +203,46 @@ def block_forward(block, sp):
                   _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
                   _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(attn), _lib.ptr(p.ticket), _lib.stream())
         c0 += cg
-    # rows no list slot owns are never written here: the FFN reads them as 2 * x_in
-    # (features + shortcut, ref quirk R12) through the owner array
-    new = torch.empty_like(x_in)
     interp = 1 if block.use_feature_interpolation else 0
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
-    _lib.call("mssvt_block_interp_scatter", _i(C), _i(nq), _i(n_upd), _i(interp), _lib.ptr(attn),
-              _lib.ptr(x_in), _lib.ptr(new), _lib.ptr(sp.indices), _lib.ptr(p.win_ind), _lib.ptr(p.num_wins),
-              _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind), _lib.ptr(upd_ind), _lib.ptr(owner), vs3, mn3,
-              _lib.stream())
-    sp.features = _ffn_tail(block, sp, new, x_in, owner)
+    FF = block.linear1.out_features
+    if (C, FF) in FFN_SHAPES:
+        # interpolation + scatter + residual are folded into the FFN's input stage through a
+        # per-voxel table (3 attention rows + weights) that only depends on the plan
+        tab = _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, mn3)
+        sp.features = _ffn_tail(block, sp, None, x_in, None, table=(tab, attn))
+    else:
+        # rows no list slot owns are never written here: the FFN reads them as 2 * x_in
+        # (features + shortcut, ref quirk R12) through the owner array
+        new = torch.empty_like(x_in)
+        _lib.call("mssvt_block_interp_scatter", _i(C), _i(nq), _i(n_upd), _i(interp), _lib.ptr(attn),
+                  _lib.ptr(x_in), _lib.ptr(new), _lib.ptr(sp.indices), _lib.ptr(p.win_ind), _lib.ptr(p.num_wins),
+                  _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind), _lib.ptr(upd_ind), _lib.ptr(owner), vs3,
+                  mn3, _lib.stream())
+        sp.features = _ffn_tail(block, sp, new, x_in, owner)
     sp.gather_dict = None
     return sp
+
+
+@torch.no_grad()
+def _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, mn3):
+    """(tab_row (N,4) int32, tab_w (N,4) f32): where each voxel's update comes from.  Geometry
+    only -> computed once per plan and (cbs_pattern, interpolation) and reused by later blocks."""
+    key = (block.cbs_pattern, interp)
+    tabs = getattr(p, "tables", None)
+    if tabs is None:
+        tabs = p.tables = {}
+    if key not in tabs:
+        dev = sp.indices.device
+        N = sp.indices.shape[0]
+        tab_row = torch.full((max(N, 1), 4), -1, dtype=torch.int32, device=dev)
+        tab_w = torch.zeros((max(N, 1), 4), dtype=torch.float32, device=dev)
+        _lib.call("mssvt_block_interp_table", _i(nq), _i(n_upd), _i(interp), _lib.ptr(sp.indices),
+                  _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind),
+                  _lib.ptr(upd_ind), _lib.ptr(owner), vs3, mn3, _i(p.cap * nq), _lib.ptr(tab_row),
+                  _lib.ptr(tab_w), _lib.stream())
+        tabs[key] = (tab_row, tab_w)
+    return tabs[key]
 
 
 def compress_supported(block, sp):
