@@ -277,6 +277,24 @@ int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_in, const i
                            const float *W2, const float *b2, float *y, const float *next_norm_w,
                            const float *next_norm_b, float next_eps, float *y_norm, void *stream);
 
+/* ======================================================================== *
+ * Part 3 -- voxelizer front-end: the index part of
+ *           DynamicVFE.forward (ref pcdet/models/backbones_3d/vfe/dynamic_vfe.py:83-93,
+ *           114-118) without a sort: occupancy bitmap + popcount rank.
+ * ======================================================================== */
+
+/* int32 words of workspace for a (batch_size, X, Y, Z) grid. */
+long long mssvt_voxelize_workspace_ints(int batch_size, int X, int Y, int Z);
+
+/* points (P, point_stride) f32 rows [b, x, y, z, ...] -> voxel_coords (capacity,4) int32 rows
+ * [b,z,y,x], sorted by (b,x,y,z) exactly like torch.unique of the reference's linear key;
+ * point_voxel (P) int32 (nullable) = index of the point's voxel, -1 if outside the grid;
+ * num_voxels_dev: device int receiving the voxel count.  host_*3: HOST float[3].          */
+int mssvt_voxelize(const float *points, int point_stride, long long num_points, int batch_size,
+                   const float *host_range_min3, const float *host_voxel_size3, int X, int Y, int Z,
+                   int voxel_capacity, int *voxel_coords, int *point_voxel, int *num_voxels_dev,
+                   int *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,3 +94,18 @@ def test_fused_ffn_kernel_matches_torch(C, FF, n):
               f(ln2.eps), _lib.ptr(yn), _lib.stream())
     np.testing.assert_allclose(y.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(yn.cpu().numpy(), want_n.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("pts,B", [(20000, 1), (160000, 2), (300000, 1), (50, 3)])
+def test_voxelizer_bit_exact(pts, B):
+    """Bitmap + rank voxelizer == sorted-unique formulation of DynamicVFE (voxel indices bit-exact)."""
+    from mssvt_amd import voxelize
+    p = synthetic.make_batch_points(pts, B, 21)
+    p[::97, 1] += 200.0  # some points outside the range
+    want_vc, want_inv, kept = synthetic.voxelize_numpy(p)
+    vc, pv = voxelize.voxelize(torch.from_numpy(p).to(DEV), synthetic.POINT_CLOUD_RANGE, synthetic.VOXEL_SIZE,
+                               synthetic.GRID_SIZE, B)
+    np.testing.assert_array_equal(vc.cpu().numpy(), want_vc)
+    pv = pv.cpu().numpy()
+    assert (pv[~kept] == -1).all()
+    np.testing.assert_array_equal(pv[kept], want_inv)
