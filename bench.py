@@ -47,7 +47,8 @@ def parse():
 
 def make_inputs(points, batch, rank, device):
     from mssvt_amd import synthetic
-    pts = synthetic.make_batch_points(points, batch, seed0=rank * batch)
+    from mssvt_amd.dist import scene_seeds
+    pts = synthetic.make_batch_points(points, batch, seed0=scene_seeds(rank, batch)[0])
     vc, _, _ = synthetic.voxelize_numpy(pts)
     g = torch.Generator().manual_seed(1000 + rank)
     feats = torch.randn(vc.shape[0], 128, generator=g)
@@ -103,17 +104,12 @@ def cpu_baseline(net, vc_np, feats_np, batch):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from mssvt_amd import dist as mdist
+    rank, world, local_rank = mdist.env_rank_world()
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the hot path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    dist = mdist.init("nccl", dev)
 
     from mssvt_amd import config, roofline
     torch.manual_seed(0)
@@ -129,22 +125,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, out = mdist.timed_steps(step, args.steps, dist, dev)
 
     res = None
     if rank == 0:

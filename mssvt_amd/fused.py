@@ -398,9 +398,25 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         K = blk.key_num_sample
         n_keys = int((p.k_mask[g][:nw] == 0).sum())
         n_q = int((q_ind[:nw] >= 0).sum())
+        # second heaviest kernel: the fused FFN on the fp32 matrix cores
+        interp = 1 if blk.use_feature_interpolation else 0
+        upd_ind, n_upd, owner = (p.ind_win1, blk.max_num_win1, p.owner_win1) if interp else (q_ind, nq, _query(blk, p)[2])
+        tab = _interp_table(blk, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, mn3)
+        abuf = _attn_buffer(p, nq, C, x_in.device)
+        abuf.zero_()
+        sp._next_norm1 = net.backbone[1].norm1
+        ms_ffn = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf)), 20)
     alg = nw * (16 + 4 + 4 * nq + 5 * K) + (n_keys + n_q) * (4 * cg + 16) + n_q * 4 * cg
     achieved = alg / (ms * 1e-3) / 1e9
+    N, FF = x_in.shape[0], blk.linear1.out_features
+    flop = 4.0 * C * FF * N
+    tfs = flop / (ms_ffn * 1e-3) / 1e12
     return {"bound": "hbm", "kernel": "k_block_attn (group 1: win2 keys)", "achieved": achieved, "peak": peak_gbs,
             "unit": "GB/s", "frac": achieved / peak_gbs, "traffic": None, "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": ms * 1e3,
-            "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q}}
+            "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q},
+            "note": "latency/issue bound, not bandwidth bound (DESIGN.md section 5)",
+            "second_kernel": {"bound": "mfma", "kernel": "k_ffn<128,256> (fp32 MFMA, incl. interpolation input + "
+                              "next norm1)", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3,
+                              "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_ffn * 1e3,
+                              "units_per_launch": {"voxels": N}}}

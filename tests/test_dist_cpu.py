@@ -1,0 +1,61 @@
+"""N>1 path on CPU: two gloo ranks shard the scenes, time a stand-in step between barriers and
+agree on the max-over-ranks time; no collective touches the data path."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import time
+    from mssvt_amd import dist as mdist, synthetic
+    d = mdist.init("gloo")
+    seeds = mdist.scene_seeds(rank, 2)
+    vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(500, 2, seeds[0]))
+
+    def step():  # rank 1 is slower: the reported time must be ITS time on both ranks
+        time.sleep(0.02 * (rank + 1))
+        return vc.shape[0]
+
+    elapsed, out = mdist.timed_steps(step, 3, d, torch.device("cpu"), sync=lambda: None)
+    q.put((rank, seeds, elapsed, out))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_two_rank_sharding_and_timing():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, t0, n0), (r1, s1, t1, n1) = res
+    assert s0 == [0, 1] and s1 == [2, 3]  # disjoint, gap-free scene assignment
+    assert abs(t0 - t1) < 1e-9 and t0 >= 3 * 0.04  # both ranks report the slowest rank's time
+    assert n0 > 0 and n1 > 0 and n0 != n1  # different scenes on different ranks
+
+
+def test_single_process_is_a_noop_group():
+    from mssvt_amd import dist as mdist
+    os.environ.pop("WORLD_SIZE", None)
+    os.environ.pop("RANK", None)
+    assert mdist.init("gloo") is None
+    el, out = mdist.timed_steps(lambda: 7, 2, None, None, sync=lambda: None)
+    assert out == 7 and el >= 0
