@@ -105,6 +105,88 @@ __device__ __forceinline__ void fps_on_list(const int *packed, int n, int m, int
     }
 }
 
+// Fast path of the same sampler for the case that matters: the list holds nv <= 64 valid entries
+// (front-packed, as K3 produces them) followed by padding, and nv <= bs.  All padding slots carry
+// the same offset (0,0,0), hence the same running min-distance `tpad`, so nothing needs to be
+// scanned per slot.  The reference block is reproduced analytically:
+//   * reference thread vt visits slots vt, vt+bs (n <= 2*bs - 1): for vt < nv that is one valid slot
+//     then (if it exists) one padding slot, taken only if tpad is STRICTLY larger; for vt >= nv it
+//     is padding only -> (tpad, vt);
+//   * the shared-memory tree keeps the lower slot on ties at every level (strides bs/2 ... 1), i.e.
+//     among threads with the maximal value the one with the smallest BIT-REVERSED id wins.
+// One lane per valid entry, min-distances in registers, two wave reductions per round, no LDS.
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void fps_on_list_fast(const int *packed, int n, int nv, int m, int bs,
+                                                 int *fps_out, int lane) {
+    int L = 0;
+    while ((1 << L) < bs) ++L;
+    const bool mine = lane < nv;
+    const int pk = packed[mine ? lane : 0];
+    const float xk = (float)((pk & 255) - 64), yk = (float)(((pk >> 8) & 255) - 64),
+                zk = (float)(((pk >> 16) & 255) - 64);
+    float tk = 1e10f, tpad = 1e10f;
+    const unsigned int myrev = mine ? (__brev((unsigned int)lane) >> (32 - L)) : 0xFFFFFFFFu;
+    const bool has_second = mine && lane + bs < n;  // this thread's second slot (padding)
+    // pure-padding threads vt in [nv, bs): the tree favours the smallest bit-reversed id
+    const bool padgroup = nv < bs;
+    unsigned int vp_rev = 0xFFFFFFFFu;
+    int vp = 0;
+    if (padgroup) {
+        unsigned int best = 0xFFFFFFFFu;
+        for (int vt = nv + lane; vt < bs; vt += MSSVT_WAVE) {
+            const unsigned int r = __brev((unsigned int)vt) >> (32 - L);
+            best = r < best ? r : best;
+        }
+        vp_rev = wave_min_u32(best);
+        vp = (int)(__brev(vp_rev) >> (32 - L));  // bit reversal is an involution on L bits
+    }
+    int old = 0;
+    if (lane == 0) fps_out[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        float x1 = 0.f, y1 = 0.f, z1 = 0.f;  // a padding slot sits at offset (0,0,0)
+        if (old < nv) {
+            x1 = __shfl(xk, old);
+            y1 = __shfl(yk, old);
+            z1 = __shfl(zk, old);
+        }
+        {
+            const float dx = xk - x1, dy = yk - y1, dz = zk - z1;
+            tk = fminf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), tk);
+            const float px = 0.f - x1, py = 0.f - y1, pz = 0.f - z1;
+            tpad = fminf(__builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px)), tpad);
+        }
+        float best = mine ? tk : -INFINITY;
+        int besti = lane;
+        if (has_second && tpad > best) {
+            best = tpad;
+            besti = lane + bs;
+        }
+        const float M = wave_max(best);
+        const unsigned int kmin = wave_min_u32((mine && best == M) ? myrev : 0xFFFFFFFFu);
+        int pick;
+        if (padgroup && (nv == 0 || tpad > M || (tpad == M && vp_rev < kmin))) {
+            pick = vp;
+        } else {
+            const unsigned long long wm = __ballot(mine && best == M && myrev == kmin);
+            pick = __shfl(besti, __ffsll((long long)wm) - 1);
+        }
+        old = pick;
+        if (lane == 0) fps_out[j] = old;
+        if (M <= 0.f && (!padgroup || tpad <= 0.f) && !(nv < n && tpad > 0.f)) {
+            // every remaining min-distance is 0: all further rounds tie completely and return slot 0
+            for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
+            if (old == 0) break;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanArgs a) {
     extern __shared__ int lds[];
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
@@ -214,7 +296,13 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         const int *lind = scale ? l2_ind : l1_ind;
         const int *lc = scale ? l2_c : l1_c;
         const int n = scale ? a.max_win2 : a.max_win1;
-        fps_on_list(lc, n, K, scale ? a.bs2 : a.bs1, temp, bv, bidx, fps_out, lane);
+        const int bs = scale ? a.bs2 : a.bs1;
+        const int nv = min(scale ? cnt_w2 : cnt_w1, n);
+        if (nv <= MSSVT_WAVE && nv <= bs && bs >= 2)
+            fps_on_list_fast(lc, n, nv, K, bs, fps_out, lane);
+        else
+            fps_on_list(lc, n, K, bs, temp, bv, bidx, fps_out, lane);
+        wave_lds_sync();
         int *kout = (scale ? a.k_ind2 : a.k_ind1) + (size_t)w * K;
         unsigned char *mout = (scale ? a.k_mask2 : a.k_mask1) + (size_t)w * K;
         for (int j = lane; j < K; j += MSSVT_WAVE) {
