@@ -169,7 +169,11 @@ int mssvt_window_partition_compact(int x_wgs, int y_wgs, int z_wgs, int x_ws, in
  * padded); k_ind1/k_ind2 (cap,K) sampled key voxels of the win1 / win2 list (an EMPTY
  * slot picked by FPS becomes voxel 0, as in the reference); k_mask1/k_mask2 (cap,K)
  * bytes, 1 = masked; win_vstart (cap) first feature row of the window's sample;
- * owner_* (N) pre-filled -1: highest flat list slot (w*max_num + s) holding the voxel. */
+ * owner_* (N) pre-filled -1: highest flat list slot (w*max_num + s) holding the voxel.
+ * Optional resolved metadata (kmeta1 == NULL: skipped): qmeta_* (cap,max_num_*,4), kmeta1/2
+ * (cap,K,4) f32 = (voxel centre - window centre in metres, bits of the global feature row or
+ * -1 for empty / masked slots); wcentre (cap,4) = window centre; nq_valid (3,cap) = valid odd /
+ * even / win1 entries per window.  indices (N,4) voxel coords.                               */
 int mssvt_window_plan_two(
     int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
     int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
@@ -178,24 +182,31 @@ int mssvt_window_plan_two(
     const int *num_wins_dev, int win_capacity, const int *xyz_to_vidx, const int *v_bs_cnt,
     int *ind_odd, int *ind_even, int *ind_win1, int *k_ind1, int *k_ind2, unsigned char *k_mask1,
     unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
-    void *stream);
+    const int *indices, const float *host_voxel_size3, const float *host_range_min3,
+    const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
+    float *kmeta2, float *wcentre, int *nq_valid, void *stream);
+
+/* Work order for mssvt_block_attention_group: perm (cap) = the windows with >= 1 valid query,
+ * sorted by descending nq_valid (cap) (one row of the plan's (3,cap) nq_valid: odd / even /
+ * win1); num_active_dev = how many.  Heavy windows first keeps the persistent kernel's tail short. */
+int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int max_queries, int *perm,
+                     int *num_active_dev, void *stream);
 
 /* Fused attention of ONE head group of a Block (channels [c0, c0+Cg), Cg = heads*head_dim
  * <= 64): gathers + positional MLP + MixedScaleAttention (ref mssvt_backbone.py:260-295,
  * mssvt_utils.py:112-150) for every valid query of every window.  xhat (N,C) = norm1
- * output; q_ind (cap,nq); k_ind/k_mask (cap,K) of the scale this group attends to; Wq
- * (Cg,Cg), Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) + biases = the module's parameters;
- * attn (cap,nq,C): rows of valid query slots, columns [c0,c0+Cg) are written.
- * host_*3: HOST pointers to 3 floats [x,y,z].  work_counter: 128 device ints of scratch
- * (windows are handed to wavefronts through 8 sharded tickets; zeroed by the call).    */
+ * output; qmeta (cap,nq,4) / kmeta (cap,K,4) / wcentre (cap,4): the plan kernel's resolved
+ * metadata for the query list of this block's cbs_pattern and the key scale this group
+ * attends to; perm / num_active_dev: the work order of mssvt_plan_order; Wq (Cg,Cg), Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) + biases = the module's
+ * parameters; attn (cap*nq [+1],C): rows of valid query slots, columns [c0,c0+Cg) are
+ * written.  work_counter: 128 device ints of scratch (windows are handed to wavefronts
+ * through 8 sharded tickets; zeroed by the call).                                     */
 int mssvt_block_attention_group(
     int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
-    const float *xhat, const int *indices, const int *win_ind, const int *num_wins_dev,
-    const int *win_vstart, const int *q_ind, const int *k_ind, const unsigned char *k_mask,
-    const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3,
-    const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo,
-    const float *bo, const float *Wpos, const float *bpos, float *attn, int *work_counter,
-    void *stream);
+    const float *xhat, const int *num_active_dev, const int *perm, const float *qmeta,
+    const float *kmeta, const float *wcentre, const float *Wq, const float *bq, const float *Wkv, const float *bkv,
+    const float *Wo, const float *bo, const float *Wpos, const float *bpos, float *attn,
+    int *work_counter, void *stream);
 
 /* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
  * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):

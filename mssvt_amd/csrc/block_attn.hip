@@ -29,6 +29,7 @@
 // LDS (floats): WqT | Wk | WvT | WoT (Cg^2 each) | bq bv bo | per wave:
 //   see k_block_attn below.
 #include "common.hip.h"
+#include <stdlib.h>
 
 #define ATTN_MAX_WAVES 8
 
@@ -37,13 +38,16 @@ struct AttnArgs {
     float scale;
     int nq, K;
     const float *xhat;
-    const int *indices, *win_ind, *num_wins, *win_vstart, *q_ind, *k_ind;
-    const unsigned char *k_mask;
-    float vsx, vsy, vsz, minx, miny, minz, wsx, wsy, wsz;
+    const int *num_wins;  // number of entries of `perm` (windows with at least one valid query)
+    const int *perm;      // work order: heavy windows first
+    // per-slot metadata resolved by the plan kernel (window_plan.hip): (rel.x, rel.y, rel.z,
+    // bits(global feature row or -1)); wcentre = window centre in metres
+    const float4 *qmeta, *kmeta, *wcentre;
     const float *Wq, *bq, *Wkv, *bkv, *Wo, *bo, *Wp, *bp;
     float *attn;
     int *work_counter;  // 128 device ints (8 counters, one per 64-B line), zeroed per launch
     int wave_floats;
+    int dbg;
 };
 
 // cell centre in metres, one rounding per op like the reference's torch expression
@@ -145,70 +149,90 @@ __global__ void __launch_bounds__(ATTN_MAX_WAVES *MSSVT_WAVE) k_block_attn(AttnA
     // serialise (~88 tickets/us chip-wide), so there are 8 counters on separate cache
     // lines; counter c owns the windows w == c (mod 8) and is drawn 2 windows at a time,
     // first by the workgroups with blockIdx == c (mod 8) (one XCD under round-robin
-    // placement; speed only), then by anybody (work stealing).
-    int shard = blockIdx.x & 7, tries = 0, t_next = 0, t_end = 0;
-    for (;;) {
-        if (t_next >= t_end) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(a.work_counter + 16 * shard, 2);
-            t_next = __builtin_amdgcn_readfirstlane(t);
-            t_end = t_next + 2;
-        }
-        const int w = t_next * 8 + shard;
-        if (w >= nw) {  // this shard is drained: move on to the next one
-            if (++tries >= 8) break;
-            shard = (shard + 1) & 7;
-            t_next = t_end = 0;
-            continue;
-        }
-        ++t_next;
-        const int4 wi = reinterpret_cast<const int4 *>(a.win_ind)[w];  // [b,wz,wy,wx]
-        const int vstart = a.win_vstart[w];
-        const float cxm = centre_of(wi.w, a.wsx, a.minx), cym = centre_of(wi.z, a.wsy, a.miny),
-                    czm = centre_of(wi.y, a.wsz, a.minz);
-        const float posc = bpv + wp[3] * cxm + wp[4] * cym + wp[5] * czm;  // window part of the pos. MLP
-        // ---- metadata, all rows of the window at once (2 dependent memory latencies) --------
-        // unmasked keys -> compact list {row, rel. coordinates}; valid queries likewise
-        int nkv = 0, nqv = 0;
-        for (int j0 = 0; j0 < a.K; j0 += MSSVT_WAVE) {
-            const int j = j0 + lane;
-            const bool ok = j < a.K && a.k_mask[(size_t)w * a.K + j] == 0;
-            int row = 0;
-            int4 vi = make_int4(0, 0, 0, 0);
-            if (ok) {
-                row = vstart + a.k_ind[(size_t)w * a.K + j];
-                vi = reinterpret_cast<const int4 *>(a.indices)[row];
+    // placement; speed only), then by anybody (work stealing).  The ticket for the NEXT
+    // pair is requested while the current pair is being processed, and the next window's
+    // metadata is loaded while the current window computes, so neither latency is exposed.
+    constexpr int TPA = 1;  // windows per ticket: 1 keeps the tail short (a wave holds <= 2 windows)
+    int shard = blockIdx.x & 7, tries = 0, pair_lo = 0, pair_pos = TPA, pend = 0;
+    bool have_pend = false;
+    auto ticket_async = [&]() {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(a.work_counter + 16 * shard, TPA);
+        return t;
+    };
+    auto next_window = [&]() -> int {
+        for (;;) {
+            if (pair_pos >= TPA) {
+                if (!have_pend) pend = ticket_async();
+                pair_lo = __builtin_amdgcn_readfirstlane(pend);  // waits for the atomic issued a pair ago
+                pend = ticket_async();
+                have_pend = true;
+                pair_pos = 0;
             }
+            const int t = (pair_lo + pair_pos) * 8 + shard;
+            ++pair_pos;
+            if (t < nw) return a.perm[t];
+            if (++tries >= 8) return -1;  // every shard drained
+            shard = (shard + 1) & 7;
+            pair_pos = TPA;
+            have_pend = false;
+        }
+    };
+    const float4 none4 = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
+    // metadata of a window, one slot per lane (first 64 query slots; the rest is read on demand)
+    auto load_meta = [&](int w, float4 &km, float4 &qm, float4 &wc) {
+        km = lane < a.K ? a.kmeta[(size_t)w * a.K + lane] : none4;
+        qm = lane < a.nq ? a.qmeta[(size_t)w * a.nq + lane] : none4;
+        wc = a.wcentre[w];
+    };
+
+    int w = next_window();
+    float4 km_c = none4, qm_c = none4, wc_c = none4;
+    if (w >= 0) load_meta(w, km_c, qm_c, wc_c);
+    while (w >= 0) {
+        int w_next = -1;
+        float4 km_n = none4, qm_n = none4, wc_n = none4;
+        if (!(a.dbg & 1)) {
+            w_next = next_window();
+            if (w_next >= 0) load_meta(w_next, km_n, qm_n, wc_n);
+        }
+
+        const float cxm = wc_c.x, cym = wc_c.y, czm = wc_c.z;
+        const float posc = bpv + wp[3] * cxm + wp[4] * cym + wp[5] * czm;  // window part of the pos. MLP
+        // ---- unmasked keys / valid queries -> compact lists {row, rel. coordinates} ---------------
+        int nkv = 0, nqv = 0;
+        {
+            const int row = __builtin_bit_cast(int, km_c.w);
+            const bool ok = row >= 0;
             const unsigned long long m = __ballot(ok);
             if (ok) {
-                const int p = nkv + __popcll(m & ((1ull << lane) - 1ull));
+                const int p = __popcll(m & ((1ull << lane) - 1ull));
                 krow[p] = row;
-                krel[3 * p + 0] = centre_of(vi.w, a.vsx, a.minx) - cxm;
-                krel[3 * p + 1] = centre_of(vi.z, a.vsy, a.miny) - cym;
-                krel[3 * p + 2] = centre_of(vi.y, a.vsz, a.minz) - czm;
+                krel[3 * p + 0] = km_c.x;
+                krel[3 * p + 1] = km_c.y;
+                krel[3 * p + 2] = km_c.z;
             }
-            nkv += __popcll(m);
+            nkv = __popcll(m);
         }
         for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {
             const int qi = q0 + lane;
-            int qid = -1;
-            if (qi < a.nq) qid = a.q_ind[(size_t)w * a.nq + qi];
-            const bool ok = qid >= 0;
-            int4 vi = make_int4(0, 0, 0, 0);
-            if (ok) vi = reinterpret_cast<const int4 *>(a.indices)[vstart + qid];
+            float4 qm = qm_c;
+            if (q0 > 0) qm = qi < a.nq ? a.qmeta[(size_t)w * a.nq + qi] : none4;
+            const int row = __builtin_bit_cast(int, qm.w);
+            const bool ok = row >= 0;
             const unsigned long long m = __ballot(ok);
             if (ok) {
                 const int p = nqv + __popcll(m & ((1ull << lane) - 1ull));
-                qrow[p] = vstart + qid;
+                qrow[p] = row;
                 qslot[p] = qi;
-                qrel[3 * p + 0] = centre_of(vi.w, a.vsx, a.minx) - cxm;
-                qrel[3 * p + 1] = centre_of(vi.z, a.vsy, a.miny) - cym;
-                qrel[3 * p + 2] = centre_of(vi.y, a.vsz, a.minz) - czm;
+                qrel[3 * p + 0] = qm.x;
+                qrel[3 * p + 1] = qm.y;
+                qrel[3 * p + 2] = qm.z;
             }
             nqv += __popcll(m);
         }
         wave_lds_sync();
-        if (nqv == 0) continue;  // nothing to update from this window (wave-uniform)
+        if (nqv > 0) {
         // ---- key tokens: LN'd feature slice + positional embedding -> LDS; 16 row loads in
         //      flight per step (one latency per 16 keys) --------------------------------------
         for (int jb = 0; jb < nkv; jb += 16) {
@@ -367,7 +391,16 @@ __global__ void __launch_bounds__(ATTN_MAX_WAVES *MSSVT_WAVE) k_block_attn(AttnA
             wave_lds_sync();  // xq (= vb) is rewritten by the next query
           }
         }
+        }  // nqv > 0
         wave_lds_sync();  // keys / lists are rewritten for the next window
+        if (a.dbg & 1) {
+            w_next = next_window();
+            if (w_next >= 0) load_meta(w_next, km_n, qm_n, wc_n);
+        }
+        w = w_next;
+        km_c = km_n;
+        qm_c = qm_n;
+        wc_c = wc_n;
     }
 }
 
@@ -402,15 +435,13 @@ static int launch_block_attn(AttnArgs &a, hipStream_t stream) {
 
 extern "C" int mssvt_block_attention_group(
     int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
-    const float *xhat, const int *indices, const int *win_ind, const int *num_wins_dev,
-    const int *win_vstart, const int *q_ind, const int *k_ind, const unsigned char *k_mask,
-    const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3, const float *Wq,
-    const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
+    const float *xhat, const int *num_active_dev, const int *perm, const float *qmeta, const float *kmeta,
+    const float *wcentre, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
     const float *Wpos, const float *bpos, float *attn, int *work_counter, void *stream) {
     if (!work_counter) return MSSVT_E_BADARG;
-    if (!xhat || !indices || !win_ind || !num_wins_dev || !win_vstart || !q_ind || !k_ind || !k_mask ||
-        !host_voxel_size3 || !host_range_min3 || !host_win_size3 || !Wq || !bq || !Wkv || !bkv || !Wo || !bo || !Wpos ||
-        !bpos || !attn || C <= 0 || Cg <= 0 || heads <= 0 || head_dim <= 0 || nq <= 0 || key_num_sample <= 0)
+    if (!xhat || !num_active_dev || !perm || !qmeta || !kmeta || !wcentre || !Wq || !bq || !Wkv || !bkv || !Wo || !bo ||
+        !Wpos || !bpos || !attn || C <= 0 || Cg <= 0 || heads <= 0 || head_dim <= 0 || nq <= 0 ||
+        key_num_sample <= 0)
         return MSSVT_E_BADARG;
     if (Cg != heads * head_dim || c0 < 0 || c0 + Cg > C) return MSSVT_E_BADARG;
     // one channel per lane, heads aligned to 4-float LDS vectors, <= 8 heads per group
@@ -418,14 +449,14 @@ extern "C" int mssvt_block_attention_group(
     AttnArgs a;
     a.C = C; a.c0 = c0; a.heads = heads; a.hd = head_dim; a.scale = scale;
     a.nq = nq; a.K = key_num_sample;
-    a.xhat = xhat; a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev;
-    a.win_vstart = win_vstart; a.q_ind = q_ind; a.k_ind = k_ind; a.k_mask = k_mask;
-    a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
-    a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
-    a.wsx = host_win_size3[0]; a.wsy = host_win_size3[1]; a.wsz = host_win_size3[2];
+    a.xhat = xhat; a.num_wins = num_active_dev; a.perm = perm;
+    a.qmeta = reinterpret_cast<const float4 *>(qmeta);
+    a.kmeta = reinterpret_cast<const float4 *>(kmeta);
+    a.wcentre = reinterpret_cast<const float4 *>(wcentre);
     a.Wq = Wq; a.bq = bq; a.Wkv = Wkv; a.bkv = bkv; a.Wo = Wo; a.bo = bo; a.Wp = Wpos; a.bp = bpos;
     a.attn = attn;
     a.work_counter = work_counter;
+    a.dbg = getenv("MSSVT_DBG") ? atoi(getenv("MSSVT_DBG")) : 0;
     hipStream_t st = (hipStream_t)stream;
 #define MSSVT_ATTN_CASE(cg, hd)                                   \
     if (Cg == cg && head_dim == hd)                               \

@@ -38,8 +38,20 @@ struct PlanArgs {
     unsigned char *k_mask1, *k_mask2;
     int *win_vstart;
     int *owner_win1, *owner_odd, *owner_even;
+    // resolved metadata for the attention kernel (optional, all or none): per slot a float4
+    // (rel.x, rel.y, rel.z, bits(global feature row or -1)); rel = voxel centre - window centre in
+    // metres, computed exactly as ref with_coords does (mssvt_backbone.py:132-137, :269-276)
+    float4 *qmeta_odd, *qmeta_even, *qmeta_win1, *kmeta1, *kmeta2, *wcentre;
+    int *nq_valid;  // (3, cap): valid odd / even / win1 entries per window (work estimate)
+    int win_capacity;
+    const int *indices;
+    float vsx, vsy, vsz, minx, miny, minz, wsx, wsy, wsz;
     int lds_words_per_wave;
 };
+
+__device__ __forceinline__ float plan_centre(int idx, float cell, float lo) {
+    return __fadd_rn(__fmul_rn(__fadd_rn((float)idx, 0.5f), cell), lo);
+}
 
 #define PACK0 (64 | (64 << 8) | (64 << 16))
 __device__ __forceinline__ int pack_off(int ox, int oy, int oz) {
@@ -214,6 +226,11 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
     }
     for (int k = lane; k < a.max_odd; k += MSSVT_WAVE) a.ind_odd[(size_t)w * a.max_odd + k] = -1;
     for (int k = lane; k < a.max_even; k += MSSVT_WAVE) a.ind_even[(size_t)w * a.max_even + k] = -1;
+    const float4 none = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
+    if (a.kmeta1) {
+        for (int k = lane; k < a.max_odd; k += MSSVT_WAVE) a.qmeta_odd[(size_t)w * a.max_odd + k] = none;
+        for (int k = lane; k < a.max_even; k += MSSVT_WAVE) a.qmeta_even[(size_t)w * a.max_even + k] = none;
+    }
     wave_lds_sync();
 
     const int4 wi = reinterpret_cast<const int4 *>(a.win_indices)[w];  // [b,wz,wy,wx]
@@ -223,6 +240,9 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
     if (lane == 0) a.win_vstart[w] = vstart;
     const int cx = wi.w * a.x_ws + a.x_ws / 2, cy = wi.z * a.y_ws + a.y_ws / 2,
               cz = wi.y * a.z_ws + a.z_ws / 2;
+    const float wcx = plan_centre(wi.w, a.wsx, a.minx), wcy = plan_centre(wi.z, a.wsy, a.miny),
+                wcz = plan_centre(wi.y, a.wsz, a.minz);
+    if (a.kmeta1 && lane == 0) a.wcentre[w] = make_float4(wcx, wcy, wcz, 0.f);
     const int e0 = a.n_odd, e1 = e0 + a.n_even, e2 = e1 + a.n_win1, total = e2 + a.n_win2;
     int cnt_odd = 0, cnt_even = 0, cnt_w1 = 0, cnt_w2 = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -258,6 +278,10 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
                 const int p = cnt_odd + __popcll(m_odd & below);
                 if (p < a.max_odd) {
                     a.ind_odd[(size_t)w * a.max_odd + p] = sv;
+                    if (a.kmeta1)
+                        a.qmeta_odd[(size_t)w * a.max_odd + p] = make_float4(
+                            plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
+                            plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
                     atomicMax(a.owner_odd + vstart + sv, w * a.max_odd + p);
                 }
             }
@@ -265,6 +289,10 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
                 const int p = cnt_even + __popcll(m_even & below);
                 if (p < a.max_even) {
                     a.ind_even[(size_t)w * a.max_even + p] = sv;
+                    if (a.kmeta1)
+                        a.qmeta_even[(size_t)w * a.max_even + p] = make_float4(
+                            plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
+                            plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
                     atomicMax(a.owner_even + vstart + sv, w * a.max_even + p);
                 }
             }
@@ -288,7 +316,26 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         cnt_w2 += __popcll(m_all);
     }
     wave_lds_sync();
-    for (int k = lane; k < a.max_win1; k += MSSVT_WAVE) a.ind_win1[(size_t)w * a.max_win1 + k] = l1_ind[k];
+    if (a.kmeta1 && lane == 0) {
+        a.nq_valid[w] = min(cnt_odd, a.max_odd);
+        a.nq_valid[a.win_capacity + w] = min(cnt_even, a.max_even);
+        a.nq_valid[2 * a.win_capacity + w] = min(cnt_w1, a.max_win1);
+    }
+    for (int k = lane; k < a.max_win1; k += MSSVT_WAVE) {
+        const int sv = l1_ind[k];
+        a.ind_win1[(size_t)w * a.max_win1 + k] = sv;
+        if (a.kmeta1) {
+            float4 m = none;
+            if (sv >= 0) {
+                const int pk = l1_c[k];
+                m = make_float4(plan_centre(cx + (pk & 255) - 64, a.vsx, a.minx) - wcx,
+                                plan_centre(cy + ((pk >> 8) & 255) - 64, a.vsy, a.miny) - wcy,
+                                plan_centre(cz + ((pk >> 16) & 255) - 64, a.vsz, a.minz) - wcz,
+                                __builtin_bit_cast(float, vstart + sv));
+            }
+            a.qmeta_win1[(size_t)w * a.max_win1 + k] = m;
+        }
+    }
 
     // ---- K7 + K8 + masks for both scales (ref mssvt_backbone.py:247-258) -----------
     const int K = a.key_num_sample;
@@ -311,7 +358,27 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
             // truncates toward zero -> a picked EMPTY slot (-1) becomes voxel 0 of the sample
             const int kid = (int)((float)lind[f] + 0.1f);
             kout[j] = kid;
-            mout[j] = (unsigned char)(((j > 0 && f == 0) || kid < 0) ? 1 : 0);
+            const bool masked = (j > 0 && f == 0) || kid < 0;
+            mout[j] = (unsigned char)(masked ? 1 : 0);
+            if (a.kmeta1) {
+                float4 m = none;
+                if (!masked) {
+                    float px, py, pz;
+                    if (lind[f] >= 0) {  // a list entry: its voxel is the window centre cell + offset
+                        const int pk = lc[f];
+                        px = plan_centre(cx + (pk & 255) - 64, a.vsx, a.minx);
+                        py = plan_centre(cy + ((pk >> 8) & 255) - 64, a.vsy, a.miny);
+                        pz = plan_centre(cz + ((pk >> 16) & 255) - 64, a.vsz, a.minz);
+                    } else {  // the reference quirk: an empty slot became voxel 0 of the sample
+                        const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + kid];
+                        px = plan_centre(vi.w, a.vsx, a.minx);
+                        py = plan_centre(vi.z, a.vsy, a.miny);
+                        pz = plan_centre(vi.y, a.vsz, a.minz);
+                    }
+                    m = make_float4(px - wcx, py - wcy, pz - wcz, __builtin_bit_cast(float, vstart + kid));
+                }
+                (scale ? a.kmeta2 : a.kmeta1)[(size_t)w * K + j] = m;
+            }
         }
         wave_lds_sync();
     }
@@ -333,7 +400,9 @@ extern "C" int mssvt_window_plan_two(
     const int *num_wins_dev, int win_capacity, const int *xyz_to_vidx, const int *v_bs_cnt,
     int *ind_odd, int *ind_even, int *ind_win1, int *k_ind1, int *k_ind2, unsigned char *k_mask1,
     unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
-    void *stream) {
+    const int *indices, const float *host_voxel_size3, const float *host_range_min3,
+    const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
+    float *kmeta2, float *wcentre, int *nq_valid, void *stream) {
     if (!win_indices || !num_wins_dev || !xyz_to_vidx || !v_bs_cnt || !ind_odd || !ind_even ||
         !ind_win1 || !k_ind1 || !k_ind2 || !k_mask1 || !k_mask2 || !win_vstart || !owner_win1 ||
         !owner_odd || !owner_even || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
@@ -359,6 +428,25 @@ extern "C" int mssvt_window_plan_two(
     a.k_ind1 = k_ind1; a.k_ind2 = k_ind2; a.k_mask1 = k_mask1; a.k_mask2 = k_mask2;
     a.win_vstart = win_vstart;
     a.owner_win1 = owner_win1; a.owner_odd = owner_odd; a.owner_even = owner_even;
+    a.qmeta_odd = reinterpret_cast<float4 *>(qmeta_odd);
+    a.qmeta_even = reinterpret_cast<float4 *>(qmeta_even);
+    a.qmeta_win1 = reinterpret_cast<float4 *>(qmeta_win1);
+    a.kmeta1 = reinterpret_cast<float4 *>(kmeta1);
+    a.kmeta2 = reinterpret_cast<float4 *>(kmeta2);
+    a.wcentre = reinterpret_cast<float4 *>(wcentre);
+    a.nq_valid = nq_valid;
+    a.win_capacity = win_capacity;
+    a.indices = indices;
+    if (kmeta1) {
+        if (!qmeta_odd || !qmeta_even || !qmeta_win1 || !kmeta2 || !wcentre || !nq_valid || !indices || !host_voxel_size3 ||
+            !host_range_min3 || !host_win_size3)
+            return MSSVT_E_BADARG;
+        a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
+        a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
+        a.wsx = host_win_size3[0]; a.wsy = host_win_size3[1]; a.wsz = host_win_size3[2];
+    } else {
+        a.vsx = a.vsy = a.vsz = a.minx = a.miny = a.minz = a.wsx = a.wsy = a.wsz = 0.f;
+    }
     const int nmax = max_num_win1 > max_num_win2 ? max_num_win1 : max_num_win2;
     const int bsmax = a.bs1 > a.bs2 ? a.bs1 : a.bs2;
     a.lds_words_per_wave = 2 * max_num_win1 + 2 * max_num_win2 + nmax + key_num_sample + 2 * bsmax;
@@ -372,5 +460,45 @@ extern "C" int mssvt_window_plan_two(
         if (e != hipSuccess) return (int)e;
     }
     k_window_plan<<<divup(win_capacity, wpb), wpb * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
+    return mssvt_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Work order for the attention kernel: windows sorted by DESCENDING number of valid queries
+// (their cost varies from 0 to 20+ queries; heavy ones first keeps the tail of the persistent
+// kernel short -- longest-processing-time-first), windows without a query dropped.
+// One workgroup: LDS histogram -> scan -> scatter (counting sort; order inside a bucket is
+// arbitrary, which is harmless: every window writes only its own rows).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_plan_order(const int *num_wins, const int *nq_valid, int max_key,
+                                                     int *perm, int *num_active) {
+    __shared__ int hist[260];
+    __shared__ int offs[260];
+    const int nw = *num_wins;
+    for (int k = threadIdx.x; k < 260; k += 1024) hist[k] = 0;
+    __syncthreads();
+    for (int w = threadIdx.x; w < nw; w += 1024) atomicAdd(&hist[min(nq_valid[w], max_key)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = max_key; k >= 1; --k) {
+            offs[k] = run;
+            run += hist[k];
+        }
+        offs[0] = run;
+        *num_active = run;
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < nw; w += 1024) {
+        const int k = min(nq_valid[w], max_key);
+        if (k > 0) perm[atomicAdd(&offs[k], 1)] = w;
+    }
+}
+
+extern "C" int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int max_queries, int *perm,
+                                int *num_active_dev, void *stream) {
+    if (!num_wins_dev || !nq_valid || !perm || !num_active_dev || max_queries <= 0) return MSSVT_E_BADARG;
+    k_plan_order<<<1, 1024, 0, (hipStream_t)stream>>>(num_wins_dev, nq_valid, max_queries > 256 ? 256 : max_queries,
+                                                     perm, num_active_dev);
     return mssvt_launch_status();
 }

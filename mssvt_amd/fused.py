@@ -92,6 +92,12 @@ def two_scale_plan(block, sp):
     p.k_mask = [torch.empty((cap, K), dtype=torch.uint8, device=dev) for _ in range(2)]
     p.win_vstart = torch.empty(cap, dtype=torch.int32, device=dev)
     p.ticket = torch.zeros(128, dtype=torch.int32, device=dev)
+    f4 = lambda n: torch.empty((cap, n, 4), dtype=torch.float32, device=dev)  # noqa: E731
+    p.qmeta_odd, p.qmeta_even, p.qmeta_win1 = f4(n_o), f4(n_e), f4(n1)
+    p.kmeta = [f4(K), f4(K)]
+    p.wcentre = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+    p.nq_valid = torch.empty((3, cap), dtype=torch.int32, device=dev)
+    p.orders = {}
     owners = torch.full((3, cap), -1, dtype=torch.int32, device=dev)
     p.owner_win1, p.owner_odd, p.owner_even = owners[0], owners[1], owners[2]
     t = block._tables_on(dev)
@@ -103,7 +109,9 @@ def two_scale_plan(block, sp):
               _lib.ptr(st["v_bs_cnt"]), _lib.ptr(p.ind_odd), _lib.ptr(p.ind_even), _lib.ptr(p.ind_win1),
               _lib.ptr(p.k_ind[0]), _lib.ptr(p.k_ind[1]), _lib.ptr(p.k_mask[0]), _lib.ptr(p.k_mask[1]),
               _lib.ptr(p.win_vstart), _lib.ptr(p.owner_win1), _lib.ptr(p.owner_odd), _lib.ptr(p.owner_even),
-              _lib.stream())
+              _lib.ptr(sp.indices), _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m),
+              _lib.ptr(p.qmeta_odd), _lib.ptr(p.qmeta_even), _lib.ptr(p.qmeta_win1), _lib.ptr(p.kmeta[0]),
+              _lib.ptr(p.kmeta[1]), _lib.ptr(p.wcentre), _lib.ptr(p.nq_valid), _lib.stream())
     st["plans"][key] = p
     return p
 
@@ -127,6 +135,25 @@ def _query(block, p):
     if block.cbs_pattern == 1:
         return p.ind_odd, block.max_num_odd, p.owner_odd
     return p.ind_win1, block.max_num_win1, p.owner_win1
+
+
+def _qmeta(block, p):
+    return {0: p.qmeta_even, 1: p.qmeta_odd, 2: p.qmeta_win1}[block.cbs_pattern]
+
+
+@torch.no_grad()
+def _work_order(block, p, nq):
+    """(perm, num_active): windows with queries for this cbs_pattern, heaviest first."""
+    pat = block.cbs_pattern
+    if pat not in p.orders:
+        dev = p.win_ind.device
+        perm = torch.empty(p.cap, dtype=torch.int32, device=dev)
+        n_act = torch.zeros(1, dtype=torch.int32, device=dev)
+        row = {1: 0, 0: 1, 2: 2}[pat]  # nq_valid rows: odd, even, win1
+        _lib.call("mssvt_plan_order", _lib.ptr(p.num_wins), _lib.ptr(p.nq_valid[row]), _i(nq), _lib.ptr(perm),
+                  _lib.ptr(n_act), _lib.stream())
+        p.orders[pat] = (perm, n_act)
+    return p.orders[pat]
 
 
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
@@ -189,6 +216,7 @@ def block_forward(block, sp):
     p = two_scale_plan(block, sp)
     q_ind, nq, owner_q = _query(block, p)
     attn = _attn_buffer(p, nq, C, x_in.device)
+    perm, n_act = _work_order(block, p, nq)
     ma = block.ms_attn
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
     wpos, bpos = block.pos_proj[0].weight, block.pos_proj[0].bias
@@ -196,9 +224,8 @@ def block_forward(block, sp):
     for g, heads in enumerate(ma.num_heads):
         cg = ma.scale_dims[g]
         _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(heads), _i(ma.per_head_dim),
-                  _f(ma.scale), _i(nq), _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(sp.indices),
-                  _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _lib.ptr(p.win_vstart), _lib.ptr(q_ind),
-                  _lib.ptr(p.k_ind[g]), _lib.ptr(p.k_mask[g]), vs3, mn3, ws3,
+                  _f(ma.scale), _i(nq), _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(n_act), _lib.ptr(perm),
+                  _lib.ptr(_qmeta(block, p)), _lib.ptr(p.kmeta[g]), _lib.ptr(p.wcentre),
                   _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                   _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
                   _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(attn), _lib.ptr(p.ticket), _lib.stream())
@@ -378,6 +405,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         xhat = F.layer_norm(x_in, (C,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         q_ind, nq, _ = _query(blk, p)
         attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
+        perm, n_act = _work_order(blk, p, nq)
         ma = blk.ms_attn
         g = 1
         cg, c0 = ma.scale_dims[g], ma.scale_dims[0]
@@ -386,8 +414,8 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         def launch():
             _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(ma.num_heads[g]),
                       _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(blk.key_num_sample), _lib.ptr(xhat),
-                      _lib.ptr(sp.indices), _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _lib.ptr(p.win_vstart),
-                      _lib.ptr(q_ind), _lib.ptr(p.k_ind[g]), _lib.ptr(p.k_mask[g]), vs3, mn3, ws3,
+                      _lib.ptr(n_act), _lib.ptr(perm), _lib.ptr(_qmeta(blk, p)), _lib.ptr(p.kmeta[g]),
+                      _lib.ptr(p.wcentre),
                       _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                       _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
                       _lib.ptr(blk.pos_proj[0].weight), _lib.ptr(blk.pos_proj[0].bias), _lib.ptr(attn),
@@ -406,7 +434,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         abuf.zero_()
         sp._next_norm1 = net.backbone[1].norm1
         ms_ffn = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf)), 20)
-    alg = nw * (16 + 4 + 4 * nq + 5 * K) + (n_keys + n_q) * (4 * cg + 16) + n_q * 4 * cg
+    alg = nw * (16 + 16 * (nq + K)) + (n_keys + n_q) * 4 * cg + n_q * 4 * cg
     achieved = alg / (ms * 1e-3) / 1e9
     N, FF = x_in.shape[0], blk.linear1.out_features
     flop = 4.0 * C * FF * N
