@@ -188,25 +188,28 @@ int mssvt_window_plan_two(
 
 /* Work order for mssvt_block_attention_group: perm (cap) = the windows with >= 1 valid query,
  * sorted by descending nq_valid (cap) (one row of the plan's (3,cap) nq_valid: odd / even /
- * win1); num_active_dev = how many.  Heavy windows first keeps the persistent kernel's tail short. */
+ * win1); num_active_dev = how many; q_off (cap) = exclusive prefix sum of nq_valid in window
+ * order (= first compact query row of each window).  Heavy windows first keeps the persistent
+ * kernels' tails short. */
 int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int max_queries, int *perm,
-                     int *num_active_dev, void *stream);
+                     int *num_active_dev, int *q_off, void *stream);
 
 /* Fused attention of ONE head group of a Block (channels [c0, c0+Cg), Cg = heads*head_dim
  * <= 64): gathers + positional MLP + MixedScaleAttention (ref mssvt_backbone.py:260-295,
  * mssvt_utils.py:112-150) for every valid query of every window.  xhat (N,C) = norm1
  * output; qmeta (cap,nq,4) / kmeta (cap,K,4) / wcentre (cap,4): the plan kernel's resolved
  * metadata for the query list of this block's cbs_pattern and the key scale this group
- * attends to; perm / num_active_dev: the work order of mssvt_plan_order; Wq (Cg,Cg), Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) + biases = the module's
- * parameters; attn (cap*nq [+1],C): rows of valid query slots, columns [c0,c0+Cg) are
- * written.  work_counter: 128 device ints of scratch (windows are handed to wavefronts
- * through 8 sharded tickets; zeroed by the call).                                     */
+ * attends to; perm / num_active_dev / q_off: the work order of mssvt_plan_order; Wq (Cg,Cg),
+ * Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) + biases = the module's parameters; qbuf: scratch of
+ * (sum of nq_valid) x 4*ceil(heads/4)*Cg floats (<= num_voxels rows: query lists are
+ * disjoint) handed between the call's three launches (queries / keys+softmax / output);
+ * attn (cap*nq [+1],C): rows of valid query slots, columns [c0,c0+Cg) are written.   */
 int mssvt_block_attention_group(
     int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
-    const float *xhat, const int *num_active_dev, const int *perm, const float *qmeta,
-    const float *kmeta, const float *wcentre, const float *Wq, const float *bq, const float *Wkv, const float *bkv,
-    const float *Wo, const float *bo, const float *Wpos, const float *bpos, float *attn,
-    int *work_counter, void *stream);
+    const float *xhat, const int *num_active_dev, const int *perm, const int *q_off, const float *qmeta,
+    const float *kmeta, const float *wcentre, const float *Wq, const float *bq, const float *Wkv,
+    const float *bkv, const float *Wo, const float *bo, const float *Wpos, const float *bpos, float *qbuf,
+    float *attn, void *stream);
 
 /* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
  * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):

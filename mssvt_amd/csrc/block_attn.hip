@@ -4,34 +4,34 @@
 //   7 x K5 feature/coordinate gathers           (ref: mssvt_backbone.py:260-268)
 //   relative coordinates + positional MLP        (ref: :269-282, pos_proj :43-47)
 //   MixedScaleAttention.forward for group g      (ref: mssvt_utils.py:112-150)
-// and, in a second kernel, K9 + K10 + the interpolation weights + the per-sample
-// index_put scatter + the first residual        (ref: mssvt_backbone.py:298-338).
-// Nothing padded is written to HBM: per window only the valid query rows (x C/G
-// channels) leave the kernel.
+// and, in the table kernel at the end of this file, K9 + K10 + the interpolation weights
+// (ref: mssvt_backbone.py:298-311).  Nothing padded is written to HBM.
 //
-// Work decomposition.  Windows are tiny and ragged (160k-point scene: ~2 valid
-// queries and ~4 + ~20 unmasked keys per window) while the projection weights are
-// small (4 * Cg^2 floats per group), so the kernel is PERSISTENT: each workgroup
-// stages the group's weights in LDS once (64 KiB at Cg = 64), then its wavefronts
-// walk the windows, ONE WAVEFRONT PER WINDOW, lane = channel of the group's slice,
-// so every feature row is read as one coalesced 256-B segment.
+// Arithmetic is re-associated around the small side of the problem (#queries << #keys: ~2 valid
+// queries against ~4 + ~20 unmasked keys per window at 160k points): with q' = Wq x_q + b_q,
+//   score_h(k)  = scale q'_h . (Wk_h x_k + bk_h) = (scale Wk_h^T q'_h) . x_k + const_h
+//   out_h       = sum_k p_hk (Wv_h x_k + bv_h)   = Wv_h (sum_k p_hk x_k) + bv_h
+// (const_h cancels in the softmax, sum_k p_hk = 1): keys are never projected; per query 4 mat-vecs
+// of size Cg^2, per (query,key) pair 2*heads*Cg MACs.  Masked key slots (additive -100 in the
+// reference -> relative weight <= e^-100) are skipped; slot 0 of each scale is never masked, so
+// no key set is empty.  Differences to the reference are re-association only (~1e-6 relative).
 //
-// Arithmetic is re-associated around the small side of the problem (#queries <<
-// #keys): with q' = scale * (Wq x_q + b_q),
-//   score_h(k)  = q'_h . (Wk_h x_k + bk_h) = (Wk_h^T q'_h) . x_k + const_h
-//   out_h       = sum_k p_hk (Wv_h x_k + bv_h) = Wv_h (sum_k p_hk x_k) + bv_h
-// (const_h cancels in the softmax, sum_k p_hk = 1), i.e. keys are never projected:
-// per query 4 mat-vecs of size Cg^2, per (query,key) pair 2*heads*Cg MACs.  Masked
-// key slots (additive -100 in the reference -> relative weight <= e^-100) are
-// skipped; slot 0 of each scale is never masked, so no key set is empty.
-// Differences to the reference are re-association only (~1e-6 relative).
+// THREE PHASES, one launch each, all "one wavefront per window, lane = channel":
+//   A  queries : x_q = xhat row + pos. embedding; q' = Wq x_q + b; qt_h = scale Wk_h^T q'_h -> qbuf
+//   B  keys    : key tokens (xhat rows + pos. embedding) -> LDS; per query scores, softmax,
+//                xbar_h = sum_k p_hk x_k -> qbuf (in place of qt)
+//   C  output  : v = Wv xbar_{head} + bv; out = Wo v + bo -> attn rows
+// A single fused kernel (first version) needs all four Cg x Cg matrices (64 KiB) PLUS the key tile
+// (9 KiB per wave) in LDS: 7-8 waves per CU, every LDS / DPP / gather latency exposed (all pipes
+// ~25 % busy, 190 us per launch).  Split, A and C hold two matrices and ~1 KiB per wave, B holds no
+// weights at all: 16+ waves per CU each.  The price is one 4*HP*Cg-byte row per query and group
+// written by A, rewritten by B, read by C (qbuf, L2/MALL resident).
 //
-// LDS (floats): WqT | Wk | WvT | WoT (Cg^2 each) | bq bv bo | per wave:
-//   see k_block_attn below.
+// Windows are processed in the plan's work order (heaviest first, mssvt_plan_order), dealt
+// round-robin to the wavefronts of a persistent grid.
 #include "common.hip.h"
-#include <stdlib.h>
 
-#define ATTN_MAX_WAVES 8
+#define ATTN_MAX_WAVES 16
 
 struct AttnArgs {
     int C, c0, heads, hd;
@@ -40,34 +40,25 @@ struct AttnArgs {
     const float *xhat;
     const int *num_wins;  // number of entries of `perm` (windows with at least one valid query)
     const int *perm;      // work order: heavy windows first
+    const int *q_off;     // (cap) first compact query row of each window
     // per-slot metadata resolved by the plan kernel (window_plan.hip): (rel.x, rel.y, rel.z,
     // bits(global feature row or -1)); wcentre = window centre in metres
     const float4 *qmeta, *kmeta, *wcentre;
     const float *Wq, *bq, *Wkv, *bkv, *Wo, *bo, *Wp, *bp;
+    float *qbuf;  // (query rows, HP*CG): qt after phase A, xbar after phase B
     float *attn;
-    int *work_counter;  // 128 device ints (8 counters, one per 64-B line), zeroed per launch
     int wave_floats;
-    int dbg;
 };
-
-// cell centre in metres, one rounding per op like the reference's torch expression
-// (ref: with_coords, mssvt_backbone.py:132-137)
-__device__ __forceinline__ float centre_of(int idx, float cell, float lo) {
-    return __fadd_rn(__fmul_rn(__fadd_rn((float)idx, 0.5f), cell), lo);
-}
-
 
 // y[lane] = bias + sum_i W4[i/4][lane][i%4] * x[i]: the matrix is stored so that one
 // ds_read_b128 per lane brings 4 consecutive inputs' weights, x comes as a broadcast
-// ds_read_b128; CG/4 fully unrolled steps keep ~2*CG/4 LDS reads in flight.
+// ds_read_b128; 8 steps (16 reads) are issued back to back, THEN consumed (left alone hipcc
+// keeps only two reads in flight: s_waitcnt lgkmcnt(2) after every pair).
 template <int CG>
 __device__ __forceinline__ float matvec4(const float *W4, const float *x, int cl, float bias) {
     const float4 *w = reinterpret_cast<const float4 *>(W4) + cl;
     const float4 *xv = reinterpret_cast<const float4 *>(x);
     float a0 = bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    // 8 steps (16 ds_read_b128) are issued back to back, THEN consumed: with <= 2 waves per
-    // SIMD nobody else hides the ~100-cycle LDS latency, and left alone hipcc keeps only
-    // two reads in flight (s_waitcnt lgkmcnt(2) after every pair).
     constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
 #pragma unroll
     for (int b = 0; b < CG / 4; b += STEP) {
@@ -90,259 +81,224 @@ __device__ __forceinline__ float matvec4(const float *W4, const float *x, int cl
     return (a0 + a1) + (a2 + a3);
 }
 
-// CG = channels of the head group (compile time, multiple of 4, <= 64), HP = padded
-// head count (4 or 8).  LDS (floats): WqT4 | WkT4 | WvT4 | WoT4 (CG^2 each, the
-// [i/4][lane][i%4] layout above) | bq bv bo | per wave: keys[K][CG+4], xq[CG], qp[CG],
-// qt[HP][CG], pb[K][HP], xbar[HP][CG+4], vb[CG], krow[K].
-template <int CG, int HD, int HP>
-__global__ void __launch_bounds__(ATTN_MAX_WAVES *MSSVT_WAVE) k_block_attn(AttnArgs a) {
+// PHASE 0 = A (queries), 1 = B (keys / softmax), 2 = C (output projections)
+template <int CG, int HD, int HP, int PHASE>
+__global__ void __launch_bounds__(ATTN_MAX_WAVES *MSSVT_WAVE) k_attn_phase(AttnArgs a) {
     extern __shared__ float4 lds4[];
     float *lds = reinterpret_cast<float *>(lds4);
-    constexpr int CG2 = CG * CG, KS = CG + 4;
-    float *WqT = lds, *WkT = WqT + CG2, *WvT = WkT + CG2, *WoT = WvT + CG2;
-    float *bq = WoT + CG2, *bv = bq + CG, *bo = bv + CG;
+    constexpr int CG2 = CG * CG, KS = CG + 4, NH = CG / HD;
+    constexpr int QROW = HP * CG;  // floats per (query, group) row of qbuf
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
-    float *wbase = bo + CG + (size_t)wv * a.wave_floats;
-    float *keys = wbase;
-    float *xq = keys + a.K * KS;
-    float *qp = xq + CG;
-    float *qt = qp + CG;
-    float *pb = qt + HP * CG;
-    float *xbar = pb + a.K * HP;
-    float *vb = xq;  // xq is dead once q' exists; v lives in the same CG floats
-    float *krel = xbar + HP * KS;  // [K][3] key coordinates relative to the window centre
-    float *qrel = krel + 3 * a.K;  // [nq][3]
-    int *krow = reinterpret_cast<int *>(qrel + 3 * a.nq);
-    int *qrow = krow + a.K;
-    int *qslot = qrow + a.nq;
-
-    // ---- stage this group's weights once per persistent workgroup ---------------------
-    for (int e = threadIdx.x; e < CG2; e += blockDim.x) {
-        const int o = e / CG, i = e % CG;  // nn.Linear weight [o][i]
-        const int t_io = ((i >> 2) * CG + o) * 4 + (i & 3);  // input index i in the b128, lane = output o
-        const int t_oi = ((o >> 2) * CG + i) * 4 + (o & 3);  // summed index o in the b128, lane = i
-        WqT[t_io] = a.Wq[e];
-        WkT[t_oi] = a.Wkv[e];        // rows [0,CG) of to_kvs = K projection; folded onto the query
-        WvT[t_io] = a.Wkv[CG2 + e];  // rows [CG,2CG) = V projection
-        WoT[t_io] = a.Wo[e];
-    }
-    for (int e = threadIdx.x; e < CG; e += blockDim.x) {
-        bq[e] = a.bq[e];
-        bv[e] = a.bkv[CG + e];
-        bo[e] = a.bo[e];
-    }
-    __syncthreads();
-
     const bool act = lane < CG;
     const int cl = act ? lane : 0;
-    float wp[6], bpv;  // positional MLP row of this lane's channel (ref pos_proj.0: (C,6,1))
-#pragma unroll
-    for (int t = 0; t < 6; ++t) wp[t] = a.Wp[(size_t)(a.c0 + cl) * 6 + t];
-    bpv = a.bp[a.c0 + cl];
-    const int nw = *a.num_wins;
-    const bool two_heads = a.K <= 32;  // score pass: lane = key + 32 * (head & 1)
-    const int my_h = cl / a.hd;
-    const int heads = a.heads;
-
-    // Windows are handed out dynamically: their cost varies by >10x (0..20 queries x 1..32
-    // keys) and a static split leaves most waves idle at the end.  One counter would
-    // serialise (~88 tickets/us chip-wide), so there are 8 counters on separate cache
-    // lines; counter c owns the windows w == c (mod 8) and is drawn 2 windows at a time,
-    // first by the workgroups with blockIdx == c (mod 8) (one XCD under round-robin
-    // placement; speed only), then by anybody (work stealing).  The ticket for the NEXT
-    // pair is requested while the current pair is being processed, and the next window's
-    // metadata is loaded while the current window computes, so neither latency is exposed.
-    constexpr int TPA = 1;  // windows per ticket: 1 keeps the tail short (a wave holds <= 2 windows)
-    int shard = blockIdx.x & 7, tries = 0, pair_lo = 0, pair_pos = TPA, pend = 0;
-    bool have_pend = false;
-    auto ticket_async = [&]() {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(a.work_counter + 16 * shard, TPA);
-        return t;
-    };
-    auto next_window = [&]() -> int {
-        for (;;) {
-            if (pair_pos >= TPA) {
-                if (!have_pend) pend = ticket_async();
-                pair_lo = __builtin_amdgcn_readfirstlane(pend);  // waits for the atomic issued a pair ago
-                pend = ticket_async();
-                have_pend = true;
-                pair_pos = 0;
+    // ---- weights of this phase, once per persistent workgroup ------------------------------
+    float *W0 = lds, *W1 = W0 + CG2, *b0 = W1 + CG2, *b1 = b0 + CG;
+    float *wbase = (PHASE == 1 ? lds : b1 + CG) + (size_t)wv * a.wave_floats;
+    if (PHASE != 1) {
+        for (int e = threadIdx.x; e < CG2; e += blockDim.x) {
+            const int o = e / CG, i = e % CG;  // nn.Linear weight [o][i]
+            const int t_io = ((i >> 2) * CG + o) * 4 + (i & 3);  // input index i in the b128, lane = output o
+            const int t_oi = ((o >> 2) * CG + i) * 4 + (o & 3);  // summed index o in the b128, lane = i
+            if (PHASE == 0) {
+                W0[t_io] = a.Wq[e];   // q' = Wq x
+                W1[t_oi] = a.Wkv[e];  // rows [0,CG) of to_kvs = K projection, folded onto the query
+            } else {
+                W0[t_io] = a.Wkv[CG2 + e];  // rows [CG,2CG) = V projection
+                W1[t_io] = a.Wo[e];
             }
-            const int t = (pair_lo + pair_pos) * 8 + shard;
-            ++pair_pos;
-            if (t < nw) return a.perm[t];
-            if (++tries >= 8) return -1;  // every shard drained
-            shard = (shard + 1) & 7;
-            pair_pos = TPA;
-            have_pend = false;
         }
-    };
+        for (int e = threadIdx.x; e < CG; e += blockDim.x) {
+            b0[e] = PHASE == 0 ? a.bq[e] : a.bkv[CG + e];
+            b1[e] = PHASE == 0 ? 0.f : a.bo[e];
+        }
+        __syncthreads();
+    }
+    // static round-robin over the heaviest-first work order: wave i takes entries i, i + T, i + 2T ...
+    // (T = waves in the grid), i.e. one window of every weight tier -- as balanced as dynamic tickets
+    // without their atomics (a drained single-address ticket costs ~11 ns chip-wide, x 8192 waves)
+    const int n_act = *a.num_wins;
+    const int wstep = gridDim.x * (blockDim.x / MSSVT_WAVE);
+    const int wfirst = blockIdx.x * (blockDim.x / MSSVT_WAVE) + wv;
     const float4 none4 = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
-    // metadata of a window, one slot per lane (first 64 query slots; the rest is read on demand)
-    auto load_meta = [&](int w, float4 &km, float4 &qm, float4 &wc) {
-        km = lane < a.K ? a.kmeta[(size_t)w * a.K + lane] : none4;
-        qm = lane < a.nq ? a.qmeta[(size_t)w * a.nq + lane] : none4;
-        wc = a.wcentre[w];
-    };
 
-    int w = next_window();
-    float4 km_c = none4, qm_c = none4, wc_c = none4;
-    if (w >= 0) load_meta(w, km_c, qm_c, wc_c);
-    while (w >= 0) {
-        int w_next = -1;
-        float4 km_n = none4, qm_n = none4, wc_n = none4;
-        if (!(a.dbg & 1)) {
-            w_next = next_window();
-            if (w_next >= 0) load_meta(w_next, km_n, qm_n, wc_n);
-        }
-
-        const float cxm = wc_c.x, cym = wc_c.y, czm = wc_c.z;
-        const float posc = bpv + wp[3] * cxm + wp[4] * cym + wp[5] * czm;  // window part of the pos. MLP
-        // ---- unmasked keys / valid queries -> compact lists {row, rel. coordinates} ---------------
-        int nkv = 0, nqv = 0;
-        {
-            const int row = __builtin_bit_cast(int, km_c.w);
-            const bool ok = row >= 0;
-            const unsigned long long m = __ballot(ok);
-            if (ok) {
-                const int p = __popcll(m & ((1ull << lane) - 1ull));
-                krow[p] = row;
-                krel[3 * p + 0] = km_c.x;
-                krel[3 * p + 1] = km_c.y;
-                krel[3 * p + 2] = km_c.z;
-            }
-            nkv = __popcll(m);
-        }
-        for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {
-            const int qi = q0 + lane;
-            float4 qm = qm_c;
-            if (q0 > 0) qm = qi < a.nq ? a.qmeta[(size_t)w * a.nq + qi] : none4;
-            const int row = __builtin_bit_cast(int, qm.w);
-            const bool ok = row >= 0;
-            const unsigned long long m = __ballot(ok);
-            if (ok) {
-                const int p = nqv + __popcll(m & ((1ull << lane) - 1ull));
-                qrow[p] = row;
-                qslot[p] = qi;
-                qrel[3 * p + 0] = qm.x;
-                qrel[3 * p + 1] = qm.y;
-                qrel[3 * p + 2] = qm.z;
-            }
-            nqv += __popcll(m);
-        }
-        wave_lds_sync();
-        if (nqv > 0) {
-        // ---- key tokens: LN'd feature slice + positional embedding -> LDS; 16 row loads in
-        //      flight per step (one latency per 16 keys) --------------------------------------
-        for (int jb = 0; jb < nkv; jb += 16) {
-            // unconditional loads (index clamped to the last key): a guarded load makes hipcc
-            // branch around it and wait for each one in turn
-            float val[16];
+    if (PHASE == 0) {
+        // =========================== A: queries -> qt ==========================================
+        float *xq = wbase, *qp = xq + CG;
+        float *qrel = qp + CG;
+        int *qrow = reinterpret_cast<int *>(qrel + 3 * a.nq);
+        float wp[6], bpv;  // positional MLP row of this lane's channel (ref pos_proj.0: (C,6,1))
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int jc = min(jb + u, nkv - 1);
-                val[u] = a.xhat[(size_t)krow[jc] * a.C + a.c0 + cl];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int jj = jb + u, jc = min(jj, nkv - 1);
-                const float pos = fmaxf(posc + wp[0] * krel[3 * jc] + wp[1] * krel[3 * jc + 1] +
-                                        wp[2] * krel[3 * jc + 2], 0.0f);
-                if (jj < nkv && act) keys[jj * KS + lane] = val[u] + pos;
-            }
-        }
-        // ---- queries (their rows are fetched 4 at a time) ---------------------------------------
-        for (int qb = 0; qb < nqv; qb += 4) {
-          float qval[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-              qval[u] = a.xhat[(size_t)qrow[min(qb + u, nqv - 1)] * a.C + a.c0 + cl];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int qq = qb + u;
-            if (qq >= nqv) break;
-            const int qi = qslot[qq];
-            const float pos = fmaxf(posc + wp[0] * qrel[3 * qq] + wp[1] * qrel[3 * qq + 1] + wp[2] * qrel[3 * qq + 2], 0.0f);
-            if (act) xq[lane] = qval[u] + pos;
-            wave_lds_sync();
-            // q' = Wq xq + bq                       (lane = output channel)
-            // q' = Wq xq + bq                       (lane = output channel)
-            const float qpv = matvec4<CG>(WqT, xq, cl, bq[cl]);
-            if (act) qp[lane] = qpv;
-            wave_lds_sync();
-            // qt_h = scale * Wk_h^T q'_h            (lane = input channel; all heads, fully unrolled)
-            {
-                const float4 *wk = reinterpret_cast<const float4 *>(WkT) + cl;
-                const float4 *qv = reinterpret_cast<const float4 *>(qp);
-                float acc[CG / HD];
-#pragma unroll
-                for (int h = 0; h < CG / HD; ++h) acc[h] = 0.f;
-                constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
-#pragma unroll
-                for (int b = 0; b < CG / 4; b += STEP) {
-                    float4 wv4[STEP], q4[STEP];
-#pragma unroll
-                    for (int i = 0; i < STEP; ++i) {
-                        wv4[i] = wk[(b + i) * CG];
-                        q4[i] = qv[b + i];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < STEP; ++i) {
-                        const int h = ((b + i) * 4) / HD;  // compile-time after unrolling
-                        acc[h] = __builtin_fmaf(wv4[i].x, q4[i].x, acc[h]);
-                        acc[h] = __builtin_fmaf(wv4[i].y, q4[i].y, acc[h]);
-                        acc[h] = __builtin_fmaf(wv4[i].z, q4[i].z, acc[h]);
-                        acc[h] = __builtin_fmaf(wv4[i].w, q4[i].w, acc[h]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 6; ++t) wp[t] = a.Wp[(size_t)(a.c0 + cl) * 6 + t];
+        bpv = a.bp[a.c0 + cl];
+        for (int wi = wfirst; wi < n_act; wi += wstep) {
+            const int w = a.perm[wi];
+            const float4 wc = a.wcentre[w];
+            const float posc = bpv + wp[3] * wc.x + wp[4] * wc.y + wp[5] * wc.z;  // window part of the pos. MLP
+            int nqv = 0;
+            for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {
+                const int qi = q0 + lane;
+                const float4 qm = qi < a.nq ? a.qmeta[(size_t)w * a.nq + qi] : none4;
+                const int row = __builtin_bit_cast(int, qm.w);
+                const bool ok = row >= 0;
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int p = nqv + __popcll(m & ((1ull << lane) - 1ull));
+                    qrow[p] = row;
+                    qrel[3 * p + 0] = qm.x;
+                    qrel[3 * p + 1] = qm.y;
+                    qrel[3 * p + 2] = qm.z;
                 }
-                if (act) {
-#pragma unroll
-                    for (int h = 0; h < CG / HD; ++h) qt[h * CG + lane] = acc[h] * a.scale;
-                }
+                nqv += __popcll(m);
             }
             wave_lds_sync();
-            // scores + softmax                      (lane = key, two heads side by side when K <= 32)
-            {
-                const int j = two_heads ? (lane & 31) : lane;
-                const int npass = two_heads ? (heads + 1) / 2 : heads;
-                const float4 *kr = reinterpret_cast<const float4 *>(keys + (j < nkv ? j : 0) * KS);
-                for (int p = 0; p < npass; ++p) {
-                    const int h = two_heads ? 2 * p + (lane >> 5) : p;
-                    const bool on = j < nkv && h < heads;
-                    const float4 *qh = reinterpret_cast<const float4 *>(qt + (h < heads ? h : 0) * CG);
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            const size_t qbase = (size_t)a.q_off[w];
+            for (int qb = 0; qb < nqv; qb += 4) {
+                float qval[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)  // unconditional (clamped) loads: no branch + wait per element
+                    qval[u] = a.xhat[(size_t)qrow[min(qb + u, nqv - 1)] * a.C + a.c0 + cl];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int qq = qb + u;
+                    if (qq >= nqv) break;
+                    const float pos = fmaxf(posc + wp[0] * qrel[3 * qq] + wp[1] * qrel[3 * qq + 1] + wp[2] * qrel[3 * qq + 2], 0.0f);
+                    if (act) xq[lane] = qval[u] + pos;
+                    wave_lds_sync();
+                    const float qpv = matvec4<CG>(W0, xq, cl, b0[cl]);  // q' = Wq xq + bq (lane = output)
+                    if (act) qp[lane] = qpv;
+                    wave_lds_sync();
+                    // qt_h = scale * Wk_h^T q'_h   (lane = input channel; all heads, fully unrolled)
+                    const float4 *wk = reinterpret_cast<const float4 *>(W1) + cl;
+                    const float4 *qv = reinterpret_cast<const float4 *>(qp);
+                    float acc[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) acc[h] = 0.f;
                     constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
 #pragma unroll
                     for (int b = 0; b < CG / 4; b += STEP) {
-                        float4 kk[STEP], qq[STEP];
+                        float4 wv4[STEP], q4[STEP];
 #pragma unroll
                         for (int i = 0; i < STEP; ++i) {
-                            kk[i] = kr[b + i];
-                            qq[i] = qh[b + i];
+                            wv4[i] = wk[(b + i) * CG];
+                            q4[i] = qv[b + i];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < STEP; ++i) {
-                            s0 = __builtin_fmaf(kk[i].x, qq[i].x, s0);
-                            s1 = __builtin_fmaf(kk[i].y, qq[i].y, s1);
-                            s2 = __builtin_fmaf(kk[i].z, qq[i].z, s2);
-                            s3 = __builtin_fmaf(kk[i].w, qq[i].w, s3);
+                            const int h = ((b + i) * 4) / HD;  // compile-time after unrolling
+                            acc[h] = __builtin_fmaf(wv4[i].x, q4[i].x, acc[h]);
+                            acc[h] = __builtin_fmaf(wv4[i].y, q4[i].y, acc[h]);
+                            acc[h] = __builtin_fmaf(wv4[i].z, q4[i].z, acc[h]);
+                            acc[h] = __builtin_fmaf(wv4[i].w, q4[i].w, acc[h]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    const float sc = on ? (s0 + s1) + (s2 + s3) : -INFINITY;
-                    const float mx = two_heads ? half_max(sc) : wave_max(sc);
-                    const float e = on ? __expf(sc - mx) : 0.0f;
-                    const float sum = two_heads ? half_sum(e) : wave_sum(e);
-                    if (j < a.K && h < heads) pb[j * HP + h] = e * __builtin_amdgcn_rcpf(sum);  // 0 for unused rows
+                    if (act) {
+                        float *dst = a.qbuf + (qbase + qq) * QROW + lane;
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) dst[h * CG] = acc[h] * a.scale;
+                    }
+                    wave_lds_sync();  // xq / qp are rewritten by the next query
                 }
             }
             wave_lds_sync();
-            // xbar_h = sum_k p_hk x_k                (lane = channel, all heads at once, 8 keys per step)
+        }
+    } else if (PHASE == 1) {
+        // =========================== B: keys, scores, softmax, xbar =============================
+        float *keys = wbase;
+        float *qt = keys + a.K * KS;
+        float *pb = qt + HP * CG;
+        float *krel = pb + a.K * HP;
+        int *krow = reinterpret_cast<int *>(krel + 3 * a.K);
+        float wp[6], bpv;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) wp[t] = a.Wp[(size_t)(a.c0 + cl) * 6 + t];
+        bpv = a.bp[a.c0 + cl];
+        const bool two_heads = a.K <= 32;  // score pass: lane = key + 32 * (head & 1)
+        const int heads = a.heads;
+        for (int wi = wfirst; wi < n_act; wi += wstep) {
+            const int w = a.perm[wi];
+            const float4 wc = a.wcentre[w];
+            const float posc = bpv + wp[3] * wc.x + wp[4] * wc.y + wp[5] * wc.z;
+            int nkv = 0, nqv = 0;
             {
+                const float4 km = lane < a.K ? a.kmeta[(size_t)w * a.K + lane] : none4;
+                const int row = __builtin_bit_cast(int, km.w);
+                const bool ok = row >= 0;
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int p = __popcll(m & ((1ull << lane) - 1ull));
+                    krow[p] = row;
+                    krel[3 * p + 0] = km.x;
+                    krel[3 * p + 1] = km.y;
+                    krel[3 * p + 2] = km.z;
+                }
+                nkv = __popcll(m);
+            }
+            for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {  // only the count is needed here
+                const int qi = q0 + lane;
+                const float4 qm = qi < a.nq ? a.qmeta[(size_t)w * a.nq + qi] : none4;
+                nqv += __popcll(__ballot(__builtin_bit_cast(int, qm.w) >= 0));
+            }
+            wave_lds_sync();
+            // key tokens: LN'd feature slice + positional embedding -> LDS, 16 row loads in flight
+            for (int jb = 0; jb < nkv; jb += 16) {
+                float val[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) val[u] = a.xhat[(size_t)krow[min(jb + u, nkv - 1)] * a.C + a.c0 + cl];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int jj = jb + u, jc = min(jj, nkv - 1);
+                    const float pos = fmaxf(posc + wp[0] * krel[3 * jc] + wp[1] * krel[3 * jc + 1] + wp[2] * krel[3 * jc + 2], 0.0f);
+                    if (jj < nkv && act) keys[jj * KS + lane] = val[u] + pos;
+                }
+            }
+            const size_t qbase = (size_t)a.q_off[w];
+            for (int qq = 0; qq < nqv; ++qq) {
+                float *qrowp = a.qbuf + (qbase + qq) * QROW;
+                if (act) {
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) qt[h * CG + lane] = qrowp[h * CG + lane];
+                }
+                wave_lds_sync();
+                // scores + softmax   (lane = key, two heads side by side when K <= 32)
+                {
+                    const int j = two_heads ? (lane & 31) : lane;
+                    const int npass = two_heads ? (heads + 1) / 2 : heads;
+                    const float4 *kr = reinterpret_cast<const float4 *>(keys + (j < nkv ? j : 0) * KS);
+                    for (int p = 0; p < npass; ++p) {
+                        const int h = two_heads ? 2 * p + (lane >> 5) : p;
+                        const bool on = j < nkv && h < heads;
+                        const float4 *qh = reinterpret_cast<const float4 *>(qt + (h < heads ? h : 0) * CG);
+                        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                        constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
+#pragma unroll
+                        for (int b = 0; b < CG / 4; b += STEP) {
+                            float4 kk[STEP], qv4[STEP];
+#pragma unroll
+                            for (int i = 0; i < STEP; ++i) {
+                                kk[i] = kr[b + i];
+                                qv4[i] = qh[b + i];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < STEP; ++i) {
+                                s0 = __builtin_fmaf(kk[i].x, qv4[i].x, s0);
+                                s1 = __builtin_fmaf(kk[i].y, qv4[i].y, s1);
+                                s2 = __builtin_fmaf(kk[i].z, qv4[i].z, s2);
+                                s3 = __builtin_fmaf(kk[i].w, qv4[i].w, s3);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const float sc = on ? (s0 + s1) + (s2 + s3) : -INFINITY;
+                        const float mx = two_heads ? half_max(sc) : wave_max(sc);
+                        const float e = on ? __expf(sc - mx) : 0.0f;
+                        const float sum = two_heads ? half_sum(e) : wave_sum(e);
+                        if (j < a.K && h < heads) pb[j * HP + h] = e * __builtin_amdgcn_rcpf(sum);  // 0 for unused rows
+                    }
+                }
+                wave_lds_sync();
+                // xbar_h = sum_k p_hk x_k   (lane = channel, all heads at once, 8 keys per step)
                 float acc[HP];
 #pragma unroll
                 for (int h = 0; h < HP; ++h) acc[h] = 0.f;
@@ -377,71 +333,104 @@ __global__ void __launch_bounds__(ATTN_MAX_WAVES *MSSVT_WAVE) k_block_attn(AttnA
                 if (act) {
 #pragma unroll
                     for (int h = 0; h < HP; ++h)
-                        if (h < heads) xbar[h * KS + lane] = acc[h];
+                        if (h < NH) qrowp[h * CG + lane] = acc[h];  // xbar replaces qt in place
                 }
+                wave_lds_sync();  // qt / pb are rewritten by the next query
+            }
+            wave_lds_sync();  // keys / lists are rewritten for the next window
+        }
+    } else {
+        // =========================== C: v = Wv xbar + bv, out = Wo v + bo ========================
+        float *xbar = wbase;        // [HP][KS]
+        float *vb = xbar + HP * KS;  // [CG]
+        int *qslot = reinterpret_cast<int *>(vb + CG);
+        const int my_h = cl / HD;
+        for (int wi = wfirst; wi < n_act; wi += wstep) {
+            const int w = a.perm[wi];
+            int nqv = 0;
+            for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {
+                const int qi = q0 + lane;
+                const float4 qm = qi < a.nq ? a.qmeta[(size_t)w * a.nq + qi] : none4;
+                const bool ok = __builtin_bit_cast(int, qm.w) >= 0;
+                const unsigned long long m = __ballot(ok);
+                if (ok) qslot[nqv + __popcll(m & ((1ull << lane) - 1ull))] = qi;
+                nqv += __popcll(m);
             }
             wave_lds_sync();
-            // v = Wv xbar_{head(o)} + bv             (lane = output channel o)
-            const float vbv = matvec4<CG>(WvT, xbar + my_h * KS, cl, bv[cl]);
-            if (act) vb[lane] = vbv;
+            const size_t qbase = (size_t)a.q_off[w];
+            for (int qq = 0; qq < nqv; ++qq) {
+                const float *qrowp = a.qbuf + (qbase + qq) * QROW;
+                if (act) {
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) xbar[h * KS + lane] = qrowp[h * CG + lane];
+                }
+                wave_lds_sync();
+                const float vbv = matvec4<CG>(W0, xbar + my_h * KS, cl, b0[cl]);  // lane = output channel o
+                if (act) vb[lane] = vbv;
+                wave_lds_sync();
+                const float out = matvec4<CG>(W1, vb, cl, b1[cl]);
+                if (act) a.attn[((size_t)w * a.nq + qslot[qq]) * a.C + a.c0 + lane] = out;
+                wave_lds_sync();  // xbar / vb are rewritten by the next query
+            }
             wave_lds_sync();
-            // out = Wo v + bo
-            const float out = matvec4<CG>(WoT, vb, cl, bo[cl]);
-            if (act) a.attn[((size_t)w * a.nq + qi) * a.C + a.c0 + lane] = out;
-            wave_lds_sync();  // xq (= vb) is rewritten by the next query
-          }
         }
-        }  // nqv > 0
-        wave_lds_sync();  // keys / lists are rewritten for the next window
-        if (a.dbg & 1) {
-            w_next = next_window();
-            if (w_next >= 0) load_meta(w_next, km_n, qm_n, wc_n);
-        }
-        w = w_next;
-        km_c = km_n;
-        qm_c = qm_n;
-        wc_c = wc_n;
     }
 }
 
-template <int CG, int HD, int HP>
-static int launch_block_attn(AttnArgs &a, hipStream_t stream) {
+template <int CG, int HD, int HP, int PHASE>
+static int launch_attn_phase(AttnArgs a, hipStream_t stream) {
     constexpr int KS = CG + 4;
-    a.wave_floats = a.K * KS + 2 * CG + HP * CG + a.K * HP + HP * KS + 4 * a.K + 5 * a.nq;
+    size_t fixed = 0;
+    if (PHASE == 0) {
+        a.wave_floats = 2 * CG + 4 * a.nq;
+        fixed = (size_t)2 * CG * CG + 2 * CG;
+    } else if (PHASE == 1) {
+        a.wave_floats = a.K * KS + HP * CG + a.K * HP + 4 * a.K;
+        fixed = 0;
+    } else {
+        a.wave_floats = HP * KS + CG + a.nq;
+        fixed = (size_t)2 * CG * CG + 2 * CG;
+    }
     a.wave_floats = (a.wave_floats + 3) & ~3;  // keep every wave's region 16-B aligned
-    const size_t fixed = (size_t)4 * CG * CG + 3 * CG;
     int waves = ATTN_MAX_WAVES;
     while (waves > 1 && (fixed + (size_t)waves * a.wave_floats) * 4 > 160 * 1024) --waves;
     const size_t lds_bytes = (fixed + (size_t)waves * a.wave_floats) * 4;
     if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_attn<CG, HD, HP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_phase<CG, HD, HP, PHASE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    // persistent grid: as many workgroups per CU as the LDS footprint admits (256 CUs on MI355X)
+    // persistent grid: as many workgroups per CU as LDS and the 32-wave limit admit (256 CUs on MI355X)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    int per_cu = (int)((160 * 1024) / lds_bytes);
+    int per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+    if (per_cu > 32 / waves) per_cu = 32 / waves;
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
-    hipError_t me = hipMemsetAsync(a.work_counter, 0, 128 * sizeof(int), stream);
-    if (me != hipSuccess) return (int)me;
-    k_block_attn<CG, HD, HP><<<cus * per_cu, waves * MSSVT_WAVE, lds_bytes, stream>>>(a);
+    k_attn_phase<CG, HD, HP, PHASE><<<cus * per_cu, waves * MSSVT_WAVE, lds_bytes, stream>>>(a);
     return mssvt_launch_status();
+}
+
+template <int CG, int HD, int HP>
+static int launch_block_attn(AttnArgs &a, hipStream_t stream) {
+    int rc = launch_attn_phase<CG, HD, HP, 0>(a, stream);
+    if (rc) return rc;
+    rc = launch_attn_phase<CG, HD, HP, 1>(a, stream);
+    if (rc) return rc;
+    return launch_attn_phase<CG, HD, HP, 2>(a, stream);
 }
 
 extern "C" int mssvt_block_attention_group(
     int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
-    const float *xhat, const int *num_active_dev, const int *perm, const float *qmeta, const float *kmeta,
-    const float *wcentre, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
-    const float *Wpos, const float *bpos, float *attn, int *work_counter, void *stream) {
-    if (!work_counter) return MSSVT_E_BADARG;
-    if (!xhat || !num_active_dev || !perm || !qmeta || !kmeta || !wcentre || !Wq || !bq || !Wkv || !bkv || !Wo || !bo ||
-        !Wpos || !bpos || !attn || C <= 0 || Cg <= 0 || heads <= 0 || head_dim <= 0 || nq <= 0 ||
-        key_num_sample <= 0)
+    const float *xhat, const int *num_active_dev, const int *perm, const int *q_off, const float *qmeta,
+    const float *kmeta, const float *wcentre, const float *Wq, const float *bq, const float *Wkv,
+    const float *bkv, const float *Wo, const float *bo, const float *Wpos, const float *bpos, float *qbuf,
+    float *attn, void *stream) {
+    if (!xhat || !num_active_dev || !perm || !q_off || !qmeta || !kmeta || !wcentre || !Wq || !bq || !Wkv ||
+        !bkv || !Wo || !bo || !Wpos || !bpos || !qbuf || !attn || C <= 0 || Cg <= 0 || heads <= 0 ||
+        head_dim <= 0 || nq <= 0 || key_num_sample <= 0)
         return MSSVT_E_BADARG;
     if (Cg != heads * head_dim || c0 < 0 || c0 + Cg > C) return MSSVT_E_BADARG;
     // one channel per lane, heads aligned to 4-float LDS vectors, <= 8 heads per group
@@ -449,14 +438,14 @@ extern "C" int mssvt_block_attention_group(
     AttnArgs a;
     a.C = C; a.c0 = c0; a.heads = heads; a.hd = head_dim; a.scale = scale;
     a.nq = nq; a.K = key_num_sample;
-    a.xhat = xhat; a.num_wins = num_active_dev; a.perm = perm;
+    a.xhat = xhat; a.num_wins = num_active_dev; a.perm = perm; a.q_off = q_off;
     a.qmeta = reinterpret_cast<const float4 *>(qmeta);
     a.kmeta = reinterpret_cast<const float4 *>(kmeta);
     a.wcentre = reinterpret_cast<const float4 *>(wcentre);
     a.Wq = Wq; a.bq = bq; a.Wkv = Wkv; a.bkv = bkv; a.Wo = Wo; a.bo = bo; a.Wp = Wpos; a.bp = bpos;
+    a.qbuf = qbuf;
     a.attn = attn;
-    a.work_counter = work_counter;
-    a.dbg = getenv("MSSVT_DBG") ? atoi(getenv("MSSVT_DBG")) : 0;
+    a.wave_floats = 0;
     hipStream_t st = (hipStream_t)stream;
 #define MSSVT_ATTN_CASE(cg, hd)                                   \
     if (Cg == cg && head_dim == hd)                               \
@@ -474,6 +463,12 @@ extern "C" int mssvt_block_attention_group(
     MSSVT_ATTN_CASE(64, 32)
     return MSSVT_E_TOOLARGE;  // shape not instantiated: the caller falls back to the operator path
 #undef MSSVT_ATTN_CASE
+}
+
+// cell centre in metres, one rounding per op like the reference's torch expression
+// (ref: with_coords, mssvt_backbone.py:132-137)
+__device__ __forceinline__ float centre_of(int idx, float cell, float lo) {
+    return __fadd_rn(__fmul_rn(__fadd_rn((float)idx, 0.5f), cell), lo);
 }
 
 // ---------------------------------------------------------------------------------

@@ -470,35 +470,78 @@ extern "C" int mssvt_window_plan_two(
 // One workgroup: LDS histogram -> scan -> scatter (counting sort; order inside a bucket is
 // arbitrary, which is harmless: every window writes only its own rows).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_plan_order(const int *num_wins, const int *nq_valid, int max_key,
-                                                     int *perm, int *num_active) {
-    __shared__ int hist[260];
-    __shared__ int offs[260];
+#define PO_WAVES 16
+#define PO_KEYS 257
+__global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *num_wins, const int *nq_valid, int max_key,
+                                                                     int *perm, int *num_active, int *q_off) {
+    // per-wave histograms: copies sit PO_KEYS (odd) words apart -> different LDS banks, so the 16
+    // waves' atomics on the few populated keys proceed in parallel
+    __shared__ int hist[PO_WAVES][PO_KEYS];
+    __shared__ int key_base[PO_KEYS];
+    __shared__ int wave_q[PO_WAVES];
     const int nw = *num_wins;
-    for (int k = threadIdx.x; k < 260; k += 1024) hist[k] = 0;
+    const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    for (int k = threadIdx.x; k < PO_WAVES * PO_KEYS; k += blockDim.x) (&hist[0][0])[k] = 0;
     __syncthreads();
-    for (int w = threadIdx.x; w < nw; w += 1024) atomicAdd(&hist[min(nq_valid[w], max_key)], 1);
+    // each wave owns a contiguous run of windows: histogram + local exclusive scan of nq_valid
+    const int per_wave = (nw + PO_WAVES - 1) / PO_WAVES;
+    const int wb = min(wv * per_wave, nw), we = min(wb + per_wave, nw);
+    int carry = 0;
+    for (int base = wb; base < we; base += MSSVT_WAVE) {
+        const int w = base + lane;
+        const int v = w < we ? nq_valid[w] : 0;
+        if (w < we) atomicAdd(&hist[wv][min(v, max_key)], 1);
+        int incl = v;
+        for (int off = 1; off < MSSVT_WAVE; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (w < we) q_off[w] = carry + incl - v;
+        carry += __shfl(incl, MSSVT_WAVE - 1);
+    }
+    if (lane == 0) wave_q[wv] = carry;
+    __syncthreads();
+    int qbase = 0;
+    for (int i = 0; i < wv; ++i) qbase += wave_q[i];
+    for (int base = wb; base < we; base += MSSVT_WAVE) {
+        const int w = base + lane;
+        if (w < we) q_off[w] += qbase;  // written by this very lane above
+    }
+    // hist[wv][k] -> exclusive prefix over the waves (stable within a key), key totals -> key_base
+    if (threadIdx.x <= max_key) {
+        int run = 0;
+        for (int i = 0; i < PO_WAVES; ++i) {
+            const int c = hist[i][threadIdx.x];
+            hist[i][threadIdx.x] = run;
+            run += c;
+        }
+        key_base[threadIdx.x] = run;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
-        for (int k = max_key; k >= 1; --k) {
-            offs[k] = run;
-            run += hist[k];
+        for (int k = max_key; k >= 1; --k) {  // heaviest key first
+            const int c = key_base[k];
+            key_base[k] = run;
+            run += c;
         }
-        offs[0] = run;
         *num_active = run;
     }
     __syncthreads();
-    for (int w = threadIdx.x; w < nw; w += 1024) {
-        const int k = min(nq_valid[w], max_key);
-        if (k > 0) perm[atomicAdd(&offs[k], 1)] = w;
+    for (int base = wb; base < we; base += MSSVT_WAVE) {
+        const int w = base + lane;
+        if (w < we) {
+            const int k = min(nq_valid[w], max_key);
+            if (k > 0) perm[key_base[k] + atomicAdd(&hist[wv][k], 1)] = w;
+        }
     }
 }
 
 extern "C" int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int max_queries, int *perm,
-                                int *num_active_dev, void *stream) {
-    if (!num_wins_dev || !nq_valid || !perm || !num_active_dev || max_queries <= 0) return MSSVT_E_BADARG;
-    k_plan_order<<<1, 1024, 0, (hipStream_t)stream>>>(num_wins_dev, nq_valid, max_queries > 256 ? 256 : max_queries,
-                                                     perm, num_active_dev);
+                                int *num_active_dev, int *q_off, void *stream) {
+    if (!num_wins_dev || !nq_valid || !perm || !num_active_dev || !q_off || max_queries <= 0)
+        return MSSVT_E_BADARG;
+    k_plan_order<<<1, PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, nq_valid, max_queries > 256 ? 256 : max_queries,
+                                                     perm, num_active_dev, q_off);
     return mssvt_launch_status();
 }

@@ -91,7 +91,7 @@ def two_scale_plan(block, sp):
     p.k_ind = [torch.empty((cap, K), dtype=torch.int32, device=dev) for _ in range(2)]
     p.k_mask = [torch.empty((cap, K), dtype=torch.uint8, device=dev) for _ in range(2)]
     p.win_vstart = torch.empty(cap, dtype=torch.int32, device=dev)
-    p.ticket = torch.zeros(128, dtype=torch.int32, device=dev)
+    p.qbuf = None
     f4 = lambda n: torch.empty((cap, n, 4), dtype=torch.float32, device=dev)  # noqa: E731
     p.qmeta_odd, p.qmeta_even, p.qmeta_win1 = f4(n_o), f4(n_e), f4(n1)
     p.kmeta = [f4(K), f4(K)]
@@ -143,17 +143,28 @@ def _qmeta(block, p):
 
 @torch.no_grad()
 def _work_order(block, p, nq):
-    """(perm, num_active): windows with queries for this cbs_pattern, heaviest first."""
+    """(perm, num_active, q_off): windows with queries for this cbs_pattern, heaviest first, and the
+    first compact query row of every window."""
     pat = block.cbs_pattern
     if pat not in p.orders:
         dev = p.win_ind.device
         perm = torch.empty(p.cap, dtype=torch.int32, device=dev)
         n_act = torch.zeros(1, dtype=torch.int32, device=dev)
+        q_off = torch.empty(p.cap, dtype=torch.int32, device=dev)
         row = {1: 0, 0: 1, 2: 2}[pat]  # nq_valid rows: odd, even, win1
         _lib.call("mssvt_plan_order", _lib.ptr(p.num_wins), _lib.ptr(p.nq_valid[row]), _i(nq), _lib.ptr(perm),
-                  _lib.ptr(n_act), _lib.stream())
-        p.orders[pat] = (perm, n_act)
+                  _lib.ptr(n_act), _lib.ptr(q_off), _lib.stream())
+        p.orders[pat] = (perm, n_act, q_off)
     return p.orders[pat]
+
+
+def _query_scratch(p, num_voxels, ma, dev):
+    """qbuf of mssvt_block_attention_group: one row per valid query (query lists are disjoint, so at
+    most one per voxel), wide enough for the widest head group."""
+    width = max(4 * ((h + 3) // 4) * cg for h, cg in zip(ma.num_heads, ma.scale_dims))
+    if p.qbuf is None or p.qbuf.shape[0] < num_voxels or p.qbuf.shape[1] < width:
+        p.qbuf = torch.empty((max(num_voxels, 1), width), dtype=torch.float32, device=dev)
+    return p.qbuf
 
 
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
@@ -216,8 +227,9 @@ def block_forward(block, sp):
     p = two_scale_plan(block, sp)
     q_ind, nq, owner_q = _query(block, p)
     attn = _attn_buffer(p, nq, C, x_in.device)
-    perm, n_act = _work_order(block, p, nq)
+    perm, n_act, q_off = _work_order(block, p, nq)
     ma = block.ms_attn
+    qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
     wpos, bpos = block.pos_proj[0].weight, block.pos_proj[0].bias
     c0 = 0
@@ -225,10 +237,10 @@ def block_forward(block, sp):
         cg = ma.scale_dims[g]
         _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(heads), _i(ma.per_head_dim),
                   _f(ma.scale), _i(nq), _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(n_act), _lib.ptr(perm),
-                  _lib.ptr(_qmeta(block, p)), _lib.ptr(p.kmeta[g]), _lib.ptr(p.wcentre),
+                  _lib.ptr(q_off), _lib.ptr(_qmeta(block, p)), _lib.ptr(p.kmeta[g]), _lib.ptr(p.wcentre),
                   _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                   _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
-                  _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(attn), _lib.ptr(p.ticket), _lib.stream())
+                  _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(qbuf), _lib.ptr(attn), _lib.stream())
         c0 += cg
     interp = 1 if block.use_feature_interpolation else 0
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
@@ -405,8 +417,9 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         xhat = F.layer_norm(x_in, (C,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         q_ind, nq, _ = _query(blk, p)
         attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
-        perm, n_act = _work_order(blk, p, nq)
+        perm, n_act, q_off = _work_order(blk, p, nq)
         ma = blk.ms_attn
+        qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
         g = 1
         cg, c0 = ma.scale_dims[g], ma.scale_dims[0]
         vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
@@ -414,12 +427,12 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         def launch():
             _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(ma.num_heads[g]),
                       _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(blk.key_num_sample), _lib.ptr(xhat),
-                      _lib.ptr(n_act), _lib.ptr(perm), _lib.ptr(_qmeta(blk, p)), _lib.ptr(p.kmeta[g]),
+                      _lib.ptr(n_act), _lib.ptr(perm), _lib.ptr(q_off), _lib.ptr(_qmeta(blk, p)), _lib.ptr(p.kmeta[g]),
                       _lib.ptr(p.wcentre),
                       _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                       _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
-                      _lib.ptr(blk.pos_proj[0].weight), _lib.ptr(blk.pos_proj[0].bias), _lib.ptr(attn),
-                      _lib.ptr(p.ticket), _lib.stream())
+                      _lib.ptr(blk.pos_proj[0].weight), _lib.ptr(blk.pos_proj[0].bias), _lib.ptr(qbuf),
+                      _lib.ptr(attn), _lib.stream())
 
         ms = event_time_ms(launch, 20)
         nw = int(p.num_wins.item())
