@@ -186,30 +186,37 @@ int mssvt_window_plan_two(
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
     float *kmeta2, float *wcentre, int *nq_valid, void *stream);
 
-/* Work order for mssvt_block_attention_group: perm (cap) = the windows with >= 1 valid query,
- * sorted by descending nq_valid (cap) (one row of the plan's (3,cap) nq_valid: odd / even /
- * win1); num_active_dev = how many; q_off (cap) = exclusive prefix sum of nq_valid in window
- * order (= first compact query row of each window).  Heavy windows first keeps the persistent
- * kernels' tails short. */
-int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int max_queries, int *perm,
-                     int *num_active_dev, int *q_off, void *stream);
+/* Work order and compact query rows for mssvt_block_attention_group, from one row of the
+ * plan's (3,cap) nq_valid (odd / even / win1) and that list's qmeta (cap,nq,4):
+ *   perm (cap)          the windows with >= 1 valid query, sorted by descending nq_valid;
+ *   num_active_dev      how many;
+ *   q_off (cap)         exclusive prefix sum of nq_valid in window order = first compact
+ *                       query row of each window;
+ *   qrow_meta (rows,4)  per compact row: the slot's qmeta entry (rel.xyz, bits(feature row));
+ *   qrow_src (rows,2)   per compact row: (window, attn row = window * nq + slot);
+ *   num_rows_dev        total rows (<= num_voxels: the query lists of one pattern are
+ *                       disjoint); rows beyond row_capacity are dropped.                  */
+int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int nq, const float *qmeta,
+                     int win_capacity, int row_capacity, int *perm, int *num_active_dev, int *q_off,
+                     float *qrow_meta, int *qrow_src, int *num_rows_dev, void *stream);
 
 /* Fused attention of ONE head group of a Block (channels [c0, c0+Cg), Cg = heads*head_dim
  * <= 64): gathers + positional MLP + MixedScaleAttention (ref mssvt_backbone.py:260-295,
  * mssvt_utils.py:112-150) for every valid query of every window.  xhat (N,C) = norm1
- * output; qmeta (cap,nq,4) / kmeta (cap,K,4) / wcentre (cap,4): the plan kernel's resolved
- * metadata for the query list of this block's cbs_pattern and the key scale this group
- * attends to; perm / num_active_dev / q_off: the work order of mssvt_plan_order; Wq (Cg,Cg),
- * Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) + biases = the module's parameters; qbuf: scratch of
- * (sum of nq_valid) x 4*ceil(heads/4)*Cg floats (<= num_voxels rows: query lists are
- * disjoint) handed between the call's three launches (queries / keys+softmax / output);
- * attn (cap*nq [+1],C): rows of valid query slots, columns [c0,c0+Cg) are written.   */
+ * output; perm / num_active_dev / q_off / qrow_meta / qrow_src / num_rows_dev: from
+ * mssvt_plan_order for the query list of this block's cbs_pattern, nq_valid = the row it
+ * was built from; kmeta (cap,K,4) / wcentre (cap,4): the plan kernel's resolved metadata of
+ * the key scale this group attends to; Wq (Cg,Cg), Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) +
+ * biases = the module's parameters; qbuf: scratch of row_capacity x 4*ceil(heads/4)*Cg
+ * floats handed between the call's three launches (queries / keys+softmax / output);
+ * attn (cap*nq [+1],C): rows of valid query slots, columns [c0,c0+Cg) are written.
+ * C and c0 must be multiples of 4.                                                       */
 int mssvt_block_attention_group(
     int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
-    const float *xhat, const int *num_active_dev, const int *perm, const int *q_off, const float *qmeta,
-    const float *kmeta, const float *wcentre, const float *Wq, const float *bq, const float *Wkv,
-    const float *bkv, const float *Wo, const float *bo, const float *Wpos, const float *bpos, float *qbuf,
-    float *attn, void *stream);
+    const float *xhat, const int *num_active_dev, const int *perm, const int *q_off, const int *nq_valid,
+    const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src, const float *kmeta,
+    const float *wcentre, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo,
+    const float *bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream);
 
 /* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
  * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):

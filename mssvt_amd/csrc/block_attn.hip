@@ -16,22 +16,35 @@
 // reference -> relative weight <= e^-100) are skipped; slot 0 of each scale is never masked, so
 // no key set is empty.  Differences to the reference are re-association only (~1e-6 relative).
 //
-// THREE PHASES, one launch each, all "one wavefront per window, lane = channel":
-//   A  queries : x_q = xhat row + pos. embedding; q' = Wq x_q + b; qt_h = scale Wk_h^T q'_h -> qbuf
-//   B  keys    : key tokens (xhat rows + pos. embedding) -> LDS; per query scores, softmax,
-//                xbar_h = sum_k p_hk x_k -> qbuf (in place of qt)
-//   C  output  : v = Wv xbar_{head} + bv; out = Wo v + bo -> attn rows
+// THREE LAUNCHES:
+//   A  k_attn_q  : rows = the compact list of valid queries (mssvt_plan_order), 16 per wavefront:
+//                  x_q = xhat row + pos. embedding; Q' = X_q Wq^T + b; Qt_h = scale Q'_h Wk_h -> qbuf
+//   B  k_attn_kv : one wavefront per window, lane = channel: key tokens (xhat rows + pos. embedding)
+//                  -> LDS; per query scores, softmax, xbar_h = sum_k p_hk x_k -> qbuf (in place of Qt)
+//   C  k_attn_o  : rows again: V = Xbar_{head} Wv^T + bv; out = V Wo^T + bo -> attn rows
 // A single fused kernel (first version) needs all four Cg x Cg matrices (64 KiB) PLUS the key tile
 // (9 KiB per wave) in LDS: 7-8 waves per CU, every LDS / DPP / gather latency exposed (all pipes
-// ~25 % busy, 190 us per launch).  Split, A and C hold two matrices and ~1 KiB per wave, B holds no
-// weights at all: 16+ waves per CU each.  The price is one 4*HP*Cg-byte row per query and group
-// written by A, rewritten by B, read by C (qbuf, L2/MALL resident).
+// ~25 % busy, 190 us per launch); and a per-query mat-vec re-reads a whole matrix from LDS per query.
+// Split, B holds no weights at all (14 waves per CU), and A / C are plain row-tiled GEMMs on the fp32
+// matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products, fp32 accumulation): weights are read
+// from LDS once per 16 queries.  The price is one 4*HP*Cg-byte row per query and group written by A,
+// rewritten by B, read by C (qbuf, L2/MALL resident).
 //
-// Windows are processed in the plan's work order (heaviest first, mssvt_plan_order), dealt
-// round-robin to the wavefronts of a persistent grid.
+// MFMA mapping of A and C (lane l: r = l % 16 = query row of the tile, g = l / 16): every GEMM is
+// computed TRANSPOSED, D^T[out][row] = sum_k W[out][k] X[row][k], A operand = weight rows (one
+// ds_read_b128 of the natural row-major matrix feeds 4 k-steps: k-step (S, j) <-> column 16 S + 4 g + j),
+// B operand = the activations.  The accumulator layout (lane (r, g), register i = output 4 g + i of
+// the 16-tile) then IS the B operand of the next GEMM, step by step, with no shuffle or LDS round
+// trip; and it is 4 consecutive channels of one row = one 16-byte global load / store.
+// LDS rows are padded to Cg + 4 floats: the 16 lanes of a b128 phase hit 16 x 4 distinct banks.
+//
+// Windows (B) are processed in the plan's work order (heaviest first), dealt round-robin to the
+// wavefronts of a persistent grid.
 #include "common.hip.h"
 
-#define ATTN_MAX_WAVES 16
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ATTN_ROW_WAVES 4  // waves per workgroup of the row-tiled launches
 
 struct AttnArgs {
     int C, c0, heads, hd;
@@ -41,415 +54,451 @@ struct AttnArgs {
     const int *num_wins;  // number of entries of `perm` (windows with at least one valid query)
     const int *perm;      // work order: heavy windows first
     const int *q_off;     // (cap) first compact query row of each window
-    // per-slot metadata resolved by the plan kernel (window_plan.hip): (rel.x, rel.y, rel.z,
+    const int *nq_valid;  // (cap) valid queries of each window
+    // compact query rows (mssvt_plan_order): (rel.x, rel.y, rel.z, bits(global feature row));
+    // (window, attn row)
+    const int *num_rows;
+    const float4 *qrow_meta;
+    const int2 *qrow_src;
+    // per-key-slot metadata resolved by the plan kernel (window_plan.hip): (rel.x, rel.y, rel.z,
     // bits(global feature row or -1)); wcentre = window centre in metres
-    const float4 *qmeta, *kmeta, *wcentre;
+    const float4 *kmeta, *wcentre;
     const float *Wq, *bq, *Wkv, *bkv, *Wo, *bo, *Wp, *bp;
-    float *qbuf;  // (query rows, HP*CG): qt after phase A, xbar after phase B
+    float *qbuf;  // (query rows, HP*CG): Qt after A, Xbar after B
     float *attn;
-    int wave_floats;
 };
 
-// y[lane] = bias + sum_i W4[i/4][lane][i%4] * x[i]: the matrix is stored so that one
-// ds_read_b128 per lane brings 4 consecutive inputs' weights, x comes as a broadcast
-// ds_read_b128; 8 steps (16 reads) are issued back to back, THEN consumed (left alone hipcc
-// keeps only two reads in flight: s_waitcnt lgkmcnt(2) after every pair).
-template <int CG>
-__device__ __forceinline__ float matvec4(const float *W4, const float *x, int cl, float bias) {
-    const float4 *w = reinterpret_cast<const float4 *>(W4) + cl;
-    const float4 *xv = reinterpret_cast<const float4 *>(x);
-    float a0 = bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
-#pragma unroll
-    for (int b = 0; b < CG / 4; b += STEP) {
-        float4 wv[STEP], xx[STEP];
-#pragma unroll
-        for (int i = 0; i < STEP; ++i) {
-            wv[i] = w[(b + i) * CG];
-            xx[i] = xv[b + i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < STEP; ++i) {
-            a0 = __builtin_fmaf(wv[i].x, xx[i].x, a0);
-            a1 = __builtin_fmaf(wv[i].y, xx[i].y, a1);
-            a2 = __builtin_fmaf(wv[i].z, xx[i].z, a2);
-            a3 = __builtin_fmaf(wv[i].w, xx[i].w, a3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return (a0 + a1) + (a2 + a3);
-}
+#define MFMA4(acc, av, bv)                                                    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
 
-// PHASE 0 = A (queries), 1 = B (keys / softmax), 2 = C (output projections)
-template <int CG, int HD, int HP, int PHASE>
-__global__ void __launch_bounds__(ATTN_MAX_WAVES *MSSVT_WAVE) k_attn_phase(AttnArgs a) {
+// ---- A: queries -> Qt --------------------------------------------------------------------------
+template <int CG, int HD, int HP>
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnArgs a) {
+    constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, LS = CGP + 4, NH = CG / HD, QROW = HP * CG;
     extern __shared__ float4 lds4[];
-    float *lds = reinterpret_cast<float *>(lds4);
-    constexpr int CG2 = CG * CG, KS = CG + 4, NH = CG / HD;
-    constexpr int QROW = HP * CG;  // floats per (query, group) row of qbuf
-    const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
-    const bool act = lane < CG;
-    const int cl = act ? lane : 0;
-    // ---- weights of this phase, once per persistent workgroup ------------------------------
-    float *W0 = lds, *W1 = W0 + CG2, *b0 = W1 + CG2, *b1 = b0 + CG;
-    float *wbase = (PHASE == 1 ? lds : b1 + CG) + (size_t)wv * a.wave_floats;
-    if (PHASE != 1) {
-        for (int e = threadIdx.x; e < CG2; e += blockDim.x) {
-            const int o = e / CG, i = e % CG;  // nn.Linear weight [o][i]
-            const int t_io = ((i >> 2) * CG + o) * 4 + (i & 3);  // input index i in the b128, lane = output o
-            const int t_oi = ((o >> 2) * CG + i) * 4 + (o & 3);  // summed index o in the b128, lane = i
-            if (PHASE == 0) {
-                W0[t_io] = a.Wq[e];   // q' = Wq x
-                W1[t_oi] = a.Wkv[e];  // rows [0,CG) of to_kvs = K projection, folded onto the query
-            } else {
-                W0[t_io] = a.Wkv[CG2 + e];  // rows [CG,2CG) = V projection
-                W1[t_io] = a.Wo[e];
+    float *Wq_l = reinterpret_cast<float *>(lds4);  // [o][c]   natural nn.Linear layout, padded rows
+    float *WkT_l = Wq_l + CGP * LS;                 // [c][o] = Wk[o][c]
+    float *Wp_l = WkT_l + CGP * LS;                 // [c][8] = pos_proj row (6 weights, bias, 0)
+    float *bq_l = Wp_l + CGP * 8;                   // [o]
+    for (int e = threadIdx.x; e < CGP * CGP; e += blockDim.x) {
+        const int o = e / CGP, c = e % CGP;
+        const bool in = o < CG && c < CG;
+        Wq_l[o * LS + c] = in ? a.Wq[o * CG + c] : 0.f;
+        WkT_l[c * LS + o] = in ? a.Wkv[o * CG + c] : 0.f;  // rows [0,CG) of to_kvs = K projection
+    }
+    for (int e = threadIdx.x; e < CGP * 8; e += blockDim.x) {
+        const int c = e >> 3, t = e & 7;
+        Wp_l[e] = c < CG ? (t < 6 ? a.Wp[(size_t)(a.c0 + c) * 6 + t] : (t == 6 ? a.bp[a.c0 + c] : 0.f)) : 0.f;
+    }
+    for (int e = threadIdx.x; e < CGP; e += blockDim.x) bq_l[e] = e < CG ? a.bq[e] : 0.f;
+    __syncthreads();
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    for (int tile = blockIdx.x * ATTN_ROW_WAVES + wv; tile < tiles; tile += gridDim.x * ATTN_ROW_WAVES) {
+        const int row = min(tile * 16 + r, rows - 1);
+        const float4 rm = a.qrow_meta[row];
+        const int2 src = a.qrow_src[row];
+        const float4 wc = a.wcentre[src.x];
+        const float *xrow = a.xhat + (size_t)__builtin_bit_cast(int, rm.w) * a.C + a.c0;
+        // B operand of GEMM1: this lane's 4 channels 16 S + 4 g + j of its query token
+        f32x4 xq[NT];
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+            const int c = 16 * S + 4 * g;
+            const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xrow + c)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[S] = f32x4{v.x, v.y, v.z, v.w};
+        }
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(Wp_l + (16 * S + 4 * g + j) * 8);
+                const float4 p1 = *reinterpret_cast<const float4 *>(Wp_l + (16 * S + 4 * g + j) * 8 + 4);
+                const float posc = p1.z + p0.w * wc.x + p1.x * wc.y + p1.y * wc.z;  // window part of the pos. MLP
+                xq[S][j] += fmaxf(posc + p0.x * rm.x + p0.y * rm.y + p0.z * rm.z, 0.0f);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later steps from being hoisted (VGPRs)
+        }
+        // GEMM1^T: Q'^T[o][row] = sum_c Wq[o][c] xq[row][c] + bq[o]
+        f32x4 qp[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 b = *reinterpret_cast<const float4 *>(bq_l + 16 * t + 4 * g);
+            qp[t] = f32x4{b.x, b.y, b.z, b.w};
+        }
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+            float4 w[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const float4 *>(Wq_l + (16 * t + r) * LS + 16 * S + 4 * g);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) MFMA4(qp[t], w[t].x, xq[S][0]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) MFMA4(qp[t], w[t].y, xq[S][1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) MFMA4(qp[t], w[t].z, xq[S][2]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) MFMA4(qp[t], w[t].w, xq[S][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // GEMM2^T per head: Qt_h^T[c][row] = scale sum_{o in head h} Wk[o][c] Q'[row][o]
+        const bool row_ok = tile * 16 + r < rows;
+        float *dst = a.qbuf + (size_t)(tile * 16 + r) * QROW;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (16 * t >= (h + 1) * HD || 16 * (t + 1) <= h * HD) continue;  // tile outside this head
+                // 4 consecutive outputs 16 t + 4 g + i of Q' belong to one head (HD % 4 == 0)
+                const bool mine = (HD % 16 == 0) || (16 * t + 4 * g) / HD == h;
+                const f32x4 bq4 = mine ? qp[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+                float4 w[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) w[u] = *reinterpret_cast<const float4 *>(WkT_l + (16 * u + r) * LS + 16 * t + 4 * g);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) MFMA4(acc[u], w[u].x, bq4[0]);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) MFMA4(acc[u], w[u].y, bq4[1]);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) MFMA4(acc[u], w[u].z, bq4[2]);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) MFMA4(acc[u], w[u].w, bq4[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int c = 16 * u + 4 * g;
+                if (row_ok && (CGP == CG || c < CG))
+                    *reinterpret_cast<float4 *>(dst + h * CG + c) =
+                        make_float4(acc[u][0] * a.scale, acc[u][1] * a.scale, acc[u][2] * a.scale, acc[u][3] * a.scale);
             }
         }
-        for (int e = threadIdx.x; e < CG; e += blockDim.x) {
-            b0[e] = PHASE == 0 ? a.bq[e] : a.bkv[CG + e];
-            b1[e] = PHASE == 0 ? 0.f : a.bo[e];
+    }
+}
+
+// ---- C: Xbar -> attention output rows ----------------------------------------------------------
+template <int CG, int HD, int HP>
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnArgs a) {
+    constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, LS = CGP + 4, NH = CG / HD, QROW = HP * CG;
+    extern __shared__ float4 lds4[];
+    float *Wv_l = reinterpret_cast<float *>(lds4);  // [o][c]
+    float *Wo_l = Wv_l + CGP * LS;                  // [p][o]
+    float *bv_l = Wo_l + CGP * LS, *bo_l = bv_l + CGP;
+    for (int e = threadIdx.x; e < CGP * CGP; e += blockDim.x) {
+        const int o = e / CGP, c = e % CGP;
+        const bool in = o < CG && c < CG;
+        Wv_l[o * LS + c] = in ? a.Wkv[(size_t)(CG + o) * CG + c] : 0.f;  // rows [CG,2CG) of to_kvs = V projection
+        Wo_l[o * LS + c] = in ? a.Wo[o * CG + c] : 0.f;
+    }
+    for (int e = threadIdx.x; e < CGP; e += blockDim.x) {
+        bv_l[e] = e < CG ? a.bkv[CG + e] : 0.f;
+        bo_l[e] = e < CG ? a.bo[e] : 0.f;
+    }
+    __syncthreads();
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    for (int tile = blockIdx.x * ATTN_ROW_WAVES + wv; tile < tiles; tile += gridDim.x * ATTN_ROW_WAVES) {
+        const int row = min(tile * 16 + r, rows - 1);
+        const bool row_ok = tile * 16 + r < rows;
+        const int dest = a.qrow_src[row].y;
+        const float *xb = a.qbuf + (size_t)row * QROW;
+        // GEMM3^T: V^T[o][row] = sum_c Wv[o][c] Xbar_{head(o)}[row][c] + bv[o]
+        f32x4 v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 b = *reinterpret_cast<const float4 *>(bv_l + 16 * t + 4 * g);
+            v[t] = f32x4{b.x, b.y, b.z, b.w};
         }
-        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 x[NT];
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                const int c = 16 * S + 4 * g;
+                const float4 t4 = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xb + h * CG + c)
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[S] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (16 * t >= (h + 1) * HD || 16 * (t + 1) <= h * HD) continue;
+                // A rows o = 16 t + r outside head h contribute nothing to this head's pass
+                const bool mine = (HD % 16 == 0) || (16 * t + r) / HD == h;
+#pragma unroll
+                for (int S = 0; S < NT; ++S) {
+                    float4 w = *reinterpret_cast<const float4 *>(Wv_l + (16 * t + r) * LS + 16 * S + 4 * g);
+                    if (!mine) w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    MFMA4(v[t], w.x, x[S][0]);
+                    MFMA4(v[t], w.y, x[S][1]);
+                    MFMA4(v[t], w.z, x[S][2]);
+                    MFMA4(v[t], w.w, x[S][3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // GEMM4^T: out^T[p][row] = sum_o Wo[p][o] V[row][o] + bo[p]
+        f32x4 out[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 b = *reinterpret_cast<const float4 *>(bo_l + 16 * u + 4 * g);
+            out[u] = f32x4{b.x, b.y, b.z, b.w};
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float4 w[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) w[u] = *reinterpret_cast<const float4 *>(Wo_l + (16 * u + r) * LS + 16 * t + 4 * g);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) MFMA4(out[u], w[u].x, v[t][0]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) MFMA4(out[u], w[u].y, v[t][1]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) MFMA4(out[u], w[u].z, v[t][2]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) MFMA4(out[u], w[u].w, v[t][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float *dst = a.attn + (size_t)dest * a.C + a.c0;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int c = 16 * u + 4 * g;
+            if (row_ok && (CGP == CG || c < CG))
+                *reinterpret_cast<float4 *>(dst + c) = make_float4(out[u][0], out[u][1], out[u][2], out[u][3]);
+        }
+    }
+}
+
+// ---- B: keys, scores, softmax, xbar (one wavefront per window, everything in registers) -----------
+// Per window the key tokens T[key][c] = xhat row + relu(pos. MLP) are held in registers in BOTH
+// matrix-core operand layouts (lane l: a = l % 16, g = l / 16):
+//   T1: lane (a = key % 16, g)  channels 16 S + 4 g + j   -> A operand of  S = T Qt^T   (reduce over c)
+//   T2: lane (a = c % 16,  g)   keys     16 t + 4 g + i   -> A operand of  Xbar^T = T^T P (reduce over keys)
+// The positional MLP itself is a K = 4 product (rel.x, rel.y, rel.z, 1) x (wp0, wp1, wp2, window part)
+// = one MFMA per 16 x 16 tile, computed once per layout (operands swapped).  Queries go through in
+// passes of 16 / HP (column n = query * HP + head); the softmax over keys is 8 in-lane values + two
+// cross-row shuffles, and the normalised P accumulator IS the B operand of the second product.
+// Key slots are not compacted: masked slots score -inf (the reference adds -100: weight <= e^-100).
+// No LDS, no barriers: ~130 VGPRs, 3-4 waves per SIMD.
+template <int CG, int HD, int HP, int KT>
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnArgs a) {
+    constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, NH = CG / HD, QROW = HP * CG, QPP = 16 / HP;
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    // positional MLP operand of this lane (channel 16 u + la, input g): constant part + window part
+    float wconst[NT], w3[NT], w4[NT], w5[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int c = 16 * u + la;
+        const bool in = CGP == CG || c < CG;
+        const float *wp = a.Wp + (size_t)(a.c0 + (in ? c : 0)) * 6;
+        wconst[u] = in ? (g < 3 ? wp[g] : a.bp[a.c0 + c]) : 0.f;
+        w3[u] = in && g == 3 ? wp[3] : 0.f;
+        w4[u] = in && g == 3 ? wp[4] : 0.f;
+        w5[u] = in && g == 3 ? wp[5] : 0.f;
     }
     // static round-robin over the heaviest-first work order: wave i takes entries i, i + T, i + 2T ...
     // (T = waves in the grid), i.e. one window of every weight tier -- as balanced as dynamic tickets
     // without their atomics (a drained single-address ticket costs ~11 ns chip-wide, x 8192 waves)
     const int n_act = *a.num_wins;
-    const int wstep = gridDim.x * (blockDim.x / MSSVT_WAVE);
-    const int wfirst = blockIdx.x * (blockDim.x / MSSVT_WAVE) + wv;
-    const float4 none4 = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
-
-    if (PHASE == 0) {
-        // =========================== A: queries -> qt ==========================================
-        float *xq = wbase, *qp = xq + CG;
-        float *qrel = qp + CG;
-        int *qrow = reinterpret_cast<int *>(qrel + 3 * a.nq);
-        float wp[6], bpv;  // positional MLP row of this lane's channel (ref pos_proj.0: (C,6,1))
+    const int wstep = gridDim.x * ATTN_ROW_WAVES;
+    const int K = a.K;
+    const int *kmeta_i = reinterpret_cast<const int *>(a.kmeta);
+    for (int wi = blockIdx.x * ATTN_ROW_WAVES + wv; wi < n_act; wi += wstep) {
+        const int w = a.perm[wi];
+        const float4 wc = a.wcentre[w];
+        const int nqv = a.nq_valid[w];
+        const size_t qbase = (size_t)a.q_off[w];
+        // key metadata in both layouts
+        float rel[KT];   // pos. MLP input g of key 16 t + la (1 for g = 3)
+        int row1[KT];    // feature row of key 16 t + la (0 when masked)
+        int row2[KT][4];  // feature row of key 16 t + 4 g + i, -1 when masked
 #pragma unroll
-        for (int t = 0; t < 6; ++t) wp[t] = a.Wp[(size_t)(a.c0 + cl) * 6 + t];
-        bpv = a.bp[a.c0 + cl];
-        for (int wi = wfirst; wi < n_act; wi += wstep) {
-            const int w = a.perm[wi];
-            const float4 wc = a.wcentre[w];
-            const float posc = bpv + wp[3] * wc.x + wp[4] * wc.y + wp[5] * wc.z;  // window part of the pos. MLP
-            int nqv = 0;
-            for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {
-                const int qi = q0 + lane;
-                const float4 qm = qi < a.nq ? a.qmeta[(size_t)w * a.nq + qi] : none4;
-                const int row = __builtin_bit_cast(int, qm.w);
-                const bool ok = row >= 0;
-                const unsigned long long m = __ballot(ok);
-                if (ok) {
-                    const int p = nqv + __popcll(m & ((1ull << lane) - 1ull));
-                    qrow[p] = row;
-                    qrel[3 * p + 0] = qm.x;
-                    qrel[3 * p + 1] = qm.y;
-                    qrel[3 * p + 2] = qm.z;
-                }
-                nqv += __popcll(m);
+        for (int t = 0; t < KT; ++t) {
+            const int slot = 16 * t + la;
+            const float4 km = a.kmeta[(size_t)w * K + min(slot, K - 1)];
+            const int r = __builtin_bit_cast(int, km.w);
+            row1[t] = slot < K && r >= 0 ? r : 0;
+            rel[t] = g == 0 ? km.x : (g == 1 ? km.y : (g == 2 ? km.z : 1.0f));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s2 = 16 * t + 4 * g + i;
+                const int r2 = kmeta_i[((size_t)w * K + min(s2, K - 1)) * 4 + 3];
+                row2[t][i] = s2 < K ? r2 : -1;
             }
-            wave_lds_sync();
-            const size_t qbase = (size_t)a.q_off[w];
-            for (int qb = 0; qb < nqv; qb += 4) {
-                float qval[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)  // unconditional (clamped) loads: no branch + wait per element
-                    qval[u] = a.xhat[(size_t)qrow[min(qb + u, nqv - 1)] * a.C + a.c0 + cl];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int qq = qb + u;
-                    if (qq >= nqv) break;
-                    const float pos = fmaxf(posc + wp[0] * qrel[3 * qq] + wp[1] * qrel[3 * qq + 1] + wp[2] * qrel[3 * qq + 2], 0.0f);
-                    if (act) xq[lane] = qval[u] + pos;
-                    wave_lds_sync();
-                    const float qpv = matvec4<CG>(W0, xq, cl, b0[cl]);  // q' = Wq xq + bq (lane = output)
-                    if (act) qp[lane] = qpv;
-                    wave_lds_sync();
-                    // qt_h = scale * Wk_h^T q'_h   (lane = input channel; all heads, fully unrolled)
-                    const float4 *wk = reinterpret_cast<const float4 *>(W1) + cl;
-                    const float4 *qv = reinterpret_cast<const float4 *>(qp);
-                    float acc[NH];
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) acc[h] = 0.f;
-                    constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
-#pragma unroll
-                    for (int b = 0; b < CG / 4; b += STEP) {
-                        float4 wv4[STEP], q4[STEP];
-#pragma unroll
-                        for (int i = 0; i < STEP; ++i) {
-                            wv4[i] = wk[(b + i) * CG];
-                            q4[i] = qv[b + i];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i < STEP; ++i) {
-                            const int h = ((b + i) * 4) / HD;  // compile-time after unrolling
-                            acc[h] = __builtin_fmaf(wv4[i].x, q4[i].x, acc[h]);
-                            acc[h] = __builtin_fmaf(wv4[i].y, q4[i].y, acc[h]);
-                            acc[h] = __builtin_fmaf(wv4[i].z, q4[i].z, acc[h]);
-                            acc[h] = __builtin_fmaf(wv4[i].w, q4[i].w, acc[h]);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (act) {
-                        float *dst = a.qbuf + (qbase + qq) * QROW + lane;
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) dst[h * CG] = acc[h] * a.scale;
-                    }
-                    wave_lds_sync();  // xq / qp are rewritten by the next query
-                }
-            }
-            wave_lds_sync();
         }
-    } else if (PHASE == 1) {
-        // =========================== B: keys, scores, softmax, xbar =============================
-        float *keys = wbase;
-        float *qt = keys + a.K * KS;
-        float *pb = qt + HP * CG;
-        float *krel = pb + a.K * HP;
-        int *krow = reinterpret_cast<int *>(krel + 3 * a.K);
-        float wp[6], bpv;
+        // feature rows in both layouts
+        f32x4 T1[KT][NT], T2[KT][NT];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) wp[t] = a.Wp[(size_t)(a.c0 + cl) * 6 + t];
-        bpv = a.bp[a.c0 + cl];
-        const bool two_heads = a.K <= 32;  // score pass: lane = key + 32 * (head & 1)
-        const int heads = a.heads;
-        for (int wi = wfirst; wi < n_act; wi += wstep) {
-            const int w = a.perm[wi];
-            const float4 wc = a.wcentre[w];
-            const float posc = bpv + wp[3] * wc.x + wp[4] * wc.y + wp[5] * wc.z;
-            int nkv = 0, nqv = 0;
-            {
-                const float4 km = lane < a.K ? a.kmeta[(size_t)w * a.K + lane] : none4;
-                const int row = __builtin_bit_cast(int, km.w);
-                const bool ok = row >= 0;
-                const unsigned long long m = __ballot(ok);
-                if (ok) {
-                    const int p = __popcll(m & ((1ull << lane) - 1ull));
-                    krow[p] = row;
-                    krel[3 * p + 0] = km.x;
-                    krel[3 * p + 1] = km.y;
-                    krel[3 * p + 2] = km.z;
-                }
-                nkv = __popcll(m);
+        for (int t = 0; t < KT; ++t) {
+            const float *xr = a.xhat + (size_t)row1[t] * a.C + a.c0;
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                const int c = 16 * S + 4 * g;
+                const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xr + c)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                T1[t][S] = f32x4{v.x, v.y, v.z, v.w};
             }
-            for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {  // only the count is needed here
-                const int qi = q0 + lane;
-                const float4 qm = qi < a.nq ? a.qmeta[(size_t)w * a.nq + qi] : none4;
-                nqv += __popcll(__ballot(__builtin_bit_cast(int, qm.w) >= 0));
-            }
-            wave_lds_sync();
-            // key tokens: LN'd feature slice + positional embedding -> LDS, 16 row loads in flight
-            for (int jb = 0; jb < nkv; jb += 16) {
-                float val[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) val[u] = a.xhat[(size_t)krow[min(jb + u, nkv - 1)] * a.C + a.c0 + cl];
+            for (int i = 0; i < 4; ++i) {
+                const float *x2 = a.xhat + (size_t)max(row2[t][i], 0) * a.C + a.c0;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int jj = jb + u, jc = min(jj, nkv - 1);
-                    const float pos = fmaxf(posc + wp[0] * krel[3 * jc] + wp[1] * krel[3 * jc + 1] + wp[2] * krel[3 * jc + 2], 0.0f);
-                    if (jj < nkv && act) keys[jj * KS + lane] = val[u] + pos;
+                for (int u = 0; u < NT; ++u) {
+                    const int c = 16 * u + la;
+                    T2[t][u][i] = (CGP == CG || c < CG) ? x2[c] : 0.f;
                 }
             }
-            const size_t qbase = (size_t)a.q_off[w];
-            for (int qq = 0; qq < nqv; ++qq) {
-                float *qrowp = a.qbuf + (qbase + qq) * QROW;
-                if (act) {
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) qt[h * CG + lane] = qrowp[h * CG + lane];
-                }
-                wave_lds_sync();
-                // scores + softmax   (lane = key, two heads side by side when K <= 32)
-                {
-                    const int j = two_heads ? (lane & 31) : lane;
-                    const int npass = two_heads ? (heads + 1) / 2 : heads;
-                    const float4 *kr = reinterpret_cast<const float4 *>(keys + (j < nkv ? j : 0) * KS);
-                    for (int p = 0; p < npass; ++p) {
-                        const int h = two_heads ? 2 * p + (lane >> 5) : p;
-                        const bool on = j < nkv && h < heads;
-                        const float4 *qh = reinterpret_cast<const float4 *>(qt + (h < heads ? h : 0) * CG);
-                        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                        constexpr int STEP = CG / 4 < 8 ? CG / 4 : 8;
-#pragma unroll
-                        for (int b = 0; b < CG / 4; b += STEP) {
-                            float4 kk[STEP], qv4[STEP];
-#pragma unroll
-                            for (int i = 0; i < STEP; ++i) {
-                                kk[i] = kr[b + i];
-                                qv4[i] = qh[b + i];
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int i = 0; i < STEP; ++i) {
-                                s0 = __builtin_fmaf(kk[i].x, qv4[i].x, s0);
-                                s1 = __builtin_fmaf(kk[i].y, qv4[i].y, s1);
-                                s2 = __builtin_fmaf(kk[i].z, qv4[i].z, s2);
-                                s3 = __builtin_fmaf(kk[i].w, qv4[i].w, s3);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        const float sc = on ? (s0 + s1) + (s2 + s3) : -INFINITY;
-                        const float mx = two_heads ? half_max(sc) : wave_max(sc);
-                        const float e = on ? __expf(sc - mx) : 0.0f;
-                        const float sum = two_heads ? half_sum(e) : wave_sum(e);
-                        if (j < a.K && h < heads) pb[j * HP + h] = e * __builtin_amdgcn_rcpf(sum);  // 0 for unused rows
-                    }
-                }
-                wave_lds_sync();
-                // xbar_h = sum_k p_hk x_k   (lane = channel, all heads at once, 8 keys per step)
-                float acc[HP];
-#pragma unroll
-                for (int h = 0; h < HP; ++h) acc[h] = 0.f;
-                for (int jb = 0; jb < nkv; jb += 8) {
-                    float kv[8];
-                    float4 pp[8][HP / 4];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int jj = jb + u, jc = jj < nkv ? jj : nkv - 1;  // rows >= nkv: weight 0 (see above)
-                        kv[u] = keys[jc * KS + cl];
-                        const int jp = jj < a.K ? jj : a.K - 1;
-#pragma unroll
-                        for (int h4 = 0; h4 < HP / 4; ++h4) pp[u][h4] = reinterpret_cast<const float4 *>(pb + jp * HP)[h4];
-                        if (jj >= a.K) {
-#pragma unroll
-                            for (int h4 = 0; h4 < HP / 4; ++h4) pp[u][h4] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                        for (int h4 = 0; h4 < HP / 4; ++h4) {
-                            acc[4 * h4 + 0] = __builtin_fmaf(pp[u][h4].x, kv[u], acc[4 * h4 + 0]);
-                            acc[4 * h4 + 1] = __builtin_fmaf(pp[u][h4].y, kv[u], acc[4 * h4 + 1]);
-                            acc[4 * h4 + 2] = __builtin_fmaf(pp[u][h4].z, kv[u], acc[4 * h4 + 2]);
-                            acc[4 * h4 + 3] = __builtin_fmaf(pp[u][h4].w, kv[u], acc[4 * h4 + 3]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (act) {
-#pragma unroll
-                    for (int h = 0; h < HP; ++h)
-                        if (h < NH) qrowp[h * CG + lane] = acc[h];  // xbar replaces qt in place
-                }
-                wave_lds_sync();  // qt / pb are rewritten by the next query
-            }
-            wave_lds_sync();  // keys / lists are rewritten for the next window
         }
-    } else {
-        // =========================== C: v = Wv xbar + bv, out = Wo v + bo ========================
-        float *xbar = wbase;        // [HP][KS]
-        float *vb = xbar + HP * KS;  // [CG]
-        int *qslot = reinterpret_cast<int *>(vb + CG);
-        const int my_h = cl / HD;
-        for (int wi = wfirst; wi < n_act; wi += wstep) {
-            const int w = a.perm[wi];
-            int nqv = 0;
-            for (int q0 = 0; q0 < a.nq; q0 += MSSVT_WAVE) {
-                const int qi = q0 + lane;
-                const float4 qm = qi < a.nq ? a.qmeta[(size_t)w * a.nq + qi] : none4;
-                const bool ok = __builtin_bit_cast(int, qm.w) >= 0;
-                const unsigned long long m = __ballot(ok);
-                if (ok) qslot[nqv + __popcll(m & ((1ull << lane) - 1ull))] = qi;
-                nqv += __popcll(m);
-            }
-            wave_lds_sync();
-            const size_t qbase = (size_t)a.q_off[w];
-            for (int qq = 0; qq < nqv; ++qq) {
-                const float *qrowp = a.qbuf + (qbase + qq) * QROW;
-                if (act) {
+        // + relu(positional MLP), one MFMA per tile and layout
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) xbar[h * KS + lane] = qrowp[h * CG + lane];
+        for (int u = 0; u < NT; ++u) {
+            const float wu = ((wconst[u] + w3[u] * wc.x) + w4[u] * wc.y) + w5[u] * wc.z;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f}, p2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                MFMA4(p1, wu, rel[t]);  // rows = channels 16 u + 4 g + i, column = key 16 t + la
+                MFMA4(p2, rel[t], wu);  // rows = keys 16 t + 4 g + i,     column = channel 16 u + la
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    T1[t][u][i] += fmaxf(p1[i], 0.0f);
+                    T2[t][u][i] += fmaxf(p2[i], 0.0f);
                 }
-                wave_lds_sync();
-                const float vbv = matvec4<CG>(W0, xbar + my_h * KS, cl, b0[cl]);  // lane = output channel o
-                if (act) vb[lane] = vbv;
-                wave_lds_sync();
-                const float out = matvec4<CG>(W1, vb, cl, b1[cl]);
-                if (act) a.attn[((size_t)w * a.nq + qslot[qq]) * a.C + a.c0 + lane] = out;
-                wave_lds_sync();  // xbar / vb are rewritten by the next query
             }
-            wave_lds_sync();
+        }
+        // queries, QPP per pass: column la = query * HP + head
+        const int hh = la % HP;
+        const bool head_ok = hh < NH;
+        for (int q0 = 0; q0 < nqv; q0 += QPP) {
+            const int q = q0 + la / HP;
+            const bool q_ok = q < nqv && head_ok;
+            float *qrow = a.qbuf + (qbase + min(q, nqv - 1)) * QROW + (head_ok ? hh : 0) * CG;
+            f32x4 qt[NT];
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                const int c = 16 * S + 4 * g;
+                const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(qrow + c)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                qt[S] = f32x4{v.x, v.y, v.z, v.w};
+            }
+            // scores: S[key][col] = sum_c T[key][c] Qt[col][c]
+            f32x4 sc[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) MFMA4(sc[t], T1[t][S][j], qt[S][j]);
+                }
+            }
+            // softmax over the unmasked keys: lane (col, g) holds keys 16 t + 4 g + i
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, row2[t][i] >= 0 ? sc[t][i] : -INFINITY);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = row2[t][i] >= 0 ? __expf(sc[t][i] - mx) : 0.0f;
+                    sc[t][i] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = __builtin_amdgcn_rcpf(sum);  // slot 0 of a list is never masked: sum >= 1
+            // Xbar^T[c][col] = sum_key T[key][c] P[key][col]
+            f32x4 acc[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pv = sc[t][i] * inv;
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) MFMA4(acc[u], T2[t][u][i], pv);
+                }
+            }
+            if (q_ok) {
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int c = 16 * u + 4 * g;
+                    if (CGP == CG || c < CG)  // xbar replaces qt in place (this lane's own 16 bytes)
+                        *reinterpret_cast<float4 *>(qrow + c) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+                }
+            }
         }
     }
 }
 
-template <int CG, int HD, int HP, int PHASE>
-static int launch_attn_phase(AttnArgs a, hipStream_t stream) {
-    constexpr int KS = CG + 4;
-    size_t fixed = 0;
-    if (PHASE == 0) {
-        a.wave_floats = 2 * CG + 4 * a.nq;
-        fixed = (size_t)2 * CG * CG + 2 * CG;
-    } else if (PHASE == 1) {
-        a.wave_floats = a.K * KS + HP * CG + a.K * HP + 4 * a.K;
-        fixed = 0;
-    } else {
-        a.wave_floats = HP * KS + CG + a.nq;
-        fixed = (size_t)2 * CG * CG + 2 * CG;
-    }
-    a.wave_floats = (a.wave_floats + 3) & ~3;  // keep every wave's region 16-B aligned
-    int waves = ATTN_MAX_WAVES;
-    while (waves > 1 && (fixed + (size_t)waves * a.wave_floats) * 4 > 160 * 1024) --waves;
-    const size_t lds_bytes = (fixed + (size_t)waves * a.wave_floats) * 4;
-    if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_phase<CG, HD, HP, PHASE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
-    // persistent grid: as many workgroups per CU as LDS and the 32-wave limit admit (256 CUs on MI355X)
+template <int CG, int HD, int HP>
+static int launch_block_attn(AttnArgs &a, int row_capacity, hipStream_t stream) {
+    constexpr int CGP = (CG + 15) / 16 * 16, LS = CGP + 4;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    int per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
-    if (per_cu > 32 / waves) per_cu = 32 / waves;
-    if (per_cu < 1) per_cu = 1;
-    k_attn_phase<CG, HD, HP, PHASE><<<cus * per_cu, waves * MSSVT_WAVE, lds_bytes, stream>>>(a);
+    // A / C: persistent over 16-row tiles, 4 workgroups of 4 waves per CU at most
+    const int tiles_cap = (row_capacity + 15) / 16;
+    int row_grid = (tiles_cap + ATTN_ROW_WAVES - 1) / ATTN_ROW_WAVES;
+    if (row_grid > cus * 4) row_grid = cus * 4;
+    if (row_grid < 1) row_grid = 1;
+    const size_t lds_q = ((size_t)2 * CGP * LS + CGP * 8 + CGP) * 4, lds_o = ((size_t)2 * CGP * LS + 2 * CGP) * 4;
+    k_attn_q<CG, HD, HP><<<row_grid, ATTN_ROW_WAVES * MSSVT_WAVE, lds_q, stream>>>(a);
+    // B: persistent over the work order, 8 workgroups of 4 waves per CU at most (VGPR bound)
+    const int kv_grid = cus * 8;
+    if (a.K <= 16)
+        k_attn_kv<CG, HD, HP, 1><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(a);
+    else if (a.K <= 32)
+        k_attn_kv<CG, HD, HP, 2><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(a);
+    else
+        k_attn_kv<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(a);
+    k_attn_o<CG, HD, HP><<<row_grid, ATTN_ROW_WAVES * MSSVT_WAVE, lds_o, stream>>>(a);
     return mssvt_launch_status();
-}
-
-template <int CG, int HD, int HP>
-static int launch_block_attn(AttnArgs &a, hipStream_t stream) {
-    int rc = launch_attn_phase<CG, HD, HP, 0>(a, stream);
-    if (rc) return rc;
-    rc = launch_attn_phase<CG, HD, HP, 1>(a, stream);
-    if (rc) return rc;
-    return launch_attn_phase<CG, HD, HP, 2>(a, stream);
 }
 
 extern "C" int mssvt_block_attention_group(
     int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
-    const float *xhat, const int *num_active_dev, const int *perm, const int *q_off, const float *qmeta,
-    const float *kmeta, const float *wcentre, const float *Wq, const float *bq, const float *Wkv,
-    const float *bkv, const float *Wo, const float *bo, const float *Wpos, const float *bpos, float *qbuf,
-    float *attn, void *stream) {
-    if (!xhat || !num_active_dev || !perm || !q_off || !qmeta || !kmeta || !wcentre || !Wq || !bq || !Wkv ||
-        !bkv || !Wo || !bo || !Wpos || !bpos || !qbuf || !attn || C <= 0 || Cg <= 0 || heads <= 0 ||
-        head_dim <= 0 || nq <= 0 || key_num_sample <= 0)
+    const float *xhat, const int *num_active_dev, const int *perm, const int *q_off, const int *nq_valid,
+    const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src, const float *kmeta,
+    const float *wcentre, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo,
+    const float *bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream) {
+    if (!xhat || !num_active_dev || !perm || !q_off || !nq_valid || !num_rows_dev || !qrow_meta || !qrow_src ||
+        !kmeta || !wcentre || !Wq || !bq || !Wkv || !bkv || !Wo || !bo || !Wpos || !bpos || !qbuf || !attn ||
+        C <= 0 || Cg <= 0 || heads <= 0 || head_dim <= 0 || nq <= 0 || key_num_sample <= 0 || row_capacity <= 0)
         return MSSVT_E_BADARG;
     if (Cg != heads * head_dim || c0 < 0 || c0 + Cg > C) return MSSVT_E_BADARG;
-    // one channel per lane, heads aligned to 4-float LDS vectors, <= 8 heads per group
+    // 16-byte row segments: channel offsets must be float4 aligned
+    if ((C & 3) || (c0 & 3)) return MSSVT_E_BADARG;
+    // one channel per lane, heads aligned to 4-float vectors, <= 8 heads per group
     if (Cg > MSSVT_WAVE || key_num_sample > MSSVT_WAVE || (head_dim & 3) || heads > 8) return MSSVT_E_TOOLARGE;
     AttnArgs a;
     a.C = C; a.c0 = c0; a.heads = heads; a.hd = head_dim; a.scale = scale;
     a.nq = nq; a.K = key_num_sample;
-    a.xhat = xhat; a.num_wins = num_active_dev; a.perm = perm; a.q_off = q_off;
-    a.qmeta = reinterpret_cast<const float4 *>(qmeta);
+    a.xhat = xhat; a.num_wins = num_active_dev; a.perm = perm; a.q_off = q_off; a.nq_valid = nq_valid;
+    a.num_rows = num_rows_dev;
+    a.qrow_meta = reinterpret_cast<const float4 *>(qrow_meta);
+    a.qrow_src = reinterpret_cast<const int2 *>(qrow_src);
     a.kmeta = reinterpret_cast<const float4 *>(kmeta);
     a.wcentre = reinterpret_cast<const float4 *>(wcentre);
     a.Wq = Wq; a.bq = bq; a.Wkv = Wkv; a.bkv = bkv; a.Wo = Wo; a.bo = bo; a.Wp = Wpos; a.bp = bpos;
     a.qbuf = qbuf;
     a.attn = attn;
-    a.wave_floats = 0;
     hipStream_t st = (hipStream_t)stream;
 #define MSSVT_ATTN_CASE(cg, hd)                                   \
     if (Cg == cg && head_dim == hd)                               \
-        return launch_block_attn<cg, hd, ((cg / hd + 3) / 4) * 4>(a, st);
+        return launch_block_attn<cg, hd, ((cg / hd + 3) / 4) * 4>(a, row_capacity, st);
     MSSVT_ATTN_CASE(8, 8)
     MSSVT_ATTN_CASE(16, 8)
     MSSVT_ATTN_CASE(16, 16)

@@ -54,6 +54,10 @@ __device__ __forceinline__ float half_max(float v) { v = row_max16(v); return fm
 __device__ __forceinline__ float half_sum(float v) { v = row_sum16(v); return v + __shfl_xor(v, 16); }
 __device__ __forceinline__ float wave_max(float v) { v = half_max(v); return fmaxf(v, __shfl_xor(v, 32)); }
 __device__ __forceinline__ float wave_sum(float v) { v = half_sum(v); return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ int wave_sum_i(int v) {
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 
 
 // ---------------------------------------------------------------------------

@@ -472,8 +472,10 @@ extern "C" int mssvt_window_plan_two(
 // ---------------------------------------------------------------------------------------------
 #define PO_WAVES 16
 #define PO_KEYS 257
-__global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *num_wins, const int *nq_valid, int max_key,
-                                                                     int *perm, int *num_active, int *q_off) {
+#define PO_V 8  // window batches of 64 in flight per wave (one global-load latency per PO_V batches)
+__global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE)
+    k_plan_order(const int *num_wins, const int *nq_valid, int max_key, int *perm, int *num_active, int *q_off,
+                 int *num_rows) {
     // per-wave histograms: copies sit PO_KEYS (odd) words apart -> different LDS banks, so the 16
     // waves' atomics on the few populated keys proceed in parallel
     __shared__ int hist[PO_WAVES][PO_KEYS];
@@ -483,31 +485,29 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
     for (int k = threadIdx.x; k < PO_WAVES * PO_KEYS; k += blockDim.x) (&hist[0][0])[k] = 0;
     __syncthreads();
-    // each wave owns a contiguous run of windows: histogram + local exclusive scan of nq_valid
+    // each wave owns a contiguous run of windows
     const int per_wave = (nw + PO_WAVES - 1) / PO_WAVES;
     const int wb = min(wv * per_wave, nw), we = min(wb + per_wave, nw);
-    int carry = 0;
-    for (int base = wb; base < we; base += MSSVT_WAVE) {
-        const int w = base + lane;
-        const int v = w < we ? nq_valid[w] : 0;
-        if (w < we) atomicAdd(&hist[wv][min(v, max_key)], 1);
-        int incl = v;
-        for (int off = 1; off < MSSVT_WAVE; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+    // pass 0: histogram of the query counts + the run's total
+    int total = 0;
+    for (int base = wb; base < we; base += MSSVT_WAVE * PO_V) {
+        int v[PO_V];
+#pragma unroll
+        for (int u = 0; u < PO_V; ++u) {
+            const int w = base + u * MSSVT_WAVE + lane;
+            v[u] = w < we ? nq_valid[w] : -1;
         }
-        if (w < we) q_off[w] = carry + incl - v;
-        carry += __shfl(incl, MSSVT_WAVE - 1);
+#pragma unroll
+        for (int u = 0; u < PO_V; ++u)
+            if (v[u] >= 0) {
+                atomicAdd(&hist[wv][min(v[u], max_key)], 1);
+                total += v[u];
+            }
     }
-    if (lane == 0) wave_q[wv] = carry;
+    total = wave_sum_i(total);
+    if (lane == 0) wave_q[wv] = total;
     __syncthreads();
-    int qbase = 0;
-    for (int i = 0; i < wv; ++i) qbase += wave_q[i];
-    for (int base = wb; base < we; base += MSSVT_WAVE) {
-        const int w = base + lane;
-        if (w < we) q_off[w] += qbase;  // written by this very lane above
-    }
-    // hist[wv][k] -> exclusive prefix over the waves (stable within a key), key totals -> key_base
+    // hist[wv][k] -> exclusive prefix over the waves, key totals -> key_base (heaviest key first)
     if (threadIdx.x <= max_key) {
         int run = 0;
         for (int i = 0; i < PO_WAVES; ++i) {
@@ -520,28 +520,85 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
-        for (int k = max_key; k >= 1; --k) {  // heaviest key first
+        for (int k = max_key; k >= 1; --k) {
             const int c = key_base[k];
             key_base[k] = run;
             run += c;
         }
         *num_active = run;
+        int rows = 0;
+        for (int i = 0; i < PO_WAVES; ++i) rows += wave_q[i];
+        *num_rows = rows;
     }
     __syncthreads();
-    for (int base = wb; base < we; base += MSSVT_WAVE) {
-        const int w = base + lane;
-        if (w < we) {
-            const int k = min(nq_valid[w], max_key);
-            if (k > 0) perm[key_base[k] + atomicAdd(&hist[wv][k], 1)] = w;
+    // pass 1: q_off = exclusive scan of nq_valid in window order; perm = counting sort
+    int carry = 0;
+    for (int i = 0; i < wv; ++i) carry += wave_q[i];
+    for (int base = wb; base < we; base += MSSVT_WAVE * PO_V) {
+        int v[PO_V];
+#pragma unroll
+        for (int u = 0; u < PO_V; ++u) {
+            const int w = base + u * MSSVT_WAVE + lane;
+            v[u] = w < we ? nq_valid[w] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < PO_V; ++u) {
+            const int w = base + u * MSSVT_WAVE + lane;
+            const int val = v[u] > 0 ? v[u] : 0;
+            int incl = val;
+            for (int off = 1; off < MSSVT_WAVE; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (v[u] >= 0) {
+                q_off[w] = carry + incl - val;
+                const int k = min(v[u], max_key);
+                if (k > 0) perm[key_base[k] + atomicAdd(&hist[wv][k], 1)] = w;
+            }
+            carry += __shfl(incl, MSSVT_WAVE - 1);
         }
     }
 }
 
-extern "C" int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int max_queries, int *perm,
-                                int *num_active_dev, int *q_off, void *stream) {
-    if (!num_wins_dev || !nq_valid || !perm || !num_active_dev || !q_off || max_queries <= 0)
+// compact query rows: row q_off[w] + p = the p-th valid slot of window w's query list:
+// rmeta = the slot's (rel.xyz, bits(feature row)), rsrc = (window, attn row w * nq + slot)
+__global__ void __launch_bounds__(256) k_query_rows(const int *num_wins, int nq, const float4 *qmeta, const int *q_off,
+                                                    int row_capacity, float4 *rmeta, int2 *rsrc) {
+    const int nw = *num_wins, lane = lane_id();
+    const int wstep = gridDim.x * (blockDim.x / MSSVT_WAVE);
+    for (int w = blockIdx.x * (blockDim.x / MSSVT_WAVE) + threadIdx.x / MSSVT_WAVE; w < nw; w += wstep) {
+        int run = q_off[w];
+        for (int q0 = 0; q0 < nq; q0 += MSSVT_WAVE) {
+            const int qi = q0 + lane;
+            float4 qm = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = false;
+            if (qi < nq) {
+                qm = qmeta[(size_t)w * nq + qi];
+                ok = __builtin_bit_cast(int, qm.w) >= 0;
+            }
+            const unsigned long long m = __ballot(ok);
+            const int r = run + __popcll(m & ((1ull << lane) - 1ull));
+            if (ok && r < row_capacity) {
+                rmeta[r] = qm;
+                rsrc[r] = make_int2(w, w * nq + qi);
+            }
+            run += __popcll(m);
+        }
+    }
+}
+
+extern "C" int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int nq, const float *qmeta,
+                                int win_capacity, int row_capacity, int *perm, int *num_active_dev, int *q_off,
+                                float *qrow_meta, int *qrow_src, int *num_rows_dev, void *stream) {
+    if (!num_wins_dev || !nq_valid || !qmeta || !perm || !num_active_dev || !q_off || !qrow_meta || !qrow_src ||
+        !num_rows_dev || nq <= 0 || win_capacity <= 0 || row_capacity <= 0)
         return MSSVT_E_BADARG;
-    k_plan_order<<<1, PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, nq_valid, max_queries > 256 ? 256 : max_queries,
-                                                     perm, num_active_dev, q_off);
+    k_plan_order<<<1, PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, nq_valid, nq > 256 ? 256 : nq,
+                                                                       perm, num_active_dev, q_off, num_rows_dev);
+    int grid = (win_capacity + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    k_query_rows<<<grid, 256, 0, (hipStream_t)stream>>>(num_wins_dev, nq, reinterpret_cast<const float4 *>(qmeta),
+                                                        q_off, row_capacity, reinterpret_cast<float4 *>(qrow_meta),
+                                                        reinterpret_cast<int2 *>(qrow_src));
     return mssvt_launch_status();
 }

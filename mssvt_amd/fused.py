@@ -142,19 +142,25 @@ def _qmeta(block, p):
 
 
 @torch.no_grad()
-def _work_order(block, p, nq):
-    """(perm, num_active, q_off): windows with queries for this cbs_pattern, heaviest first, and the
-    first compact query row of every window."""
+def _work_order(block, p, nq, num_voxels):
+    """Work order + compact query rows of this cbs_pattern's query list (mssvt_plan_order): dict of
+    perm, n_act, q_off, nq_valid, row_meta, row_src, n_rows, row_cap."""
     pat = block.cbs_pattern
     if pat not in p.orders:
         dev = p.win_ind.device
-        perm = torch.empty(p.cap, dtype=torch.int32, device=dev)
-        n_act = torch.zeros(1, dtype=torch.int32, device=dev)
-        q_off = torch.empty(p.cap, dtype=torch.int32, device=dev)
-        row = {1: 0, 0: 1, 2: 2}[pat]  # nq_valid rows: odd, even, win1
-        _lib.call("mssvt_plan_order", _lib.ptr(p.num_wins), _lib.ptr(p.nq_valid[row]), _i(nq), _lib.ptr(perm),
-                  _lib.ptr(n_act), _lib.ptr(q_off), _lib.stream())
-        p.orders[pat] = (perm, n_act, q_off)
+        cap_rows = max(int(num_voxels), 1)  # the query lists of one pattern are disjoint
+        o = dict(perm=torch.empty(p.cap, dtype=torch.int32, device=dev),
+                 n_act=torch.zeros(1, dtype=torch.int32, device=dev),
+                 q_off=torch.empty(p.cap, dtype=torch.int32, device=dev),
+                 nq_valid=p.nq_valid[{1: 0, 0: 1, 2: 2}[pat]],  # rows: odd, even, win1
+                 row_meta=torch.empty((cap_rows, 4), dtype=torch.float32, device=dev),
+                 row_src=torch.empty((cap_rows, 2), dtype=torch.int32, device=dev),
+                 n_rows=torch.zeros(1, dtype=torch.int32, device=dev), row_cap=cap_rows)
+        _lib.call("mssvt_plan_order", _lib.ptr(p.num_wins), _lib.ptr(o["nq_valid"]), _i(nq),
+                  _lib.ptr(_qmeta(block, p)), _i(p.cap), _i(cap_rows), _lib.ptr(o["perm"]), _lib.ptr(o["n_act"]),
+                  _lib.ptr(o["q_off"]), _lib.ptr(o["row_meta"]), _lib.ptr(o["row_src"]), _lib.ptr(o["n_rows"]),
+                  _lib.stream())
+        p.orders[pat] = o
     return p.orders[pat]
 
 
@@ -227,7 +233,7 @@ def block_forward(block, sp):
     p = two_scale_plan(block, sp)
     q_ind, nq, owner_q = _query(block, p)
     attn = _attn_buffer(p, nq, C, x_in.device)
-    perm, n_act, q_off = _work_order(block, p, nq)
+    od = _work_order(block, p, nq, N)
     ma = block.ms_attn
     qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
@@ -236,8 +242,9 @@ def block_forward(block, sp):
     for g, heads in enumerate(ma.num_heads):
         cg = ma.scale_dims[g]
         _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(heads), _i(ma.per_head_dim),
-                  _f(ma.scale), _i(nq), _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(n_act), _lib.ptr(perm),
-                  _lib.ptr(q_off), _lib.ptr(_qmeta(block, p)), _lib.ptr(p.kmeta[g]), _lib.ptr(p.wcentre),
+                  _f(ma.scale), _i(nq), _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(od["n_act"]),
+                  _lib.ptr(od["perm"]), _lib.ptr(od["q_off"]), _lib.ptr(od["nq_valid"]), _lib.ptr(od["n_rows"]),
+                  _i(od["row_cap"]), _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]), _lib.ptr(p.kmeta[g]), _lib.ptr(p.wcentre),
                   _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                   _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
                   _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(qbuf), _lib.ptr(attn), _lib.stream())
@@ -417,7 +424,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         xhat = F.layer_norm(x_in, (C,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         q_ind, nq, _ = _query(blk, p)
         attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
-        perm, n_act, q_off = _work_order(blk, p, nq)
+        od = _work_order(blk, p, nq, x_in.shape[0])
         ma = blk.ms_attn
         qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
         g = 1
@@ -427,7 +434,8 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         def launch():
             _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(ma.num_heads[g]),
                       _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(blk.key_num_sample), _lib.ptr(xhat),
-                      _lib.ptr(n_act), _lib.ptr(perm), _lib.ptr(q_off), _lib.ptr(_qmeta(blk, p)), _lib.ptr(p.kmeta[g]),
+                      _lib.ptr(od["n_act"]), _lib.ptr(od["perm"]), _lib.ptr(od["q_off"]), _lib.ptr(od["nq_valid"]),
+                      _lib.ptr(od["n_rows"]), _i(od["row_cap"]), _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]), _lib.ptr(p.kmeta[g]),
                       _lib.ptr(p.wcentre),
                       _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                       _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
