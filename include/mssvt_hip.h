@@ -269,6 +269,15 @@ int mssvt_compress_attention_group(int C, int c0, int Cg, int head_dim, float sc
                                    const int *win_vstart, const float *qp, const float *kv, float *out,
                                    void *stream);
 
+/* Rows per sample of a (N,4) [b,z,y,x] int32 index tensor -> counts (B) int32, on the device
+ * (ref: the host loops with .item() of mssvt_utils.py:35-37 / mssvt_backbone.py:124-130).   */
+int mssvt_batch_counts(const int *indices, int num_rows, int batch_size, int *counts, void *stream);
+
+/* y = LayerNorm(x) over the last dimension (N,C) f32, C in {16,32,64,128,256}
+ * (ref: norm1, mssvt_backbone.py:241); MSSVT_E_TOOLARGE otherwise.                          */
+int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, const float *bias,
+                     float eps, float *y, void *stream);
+
 /* Fused feed-forward tail of a block on the fp32 matrix cores (ref mssvt_backbone.py:336-343,
  * :383-387): x = owner && owner[v] < 0 ? 2*x_in[v] : x_new[v];
  * y = x + linear2(relu(linear1(norm(x)))); optionally y_norm = next_norm(y) (the next block's

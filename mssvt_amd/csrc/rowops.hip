@@ -1,0 +1,78 @@
+// rowops.hip -- small per-row helpers of the fused path that would otherwise be framework launches.
+//
+//   mssvt_batch_counts : rows per sample of a (N,4) [b,z,y,x] index tensor.  The reference loops over
+//                        the samples on the host with .item() (ref: mssvt_utils.py:35-37,
+//                        mssvt_backbone.py:124-130); a framework bincount costs two reductions
+//                        (min / max), a histogram and a host synchronisation.
+//   mssvt_layer_norm   : norm1 of the first block (ref: mssvt_backbone.py:241; every later norm1 is
+//                        emitted by the previous block's fused FFN epilogue, csrc/ffn.hip).
+#include "common.hip.h"
+
+__global__ void __launch_bounds__(256) k_batch_counts(const int *indices, int n, int batch_size, int *counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = i < n ? indices[4 * (size_t)i] : -1;
+    const bool ok = b >= 0 && b < batch_size;
+    // samples are contiguous: nearly every wavefront sees one sample only
+    const int b0 = __builtin_amdgcn_readfirstlane(b);
+    const unsigned long long same = __ballot(ok && b == b0);
+    if (ok && b == b0) {
+        if (lane_id() == __ffsll((long long)same) - 1) atomicAdd(counts + b0, __popcll(same));
+    } else if (ok) {
+        atomicAdd(counts + b, 1);
+    }
+}
+
+extern "C" int mssvt_batch_counts(const int *indices, int num_rows, int batch_size, int *counts, void *stream_) {
+    if (!counts || (!indices && num_rows > 0) || num_rows < 0 || batch_size <= 0) return MSSVT_E_BADARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)batch_size * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    if (num_rows > 0) k_batch_counts<<<divup(num_rows, 256), 256, 0, stream>>>(indices, num_rows, batch_size, counts);
+    return mssvt_launch_status();
+}
+
+// LPR lanes (float4 each) per row, 64 / LPR rows per wavefront instruction
+template <int LPR>
+__global__ void __launch_bounds__(256) k_layer_norm(const float *x, int n, const float *w, const float *b, float eps,
+                                                    float *y) {
+    constexpr int C = LPR * 4, RPW = MSSVT_WAVE / LPR;
+    const int lane = lane_id();
+    const size_t row = ((size_t)blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE) * RPW + lane / LPR;
+    const int col = (lane % LPR) * 4;
+    const bool live = row < (size_t)n;
+    const float4 v = live ? *reinterpret_cast<const float4 *>(x + row * C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float m = s * (1.0f / C);
+    const float dx = v.x - m, dy = v.y - m, dz = v.z - m, dw = v.w - m;
+    float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rs = rsqrtf(q * (1.0f / C) + eps);
+    const float4 g4 = *reinterpret_cast<const float4 *>(w + col);
+    const float4 b4 = *reinterpret_cast<const float4 *>(b + col);
+    if (live)
+        *reinterpret_cast<float4 *>(y + row * C + col) =
+            make_float4(dx * rs * g4.x + b4.x, dy * rs * g4.y + b4.y, dz * rs * g4.z + b4.z, dw * rs * g4.w + b4.w);
+}
+
+extern "C" int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, const float *bias,
+                                float eps, float *y, void *stream_) {
+    if (!x || !weight || !bias || !y || num_rows < 0 || C <= 0) return MSSVT_E_BADARG;
+    if (num_rows == 0) return MSSVT_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+#define LN_CASE(lpr)                                                                                         \
+    if (C == 4 * lpr) {                                                                                      \
+        const int rows_per_block = 4 * (MSSVT_WAVE / lpr);                                                   \
+        k_layer_norm<lpr><<<divup(num_rows, rows_per_block), 256, 0, stream>>>(x, num_rows, weight, bias, eps, y); \
+        return mssvt_launch_status();                                                                        \
+    }
+    LN_CASE(4)
+    LN_CASE(8)
+    LN_CASE(16)
+    LN_CASE(32)
+    LN_CASE(64)
+#undef LN_CASE
+    return MSSVT_E_TOOLARGE;  // C not in {16, 32, 64, 128, 256}: the caller uses the framework's LayerNorm
+}

@@ -150,12 +150,12 @@ def _work_order(block, p, nq, num_voxels):
         dev = p.win_ind.device
         cap_rows = max(int(num_voxels), 1)  # the query lists of one pattern are disjoint
         o = dict(perm=torch.empty(p.cap, dtype=torch.int32, device=dev),
-                 n_act=torch.zeros(1, dtype=torch.int32, device=dev),
+                 n_act=torch.empty(1, dtype=torch.int32, device=dev),
                  q_off=torch.empty(p.cap, dtype=torch.int32, device=dev),
                  nq_valid=p.nq_valid[{1: 0, 0: 1, 2: 2}[pat]],  # rows: odd, even, win1
                  row_meta=torch.empty((cap_rows, 4), dtype=torch.float32, device=dev),
                  row_src=torch.empty((cap_rows, 2), dtype=torch.int32, device=dev),
-                 n_rows=torch.zeros(1, dtype=torch.int32, device=dev), row_cap=cap_rows)
+                 n_rows=torch.empty(1, dtype=torch.int32, device=dev), row_cap=cap_rows)
         _lib.call("mssvt_plan_order", _lib.ptr(p.num_wins), _lib.ptr(o["nq_valid"]), _i(nq),
                   _lib.ptr(_qmeta(block, p)), _i(p.cap), _i(cap_rows), _lib.ptr(o["perm"]), _lib.ptr(o["n_act"]),
                   _lib.ptr(o["q_off"]), _lib.ptr(o["row_meta"]), _lib.ptr(o["row_src"]), _lib.ptr(o["n_rows"]),
@@ -219,8 +219,21 @@ def _norm1(block, sp, x_in):
     pre = getattr(sp, "_xhat", None)
     if pre is not None and pre[1] is block.norm1 and pre[2] is sp.features:
         return pre[0]
-    C = x_in.shape[1]
-    return F.layer_norm(x_in, (C,), block.norm1.weight, block.norm1.bias, block.norm1.eps)
+    return layer_norm(x_in, block.norm1)
+
+
+LN_WIDTHS = {16, 32, 64, 128, 256}  # instantiated in csrc/rowops.hip
+
+
+def layer_norm(x, norm):
+    C = x.shape[1]
+    if C not in LN_WIDTHS or x.dtype != torch.float32 or not x.is_cuda:
+        return F.layer_norm(x, (C,), norm.weight, norm.bias, norm.eps)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.call("mssvt_layer_norm", _lib.ptr(x), _i(x.shape[0]), _i(C), _lib.ptr(norm.weight), _lib.ptr(norm.bias),
+              _f(norm.eps), _lib.ptr(y), _lib.stream())
+    return y
 
 
 def block_forward(block, sp):
@@ -282,7 +295,7 @@ def _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, m
         dev = sp.indices.device
         N = sp.indices.shape[0]
         tab_row = torch.full((max(N, 1), 4), -1, dtype=torch.int32, device=dev)
-        tab_w = torch.zeros((max(N, 1), 4), dtype=torch.float32, device=dev)
+        tab_w = torch.empty((max(N, 1), 4), dtype=torch.float32, device=dev)  # written with tab_row
         _lib.call("mssvt_block_interp_table", _i(nq), _i(n_upd), _i(interp), _lib.ptr(sp.indices),
                   _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind),
                   _lib.ptr(upd_ind), _lib.ptr(owner), vs3, mn3, _i(p.cap * nq), _lib.ptr(tab_row),
@@ -319,10 +332,13 @@ def one_scale_plan(block, sp):
     # the lists of different windows are disjoint iff every table offset stays inside the window
     # (true for the tables this package generates; checked so that custom tables stay correct)
     tw = block.vox_query_table['win1']
-    lo = torch.tensor([-(w // 2) for w in block.win1_size])
-    hi = torch.tensor([w - w // 2 - 1 for w in block.win1_size])
-    tcpu = tw.cpu()
-    p.disjoint = 1 if bool(((tcpu >= lo) & (tcpu <= hi)).all()) else 0
+    cached = getattr(block, "_disjoint_cache", None)
+    if cached is None or cached[0] is not tw:
+        lo = torch.tensor([-(w // 2) for w in block.win1_size])
+        hi = torch.tensor([w - w // 2 - 1 for w in block.win1_size])
+        tcpu = tw.cpu()
+        cached = block._disjoint_cache = (tw, 1 if bool(((tcpu >= lo) & (tcpu <= hi)).all()) else 0)
+    p.disjoint = cached[1]
     overlap = 1 if p.disjoint else 8
     row_cap = cap * overlap + (cap if p.with_pad else 0)
     p.k_ind = torch.empty((cap, ns), dtype=torch.int32, device=dev)

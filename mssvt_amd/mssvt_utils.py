@@ -11,6 +11,8 @@ names, constructor arguments, attributes and state-dict keys
 the GPU: rocBLAS batched GEMMs); the module fast path runs the same arithmetic in
 the fused HIP window kernel (``mssvt_amd/fused.py``) straight from the weights.
 """
+import ctypes
+
 import torch
 from torch import nn
 
@@ -31,6 +33,13 @@ def scatter_nd(indices, updates, shape):
 def batch_counts(indices, batch_size):
     """Rows per sample, (B,) int32 on the device, no host sync (the reference loops over
     samples with ``.item()``: mssvt_utils.py:35-37, mssvt_backbone.py:124-130)."""
+    if indices.is_cuda and indices.dtype == torch.int32 and indices.is_contiguous() and indices.dim() == 2 \
+            and indices.shape[1] == 4:
+        from . import _lib
+        out = torch.empty(batch_size, dtype=torch.int32, device=indices.device)
+        _lib.call("mssvt_batch_counts", _lib.ptr(indices), ctypes.c_int(indices.shape[0]),
+                  ctypes.c_int(int(batch_size)), _lib.ptr(out), _lib.stream())
+        return out
     return torch.bincount(indices[:, 0].long(), minlength=batch_size)[:batch_size].to(torch.int32)
 
 

@@ -109,3 +109,34 @@ def test_voxelizer_bit_exact(pts, B):
     pv = pv.cpu().numpy()
     assert (pv[~kept] == -1).all()
     np.testing.assert_array_equal(pv[kept], want_inv)
+
+
+@pytest.mark.parametrize("n,B", [(0, 1), (1, 1), (1000, 3), (74270, 2), (300001, 7)])
+def test_batch_counts_bit_exact(n, B):
+    from mssvt_amd.mssvt_utils import batch_counts
+    g = torch.Generator().manual_seed(n + B)
+    b = torch.sort(torch.randint(0, B, (n,), generator=g)).values if n else torch.zeros(0, dtype=torch.long)
+    ind = torch.zeros((n, 4), dtype=torch.int32)
+    ind[:, 0] = b.int()
+    ind[:, 1:] = torch.randint(0, 400, (n, 3), generator=g).int()
+    got = batch_counts(ind.to(DEV), B).cpu()
+    ref = torch.bincount(b, minlength=B)[:B].int()
+    assert got.dtype == torch.int32 and torch.equal(got, ref)
+    # unsorted sample ids (not the detector's layout) still count correctly
+    perm = torch.randperm(n, generator=g)
+    assert torch.equal(batch_counts(ind[perm].contiguous().to(DEV), B).cpu(), ref)
+
+
+@pytest.mark.parametrize("C,n", [(16, 5), (32, 1000), (64, 777), (128, 74270), (256, 4097)])
+def test_layer_norm_kernel_matches_torch(C, n):
+    from mssvt_amd import fused
+    torch.manual_seed(C + n)
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+        x = (torch.randn(n, C, device=DEV) * 3.0 + 1.0)
+        got = fused.layer_norm(x, norm)
+        ref = torch.nn.functional.layer_norm(x.double(), (C,), norm.weight.double(), norm.bias.double(), norm.eps)
+    # fp32 LayerNorm against an fp64 reference: 1e-5 absolute on O(1) values
+    assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-5)
