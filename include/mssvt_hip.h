@@ -282,12 +282,16 @@ int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, c
  * :383-387): x = owner && owner[v] < 0 ? 2*x_in[v] : x_new[v];
  * y = x + linear2(relu(linear1(norm(x)))); optionally y_norm = next_norm(y) (the next block's
  * norm1).  x_new/x_in/y/y_norm (N,C) f32; W1 (FF,C), W2 (C,FF) as in nn.Linear.
+ * hidden != NULL: scratch of n_rows x FF floats -> two launches with LDS-resident weights
+ * (GEMM1 | GEMM2, the hidden activations make one round trip through `hidden`); NULL: one
+ * launch that streams the weights through LDS.  num_rows_dev (optional, needs hidden): the
+ * row count is read on the device and n_rows is only the capacity.
  * Instantiated for (C,FF) in {(128,256),(64,128),(32,64)}; MSSVT_E_TOOLARGE otherwise.   */
 int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *x_in, const int *owner,
                     const float *norm_w, const float *norm_b, float eps, const float *W1,
                     const float *b1, const float *W2, const float *b2, float *y,
                     const float *next_norm_w, const float *next_norm_b, float next_eps, float *y_norm,
-                    void *stream);
+                    float *hidden, const int *num_rows_dev, void *stream);
 
 /* Table form of mssvt_block_interp_scatter: for every voxel owned by a list slot, tab_row (N,4)
  * int32 = the three rows of `attn` (row = w*nq + slot; empty slots / zero weights -> zero_row) and
@@ -305,7 +309,8 @@ int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_in, const i
                            const float *tab_w, const float *attn, const float *norm_w,
                            const float *norm_b, float eps, const float *W1, const float *b1,
                            const float *W2, const float *b2, float *y, const float *next_norm_w,
-                           const float *next_norm_b, float next_eps, float *y_norm, void *stream);
+                           const float *next_norm_b, float next_eps, float *y_norm, float *hidden,
+                           const int *num_rows_dev, void *stream);
 
 /* ======================================================================== *
  * Part 3 -- voxelizer front-end: the index part of

@@ -28,6 +28,7 @@
 // through a 16 x (C+4) LDS tile per wave, which lives in the weight buffer that is idle at the
 // batch boundary.  (First version: operand-shaped global loads, 64 different lines per
 // instruction -> every line missed the 32-KiB L1 eight times: 54k cycles per 16 rows.)
+#include <stdlib.h>
 #include "common.hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,7 +37,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FFN_NW 4   // waves per workgroup
 
 struct FfnArgs {
+    int dbg;
     int n_rows;
+    const int *n_rows_dev;  // optional: the row count lives on the device (n_rows = capacity)
     const float *x_new, *x_in;  // plain input: x = owner && owner[v] < 0 ? 2 * x_in[v] : x_new[v]
     const int *owner;
     // interpolation-table input (tab_row != null):
@@ -327,7 +330,299 @@ static int launch_ffn(const FfnArgs &a, hipStream_t stream) {
     return mssvt_launch_status();
 }
 
-static int dispatch_ffn(int C, int FF, const FfnArgs &a, hipStream_t st) {
+// ---------------------------------------------------------------------------------------------
+// Split form: two launches with the WHOLE weight matrix of each GEMM resident in LDS
+// (W1: FF x (C+4) floats = 132 KiB at C=128, FF=256; W2: C x (FF+4) = 130 KiB), one 16-wave
+// workgroup per CU, 16 rows per wavefront, NO barrier after the weights are staged: waves run
+// independently, so one wave's row gathers / LayerNorm / stores overlap with the MFMAs of the
+// other three on its SIMD.  The fused kernel above streams both matrices through LDS for every
+// 64 rows (8 barriers per batch) and reaches ~40 % of the fp32 MFMA peak; the price of the split
+// is one (N, FF) round trip of the hidden activations (4*FF bytes per row written + read).
+// Both GEMMs are computed transposed (D^T[out][row]), see block_attn.hip: A = weight rows (one
+// ds_read_b128 per 4 k-steps, conflict free with the +4 padding), B = the activations held as
+// lane (row = l % 16, g = l / 16) -> channels 16 S + 4 g + j, i.e. plain 16-byte global loads; the
+// accumulator (lane (row, g), register i = output 16 t + 4 g + i) leaves as 16-byte stores.
+// ---------------------------------------------------------------------------------------------
+#define FFS_NW 16  // waves per workgroup of the split kernels
+
+#define MFMA4(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
+
+template <int C, int FF>
+__global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_up(FfnArgs a, float *hidden) {
+    constexpr int NT = C / 16, HT = FF / 16, LS = C + 4, HG = 4;
+    static_assert(HT % HG == 0, "hidden tiles are walked in groups of 4");
+    extern __shared__ float4 lds4[];
+    float *W1_l = reinterpret_cast<float *>(lds4);  // [FF][LS]
+    float *b1_l = W1_l + FF * LS, *lnw_l = b1_l + FF, *lnb_l = lnw_l + C;
+    for (int e = threadIdx.x * 4; e < FF * C; e += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(W1_l + (e / C) * LS + e % C) = *reinterpret_cast<const float4 *>(a.W1 + e);
+    for (int e = threadIdx.x; e < FF; e += blockDim.x) b1_l[e] = a.b1[e];
+    for (int e = threadIdx.x; e < C; e += blockDim.x) {
+        lnw_l[e] = a.ln_w[e];
+        lnb_l[e] = a.ln_b[e];
+    }
+    __syncthreads();
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+    const int tiles = (n + 15) >> 4;
+    // tile k * gridDim + block -> wave k % 16: the last partial round is spread over all CUs
+    for (int k = wv;; k += FFS_NW) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (tile >= tiles) break;
+        const int row = min(tile * 16 + la, n - 1);
+        const bool live = tile * 16 + la < n;
+        // ---- x = residual input of the FFN, this lane's channels 16 S + 4 g + j ----------------
+        f32x4 x[NT];
+        if (a.dbg & 2) {
+#pragma unroll
+            for (int S = 0; S < NT; ++S) x[S] = f32x4{1.f * la, 2.f, 3.f * S, 4.f};
+        } else if (a.tab_row) {
+            const int4 tr = a.tab_row[row];
+            const float4 tw = a.tab_w[row];
+            const bool unowned = tr.x < 0;
+            // an unowned voxel re-reads its own (finite) x_in row with weight 0: attention rows of
+            // never-written slots may hold NaNs, and 0 * NaN is NaN
+            const float *px = a.x_in + (size_t)row * C + 4 * g;
+            const float *p1 = unowned ? px : a.attn + (size_t)tr.x * C + 4 * g;
+            const float *p2 = unowned ? px : a.attn + (size_t)tr.y * C + 4 * g;
+            const float *p3 = unowned ? px : a.attn + (size_t)tr.z * C + 4 * g;
+            const float w1 = unowned ? 0.f : tw.x, w2 = unowned ? 0.f : tw.y, w3 = unowned ? 0.f : tw.z;
+            const float wx = unowned ? 2.0f : 1.0f;  // untouched voxel: features + shortcut = 2 * x_in
+            // 4 streams x NT/2 float4 in flight at a time (all NT would not fit 128 VGPRs)
+            constexpr int SH = NT > 1 ? NT / 2 : 1;
+#pragma unroll
+            for (int S0 = 0; S0 < NT; S0 += SH) {
+#pragma unroll
+                for (int S = S0; S < S0 + SH; ++S) {
+                    const float4 vx = *reinterpret_cast<const float4 *>(px + 16 * S);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(p1 + 16 * S);
+                    const float4 v2 = *reinterpret_cast<const float4 *>(p2 + 16 * S);
+                    const float4 v3 = *reinterpret_cast<const float4 *>(p3 + 16 * S);
+                    x[S][0] = ((v1.x * w1 + v2.x * w2) + v3.x * w3) + vx.x * wx;
+                    x[S][1] = ((v1.y * w1 + v2.y * w2) + v3.y * w3) + vx.y * wx;
+                    x[S][2] = ((v1.z * w1 + v2.z * w2) + v3.z * w3) + vx.z * wx;
+                    x[S][3] = ((v1.w * w1 + v2.w * w2) + v3.w * w3) + vx.w * wx;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const bool dbl = a.owner != nullptr && a.owner[row] < 0;  // untouched voxel (ref quirk R12)
+            const float *px = (dbl ? a.x_in : a.x_new) + (size_t)row * C + 4 * g;
+            const float wx = dbl ? 2.0f : 1.0f;
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                const float4 vx = *reinterpret_cast<const float4 *>(px + 16 * S);
+                x[S] = f32x4{vx.x * wx, vx.y * wx, vx.z * wx, vx.w * wx};
+            }
+        }
+        if (live && !(a.dbg & 8)) {  // park x in y: the second launch adds it back
+            float *py = a.y + (size_t)row * C + 4 * g;
+#pragma unroll
+            for (int S = 0; S < NT; ++S) *reinterpret_cast<float4 *>(py + 16 * S) = make_float4(x[S][0], x[S][1], x[S][2], x[S][3]);
+        }
+        // ---- LayerNorm (norm2): a row = the 4 lanes la, la+16, la+32, la+48 --------------------
+        float sum = 0.f;
+#pragma unroll
+        for (int S = 0; S < NT; ++S) sum += (x[S][0] + x[S][1]) + (x[S][2] + x[S][3]);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / C);
+        float var = 0.f;
+#pragma unroll
+        for (int S = 0; S < NT; ++S)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = x[S][j] - mean;
+                var = __builtin_fmaf(d, d, var);
+            }
+        var += __shfl_xor(var, 16);
+        var += __shfl_xor(var, 32);
+        const float rstd = rsqrtf(var * (1.0f / C) + a.eps);
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+            const float4 gw = *reinterpret_cast<const float4 *>(lnw_l + 16 * S + 4 * g);
+            const float4 gb = *reinterpret_cast<const float4 *>(lnb_l + 16 * S + 4 * g);
+            x[S][0] = (x[S][0] - mean) * rstd * gw.x + gb.x;
+            x[S][1] = (x[S][1] - mean) * rstd * gw.y + gb.y;
+            x[S][2] = (x[S][2] - mean) * rstd * gw.z + gb.z;
+            x[S][3] = (x[S][3] - mean) * rstd * gw.w + gb.w;
+        }
+        // ---- u^T[hidden][row] = relu(W1 xn + b1), 4 hidden tiles (= 4 independent chains) at a time
+        float *pu = hidden + (size_t)row * FF + 4 * g;
+#pragma unroll 1
+        for (int h0 = 0; h0 < ((a.dbg & 4) ? HG : HT); h0 += HG) {
+            f32x4 acc[HG];
+#pragma unroll
+            for (int hg = 0; hg < HG; ++hg) {
+                const float4 b = *reinterpret_cast<const float4 *>(b1_l + 16 * (h0 + hg) + 4 * g);
+                acc[hg] = f32x4{b.x, b.y, b.z, b.w};
+            }
+            const float *wbase = W1_l + (size_t)(16 * h0 + la) * LS + 4 * g;
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                float4 w[HG];
+#pragma unroll
+                for (int hg = 0; hg < HG; ++hg) w[hg] = *reinterpret_cast<const float4 *>(wbase + hg * 16 * LS + 16 * S);
+#pragma unroll
+                for (int hg = 0; hg < HG; ++hg) MFMA4(acc[hg], w[hg].x, x[S][0]);
+#pragma unroll
+                for (int hg = 0; hg < HG; ++hg) MFMA4(acc[hg], w[hg].y, x[S][1]);
+#pragma unroll
+                for (int hg = 0; hg < HG; ++hg) MFMA4(acc[hg], w[hg].z, x[S][2]);
+#pragma unroll
+                for (int hg = 0; hg < HG; ++hg) MFMA4(acc[hg], w[hg].w, x[S][3]);
+            }
+            if (live && !(a.dbg & 1)) {
+#pragma unroll
+                for (int hg = 0; hg < HG; ++hg)
+                    *reinterpret_cast<float4 *>(pu + 16 * (h0 + hg)) =
+                        make_float4(fmaxf(acc[hg][0], 0.f), fmaxf(acc[hg][1], 0.f), fmaxf(acc[hg][2], 0.f),
+                                    fmaxf(acc[hg][3], 0.f));
+            }
+        }
+    }
+}
+
+template <int C, int FF>
+__global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, const float *hidden) {
+    constexpr int NT = C / 16, HT = FF / 16, LS = FF + 4, SG = 4;
+    static_assert(HT % SG == 0, "k tiles are walked in groups of 4");
+    extern __shared__ float4 lds4[];
+    float *W2_l = reinterpret_cast<float *>(lds4);  // [C][LS]
+    float *b2_l = W2_l + C * LS, *lnw_l = b2_l + C, *lnb_l = lnw_l + C;
+    for (int e = threadIdx.x * 4; e < C * FF; e += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(W2_l + (e / FF) * LS + e % FF) = *reinterpret_cast<const float4 *>(a.W2 + e);
+    for (int e = threadIdx.x; e < C; e += blockDim.x) {
+        b2_l[e] = a.b2[e];
+        lnw_l[e] = a.y_norm ? a.ln2_w[e] : 0.f;
+        lnb_l[e] = a.y_norm ? a.ln2_b[e] : 0.f;
+    }
+    __syncthreads();
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+    const int tiles = (n + 15) >> 4;
+    for (int k = wv;; k += FFS_NW) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (tile >= tiles) break;
+        const int row = min(tile * 16 + la, n - 1);
+        const bool live = tile * 16 + la < n;
+        const float *pu = hidden + (size_t)row * FF + 4 * g;
+        float *py = a.y + (size_t)row * C + 4 * g;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 b = *reinterpret_cast<const float4 *>(b2_l + 16 * t + 4 * g);
+            acc[t] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        // hidden row in groups of 4 k-tiles, the next group's loads in flight during the MFMAs
+        float4 ub[SG], un[SG];
+#pragma unroll
+        for (int s = 0; s < SG; ++s) ub[s] = *reinterpret_cast<const float4 *>(pu + 16 * s);
+#pragma unroll 1
+        for (int S0 = 0; S0 < HT; S0 += SG) {
+            const int nxt = S0 + SG < HT ? S0 + SG : S0;
+#pragma unroll
+            for (int s = 0; s < SG; ++s) un[s] = *reinterpret_cast<const float4 *>(pu + 16 * (nxt + s));
+            const float *wbase = W2_l + (size_t)la * LS + 16 * S0 + 4 * g;
+#pragma unroll
+            for (int s = 0; s < SG; ++s) {
+                constexpr int TG = NT > 4 ? 4 : NT;  // output tiles per group: 4 independent chains
+#pragma unroll
+                for (int t0 = 0; t0 < NT; t0 += TG) {
+                    float4 w[TG];
+#pragma unroll
+                    for (int t = 0; t < TG; ++t) w[t] = *reinterpret_cast<const float4 *>(wbase + (t0 + t) * 16 * LS + 16 * s);
+#pragma unroll
+                    for (int t = 0; t < TG; ++t) MFMA4(acc[t0 + t], w[t].x, ub[s].x);
+#pragma unroll
+                    for (int t = 0; t < TG; ++t) MFMA4(acc[t0 + t], w[t].y, ub[s].y);
+#pragma unroll
+                    for (int t = 0; t < TG; ++t) MFMA4(acc[t0 + t], w[t].z, ub[s].z);
+#pragma unroll
+                    for (int t = 0; t < TG; ++t) MFMA4(acc[t0 + t], w[t].w, ub[s].w);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SG; ++s) ub[s] = un[s];
+        }
+        // ---- y = x + (W2 u + b2); x was parked in y by the first launch in this very layout ------
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 xv = *reinterpret_cast<const float4 *>(py + 16 * t);
+            acc[t][0] += xv.x; acc[t][1] += xv.y; acc[t][2] += xv.z; acc[t][3] += xv.w;
+            sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+        }
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) *reinterpret_cast<float4 *>(py + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        }
+        if (a.y_norm) {  // LayerNorm of y for the next block
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / C);
+            float var = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = acc[t][j] - mean;
+                    var = __builtin_fmaf(d, d, var);
+                }
+            var += __shfl_xor(var, 16);
+            var += __shfl_xor(var, 32);
+            const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
+            if (live) {
+                float *pn = a.y_norm + (size_t)row * C + 4 * g;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 gw = *reinterpret_cast<const float4 *>(lnw_l + 16 * t + 4 * g);
+                    const float4 gb = *reinterpret_cast<const float4 *>(lnb_l + 16 * t + 4 * g);
+                    *reinterpret_cast<float4 *>(pn + 16 * t) =
+                        make_float4((acc[t][0] - mean) * rstd * gw.x + gb.x, (acc[t][1] - mean) * rstd * gw.y + gb.y,
+                                    (acc[t][2] - mean) * rstd * gw.z + gb.z, (acc[t][3] - mean) * rstd * gw.w + gb.w);
+                }
+            }
+        }
+    }
+}
+
+template <int C, int FF>
+static int launch_ffn_split(const FfnArgs &a, float *hidden, hipStream_t stream) {
+    const size_t lds_up = ((size_t)FF * (C + 4) + FF + 2 * C) * 4, lds_down = ((size_t)C * (FF + 4) + 3 * C) * 4;
+    static_assert(((size_t)FF * (C + 4) + FF + 2 * C) * 4 <= 160 * 1024 && ((size_t)C * (FF + 4) + 3 * C) * 4 <= 160 * 1024,
+                  "weights must fit the LDS");
+    if (lds_up > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ffn_up<C, FF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (lds_down > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ffn_down<C, FF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_down);
+        if (e != hipSuccess) return (int)e;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int tiles = (a.n_rows + 15) / 16;
+    int grid = cus * (int)((160 * 1024) / (lds_up > lds_down ? lds_up : lds_down));
+    if (grid > tiles) grid = tiles;
+    if (grid < 1) return MSSVT_OK;
+    k_ffn_up<C, FF><<<grid, FFS_NW * MSSVT_WAVE, lds_up, stream>>>(a, hidden);
+    k_ffn_down<C, FF><<<grid, FFS_NW * MSSVT_WAVE, lds_down, stream>>>(a, hidden);
+    return mssvt_launch_status();
+}
+
+static int dispatch_ffn(int C, int FF, const FfnArgs &a, float *hidden, hipStream_t st) {
+    if (hidden) {
+        if (C == 128 && FF == 256) return launch_ffn_split<128, 256>(a, hidden, st);
+        if (C == 64 && FF == 128) return launch_ffn_split<64, 128>(a, hidden, st);
+        if (C == 32 && FF == 64) return launch_ffn_split<32, 64>(a, hidden, st);
+        return MSSVT_E_TOOLARGE;
+    }
+    if (a.n_rows_dev) return MSSVT_E_BADARG;  // the single-launch form sizes its grid on the host
     if (C == 128 && FF == 256) return launch_ffn<128, 256>(a, st);
     if (C == 64 && FF == 128) return launch_ffn<64, 128>(a, st);
     if (C == 32 && FF == 64) return launch_ffn<32, 64>(a, st);
@@ -338,18 +633,20 @@ extern "C" int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, co
                                const int *owner, const float *norm_w, const float *norm_b, float eps,
                                const float *W1, const float *b1, const float *W2, const float *b2,
                                float *y, const float *next_norm_w, const float *next_norm_b,
-                               float next_eps, float *y_norm, void *stream) {
+                               float next_eps, float *y_norm, float *hidden, const int *num_rows_dev,
+                               void *stream) {
     if (n_rows < 0 || !x_new || !norm_w || !norm_b || !W1 || !b1 || !W2 || !b2 || !y) return MSSVT_E_BADARG;
     if (owner && !x_in) return MSSVT_E_BADARG;
     if (y_norm && (!next_norm_w || !next_norm_b)) return MSSVT_E_BADARG;
     if (n_rows == 0) return MSSVT_OK;
     FfnArgs a;
-    a.n_rows = n_rows; a.x_new = x_new; a.x_in = x_in; a.owner = owner;
+    a.dbg = getenv("MSSVT_DBG") ? atoi(getenv("MSSVT_DBG")) : 0;
+    a.n_rows = n_rows; a.n_rows_dev = num_rows_dev; a.x_new = x_new; a.x_in = x_in; a.owner = owner;
     a.tab_row = nullptr; a.tab_w = nullptr; a.attn = nullptr;
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
     a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm;
-    return dispatch_ffn(C, FF, a, (hipStream_t)stream);
+    return dispatch_ffn(C, FF, a, hidden, (hipStream_t)stream);
 }
 
 // Same tail, fed by the interpolation table of mssvt_block_interp_table: the residual input
@@ -360,19 +657,20 @@ extern "C" int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_
                                       const float *norm_b, float eps, const float *W1, const float *b1,
                                       const float *W2, const float *b2, float *y,
                                       const float *next_norm_w, const float *next_norm_b, float next_eps,
-                                      float *y_norm, void *stream) {
+                                      float *y_norm, float *hidden, const int *num_rows_dev, void *stream) {
     if (n_rows < 0 || !x_in || !tab_row || !tab_w || !attn || !norm_w || !norm_b || !W1 || !b1 || !W2 ||
         !b2 || !y)
         return MSSVT_E_BADARG;
     if (y_norm && (!next_norm_w || !next_norm_b)) return MSSVT_E_BADARG;
     if (n_rows == 0) return MSSVT_OK;
     FfnArgs a;
-    a.n_rows = n_rows; a.x_new = nullptr; a.x_in = x_in; a.owner = nullptr;
+    a.dbg = getenv("MSSVT_DBG") ? atoi(getenv("MSSVT_DBG")) : 0;
+    a.n_rows = n_rows; a.n_rows_dev = num_rows_dev; a.x_new = nullptr; a.x_in = x_in; a.owner = nullptr;
     a.tab_row = reinterpret_cast<const int4 *>(tab_row);
     a.tab_w = reinterpret_cast<const float4 *>(tab_w);
     a.attn = attn;
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
     a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm;
-    return dispatch_ffn(C, FF, a, (hipStream_t)stream);
+    return dispatch_ffn(C, FF, a, hidden, (hipStream_t)stream);
 }

@@ -19,6 +19,8 @@ per-voxel FFN GEMMs.
 """
 import ctypes
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -174,6 +176,7 @@ def _query_scratch(p, num_voxels, ma, dev):
 
 
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
+FFN_SPLIT = os.environ.get("MSSVT_FFN_SPLIT", "1") != "0"
 
 
 def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None):
@@ -195,12 +198,15 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None):
         y_norm = None
         if nxt is not None and not has_out and nxt.normalized_shape[0] == C:
             y_norm = torch.empty_like(x_new)
+        # two launches with LDS-resident weights; the hidden activations go through this scratch
+        hidden = torch.empty((n, FF), dtype=torch.float32, device=x_new.device) if FFN_SPLIT else None
         tail = (_lib.ptr(block.norm2.weight), _lib.ptr(block.norm2.bias), _f(block.norm2.eps),
                 _lib.ptr(block.linear1.weight), _lib.ptr(block.linear1.bias), _lib.ptr(block.linear2.weight),
                 _lib.ptr(block.linear2.bias), _lib.ptr(y),
                 _lib.ptr(nxt.weight if y_norm is not None else None),
                 _lib.ptr(nxt.bias if y_norm is not None else None),
-                _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.stream())
+                _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.ptr(hidden), None,
+                _lib.stream())
         if table is not None:
             (tab_row, tab_w), attn = table
             _lib.call("mssvt_ffn_fused_interp", _i(n), _i(C), _i(FF), _lib.ptr(x_in), _lib.ptr(tab_row),

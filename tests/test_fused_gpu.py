@@ -67,8 +67,9 @@ def test_window_plan_matches_oracle(ws, m1, m2, K, B, pts):
     np.testing.assert_array_equal(p.owner_win1.cpu().numpy(), own)
 
 
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("C,FF,n", [(128, 256, 5000), (64, 128, 1000), (32, 64, 129), (128, 256, 7)])
-def test_fused_ffn_kernel_matches_torch(C, FF, n):
+def test_fused_ffn_kernel_matches_torch(C, FF, n, split):
     """LN2 + linear1 + ReLU + linear2 + residual (+ next block's norm1) on the fp32 matrix cores."""
     import ctypes
     from mssvt_amd import _lib
@@ -87,11 +88,12 @@ def test_fused_ffn_kernel_matches_torch(C, FF, n):
         want = x + l2(torch.relu(l1(ln(x))))
         want_n = ln2(want)
     y, yn = torch.empty_like(x_new), torch.empty_like(x_new)
+    hidden = torch.empty((n, FF), device=DEV) if split else None  # split: two launches, LDS-resident weights
     i, f = ctypes.c_int, ctypes.c_float
     _lib.call("mssvt_ffn_fused", i(n), i(C), i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
               _lib.ptr(ln.weight), _lib.ptr(ln.bias), f(ln.eps), _lib.ptr(l1.weight), _lib.ptr(l1.bias),
               _lib.ptr(l2.weight), _lib.ptr(l2.bias), _lib.ptr(y), _lib.ptr(ln2.weight), _lib.ptr(ln2.bias),
-              f(ln2.eps), _lib.ptr(yn), _lib.stream())
+              f(ln2.eps), _lib.ptr(yn), _lib.ptr(hidden), None, _lib.stream())
     np.testing.assert_allclose(y.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(yn.cpu().numpy(), want_n.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
