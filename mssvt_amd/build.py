@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
     procs = []
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + os.environ.get("MSSVT_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

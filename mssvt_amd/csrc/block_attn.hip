@@ -80,11 +80,25 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnAr
     float *WkT_l = Wq_l + CGP * LS;                 // [c][o] = Wk[o][c]
     float *Wp_l = WkT_l + CGP * LS;                 // [c][8] = pos_proj row (6 weights, bias, 0)
     float *bq_l = Wp_l + CGP * 8;                   // [o]
-    for (int e = threadIdx.x; e < CGP * CGP; e += blockDim.x) {
-        const int o = e / CGP, c = e % CGP;
-        const bool in = o < CG && c < CG;
-        Wq_l[o * LS + c] = in ? a.Wq[o * CG + c] : 0.f;
-        WkT_l[c * LS + o] = in ? a.Wkv[o * CG + c] : 0.f;  // rows [0,CG) of to_kvs = K projection
+    // 8 elements of each matrix in flight per thread (a plain copy loop waits for every load before
+    // its store: one global round trip per element)
+    for (int e0 = threadIdx.x; e0 < CGP * CGP; e0 += blockDim.x * 8) {
+        float vq[8], vk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
+            const bool in = e < CGP * CGP && o < CG && c < CG;
+            vq[u] = in ? a.Wq[o * CG + c] : 0.f;
+            vk[u] = in ? a.Wkv[o * CG + c] : 0.f;  // rows [0,CG) of to_kvs = K projection
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
+            if (e < CGP * CGP) {
+                Wq_l[o * LS + c] = vq[u];
+                WkT_l[c * LS + o] = vk[u];
+            }
+        }
     }
     for (int e = threadIdx.x; e < CGP * 8; e += blockDim.x) {
         const int c = e >> 3, t = e & 7;
@@ -189,11 +203,23 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnAr
     float *Wv_l = reinterpret_cast<float *>(lds4);  // [o][c]
     float *Wo_l = Wv_l + CGP * LS;                  // [p][o]
     float *bv_l = Wo_l + CGP * LS, *bo_l = bv_l + CGP;
-    for (int e = threadIdx.x; e < CGP * CGP; e += blockDim.x) {
-        const int o = e / CGP, c = e % CGP;
-        const bool in = o < CG && c < CG;
-        Wv_l[o * LS + c] = in ? a.Wkv[(size_t)(CG + o) * CG + c] : 0.f;  // rows [CG,2CG) of to_kvs = V projection
-        Wo_l[o * LS + c] = in ? a.Wo[o * CG + c] : 0.f;
+    for (int e0 = threadIdx.x; e0 < CGP * CGP; e0 += blockDim.x * 8) {
+        float vv[8], vo[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
+            const bool in = e < CGP * CGP && o < CG && c < CG;
+            vv[u] = in ? a.Wkv[(size_t)(CG + o) * CG + c] : 0.f;  // rows [CG,2CG) of to_kvs = V projection
+            vo[u] = in ? a.Wo[o * CG + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
+            if (e < CGP * CGP) {
+                Wv_l[o * LS + c] = vv[u];
+                Wo_l[o * LS + c] = vo[u];
+            }
+        }
     }
     for (int e = threadIdx.x; e < CGP; e += blockDim.x) {
         bv_l[e] = e < CG ? a.bkv[CG + e] : 0.f;

@@ -28,7 +28,6 @@
 // through a 16 x (C+4) LDS tile per wave, which lives in the weight buffer that is idle at the
 // batch boundary.  (First version: operand-shaped global loads, 64 different lines per
 // instruction -> every line missed the 32-KiB L1 eight times: 54k cycles per 16 rows.)
-#include <stdlib.h>
 #include "common.hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -37,7 +36,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FFN_NW 4   // waves per workgroup
 
 struct FfnArgs {
-    int dbg;
     int n_rows;
     const int *n_rows_dev;  // optional: the row count lives on the device (n_rows = capacity)
     const float *x_new, *x_in;  // plain input: x = owner && owner[v] < 0 ? 2 * x_in[v] : x_new[v]
@@ -343,82 +341,181 @@ static int launch_ffn(const FfnArgs &a, hipStream_t stream) {
 // lane (row = l % 16, g = l / 16) -> channels 16 S + 4 g + j, i.e. plain 16-byte global loads; the
 // accumulator (lane (row, g), register i = output 16 t + 4 g + i) leaves as 16-byte stores.
 // ---------------------------------------------------------------------------------------------
-#define FFS_NW 16  // waves per workgroup of the split kernels
+#ifdef MSSVT_STAMPS  // developer instrumentation: per-wave s_memtime stamps of the split kernels
+__device__ unsigned long long g_stamps[2 * 4 * 8 * 64];
+extern "C" int mssvt_debug_read_stamps(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#define STAMP(kid_) \
+    if (lane == 0 && blockIdx.x < 4 && si < 64) g_stamps[(((kid_) * 4 + blockIdx.x) * 8 + wv) * 64 + si++] = __builtin_readcyclecounter();
+#else
+#define STAMP(kid_)
+#endif
+#define FFS_NW 8  // waves per workgroup of the split kernels (2 per SIMD, up to 256 VGPRs each)
 
 #define MFMA4(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
 
+// Residual input of one row: x = tab.x < 0 ? 2 x_in : x_in + sum_i w_i attn[row_i]  (table form), or
+// x_new / 2 x_in by owner.  Four row pointers + weights; every stream is read with the same pattern.
+struct FfnRowSrc {
+    const float *px, *p1, *p2, *p3;
+    float w1, w2, w3, wx;
+    bool live;
+    float *py, *pu;
+};
+
+// table entry of a row (loaded one tile ahead of the gathers that need it)
+struct FfnTab {
+    int4 tr;
+    float4 tw;
+    int own;
+};
+
+__device__ __forceinline__ FfnTab ffn_tab_load(const FfnArgs &a, int tile, int n, int la) {
+    FfnTab t;
+    const int row = min(tile * 16 + la, n - 1);
+    t.tr = make_int4(0, 0, 0, 0);
+    t.tw = make_float4(0.f, 0.f, 0.f, 0.f);
+    t.own = 0;
+    if (a.tab_row) {
+        t.tr = a.tab_row[row];
+        t.tw = a.tab_w[row];
+    } else if (a.owner) {
+        t.own = a.owner[row];
+    }
+    return t;
+}
+
+template <int C, int FF>
+__device__ __forceinline__ FfnRowSrc ffn_row_src(const FfnArgs &a, float *hidden, int tile, int n, int la, int g,
+                                                 const FfnTab &t) {
+    FfnRowSrc r;
+    const int row = min(tile * 16 + la, n - 1);
+    r.live = tile * 16 + la < n;
+    r.py = a.y + (size_t)row * C + 4 * g;
+    r.pu = hidden + (size_t)row * FF + 4 * g;
+    if (a.tab_row) {
+        const bool unowned = t.tr.x < 0;
+        // an unowned voxel re-reads its own (finite) x_in row with weight 0: attention rows of
+        // never-written slots may hold NaNs, and 0 * NaN is NaN
+        r.px = a.x_in + (size_t)row * C + 4 * g;
+        r.p1 = unowned ? r.px : a.attn + (size_t)t.tr.x * C + 4 * g;
+        r.p2 = unowned ? r.px : a.attn + (size_t)t.tr.y * C + 4 * g;
+        r.p3 = unowned ? r.px : a.attn + (size_t)t.tr.z * C + 4 * g;
+        r.w1 = unowned ? 0.f : t.tw.x;
+        r.w2 = unowned ? 0.f : t.tw.y;
+        r.w3 = unowned ? 0.f : t.tw.z;
+        r.wx = unowned ? 2.0f : 1.0f;  // untouched voxel: features + shortcut = 2 * x_in
+    } else {
+        const bool dbl = a.owner != nullptr && t.own < 0;  // untouched voxel (ref quirk R12)
+        r.px = r.p1 = r.p2 = r.p3 = (dbl ? a.x_in : a.x_new) + (size_t)row * C + 4 * g;
+        r.w1 = r.w2 = r.w3 = 0.f;
+        r.wx = dbl ? 2.0f : 1.0f;
+    }
+    return r;
+}
+
+// weights -> LDS rows of LS floats, 8 float4 loads in flight per thread (a plain copy loop waits
+// for every load before its store: 17 round trips for 132 KiB)
+template <int COLS, int LS>
+__device__ __forceinline__ void ffn_stage_weights(float *dst, const float *src, int rows) {
+    constexpr int UN = 8;
+    const int total = rows * COLS;
+    for (int e0 = threadIdx.x * 4; e0 < total; e0 += blockDim.x * 4 * UN) {
+        float4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * blockDim.x * 4;
+            v[u] = e < total ? *reinterpret_cast<const float4 *>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * blockDim.x * 4;
+            if (e < total) *reinterpret_cast<float4 *>(dst + (e / COLS) * LS + e % COLS) = v[u];
+        }
+    }
+}
+
+// macros, not lambdas: handing register arrays to a lambda takes their address -> scratch memory
+#define FFN_ISSUE(src_, S0_)                                                                     \
+    _Pragma("unroll") for (int s_ = 0; s_ < SH; ++s_) {                                          \
+        rx[s_] = *reinterpret_cast<const float4 *>((src_).px + 16 * ((S0_) + s_));              \
+        if (tabbed) {                                                                            \
+            r1[s_] = *reinterpret_cast<const float4 *>((src_).p1 + 16 * ((S0_) + s_));          \
+            r2[s_] = *reinterpret_cast<const float4 *>((src_).p2 + 16 * ((S0_) + s_));          \
+            r3[s_] = *reinterpret_cast<const float4 *>((src_).p3 + 16 * ((S0_) + s_));          \
+        }                                                                                        \
+    }
+#define FFN_COMBINE(src_, S0_, dst_)                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < SH; ++s_) {                                          \
+        if (tabbed) {                                                                            \
+            dst_[(S0_) + s_][0] = ((r1[s_].x * (src_).w1 + r2[s_].x * (src_).w2) + r3[s_].x * (src_).w3) + rx[s_].x * (src_).wx; \
+            dst_[(S0_) + s_][1] = ((r1[s_].y * (src_).w1 + r2[s_].y * (src_).w2) + r3[s_].y * (src_).w3) + rx[s_].y * (src_).wx; \
+            dst_[(S0_) + s_][2] = ((r1[s_].z * (src_).w1 + r2[s_].z * (src_).w2) + r3[s_].z * (src_).w3) + rx[s_].z * (src_).wx; \
+            dst_[(S0_) + s_][3] = ((r1[s_].w * (src_).w1 + r2[s_].w * (src_).w2) + r3[s_].w * (src_).w3) + rx[s_].w * (src_).wx; \
+        } else {                                                                                 \
+            dst_[(S0_) + s_] = f32x4{rx[s_].x * (src_).wx, rx[s_].y * (src_).wx, rx[s_].z * (src_).wx, rx[s_].w * (src_).wx}; \
+        }                                                                                        \
+    }
+
 template <int C, int FF>
 __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_up(FfnArgs a, float *hidden) {
-    constexpr int NT = C / 16, HT = FF / 16, LS = C + 4, HG = 4;
+    constexpr int NT = C / 16, HT = FF / 16, LS = C + 4, HG = 4, NG = HT / HG;
+    constexpr int SH = NT > 1 ? NT / 2 : 1, NHALF = NT / SH;  // the row is gathered in NHALF pieces
     static_assert(HT % HG == 0, "hidden tiles are walked in groups of 4");
     extern __shared__ float4 lds4[];
     float *W1_l = reinterpret_cast<float *>(lds4);  // [FF][LS]
     float *b1_l = W1_l + FF * LS, *lnw_l = b1_l + FF, *lnb_l = lnw_l + C;
-    for (int e = threadIdx.x * 4; e < FF * C; e += blockDim.x * 4)
-        *reinterpret_cast<float4 *>(W1_l + (e / C) * LS + e % C) = *reinterpret_cast<const float4 *>(a.W1 + e);
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+    const int tiles = (n + 15) >> 4;
+    const bool tabbed = a.tab_row != nullptr;
+    if (n <= 0) return;
+    int si = 0;
+    (void)si;
+    STAMP(0)
+    // tile k * gridDim + block -> wave k % NW: the last partial round is spread over all CUs
+    int tile = wv * gridDim.x + blockIdx.x;
+    const bool any = tile < tiles;
+    // the first tile's table entry travels while the weights are staged
+    FfnTab tab_cur = ffn_tab_load(a, any ? tile : 0, n, la);
+    ffn_stage_weights<C, LS>(W1_l, a.W1, FF);
     for (int e = threadIdx.x; e < FF; e += blockDim.x) b1_l[e] = a.b1[e];
     for (int e = threadIdx.x; e < C; e += blockDim.x) {
         lnw_l[e] = a.ln_w[e];
         lnb_l[e] = a.ln_b[e];
     }
+    float4 rx[SH], r1[SH], r2[SH], r3[SH];
+    f32x4 x[NT], xnext[NT];
+    FfnRowSrc cur = ffn_row_src<C, FF>(a, hidden, any ? tile : 0, n, la, g, tab_cur);
+    FFN_ISSUE(cur, 0)  // in flight across the barrier
+    STAMP(0)
     __syncthreads();
-    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
-    const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
-    const int tiles = (n + 15) >> 4;
-    // tile k * gridDim + block -> wave k % 16: the last partial round is spread over all CUs
-    for (int k = wv;; k += FFS_NW) {
-        const int tile = k * gridDim.x + blockIdx.x;
-        if (tile >= tiles) break;
-        const int row = min(tile * 16 + la, n - 1);
-        const bool live = tile * 16 + la < n;
-        // ---- x = residual input of the FFN, this lane's channels 16 S + 4 g + j ----------------
-        f32x4 x[NT];
-        if (a.dbg & 2) {
+    STAMP(0)
+    if (!any) return;
+    FfnTab tab_next = ffn_tab_load(a, min(tile + FFS_NW * (int)gridDim.x, tiles - 1), n, la);
 #pragma unroll
-            for (int S = 0; S < NT; ++S) x[S] = f32x4{1.f * la, 2.f, 3.f * S, 4.f};
-        } else if (a.tab_row) {
-            const int4 tr = a.tab_row[row];
-            const float4 tw = a.tab_w[row];
-            const bool unowned = tr.x < 0;
-            // an unowned voxel re-reads its own (finite) x_in row with weight 0: attention rows of
-            // never-written slots may hold NaNs, and 0 * NaN is NaN
-            const float *px = a.x_in + (size_t)row * C + 4 * g;
-            const float *p1 = unowned ? px : a.attn + (size_t)tr.x * C + 4 * g;
-            const float *p2 = unowned ? px : a.attn + (size_t)tr.y * C + 4 * g;
-            const float *p3 = unowned ? px : a.attn + (size_t)tr.z * C + 4 * g;
-            const float w1 = unowned ? 0.f : tw.x, w2 = unowned ? 0.f : tw.y, w3 = unowned ? 0.f : tw.z;
-            const float wx = unowned ? 2.0f : 1.0f;  // untouched voxel: features + shortcut = 2 * x_in
-            // 4 streams x NT/2 float4 in flight at a time (all NT would not fit 128 VGPRs)
-            constexpr int SH = NT > 1 ? NT / 2 : 1;
-#pragma unroll
-            for (int S0 = 0; S0 < NT; S0 += SH) {
-#pragma unroll
-                for (int S = S0; S < S0 + SH; ++S) {
-                    const float4 vx = *reinterpret_cast<const float4 *>(px + 16 * S);
-                    const float4 v1 = *reinterpret_cast<const float4 *>(p1 + 16 * S);
-                    const float4 v2 = *reinterpret_cast<const float4 *>(p2 + 16 * S);
-                    const float4 v3 = *reinterpret_cast<const float4 *>(p3 + 16 * S);
-                    x[S][0] = ((v1.x * w1 + v2.x * w2) + v3.x * w3) + vx.x * wx;
-                    x[S][1] = ((v1.y * w1 + v2.y * w2) + v3.y * w3) + vx.y * wx;
-                    x[S][2] = ((v1.z * w1 + v2.z * w2) + v3.z * w3) + vx.z * wx;
-                    x[S][3] = ((v1.w * w1 + v2.w * w2) + v3.w * w3) + vx.w * wx;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            const bool dbl = a.owner != nullptr && a.owner[row] < 0;  // untouched voxel (ref quirk R12)
-            const float *px = (dbl ? a.x_in : a.x_new) + (size_t)row * C + 4 * g;
-            const float wx = dbl ? 2.0f : 1.0f;
-#pragma unroll
-            for (int S = 0; S < NT; ++S) {
-                const float4 vx = *reinterpret_cast<const float4 *>(px + 16 * S);
-                x[S] = f32x4{vx.x * wx, vx.y * wx, vx.z * wx, vx.w * wx};
-            }
+    for (int hf = 0; hf < NHALF; ++hf) {
+        if (hf > 0) FFN_ISSUE(cur, hf * SH)
+        FFN_COMBINE(cur, hf * SH, x)
+    }
+    STAMP(0)
+    for (;;) {
+        const int tile_next = tile + FFS_NW * gridDim.x;
+        const bool has_next = tile_next < tiles;
+        // the next tile's gathers are issued below and fly under this tile's MFMAs; its table entry
+        // was loaded one tile ago, the one after next is requested now
+        FfnRowSrc nxt = cur;
+        if (has_next) {
+            nxt = ffn_row_src<C, FF>(a, hidden, tile_next, n, la, g, tab_next);
+            tab_next = ffn_tab_load(a, min(tile_next + FFS_NW * (int)gridDim.x, tiles - 1), n, la);
         }
-        if (live && !(a.dbg & 8)) {  // park x in y: the second launch adds it back
-            float *py = a.y + (size_t)row * C + 4 * g;
+        // loads before stores: vmcnt retires in order, a wait for a load also waits for every store
+        // issued before it
+        if (has_next) FFN_ISSUE(nxt, 0)
+        if (cur.live) {  // park x in y: the second launch adds it back
 #pragma unroll
-            for (int S = 0; S < NT; ++S) *reinterpret_cast<float4 *>(py + 16 * S) = make_float4(x[S][0], x[S][1], x[S][2], x[S][3]);
+            for (int S = 0; S < NT; ++S) *reinterpret_cast<float4 *>(cur.py + 16 * S) = make_float4(x[S][0], x[S][1], x[S][2], x[S][3]);
         }
         // ---- LayerNorm (norm2): a row = the 4 lanes la, la+16, la+32, la+48 --------------------
         float sum = 0.f;
@@ -447,10 +544,20 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_up(FfnArgs a, float 
             x[S][2] = (x[S][2] - mean) * rstd * gw.z + gb.z;
             x[S][3] = (x[S][3] - mean) * rstd * gw.w + gb.w;
         }
-        // ---- u^T[hidden][row] = relu(W1 xn + b1), 4 hidden tiles (= 4 independent chains) at a time
-        float *pu = hidden + (size_t)row * FF + 4 * g;
-#pragma unroll 1
-        for (int h0 = 0; h0 < ((a.dbg & 4) ? HG : HT); h0 += HG) {
+        STAMP(0)
+        // ---- u^T[hidden][row] = relu(W1 xn + b1), 4 hidden tiles (= 4 independent chains) at a time;
+        // the next tile's row gathers are issued / consumed between the groups, i.e. they are in
+        // flight under this tile's MFMAs (the branches also pin that order for the scheduler)
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (has_next) {
+                if (gi == (NG > 1 ? 1 : 0)) {
+                    FFN_COMBINE(nxt, 0, xnext)
+                    if (NHALF > 1) FFN_ISSUE(nxt, SH)
+                }
+                if (NHALF > 1 && gi == NG - 1) FFN_COMBINE(nxt, SH, xnext)
+            }
+            const int h0 = gi * HG;
             f32x4 acc[HG];
 #pragma unroll
             for (int hg = 0; hg < HG; ++hg) {
@@ -458,11 +565,17 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_up(FfnArgs a, float 
                 acc[hg] = f32x4{b.x, b.y, b.z, b.w};
             }
             const float *wbase = W1_l + (size_t)(16 * h0 + la) * LS + 4 * g;
+            // weights of step S + 1 are read while step S multiplies; the barriers keep the scheduler
+            // from hoisting every ds_read of the unrolled loop to the top (VGPRs)
+            float4 w[HG], wn[HG];
+#pragma unroll
+            for (int hg = 0; hg < HG; ++hg) w[hg] = *reinterpret_cast<const float4 *>(wbase + hg * 16 * LS);
 #pragma unroll
             for (int S = 0; S < NT; ++S) {
-                float4 w[HG];
+                if (S + 1 < NT) {
 #pragma unroll
-                for (int hg = 0; hg < HG; ++hg) w[hg] = *reinterpret_cast<const float4 *>(wbase + hg * 16 * LS + 16 * S);
+                    for (int hg = 0; hg < HG; ++hg) wn[hg] = *reinterpret_cast<const float4 *>(wbase + hg * 16 * LS + 16 * (S + 1));
+                }
 #pragma unroll
                 for (int hg = 0; hg < HG; ++hg) MFMA4(acc[hg], w[hg].x, x[S][0]);
 #pragma unroll
@@ -471,58 +584,82 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_up(FfnArgs a, float 
                 for (int hg = 0; hg < HG; ++hg) MFMA4(acc[hg], w[hg].z, x[S][2]);
 #pragma unroll
                 for (int hg = 0; hg < HG; ++hg) MFMA4(acc[hg], w[hg].w, x[S][3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int hg = 0; hg < HG; ++hg) w[hg] = wn[hg];
             }
-            if (live && !(a.dbg & 1)) {
+            if (cur.live) {
 #pragma unroll
                 for (int hg = 0; hg < HG; ++hg)
-                    *reinterpret_cast<float4 *>(pu + 16 * (h0 + hg)) =
+                    *reinterpret_cast<float4 *>(cur.pu + 16 * (h0 + hg)) =
                         make_float4(fmaxf(acc[hg][0], 0.f), fmaxf(acc[hg][1], 0.f), fmaxf(acc[hg][2], 0.f),
                                     fmaxf(acc[hg][3], 0.f));
             }
-        }
+            }
+        if (!has_next) break;
+#pragma unroll
+        for (int S = 0; S < NT; ++S) x[S] = xnext[S];
+        cur = nxt;
+        tile = tile_next;
     }
 }
 
 template <int C, int FF>
 __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, const float *hidden) {
-    constexpr int NT = C / 16, HT = FF / 16, LS = FF + 4, SG = 4;
+    constexpr int NT = C / 16, HT = FF / 16, LS = FF + 4, SG = 4, NG = HT / SG;
     static_assert(HT % SG == 0, "k tiles are walked in groups of 4");
     extern __shared__ float4 lds4[];
     float *W2_l = reinterpret_cast<float *>(lds4);  // [C][LS]
     float *b2_l = W2_l + C * LS, *lnw_l = b2_l + C, *lnb_l = lnw_l + C;
-    for (int e = threadIdx.x * 4; e < C * FF; e += blockDim.x * 4)
-        *reinterpret_cast<float4 *>(W2_l + (e / FF) * LS + e % FF) = *reinterpret_cast<const float4 *>(a.W2 + e);
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+    const int tiles = (n + 15) >> 4;
+    if (n <= 0) return;
+    int tile = wv * gridDim.x + blockIdx.x;
+    const bool any = tile < tiles;
+    int row = min((any ? tile : 0) * 16 + la, n - 1);
+    const float *pu = hidden + (size_t)row * FF + 4 * g;
+    // hidden row in groups of 4 k-tiles; the next group's (at the end: the next tile's first group's)
+    // loads are in flight during the MFMAs -- and the very first group's while the weights are staged
+    float4 ub[SG], un[SG];
+#pragma unroll
+    for (int s = 0; s < SG; ++s) ub[s] = *reinterpret_cast<const float4 *>(pu + 16 * s);
+    ffn_stage_weights<FF, LS>(W2_l, a.W2, C);
     for (int e = threadIdx.x; e < C; e += blockDim.x) {
         b2_l[e] = a.b2[e];
         lnw_l[e] = a.y_norm ? a.ln2_w[e] : 0.f;
         lnb_l[e] = a.y_norm ? a.ln2_b[e] : 0.f;
     }
     __syncthreads();
-    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
-    const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
-    const int tiles = (n + 15) >> 4;
-    for (int k = wv;; k += FFS_NW) {
-        const int tile = k * gridDim.x + blockIdx.x;
-        if (tile >= tiles) break;
-        const int row = min(tile * 16 + la, n - 1);
+    if (!any) return;
+    for (;;) {
+        const int tile_next = tile + FFS_NW * gridDim.x;
+        const bool has_next = tile_next < tiles;
+        const int row_next = min(tile_next * 16 + la, n - 1);
+        const float *pu_next = hidden + (size_t)(has_next ? row_next : row) * FF + 4 * g;
         const bool live = tile * 16 + la < n;
-        const float *pu = hidden + (size_t)row * FF + 4 * g;
         float *py = a.y + (size_t)row * C + 4 * g;
         f32x4 acc[NT];
+        float4 xv[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float4 b = *reinterpret_cast<const float4 *>(b2_l + 16 * t + 4 * g);
             acc[t] = f32x4{b.x, b.y, b.z, b.w};
         }
-        // hidden row in groups of 4 k-tiles, the next group's loads in flight during the MFMAs
-        float4 ub[SG], un[SG];
 #pragma unroll
-        for (int s = 0; s < SG; ++s) ub[s] = *reinterpret_cast<const float4 *>(pu + 16 * s);
-#pragma unroll 1
-        for (int S0 = 0; S0 < HT; S0 += SG) {
-            const int nxt = S0 + SG < HT ? S0 + SG : S0;
+        for (int gi = 0; gi < NG; ++gi) {
+            const int S0 = gi * SG;
+            if (gi + 1 < NG) {
 #pragma unroll
-            for (int s = 0; s < SG; ++s) un[s] = *reinterpret_cast<const float4 *>(pu + 16 * (nxt + s));
+                for (int s = 0; s < SG; ++s) un[s] = *reinterpret_cast<const float4 *>(pu + 16 * (S0 + SG + s));
+            } else {
+#pragma unroll
+                for (int s = 0; s < SG; ++s) un[s] = *reinterpret_cast<const float4 *>(pu_next + 16 * s);
+                // x was parked in y by the first launch in this very layout
+#pragma unroll
+                for (int t = 0; t < NT; ++t) xv[t] = *reinterpret_cast<const float4 *>(py + 16 * t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const float *wbase = W2_l + (size_t)la * LS + 16 * S0 + 4 * g;
 #pragma unroll
             for (int s = 0; s < SG; ++s) {
@@ -542,15 +679,15 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
                     for (int t = 0; t < TG; ++t) MFMA4(acc[t0 + t], w[t].w, ub[s].w);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < SG; ++s) ub[s] = un[s];
         }
-        // ---- y = x + (W2 u + b2); x was parked in y by the first launch in this very layout ------
+        // ---- y = x + (W2 u + b2) -----------------------------------------------------------------
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float4 xv = *reinterpret_cast<const float4 *>(py + 16 * t);
-            acc[t][0] += xv.x; acc[t][1] += xv.y; acc[t][2] += xv.z; acc[t][3] += xv.w;
+            acc[t][0] += xv[t].x; acc[t][1] += xv[t].y; acc[t][2] += xv[t].z; acc[t][3] += xv[t].w;
             sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
         }
         if (live) {
@@ -584,6 +721,10 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
                 }
             }
         }
+        if (!has_next) break;
+        tile = tile_next;
+        row = row_next;
+        pu = pu_next;
     }
 }
 
@@ -640,7 +781,6 @@ extern "C" int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, co
     if (y_norm && (!next_norm_w || !next_norm_b)) return MSSVT_E_BADARG;
     if (n_rows == 0) return MSSVT_OK;
     FfnArgs a;
-    a.dbg = getenv("MSSVT_DBG") ? atoi(getenv("MSSVT_DBG")) : 0;
     a.n_rows = n_rows; a.n_rows_dev = num_rows_dev; a.x_new = x_new; a.x_in = x_in; a.owner = owner;
     a.tab_row = nullptr; a.tab_w = nullptr; a.attn = nullptr;
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
@@ -664,7 +804,6 @@ extern "C" int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_
     if (y_norm && (!next_norm_w || !next_norm_b)) return MSSVT_E_BADARG;
     if (n_rows == 0) return MSSVT_OK;
     FfnArgs a;
-    a.dbg = getenv("MSSVT_DBG") ? atoi(getenv("MSSVT_DBG")) : 0;
     a.n_rows = n_rows; a.n_rows_dev = num_rows_dev; a.x_new = nullptr; a.x_in = x_in; a.owner = nullptr;
     a.tab_row = reinterpret_cast<const int4 *>(tab_row);
     a.tab_w = reinterpret_cast<const float4 *>(tab_w);
