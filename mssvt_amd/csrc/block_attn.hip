@@ -335,33 +335,55 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnA
     const int wstep = gridDim.x * ATTN_ROW_WAVES;
     const int K = a.K;
     const int *kmeta_i = reinterpret_cast<const int *>(a.kmeta);
-    for (int wi = blockIdx.x * ATTN_ROW_WAVES + wv; wi < n_act; wi += wstep) {
-        const int w = a.perm[wi];
-        const float4 wc = a.wcentre[w];
-        const int nqv = a.nq_valid[w];
-        const size_t qbase = (size_t)a.q_off[w];
+    int wi = blockIdx.x * ATTN_ROW_WAVES + wv;
+    if (wi >= n_act) return;
+    // window metadata, loaded one window ahead (perm -> kmeta -> feature rows would otherwise be three
+    // dependent round trips per window)
+    int w_n;
+    float4 wc_n, km_n[KT];
+    int nqv_n, qbase_n, r2_n[KT][4];
+#define KV_LOAD_META(wi_)                                                                  \
+    {                                                                                      \
+        w_n = a.perm[wi_];                                                                 \
+        wc_n = a.wcentre[w_n];                                                             \
+        nqv_n = a.nq_valid[w_n];                                                           \
+        qbase_n = a.q_off[w_n];                                                            \
+        _Pragma("unroll") for (int t = 0; t < KT; ++t) {                                   \
+            km_n[t] = a.kmeta[(size_t)w_n * K + min(16 * t + la, K - 1)];                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+                r2_n[t][i] = kmeta_i[((size_t)w_n * K + min(16 * t + 4 * g + i, K - 1)) * 4 + 3]; \
+        }                                                                                  \
+    }
+    KV_LOAD_META(wi)
+    for (; wi < n_act; wi += wstep) {
+        const float4 wc = wc_n;
+        const int nqv = nqv_n;
+        const size_t qbase = (size_t)qbase_n;
         // key metadata in both layouts
-        float rel[KT];   // pos. MLP input g of key 16 t + la (1 for g = 3)
-        int row1[KT];    // feature row of key 16 t + la (0 when masked)
+        float rel[KT];    // pos. MLP input g of key 16 t + la (1 for g = 3)
+        int row1[KT];     // feature row of key 16 t + la (0 when masked)
         int row2[KT][4];  // feature row of key 16 t + 4 g + i, -1 when masked
+        bool used[KT];    // wave-uniform: any unmasked key in tile t (slot 0 is never masked)
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             const int slot = 16 * t + la;
-            const float4 km = a.kmeta[(size_t)w * K + min(slot, K - 1)];
-            const int r = __builtin_bit_cast(int, km.w);
+            const int r = __builtin_bit_cast(int, km_n[t].w);
             row1[t] = slot < K && r >= 0 ? r : 0;
-            rel[t] = g == 0 ? km.x : (g == 1 ? km.y : (g == 2 ? km.z : 1.0f));
+            rel[t] = g == 0 ? km_n[t].x : (g == 1 ? km_n[t].y : (g == 2 ? km_n[t].z : 1.0f));
+            bool any = false;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int s2 = 16 * t + 4 * g + i;
-                const int r2 = kmeta_i[((size_t)w * K + min(s2, K - 1)) * 4 + 3];
-                row2[t][i] = s2 < K ? r2 : -1;
+                row2[t][i] = 16 * t + 4 * g + i < K ? r2_n[t][i] : -1;
+                any = any || row2[t][i] >= 0;
             }
+            used[t] = t == 0 || __ballot(any) != 0ull;
         }
+        if (wi + wstep < n_act) KV_LOAD_META(wi + wstep)
         // feature rows in both layouts
         f32x4 T1[KT][NT], T2[KT][NT];
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
+            if (!used[t]) continue;
             const float *xr = a.xhat + (size_t)row1[t] * a.C + a.c0;
 #pragma unroll
             for (int S = 0; S < NT; ++S) {
@@ -382,10 +404,11 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnA
         }
         // + relu(positional MLP), one MFMA per tile and layout
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const float wu = ((wconst[u] + w3[u] * wc.x) + w4[u] * wc.y) + w5[u] * wc.z;
+        for (int t = 0; t < KT; ++t) {
+            if (!used[t]) continue;
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
+            for (int u = 0; u < NT; ++u) {
+                const float wu = ((wconst[u] + w3[u] * wc.x) + w4[u] * wc.y) + w5[u] * wc.z;
                 f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f}, p2 = f32x4{0.f, 0.f, 0.f, 0.f};
                 MFMA4(p1, wu, rel[t]);  // rows = channels 16 u + 4 g + i, column = key 16 t + la
                 MFMA4(p2, rel[t], wu);  // rows = keys 16 t + 4 g + i,     column = channel 16 u + la
@@ -411,16 +434,21 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnA
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
                 qt[S] = f32x4{v.x, v.y, v.z, v.w};
             }
-            // scores: S[key][col] = sum_c T[key][c] Qt[col][c]
-            f32x4 sc[KT];
+            // scores: S[key][col] = sum_c T[key][c] Qt[col][c]; even / odd channel tiles accumulate
+            // separately (two independent MFMA chains per key tile)
+            f32x4 sc[KT], sc2[KT];
 #pragma unroll
-            for (int t = 0; t < KT; ++t) sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < KT; ++t) sc[t] = sc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int S = 0; S < NT; ++S) {
+            for (int t = 0; t < KT; ++t) {
+                if (!used[t]) continue;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int S = 0; S < NT; S += 2) {
 #pragma unroll
-                    for (int t = 0; t < KT; ++t) MFMA4(sc[t], T1[t][S][j], qt[S][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        MFMA4(sc[t], T1[t][S][j], qt[S][j]);
+                        if (S + 1 < NT) MFMA4(sc2[t], T1[t][S + 1][j], qt[S + 1][j]);
+                    }
                 }
             }
             // softmax over the unmasked keys: lane (col, g) holds keys 16 t + 4 g + i
@@ -428,7 +456,10 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnA
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, row2[t][i] >= 0 ? sc[t][i] : -INFINITY);
+                for (int i = 0; i < 4; ++i) {
+                    sc[t][i] += sc2[t][i];
+                    mx = fmaxf(mx, row2[t][i] >= 0 ? sc[t][i] : -INFINITY);
+                }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float sum = 0.f;
@@ -449,6 +480,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnA
             for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
+                if (!used[t]) continue;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float pv = sc[t][i] * inv;
@@ -466,6 +498,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnA
             }
         }
     }
+#undef KV_LOAD_META
 }
 
 template <int CG, int HD, int HP>
