@@ -269,6 +269,23 @@ int mssvt_compress_attention_group(int C, int c0, int Cg, int head_dim, float sc
                                    const int *win_vstart, const float *qp, const float *kv, float *out,
                                    void *stream);
 
+/* CompressBlock attention up to (not including) the FFN tail, for ONE head group and
+ * non-overlapping window lists (ref mssvt_backbone.py:351-383; MixedScaleAttention
+ * mssvt_utils.py:112-150), four launches on the fp32 matrix cores, every count read on the
+ * device (no host synchronisation):  out (nw,C) = projs( softmax_v( scale (Wq max_v xhat_v + bq)
+ * . (Wk k_v + bk) ) (Wv k_v + bv) ),  k_v = xhat_v + pos_proj([centre_v - centre_w ; centre_w]).
+ * k_ind / win_vstart / win_cnt / pair_win: from mssvt_window_plan_one with disjoint_lists = 1,
+ * with_pad = 0.  Wpos1 (C,6), Wpos2 (C,C), Wq (C,C), Wkv (2C,C), Wo (C,C) + biases: the module's
+ * parameters.  Scratch: qp (win_capacity,C), ktok (N,C), score (N,C/head_dim), vp (N,C).
+ * Instantiated for C in {32,64,128}, head_dim in {8,16,32} (C/head_dim <= 8).               */
+int mssvt_compress_fused(
+    int C, int head_dim, float scale, int max_num_win1, int num_voxels, const int *num_wins_dev, int win_capacity,
+    const int *win_ind, const int *indices, const int *k_ind, const int *win_vstart, const int *win_cnt,
+    const int *pair_win, const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3,
+    const float *xhat, const float *Wpos1, const float *bpos1, const float *Wpos2, const float *bpos2,
+    const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
+    float *qp, float *ktok, float *score, float *vp, float *out, void *stream);
+
 /* Rows per sample of a (N,4) [b,z,y,x] int32 index tensor -> counts (B) int32, on the device
  * (ref: the host loops with .item() of mssvt_utils.py:35-37 / mssvt_backbone.py:124-130).   */
 int mssvt_batch_counts(const int *indices, int num_rows, int batch_size, int *counts, void *stream);

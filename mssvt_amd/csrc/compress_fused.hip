@@ -1,0 +1,443 @@
+// compress_fused.hip -- CompressBlock attention on the fp32 matrix cores, four launches, no host sync.
+//
+// Fast form of the reference's MixedScaleSparseTransformerCompressBlock.forward up to (not including)
+// the FFN tail (ref: mssvt_backbone.py:351-383, MixedScaleAttention mssvt_utils.py:112-150) for the
+// common configuration: ONE head group, window lists that do not overlap (every voxel is a key of
+// exactly one window: pair row = voxel row, see k_window_plan_one).  Every count is read on the
+// device; the caller synchronises once, after the whole block is enqueued, to learn the output size.
+//
+//   A  k_cmp_query : rows = windows.  q_tok = channel-wise max over the window's (zero padded) key
+//                    features (ref :370); q' = scale (Wq q_tok + bq)                       -> qp (nw, C)
+//   B  k_cmp_keys  : rows = voxels.   h = relu(Wp1 [rel ; centre] + bp1)   (one K = 8 MFMA per tile)
+//                    k_tok = xhat + relu(Wp2 h + bp2)                                      -> ktok (N, C)
+//   C  k_cmp_kv    : rows = voxels.   K = Wk k_tok + bk  -> score[v][head] = q'[window(v)] . K[v]
+//                                     V = Wv k_tok + bv                                    -> vp (N, C)
+//   D  k_cmp_out   : rows = windows.  softmax over the window's voxels, o = sum_v p_v V[v];
+//                    new = Wo o + bo                                                       -> (nw, C)
+// All of them are row-tiled GEMMs in the style of block_attn.hip / ffn.hip: one wavefront = 16 rows,
+// products computed transposed (A = weight rows from LDS, one ds_read_b128 per 4 k-steps; B = the
+// activations, lane (row = l % 16, g = l / 16) -> channels 16 S + 4 g + j = 16-byte global accesses),
+// weights resident in LDS for the whole launch, no barrier after staging.
+// Masked list slots carry an additive -100 in the reference (relative weight <= e^-100): skipped.
+#include "common.hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CF_NW 8  // waves per workgroup
+#define MFMA4(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
+
+struct CmpArgs {
+    int C, ns, num_voxels;
+    float scale;
+    const int *num_wins;  // device
+    const int *win_ind;   // (cap,4) [b,wz,wy,wx]
+    const int *indices;   // (N,4)  [b,z,y,x]
+    const int *k_ind, *win_vstart, *win_cnt;  // K4 lists
+    const int *pair_win;                      // (N) window of every voxel, -1: in no list
+    float vsx, vsy, vsz, minx, miny, minz, wsx, wsy, wsz;
+    const float *xhat;
+    const float *Wp1, *bp1, *Wp2, *bp2;  // pos_proj.0 (C,6), pos_proj.2 (C,C)
+    const float *Wq, *bq, *Wkv, *bkv, *Wo, *bo;
+    float *qp, *ktok, *score, *vp, *out;
+};
+
+__device__ __forceinline__ float cf_centre(int idx, float cell, float lo) {
+    return __fadd_rn(__fmul_rn(__fadd_rn((float)idx, 0.5f), cell), lo);  // ref with_coords :132-137
+}
+
+// rows x COLS matrix -> LDS rows of LS floats, 8 float4 in flight per thread
+template <int COLS, int LS>
+__device__ __forceinline__ void cf_stage(float *dst, const float *src, int rows) {
+    constexpr int UN = 8;
+    const int total = rows * COLS;
+    for (int e0 = threadIdx.x * 4; e0 < total; e0 += blockDim.x * 4 * UN) {
+        float4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * blockDim.x * 4;
+            v[u] = e < total ? *reinterpret_cast<const float4 *>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * blockDim.x * 4;
+            if (e < total) *reinterpret_cast<float4 *>(dst + (e / COLS) * LS + e % COLS) = v[u];
+        }
+    }
+}
+
+// D^T[out][row] += W[out][:] . x[row][:] for NT x NT tiles; acc[u] must hold the bias
+template <int NT, int LS>
+__device__ __forceinline__ void cf_gemm(f32x4 (&acc)[NT], const float *W_l, const f32x4 (&x)[NT], int la, int g) {
+    constexpr int UG = NT > 4 ? 4 : NT;  // output tiles per group = independent MFMA chains
+#pragma unroll
+    for (int u0 = 0; u0 < NT; u0 += UG) {
+        const float *wbase = W_l + (size_t)(16 * u0 + la) * LS + 4 * g;
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+            float4 w[UG];
+#pragma unroll
+            for (int u = 0; u < UG; ++u) w[u] = *reinterpret_cast<const float4 *>(wbase + u * 16 * LS + 16 * S);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) MFMA4(acc[u0 + u], w[u].x, x[S][0]);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) MFMA4(acc[u0 + u], w[u].y, x[S][1]);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) MFMA4(acc[u0 + u], w[u].z, x[S][2]);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) MFMA4(acc[u0 + u], w[u].w, x[S][3]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the ds_reads of later steps where they are (VGPRs)
+        }
+    }
+}
+
+// ---- A: queries ---------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query(CmpArgs a) {
+    constexpr int NT = C / 16, LS = C + 4;
+    extern __shared__ float4 lds4[];
+    float *Wq_l = reinterpret_cast<float *>(lds4), *bq_l = Wq_l + C * LS;
+    cf_stage<C, LS>(Wq_l, a.Wq, C);
+    for (int e = threadIdx.x; e < C; e += blockDim.x) bq_l[e] = a.bq[e];
+    __syncthreads();
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    const int nw = *a.num_wins, tiles = (nw + 15) >> 4;
+    for (int k = wv;; k += CF_NW) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (tile >= tiles) break;
+        const int w = min(tile * 16 + la, nw - 1);
+        const bool live = tile * 16 + la < nw;
+        const int cnt = a.win_cnt[w], vstart = a.win_vstart[w];
+        const int *list = a.k_ind + (size_t)w * a.ns;
+        // q_tok = max over the zero padded key features: empty slots contribute zeros (ref :370)
+        f32x4 m[NT];
+        const float init = cnt < a.ns ? 0.0f : -INFINITY;
+#pragma unroll
+        for (int S = 0; S < NT; ++S) m[S] = f32x4{init, init, init, init};
+        int cmax = cnt;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+        for (int s = 0; s < cmax; ++s) {
+            const bool on = s < cnt;
+            const float *xr = a.xhat + (size_t)(vstart + (on ? list[s] : list[0])) * C + 4 * g;
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                const float4 v = *reinterpret_cast<const float4 *>(xr + 16 * S);
+                if (on) {
+                    m[S][0] = fmaxf(m[S][0], v.x);
+                    m[S][1] = fmaxf(m[S][1], v.y);
+                    m[S][2] = fmaxf(m[S][2], v.z);
+                    m[S][3] = fmaxf(m[S][3], v.w);
+                }
+            }
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 b = *reinterpret_cast<const float4 *>(bq_l + 16 * u + 4 * g);
+            acc[u] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        cf_gemm<NT, LS>(acc, Wq_l, m, la, g);
+        if (live) {
+            float *dst = a.qp + (size_t)w * C + 4 * g;
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                *reinterpret_cast<float4 *>(dst + 16 * u) =
+                    make_float4(acc[u][0] * a.scale, acc[u][1] * a.scale, acc[u][2] * a.scale, acc[u][3] * a.scale);
+        }
+    }
+}
+
+// ---- B: key tokens --------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_keys(CmpArgs a) {
+    constexpr int NT = C / 16, LS = C + 4;
+    extern __shared__ float4 lds4[];
+    float *W2_l = reinterpret_cast<float *>(lds4), *b2_l = W2_l + C * LS;
+    cf_stage<C, LS>(W2_l, a.Wp2, C);
+    for (int e = threadIdx.x; e < C; e += blockDim.x) b2_l[e] = a.bp2[e];
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    // layer 1 as a K = 8 product: inputs d = 4 s + g of step s = (rel.x, rel.y, rel.z, c.x | c.y, c.z, 1, 0);
+    // A operand of this lane: row = channel 16 t + la of pos_proj.0 extended by its bias
+    float w1a[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float *wr = a.Wp1 + (size_t)(16 * t + la) * 6;
+        w1a[t][0] = wr[g];
+        w1a[t][1] = g == 0 ? wr[4] : (g == 1 ? wr[5] : (g == 2 ? a.bp1[16 * t + la] : 0.f));
+    }
+    __syncthreads();
+    const int n = a.num_voxels, tiles = (n + 15) >> 4;
+    for (int k = wv;; k += CF_NW) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (tile >= tiles) break;
+        const int v = min(tile * 16 + la, n - 1);
+        const bool live = tile * 16 + la < n;
+        const int pw = a.pair_win[v];
+        const int4 vi = reinterpret_cast<const int4 *>(a.indices)[v];
+        const int4 wi = reinterpret_cast<const int4 *>(a.win_ind)[max(pw, 0)];
+        const float cxm = cf_centre(wi.w, a.wsx, a.minx), cym = cf_centre(wi.z, a.wsy, a.miny),
+                    czm = cf_centre(wi.y, a.wsz, a.minz);
+        const float rx = cf_centre(vi.w, a.vsx, a.minx) - cxm, ry = cf_centre(vi.z, a.vsy, a.miny) - cym,
+                    rz = cf_centre(vi.y, a.vsz, a.minz) - czm;  // NOT masked in the CompressBlock (ref :372)
+        const float in0 = g == 0 ? rx : (g == 1 ? ry : (g == 2 ? rz : cxm));
+        const float in1 = g == 0 ? cym : (g == 1 ? czm : (g == 2 ? 1.0f : 0.0f));
+        const float *xr = a.xhat + (size_t)v * C + 4 * g;
+        float4 xv[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) xv[u] = *reinterpret_cast<const float4 *>(xr + 16 * u);
+        f32x4 h[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+            MFMA4(p, w1a[t][0], in0);
+            MFMA4(p, w1a[t][1], in1);
+            h[t] = f32x4{fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f)};
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 b = *reinterpret_cast<const float4 *>(b2_l + 16 * u + 4 * g);
+            acc[u] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        cf_gemm<NT, LS>(acc, W2_l, h, la, g);
+        if (live) {
+            float *dst = a.ktok + (size_t)v * C + 4 * g;
+            const bool in_list = pw >= 0;  // a voxel in no list (truncated window): finite dummy row
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                *reinterpret_cast<float4 *>(dst + 16 * u) =
+                    in_list ? make_float4(xv[u].x + fmaxf(acc[u][0], 0.f), xv[u].y + fmaxf(acc[u][1], 0.f),
+                                          xv[u].z + fmaxf(acc[u][2], 0.f), xv[u].w + fmaxf(acc[u][3], 0.f))
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+// ---- C: K scores + V rows ---------------------------------------------------------------------------
+template <int C, int HD>
+__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
+    constexpr int NT = C / 16, LS = C + 4, NH = C / HD;
+    static_assert(HD == 8 || HD == 16 || HD == 32, "head dims instantiated: 8, 16, 32");
+    extern __shared__ float4 lds4[];
+    float *W_l = reinterpret_cast<float *>(lds4), *b_l = W_l + 2 * C * LS;  // [Wk ; Wv] rows, [bk ; bv]
+    cf_stage<C, LS>(W_l, a.Wkv, 2 * C);
+    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) b_l[e] = a.bkv[e];
+    __syncthreads();
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    const int n = a.num_voxels, tiles = (n + 15) >> 4;
+    for (int k = wv;; k += CF_NW) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (tile >= tiles) break;
+        const int v = min(tile * 16 + la, n - 1);
+        const bool live = tile * 16 + la < n;
+        const int pw = a.pair_win[v];
+        const float *xr = a.ktok + (size_t)v * C + 4 * g;
+        const float *qr = a.qp + (size_t)max(pw, 0) * C + 4 * g;
+        f32x4 x[NT];
+        float4 q[NT];
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(xr + 16 * S);
+            x[S] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            q[S] = *reinterpret_cast<const float4 *>(qr + 16 * S);
+        }
+        // K = Wk k_tok + bk, reduced against the window's (pre-scaled) query right away
+        f32x4 acc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 b = *reinterpret_cast<const float4 *>(b_l + 16 * u + 4 * g);
+            acc[u] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        cf_gemm<NT, LS>(acc, W_l, x, la, g);
+        float part[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            part[u] = (acc[u][0] * q[u].x + acc[u][1] * q[u].y) + (acc[u][2] * q[u].z + acc[u][3] * q[u].w);
+            // this lane's 4 channels 16 u + 4 g .. belong to head (16 u + 4 g) / HD
+            if (HD >= 16) {
+                part[u] += __shfl_xor(part[u], 16);
+                part[u] += __shfl_xor(part[u], 32);
+            } else {  // HD == 8: lanes g = 0,1 -> head 2u, g = 2,3 -> head 2u + 1
+                part[u] += __shfl_xor(part[u], 16);
+            }
+        }
+        if (live && pw >= 0) {
+            float *sd = a.score + (size_t)v * NH;
+            if (HD == 16) {
+                if (g == 0) {
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) sd[u] = part[u];
+                }
+            } else if (HD == 32) {
+                if (g == 0) {
+#pragma unroll
+                    for (int u = 0; u < NT; u += 2) sd[u / 2] = part[u] + part[u + 1];
+                }
+            } else {
+                if ((g & 1) == 0) {
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) sd[2 * u + (g >> 1)] = part[u];
+                }
+            }
+        }
+        // V = Wv k_tok + bv
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 b = *reinterpret_cast<const float4 *>(b_l + C + 16 * u + 4 * g);
+            acc[u] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        cf_gemm<NT, LS>(acc, W_l + (size_t)C * LS, x, la, g);
+        if (live) {
+            float *dst = a.vp + (size_t)v * C + 4 * g;
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                *reinterpret_cast<float4 *>(dst + 16 * u) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+        }
+    }
+}
+
+// ---- D: softmax, weighted V sum, output projection --------------------------------------------------
+template <int C, int HD>
+__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
+    constexpr int NT = C / 16, LS = C + 4, NH = C / HD;
+    extern __shared__ float4 lds4[];
+    float *Wo_l = reinterpret_cast<float *>(lds4), *bo_l = Wo_l + C * LS;
+    cf_stage<C, LS>(Wo_l, a.Wo, C);
+    for (int e = threadIdx.x; e < C; e += blockDim.x) bo_l[e] = a.bo[e];
+    __syncthreads();
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    const int nw = *a.num_wins, tiles = (nw + 15) >> 4;
+    for (int k = wv;; k += CF_NW) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (tile >= tiles) break;
+        const int w = min(tile * 16 + la, nw - 1);
+        const bool live = tile * 16 + la < nw;
+        const int cnt = a.win_cnt[w], vstart = a.win_vstart[w];
+        const int *list = a.k_ind + (size_t)w * a.ns;
+        int cmax = cnt;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+        // head of this lane's channel group of tile S: hs[S] = (16 S + 4 g) / HD
+        float mx[NT], sum[NT];
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+            mx[S] = -INFINITY;
+            sum[S] = 0.f;
+        }
+        for (int s = 0; s < cmax; ++s) {
+            if (s < cnt) {
+                const float *sr = a.score + (size_t)(vstart + list[s]) * NH;
+#pragma unroll
+                for (int S = 0; S < NT; ++S) mx[S] = fmaxf(mx[S], sr[(16 * S + 4 * g) / HD]);
+            }
+        }
+        f32x4 o[NT];
+#pragma unroll
+        for (int S = 0; S < NT; ++S) o[S] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < cmax; ++s) {
+            const bool on = s < cnt;
+            const int vrow = vstart + (on ? list[s] : list[0]);
+            const float *sr = a.score + (size_t)vrow * NH;
+            const float *vr = a.vp + (size_t)vrow * C + 4 * g;
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                const float4 vv = *reinterpret_cast<const float4 *>(vr + 16 * S);
+                const float e = on ? __expf(sr[(16 * S + 4 * g) / HD] - mx[S]) : 0.0f;
+                sum[S] += e;
+                o[S][0] = __builtin_fmaf(e, vv.x, o[S][0]);
+                o[S][1] = __builtin_fmaf(e, vv.y, o[S][1]);
+                o[S][2] = __builtin_fmaf(e, vv.z, o[S][2]);
+                o[S][3] = __builtin_fmaf(e, vv.w, o[S][3]);
+            }
+        }
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+            const float inv = 1.0f / sum[S];  // every window owns >= 1 voxel
+            o[S][0] *= inv; o[S][1] *= inv; o[S][2] *= inv; o[S][3] *= inv;
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 b = *reinterpret_cast<const float4 *>(bo_l + 16 * u + 4 * g);
+            acc[u] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        cf_gemm<NT, LS>(acc, Wo_l, o, la, g);
+        if (live) {
+            float *dst = a.out + (size_t)w * C + 4 * g;
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                *reinterpret_cast<float4 *>(dst + 16 * u) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+        }
+    }
+}
+
+template <typename K>
+static int cf_prepare(K kernel, size_t lds_bytes) {
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return MSSVT_OK;
+}
+
+template <int C, int HD>
+static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t stream) {
+    constexpr int LS = C + 4;
+    const size_t lds1 = ((size_t)C * LS + C) * 4, lds2 = ((size_t)2 * C * LS + 2 * C) * 4;
+    int rc;
+    if ((rc = cf_prepare(k_cmp_query<C>, lds1)) || (rc = cf_prepare(k_cmp_keys<C>, lds1)) ||
+        (rc = cf_prepare(k_cmp_kv<C, HD>, lds2)) || (rc = cf_prepare(k_cmp_out<C, HD>, lds1)))
+        return rc;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int vt = (a.num_voxels + 15) / 16, wt = (win_capacity + 15) / 16;
+    const int per1 = (int)((160 * 1024) / lds1) > 2 ? 2 : (int)((160 * 1024) / lds1);
+    const int g_w = min(cus * per1, max(wt, 1)), g_v = min(cus * per1, max(vt, 1)), g_v2 = min(cus, max(vt, 1));
+    k_cmp_query<C><<<g_w, CF_NW * MSSVT_WAVE, lds1, stream>>>(a);
+    k_cmp_keys<C><<<g_v, CF_NW * MSSVT_WAVE, lds1, stream>>>(a);
+    k_cmp_kv<C, HD><<<g_v2, CF_NW * MSSVT_WAVE, lds2, stream>>>(a);
+    k_cmp_out<C, HD><<<g_w, CF_NW * MSSVT_WAVE, lds1, stream>>>(a);
+    return mssvt_launch_status();
+}
+
+extern "C" int mssvt_compress_fused(
+    int C, int head_dim, float scale, int max_num_win1, int num_voxels, const int *num_wins_dev, int win_capacity,
+    const int *win_ind, const int *indices, const int *k_ind, const int *win_vstart, const int *win_cnt,
+    const int *pair_win, const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3,
+    const float *xhat, const float *Wpos1, const float *bpos1, const float *Wpos2, const float *bpos2,
+    const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
+    float *qp, float *ktok, float *score, float *vp, float *out, void *stream) {
+    if (!num_wins_dev || !win_ind || !indices || !k_ind || !win_vstart || !win_cnt || !pair_win ||
+        !host_voxel_size3 || !host_range_min3 || !host_win_size3 || !xhat || !Wpos1 || !bpos1 || !Wpos2 || !bpos2 ||
+        !Wq || !bq || !Wkv || !bkv || !Wo || !bo || !qp || !ktok || !score || !vp || !out || C <= 0 ||
+        head_dim <= 0 || max_num_win1 <= 0 || num_voxels < 0 || win_capacity <= 0)
+        return MSSVT_E_BADARG;
+    if (C % head_dim) return MSSVT_E_BADARG;
+    if (num_voxels == 0) return MSSVT_OK;
+    CmpArgs a;
+    a.C = C; a.ns = max_num_win1; a.num_voxels = num_voxels; a.scale = scale;
+    a.num_wins = num_wins_dev; a.win_ind = win_ind; a.indices = indices;
+    a.k_ind = k_ind; a.win_vstart = win_vstart; a.win_cnt = win_cnt; a.pair_win = pair_win;
+    a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
+    a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
+    a.wsx = host_win_size3[0]; a.wsy = host_win_size3[1]; a.wsz = host_win_size3[2];
+    a.xhat = xhat; a.Wp1 = Wpos1; a.bp1 = bpos1; a.Wp2 = Wpos2; a.bp2 = bpos2;
+    a.Wq = Wq; a.bq = bq; a.Wkv = Wkv; a.bkv = bkv; a.Wo = Wo; a.bo = bo;
+    a.qp = qp; a.ktok = ktok; a.score = score; a.vp = vp; a.out = out;
+    hipStream_t st = (hipStream_t)stream;
+#define CF_CASE(c, hd) \
+    if (C == c && head_dim == hd) return launch_compress<c, hd>(a, win_capacity, st);
+    CF_CASE(128, 16)
+    CF_CASE(128, 32)
+    CF_CASE(64, 8)
+    CF_CASE(64, 16)
+    CF_CASE(64, 32)
+    CF_CASE(32, 8)
+    CF_CASE(32, 16)
+    CF_CASE(32, 32)
+#undef CF_CASE
+    return MSSVT_E_TOOLARGE;  // shape not instantiated: the caller uses the ragged kernels of compress.hip
+}

@@ -199,11 +199,24 @@ __device__ __forceinline__ void fps_on_list_fast(const int *packed, int n, int n
     }
 }
 
+#ifdef MSSVT_STAMPS  // developer instrumentation
+__device__ unsigned long long g_plan_stamps[64 * 16];
+extern "C" int mssvt_debug_read_plan_stamps(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_plan_stamps), sizeof(g_plan_stamps));
+}
+#define PSTAMP() if (lane == 0 && w < 64 && si < 16) g_plan_stamps[w * 16 + si++] = __builtin_readcyclecounter();
+#else
+#define PSTAMP()
+#endif
+
 __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanArgs a) {
     extern __shared__ int lds[];
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
     const int w = blockIdx.x * (blockDim.x / MSSVT_WAVE) + wv;
     if (w >= *a.num_wins) return;  // wave-uniform
+    int si = 0;
+    (void)si;
+    PSTAMP()
     int *base = lds + (size_t)wv * a.lds_words_per_wave;
     int *l1_ind = base;
     int *l1_c = l1_ind + a.max_win1;
@@ -232,6 +245,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         for (int k = lane; k < a.max_even; k += MSSVT_WAVE) a.qmeta_even[(size_t)w * a.max_even + k] = none;
     }
     wave_lds_sync();
+    PSTAMP()
 
     const int4 wi = reinterpret_cast<const int4 *>(a.win_indices)[w];  // [b,wz,wy,wx]
     const slot_t *tab = a.table + (size_t)wi.x * a.hash_size;
@@ -316,6 +330,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         cnt_w2 += __popcll(m_all);
     }
     wave_lds_sync();
+    PSTAMP()
     if (a.kmeta1 && lane == 0) {
         a.nq_valid[w] = min(cnt_odd, a.max_odd);
         a.nq_valid[a.win_capacity + w] = min(cnt_even, a.max_even);
@@ -337,6 +352,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         }
     }
 
+    PSTAMP()
     // ---- K7 + K8 + masks for both scales (ref mssvt_backbone.py:247-258) -----------
     const int K = a.key_num_sample;
     for (int scale = 0; scale < 2; ++scale) {
@@ -350,6 +366,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         else
             fps_on_list(lc, n, K, bs, temp, bv, bidx, fps_out, lane);
         wave_lds_sync();
+        PSTAMP()
         int *kout = (scale ? a.k_ind2 : a.k_ind1) + (size_t)w * K;
         unsigned char *mout = (scale ? a.k_mask2 : a.k_mask1) + (size_t)w * K;
         for (int j = lane; j < K; j += MSSVT_WAVE) {
@@ -381,6 +398,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
             }
         }
         wave_lds_sync();
+        PSTAMP()
     }
 }
 

@@ -177,9 +177,10 @@ def _query_scratch(p, num_voxels, ma, dev):
 
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
 FFN_SPLIT = os.environ.get("MSSVT_FFN_SPLIT", "1") != "0"
+CMP_FUSED = os.environ.get("MSSVT_CMP_FUSED", "1") != "0"
 
 
-def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None):
+def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=None, apply_out=True):
     """y = x + linear2(relu(linear1(norm2(x)))) (+ out_linear) with x = x_new, or 2*x_in on rows
     no list slot owns.  One fused MFMA kernel when the shape is instantiated; it also emits the
     NEXT block's norm1(y) (sp._xhat) so that LayerNorm never runs as a launch of its own."""
@@ -199,14 +200,15 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None):
         if nxt is not None and not has_out and nxt.normalized_shape[0] == C:
             y_norm = torch.empty_like(x_new)
         # two launches with LDS-resident weights; the hidden activations go through this scratch
-        hidden = torch.empty((n, FF), dtype=torch.float32, device=x_new.device) if FFN_SPLIT else None
+        split = FFN_SPLIT or n_rows_dev is not None  # a device-side row count needs the two-launch form
+        hidden = torch.empty((n, FF), dtype=torch.float32, device=x_new.device) if split else None
         tail = (_lib.ptr(block.norm2.weight), _lib.ptr(block.norm2.bias), _f(block.norm2.eps),
                 _lib.ptr(block.linear1.weight), _lib.ptr(block.linear1.bias), _lib.ptr(block.linear2.weight),
                 _lib.ptr(block.linear2.bias), _lib.ptr(y),
                 _lib.ptr(nxt.weight if y_norm is not None else None),
                 _lib.ptr(nxt.bias if y_norm is not None else None),
-                _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.ptr(hidden), None,
-                _lib.stream())
+                _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.ptr(hidden),
+                _lib.ptr(n_rows_dev), _lib.stream())
         if table is not None:
             (tab_row, tab_w), attn = table
             _lib.call("mssvt_ffn_fused_interp", _i(n), _i(C), _i(FF), _lib.ptr(x_in), _lib.ptr(tab_row),
@@ -215,7 +217,7 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None):
             _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
                       *tail)
         sp._xhat = (y_norm, nxt, y) if y_norm is not None else None
-    if hasattr(block, 'out_linear'):
+    if apply_out and hasattr(block, 'out_linear'):
         y = block.out_linear(y)
     return y
 
@@ -320,9 +322,9 @@ def compress_supported(block, sp):
 
 
 @torch.no_grad()
-def one_scale_plan(block, sp):
-    """K2 + K4 + pair-row allocation for a CompressBlock; one host sync (the block's output
-    shape is data dependent anyway)."""
+def one_scale_plan(block, sp, sync=True):
+    """K2 + K4 + pair-row allocation for a CompressBlock; sync=True: one host sync here (the ragged
+    kernels size their buffers with the window count), sync=False: the caller reads p.ws later."""
     st = level_state(sp)
     dev = sp.indices.device
     N, B, H = sp.indices.shape[0], sp.batch_size, sp.hash_size
@@ -362,16 +364,74 @@ def one_scale_plan(block, sp):
               _lib.ptr(p.win_vstart),
               _lib.ptr(p.win_cnt), _lib.ptr(p.pair_base), _lib.ptr(p.pair_win), _lib.ptr(p.pair_vox),
               _lib.ptr(p.num_rows), _lib.stream())
+    p.ws, p.N = ws, N
+    if not sync:
+        return p
     status, p.nw, p.R = ws[:3].tolist()  # the forward's single host sync
     if p.disjoint:
         p.R = N + (p.nw if p.with_pad else 0)  # rows = voxel rows (+ one pad row per window)
         p.num_rows = torch.full((1,), p.R, dtype=torch.int32, device=dev)
-    p.N = N
+    _check_plan_status(block, status, H)
+    return p
+
+
+def _check_plan_status(block, status, H):
     if status & mssvt_ops.ST_WINDOW_OVERFLOW:
         raise _lib.MssvtHipError("a sample has more than max_num_wins=%d windows" % block.max_num_wins)
     if status & mssvt_ops.ST_TABLE_OVERFLOW:
         raise _lib.MssvtHipError("window hash table overflow (hash_size=%d)" % H)
-    return p
+
+
+CMP_SHAPES = {(128, 16), (128, 32), (64, 8), (64, 16), (64, 32), (32, 8), (32, 16), (32, 32)}  # csrc/compress_fused.hip
+
+
+def _compress_fused_ok(block, sp, C):
+    """One head group, C / head_dim instantiated, FFN shape instantiated, window lists that cannot overlap."""
+    ma = block.ms_attn
+    if ma.num_head_groups != 1 or (C, ma.per_head_dim) not in CMP_SHAPES:
+        return False
+    if (C, block.linear1.out_features) not in FFN_SHAPES or block.linear1.in_features != C:
+        return False
+    if len(block.pos_proj) < 3 or tuple(block.pos_proj[0].weight.shape[:2]) != (C, 6):
+        return False
+    return True
+
+
+@torch.no_grad()
+def _compress_forward_fused(block, sp, xhat, x_in):
+    """Four MFMA launches + the two FFN launches, all counts on the device; ONE host sync at the end
+    (the output shape)."""
+    C = x_in.shape[1]
+    dev = x_in.device
+    p = one_scale_plan(block, sp, sync=False)
+    if not p.disjoint or p.with_pad:
+        return None, p
+    N, cap_w, ns = p.N, max(p.N, 1), block.max_num_win1
+    ma = block.ms_attn
+    vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    qp, ktok, score, vp, new = f32(cap_w, C), f32(max(N, 1), C), f32(max(N, 1), C // ma.per_head_dim), \
+        f32(max(N, 1), C), f32(cap_w, C)
+    _lib.call("mssvt_compress_fused", _i(C), _i(ma.per_head_dim), _f(ma.scale), _i(ns), _i(N), _lib.ptr(p.num_wins),
+              _i(cap_w), _lib.ptr(p.win_ind), _lib.ptr(sp.indices), _lib.ptr(p.k_ind), _lib.ptr(p.win_vstart),
+              _lib.ptr(p.win_cnt), _lib.ptr(p.pair_win), vs3, mn3, ws3, _lib.ptr(xhat),
+              _lib.ptr(block.pos_proj[0].weight), _lib.ptr(block.pos_proj[0].bias),
+              _lib.ptr(block.pos_proj[2].weight), _lib.ptr(block.pos_proj[2].bias),
+              _lib.ptr(ma.to_qs[0].weight), _lib.ptr(ma.to_qs[0].bias), _lib.ptr(ma.to_kvs[0].weight),
+              _lib.ptr(ma.to_kvs[0].bias), _lib.ptr(ma.projs[0].weight), _lib.ptr(ma.projs[0].bias),
+              _lib.ptr(qp), _lib.ptr(ktok), _lib.ptr(score), _lib.ptr(vp), _lib.ptr(new), _lib.stream())
+    y = _ffn_tail(block, sp, new, n_rows_dev=p.num_wins, apply_out=False)  # no residual to the block input (ref :383-385)
+    status, nw, _ = p.ws[:3].tolist()  # the forward's single host sync: the output shape
+    _check_plan_status(block, status, sp.hash_size)
+    p.nw = nw
+    pre = getattr(sp, "_xhat", None)
+    y = y[:nw]
+    if hasattr(block, 'out_linear'):
+        y = block.out_linear(y)
+        sp._xhat = None
+    elif pre is not None:
+        sp._xhat = (pre[0][:nw], pre[1], y)
+    return y, p
 
 
 def compress_forward(block, sp):
@@ -382,6 +442,10 @@ def compress_forward(block, sp):
     x_in = sp.features.contiguous()
     C = x_in.shape[1]
     dev = x_in.device
+    if CMP_FUSED and _compress_fused_ok(block, sp, C):
+        y, p = _compress_forward_fused(block, sp, xhat, x_in)
+        if y is not None:
+            return _compress_finish(sp, p, y)
     p = one_scale_plan(block, sp)
     nw, R, ns = p.nw, p.R, block.max_num_win1
     ma = block.ms_attn
@@ -418,8 +482,15 @@ def compress_forward(block, sp):
         outs.append(ma.projs[g](pre[:, c0:c0 + cg]))
         c0 += cg
     new = (outs[0] if G == 1 else torch.cat(outs, dim=-1))[:nw].contiguous()
-    sp.features = _ffn_tail(block, sp, new)  # no residual to the block input (ref :383-385)
-    sp.indices = p.win_ind[:nw].contiguous()
+    return _compress_finish(sp, p, _ffn_tail(block, sp, new))  # no residual to the block input (ref :383-385)
+
+
+def _compress_finish(sp, p, features):
+    sp.features = features
+    pre = getattr(sp, "_xhat", None)
+    if pre is not None:
+        sp._xhat = (pre[0], pre[1], features)
+    sp.indices = p.win_ind[:p.nw].contiguous()
     sp.spatial_shape = p.new_spatial_shape
     sp.voxel_size = p.win_size_m
     sp.map_table = p.win_table
