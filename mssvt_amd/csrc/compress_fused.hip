@@ -90,12 +90,27 @@ __device__ __forceinline__ void cf_gemm(f32x4 (&acc)[NT], const float *W_l, cons
     }
 }
 
+// The K4 lists of a tile's 16 windows -> LDS (one coalesced round trip instead of one dependent
+// load per list step); lst[r * ns + s] = global feature row of slot s of window r (or of slot 0 when
+// s >= cnt: a valid row whose contribution is masked by the caller)
+__device__ __forceinline__ void cf_stage_lists(int *lst, const CmpArgs &a, int tile, int nw, int lane) {
+    const int total = 16 * a.ns;
+    for (int e = lane; e < total; e += MSSVT_WAVE) {
+        const int r = e / a.ns, sl = e % a.ns;
+        const int w = min(tile * 16 + r, nw - 1);
+        const int cnt = a.win_cnt[w];
+        lst[e] = a.win_vstart[w] + a.k_ind[(size_t)w * a.ns + (sl < cnt ? sl : 0)];
+    }
+    wave_lds_sync();
+}
+
 // ---- A: queries ---------------------------------------------------------------------------------
 template <int C>
 __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query(CmpArgs a) {
     constexpr int NT = C / 16, LS = C + 4;
     extern __shared__ float4 lds4[];
     float *Wq_l = reinterpret_cast<float *>(lds4), *bq_l = Wq_l + C * LS;
+    int *lst = reinterpret_cast<int *>(bq_l + C) + (threadIdx.x / MSSVT_WAVE) * 16 * a.ns;
     cf_stage<C, LS>(Wq_l, a.Wq, C);
     for (int e = threadIdx.x; e < C; e += blockDim.x) bq_l[e] = a.bq[e];
     __syncthreads();
@@ -106,8 +121,9 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query(CmpArgs a) {
         if (tile >= tiles) break;
         const int w = min(tile * 16 + la, nw - 1);
         const bool live = tile * 16 + la < nw;
-        const int cnt = a.win_cnt[w], vstart = a.win_vstart[w];
-        const int *list = a.k_ind + (size_t)w * a.ns;
+        const int cnt = a.win_cnt[w];
+        cf_stage_lists(lst, a, tile, nw, lane);
+        const int *list = lst + la * a.ns;
         // q_tok = max over the zero padded key features: empty slots contribute zeros (ref :370)
         f32x4 m[NT];
         const float init = cnt < a.ns ? 0.0f : -INFINITY;
@@ -116,18 +132,22 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query(CmpArgs a) {
         int cmax = cnt;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) cmax = max(cmax, __shfl_xor(cmax, off));
-        for (int s = 0; s < cmax; ++s) {
-            const bool on = s < cnt;
-            const float *xr = a.xhat + (size_t)(vstart + (on ? list[s] : list[0])) * C + 4 * g;
+        // two list steps per iteration: 2 x NT row loads in flight (slots >= cnt re-read slot 0: max unchanged)
+        for (int s = 0; s < cmax; s += 2) {
+            const float *x0 = a.xhat + (size_t)list[s] * C + 4 * g;
+            const float *x1 = a.xhat + (size_t)list[min(s + 1, a.ns - 1)] * C + 4 * g;
+            float4 v0[NT], v1[NT];
 #pragma unroll
             for (int S = 0; S < NT; ++S) {
-                const float4 v = *reinterpret_cast<const float4 *>(xr + 16 * S);
-                if (on) {
-                    m[S][0] = fmaxf(m[S][0], v.x);
-                    m[S][1] = fmaxf(m[S][1], v.y);
-                    m[S][2] = fmaxf(m[S][2], v.z);
-                    m[S][3] = fmaxf(m[S][3], v.w);
-                }
+                v0[S] = *reinterpret_cast<const float4 *>(x0 + 16 * S);
+                v1[S] = *reinterpret_cast<const float4 *>(x1 + 16 * S);
+            }
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                m[S][0] = fmaxf(m[S][0], fmaxf(v0[S].x, v1[S].x));
+                m[S][1] = fmaxf(m[S][1], fmaxf(v0[S].y, v1[S].y));
+                m[S][2] = fmaxf(m[S][2], fmaxf(v0[S].z, v1[S].z));
+                m[S][3] = fmaxf(m[S][3], fmaxf(v0[S].w, v1[S].w));
             }
         }
         f32x4 acc[NT];
@@ -302,6 +322,7 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
     constexpr int NT = C / 16, LS = C + 4, NH = C / HD;
     extern __shared__ float4 lds4[];
     float *Wo_l = reinterpret_cast<float *>(lds4), *bo_l = Wo_l + C * LS;
+    int *lst = reinterpret_cast<int *>(bo_l + C) + (threadIdx.x / MSSVT_WAVE) * 16 * a.ns;
     cf_stage<C, LS>(Wo_l, a.Wo, C);
     for (int e = threadIdx.x; e < C; e += blockDim.x) bo_l[e] = a.bo[e];
     __syncthreads();
@@ -312,42 +333,46 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
         if (tile >= tiles) break;
         const int w = min(tile * 16 + la, nw - 1);
         const bool live = tile * 16 + la < nw;
-        const int cnt = a.win_cnt[w], vstart = a.win_vstart[w];
-        const int *list = a.k_ind + (size_t)w * a.ns;
+        const int cnt = a.win_cnt[w];
+        cf_stage_lists(lst, a, tile, nw, lane);
+        const int *list = lst + la * a.ns;
         int cmax = cnt;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) cmax = max(cmax, __shfl_xor(cmax, off));
-        // head of this lane's channel group of tile S: hs[S] = (16 S + 4 g) / HD
+        // online softmax over the window's voxels, one pass; this lane's channel group of tile S belongs
+        // to head (16 S + 4 g) / HD
         float mx[NT], sum[NT];
+        f32x4 o[NT];
 #pragma unroll
         for (int S = 0; S < NT; ++S) {
             mx[S] = -INFINITY;
             sum[S] = 0.f;
+            o[S] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int s = 0; s < cmax; ++s) {
-            if (s < cnt) {
-                const float *sr = a.score + (size_t)(vstart + list[s]) * NH;
-#pragma unroll
-                for (int S = 0; S < NT; ++S) mx[S] = fmaxf(mx[S], sr[(16 * S + 4 * g) / HD]);
-            }
-        }
-        f32x4 o[NT];
-#pragma unroll
-        for (int S = 0; S < NT; ++S) o[S] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < cmax; ++s) {
             const bool on = s < cnt;
-            const int vrow = vstart + (on ? list[s] : list[0]);
+            const int vrow = list[s];
             const float *sr = a.score + (size_t)vrow * NH;
             const float *vr = a.vp + (size_t)vrow * C + 4 * g;
+            float4 vv[NT];
+            float sc[NT];
 #pragma unroll
             for (int S = 0; S < NT; ++S) {
-                const float4 vv = *reinterpret_cast<const float4 *>(vr + 16 * S);
-                const float e = on ? __expf(sr[(16 * S + 4 * g) / HD] - mx[S]) : 0.0f;
-                sum[S] += e;
-                o[S][0] = __builtin_fmaf(e, vv.x, o[S][0]);
-                o[S][1] = __builtin_fmaf(e, vv.y, o[S][1]);
-                o[S][2] = __builtin_fmaf(e, vv.z, o[S][2]);
-                o[S][3] = __builtin_fmaf(e, vv.w, o[S][3]);
+                vv[S] = *reinterpret_cast<const float4 *>(vr + 16 * S);
+                sc[S] = sr[(16 * S + 4 * g) / HD];
+            }
+            if (on) {
+#pragma unroll
+                for (int S = 0; S < NT; ++S) {
+                    const float mn = fmaxf(mx[S], sc[S]);
+                    const float corr = __expf(mx[S] - mn), e = __expf(sc[S] - mn);  // first step: exp(-inf) = 0
+                    mx[S] = mn;
+                    sum[S] = sum[S] * corr + e;
+                    o[S][0] = __builtin_fmaf(e, vv[S].x, o[S][0] * corr);
+                    o[S][1] = __builtin_fmaf(e, vv[S].y, o[S][1] * corr);
+                    o[S][2] = __builtin_fmaf(e, vv[S].z, o[S][2] * corr);
+                    o[S][3] = __builtin_fmaf(e, vv[S].w, o[S][3] * corr);
+                }
             }
         }
 #pragma unroll
@@ -385,9 +410,11 @@ template <int C, int HD>
 static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t stream) {
     constexpr int LS = C + 4;
     const size_t lds1 = ((size_t)C * LS + C) * 4, lds2 = ((size_t)2 * C * LS + 2 * C) * 4;
+    const size_t lds1w = lds1 + (size_t)CF_NW * 16 * a.ns * 4;  // + the tile's K4 lists per wave
+    if (lds1w > 160 * 1024) return MSSVT_E_TOOLARGE;
     int rc;
-    if ((rc = cf_prepare(k_cmp_query<C>, lds1)) || (rc = cf_prepare(k_cmp_keys<C>, lds1)) ||
-        (rc = cf_prepare(k_cmp_kv<C, HD>, lds2)) || (rc = cf_prepare(k_cmp_out<C, HD>, lds1)))
+    if ((rc = cf_prepare(k_cmp_query<C>, lds1w)) || (rc = cf_prepare(k_cmp_keys<C>, lds1)) ||
+        (rc = cf_prepare(k_cmp_kv<C, HD>, lds2)) || (rc = cf_prepare(k_cmp_out<C, HD>, lds1w)))
         return rc;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
@@ -395,11 +422,12 @@ static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t strea
         cus = 256;
     const int vt = (a.num_voxels + 15) / 16, wt = (win_capacity + 15) / 16;
     const int per1 = (int)((160 * 1024) / lds1) > 2 ? 2 : (int)((160 * 1024) / lds1);
-    const int g_w = min(cus * per1, max(wt, 1)), g_v = min(cus * per1, max(vt, 1)), g_v2 = min(cus, max(vt, 1));
-    k_cmp_query<C><<<g_w, CF_NW * MSSVT_WAVE, lds1, stream>>>(a);
+    const int per1w = (int)((160 * 1024) / lds1w) > 2 ? 2 : (int)((160 * 1024) / lds1w);
+    const int g_w = min(cus * (per1w < 1 ? 1 : per1w), max(wt, 1)), g_v = min(cus * per1, max(vt, 1)), g_v2 = min(cus, max(vt, 1));
+    k_cmp_query<C><<<g_w, CF_NW * MSSVT_WAVE, lds1w, stream>>>(a);
     k_cmp_keys<C><<<g_v, CF_NW * MSSVT_WAVE, lds1, stream>>>(a);
     k_cmp_kv<C, HD><<<g_v2, CF_NW * MSSVT_WAVE, lds2, stream>>>(a);
-    k_cmp_out<C, HD><<<g_w, CF_NW * MSSVT_WAVE, lds1, stream>>>(a);
+    k_cmp_out<C, HD><<<g_w, CF_NW * MSSVT_WAVE, lds1w, stream>>>(a);
     return mssvt_launch_status();
 }
 
