@@ -302,13 +302,15 @@ int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, c
  * hidden != NULL: scratch of n_rows x FF floats -> two launches with LDS-resident weights
  * (GEMM1 | GEMM2, the hidden activations make one round trip through `hidden`); NULL: one
  * launch that streams the weights through LDS.  num_rows_dev (optional, needs hidden): the
- * row count is read on the device and n_rows is only the capacity.
+ * row count is read on the device and n_rows is only the capacity.  phases: 3 = the whole
+ * tail; with hidden != NULL 1 = only the first launch (LayerNorm + GEMM1 + ReLU -> hidden,
+ * x parked in y), 2 = only the second (GEMM2 + residual + next norm) -- for measurement.
  * Instantiated for (C,FF) in {(128,256),(64,128),(32,64)}; MSSVT_E_TOOLARGE otherwise.   */
 int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *x_in, const int *owner,
                     const float *norm_w, const float *norm_b, float eps, const float *W1,
                     const float *b1, const float *W2, const float *b2, float *y,
                     const float *next_norm_w, const float *next_norm_b, float next_eps, float *y_norm,
-                    float *hidden, const int *num_rows_dev, void *stream);
+                    float *hidden, const int *num_rows_dev, int phases, void *stream);
 
 /* Table form of mssvt_block_interp_scatter: for every voxel owned by a list slot, tab_row (N,4)
  * int32 = the three rows of `attn` (row = w*nq + slot; empty slots / zero weights -> zero_row) and
@@ -327,7 +329,7 @@ int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_in, const i
                            const float *norm_b, float eps, const float *W1, const float *b1,
                            const float *W2, const float *b2, float *y, const float *next_norm_w,
                            const float *next_norm_b, float next_eps, float *y_norm, float *hidden,
-                           const int *num_rows_dev, void *stream);
+                           const int *num_rows_dev, int phases, void *stream);
 
 /* ======================================================================== *
  * Part 3 -- voxelizer front-end: the index part of

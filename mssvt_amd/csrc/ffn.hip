@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
 }
 
 template <int C, int FF>
-static int launch_ffn_split(const FfnArgs &a, float *hidden, hipStream_t stream) {
+static int launch_ffn_split(const FfnArgs &a, float *hidden, int phases, hipStream_t stream) {
     const size_t lds_up = ((size_t)FF * (C + 4) + FF + 2 * C) * 4, lds_down = ((size_t)C * (FF + 4) + 3 * C) * 4;
     static_assert(((size_t)FF * (C + 4) + FF + 2 * C) * 4 <= 160 * 1024 && ((size_t)C * (FF + 4) + 3 * C) * 4 <= 160 * 1024,
                   "weights must fit the LDS");
@@ -751,18 +751,19 @@ static int launch_ffn_split(const FfnArgs &a, float *hidden, hipStream_t stream)
     int grid = cus * (int)((160 * 1024) / (lds_up > lds_down ? lds_up : lds_down));
     if (grid > tiles) grid = tiles;
     if (grid < 1) return MSSVT_OK;
-    k_ffn_up<C, FF><<<grid, FFS_NW * MSSVT_WAVE, lds_up, stream>>>(a, hidden);
-    k_ffn_down<C, FF><<<grid, FFS_NW * MSSVT_WAVE, lds_down, stream>>>(a, hidden);
+    if (phases & 1) k_ffn_up<C, FF><<<grid, FFS_NW * MSSVT_WAVE, lds_up, stream>>>(a, hidden);
+    if (phases & 2) k_ffn_down<C, FF><<<grid, FFS_NW * MSSVT_WAVE, lds_down, stream>>>(a, hidden);
     return mssvt_launch_status();
 }
 
-static int dispatch_ffn(int C, int FF, const FfnArgs &a, float *hidden, hipStream_t st) {
+static int dispatch_ffn(int C, int FF, const FfnArgs &a, float *hidden, int phases, hipStream_t st) {
     if (hidden) {
-        if (C == 128 && FF == 256) return launch_ffn_split<128, 256>(a, hidden, st);
-        if (C == 64 && FF == 128) return launch_ffn_split<64, 128>(a, hidden, st);
-        if (C == 32 && FF == 64) return launch_ffn_split<32, 64>(a, hidden, st);
+        if (C == 128 && FF == 256) return launch_ffn_split<128, 256>(a, hidden, phases, st);
+        if (C == 64 && FF == 128) return launch_ffn_split<64, 128>(a, hidden, phases, st);
+        if (C == 32 && FF == 64) return launch_ffn_split<32, 64>(a, hidden, phases, st);
         return MSSVT_E_TOOLARGE;
     }
+    if (phases != 3) return MSSVT_E_BADARG;
     if (a.n_rows_dev) return MSSVT_E_BADARG;  // the single-launch form sizes its grid on the host
     if (C == 128 && FF == 256) return launch_ffn<128, 256>(a, st);
     if (C == 64 && FF == 128) return launch_ffn<64, 128>(a, st);
@@ -775,7 +776,7 @@ extern "C" int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, co
                                const float *W1, const float *b1, const float *W2, const float *b2,
                                float *y, const float *next_norm_w, const float *next_norm_b,
                                float next_eps, float *y_norm, float *hidden, const int *num_rows_dev,
-                               void *stream) {
+                               int phases, void *stream) {
     if (n_rows < 0 || !x_new || !norm_w || !norm_b || !W1 || !b1 || !W2 || !b2 || !y) return MSSVT_E_BADARG;
     if (owner && !x_in) return MSSVT_E_BADARG;
     if (y_norm && (!next_norm_w || !next_norm_b)) return MSSVT_E_BADARG;
@@ -786,7 +787,7 @@ extern "C" int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, co
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
     a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm;
-    return dispatch_ffn(C, FF, a, hidden, (hipStream_t)stream);
+    return dispatch_ffn(C, FF, a, hidden, phases, (hipStream_t)stream);
 }
 
 // Same tail, fed by the interpolation table of mssvt_block_interp_table: the residual input
@@ -797,7 +798,8 @@ extern "C" int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_
                                       const float *norm_b, float eps, const float *W1, const float *b1,
                                       const float *W2, const float *b2, float *y,
                                       const float *next_norm_w, const float *next_norm_b, float next_eps,
-                                      float *y_norm, float *hidden, const int *num_rows_dev, void *stream) {
+                                      float *y_norm, float *hidden, const int *num_rows_dev, int phases,
+                                      void *stream) {
     if (n_rows < 0 || !x_in || !tab_row || !tab_w || !attn || !norm_w || !norm_b || !W1 || !b1 || !W2 ||
         !b2 || !y)
         return MSSVT_E_BADARG;
@@ -811,5 +813,5 @@ extern "C" int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
     a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm;
-    return dispatch_ffn(C, FF, a, hidden, (hipStream_t)stream);
+    return dispatch_ffn(C, FF, a, hidden, phases, (hipStream_t)stream);
 }

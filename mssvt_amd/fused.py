@@ -180,7 +180,7 @@ FFN_SPLIT = os.environ.get("MSSVT_FFN_SPLIT", "1") != "0"
 CMP_FUSED = os.environ.get("MSSVT_CMP_FUSED", "1") != "0"
 
 
-def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=None, apply_out=True):
+def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=None, apply_out=True, phases=3):
     """y = x + linear2(relu(linear1(norm2(x)))) (+ out_linear) with x = x_new, or 2*x_in on rows
     no list slot owns.  One fused MFMA kernel when the shape is instantiated; it also emits the
     NEXT block's norm1(y) (sp._xhat) so that LayerNorm never runs as a launch of its own."""
@@ -208,7 +208,7 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=No
                 _lib.ptr(nxt.weight if y_norm is not None else None),
                 _lib.ptr(nxt.bias if y_norm is not None else None),
                 _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.ptr(hidden),
-                _lib.ptr(n_rows_dev), _lib.stream())
+                _lib.ptr(n_rows_dev), _i(phases), _lib.stream())
         if table is not None:
             (tab_row, tab_w), attn = table
             _lib.call("mssvt_ffn_fused_interp", _i(n), _i(C), _i(FF), _lib.ptr(x_in), _lib.ptr(tab_row),
@@ -500,11 +500,17 @@ def _compress_finish(sp, p, features):
     return sp
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix-core peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
+
+
 def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
-    """Roofline of the fused attention kernel (group 1 = the win2 scale, the larger one) on the
-    bench inputs.  Algorithmic bytes per launch: per window 16 B (window row) + 4 B
-    (vstart) + 4*nq + 5*K B (lists + masks) ; per valid key / query row a 4*Cg-byte feature slice
-    + 16 B of voxel indices ; per valid query 4*Cg bytes written."""
+    """Roofline of the dominant kernel of the frame on the bench inputs: k_ffn_up<128,256> (LayerNorm +
+    GEMM1 + ReLU of the FFN tail, 5 launches per frame, the largest share of GPU time), timed alone
+    with HIP events through the `phases` argument of the C entry point.  It is bound by the fp32 matrix
+    cores: algorithmic FLOP per launch = 2 * C * FF per voxel row.  The other
+    two heavy kernels are reported beside it: k_ffn_down (same bound) and the attention call of head
+    group 1 (3 launches; gather-latency bound, its HBM roofline is given for reference)."""
+    import json
     from .mssvt_utils import SparseTensor
     blk = net.backbone[0]
     with torch.no_grad():
@@ -514,7 +520,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         p = two_scale_plan(blk, sp)
         x_in = sp.features.contiguous()
         C = x_in.shape[1]
-        xhat = F.layer_norm(x_in, (C,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        xhat = layer_norm(x_in, blk.norm1)
         q_ind, nq, _ = _query(blk, p)
         attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
         od = _work_order(blk, p, nq, x_in.shape[0])
@@ -522,43 +528,57 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
         g = 1
         cg, c0 = ma.scale_dims[g], ma.scale_dims[0]
-        vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
+        vs3, mn3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3])
 
-        def launch():
+        def launch_attn():
             _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(ma.num_heads[g]),
                       _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(blk.key_num_sample), _lib.ptr(xhat),
                       _lib.ptr(od["n_act"]), _lib.ptr(od["perm"]), _lib.ptr(od["q_off"]), _lib.ptr(od["nq_valid"]),
-                      _lib.ptr(od["n_rows"]), _i(od["row_cap"]), _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]), _lib.ptr(p.kmeta[g]),
-                      _lib.ptr(p.wcentre),
+                      _lib.ptr(od["n_rows"]), _i(od["row_cap"]), _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]),
+                      _lib.ptr(p.kmeta[g]), _lib.ptr(p.wcentre),
                       _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
                       _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
                       _lib.ptr(blk.pos_proj[0].weight), _lib.ptr(blk.pos_proj[0].bias), _lib.ptr(qbuf),
                       _lib.ptr(attn), _lib.stream())
 
-        ms = event_time_ms(launch, 20)
+        ms_attn = event_time_ms(launch_attn, 20)
         nw = int(p.num_wins.item())
         K = blk.key_num_sample
         n_keys = int((p.k_mask[g][:nw] == 0).sum())
         n_q = int((q_ind[:nw] >= 0).sum())
-        # second heaviest kernel: the fused FFN on the fp32 matrix cores
         interp = 1 if blk.use_feature_interpolation else 0
         upd_ind, n_upd, owner = (p.ind_win1, blk.max_num_win1, p.owner_win1) if interp else (q_ind, nq, _query(blk, p)[2])
         tab = _interp_table(blk, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, mn3)
         abuf = _attn_buffer(p, nq, C, x_in.device)
         abuf.zero_()
         sp._next_norm1 = net.backbone[1].norm1
-        ms_ffn = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf)), 20)
-    alg = nw * (16 + 16 * (nq + K)) + (n_keys + n_q) * 4 * cg + n_q * 4 * cg
-    achieved = alg / (ms * 1e-3) / 1e9
+        ms_up = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf), phases=1), 20)
+        ms_down = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf), phases=2), 20)
     N, FF = x_in.shape[0], blk.linear1.out_features
-    flop = 4.0 * C * FF * N
-    tfs = flop / (ms_ffn * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "k_block_attn (group 1: win2 keys)", "achieved": achieved, "peak": peak_gbs,
-            "unit": "GB/s", "frac": achieved / peak_gbs, "traffic": None, "algorithmic_bytes_per_launch": alg,
-            "avg_launch_us": ms * 1e3,
-            "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q},
-            "note": "latency/issue bound, not bandwidth bound (DESIGN.md section 5)",
-            "second_kernel": {"bound": "mfma", "kernel": "k_ffn<128,256> (fp32 MFMA, incl. interpolation input + "
-                              "next norm1)", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3,
-                              "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_ffn * 1e3,
-                              "units_per_launch": {"voxels": N}}}
+    flop = 2.0 * C * FF * N
+    tf_up = flop / (ms_up * 1e-3) / 1e12
+    tf_down = flop / (ms_down * 1e-3) / 1e12
+    alg = nw * (16 + 16 * (nq + K)) + (n_keys + n_q) * 4 * cg + 3 * n_q * 16 * cg
+    gbs = alg / (ms_attn * 1e-3) / 1e9
+    # HBM bytes per launch of k_ffn_up from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for
+    # 16-B-per-lane reads on gfx950); bench.py cannot collect counters itself
+    traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get("k_ffn_up<128,256>", {}).get("hbm_bytes_per_launch")
+    return {"bound": "mfma", "kernel": "k_ffn_up<128,256> (norm2 + GEMM1 + ReLU of the FFN tail, fp32 MFMA; input built "
+                                       "from x_in + 3 attention rows)",
+            "achieved": tf_up, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_up / MFMA_F32_PEAK_TFLOPS,
+            "traffic": traffic, "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_up * 1e3,
+            "units_per_launch": {"voxel_rows": N, "flop_per_row": 2 * C * FF},
+            "other_kernels": [
+                {"bound": "mfma", "kernel": "k_ffn_down<128,256> (GEMM2 + residual + next norm1)", "achieved": tf_down,
+                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_down / MFMA_F32_PEAK_TFLOPS,
+                 "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_down * 1e3},
+                {"bound": "hbm", "kernel": "mssvt_block_attention_group, group 1 (k_attn_q + k_attn_kv + k_attn_o)",
+                 "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs,
+                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": ms_attn * 1e3,
+                 "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q},
+                 "note": "gather-latency / MFMA-issue bound, not bandwidth bound (DESIGN.md section 4)"}]}

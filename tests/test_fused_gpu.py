@@ -93,7 +93,7 @@ def test_fused_ffn_kernel_matches_torch(C, FF, n, split):
     _lib.call("mssvt_ffn_fused", i(n), i(C), i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
               _lib.ptr(ln.weight), _lib.ptr(ln.bias), f(ln.eps), _lib.ptr(l1.weight), _lib.ptr(l1.bias),
               _lib.ptr(l2.weight), _lib.ptr(l2.bias), _lib.ptr(y), _lib.ptr(ln2.weight), _lib.ptr(ln2.bias),
-              f(ln2.eps), _lib.ptr(yn), _lib.ptr(hidden), None, _lib.stream())
+              f(ln2.eps), _lib.ptr(yn), _lib.ptr(hidden), None, i(3), _lib.stream())
     np.testing.assert_allclose(y.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(yn.cpu().numpy(), want_n.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
