@@ -354,7 +354,9 @@ def one_scale_plan(block, sp, sync=True):
     p.win_cnt = torch.empty(cap, dtype=torch.int32, device=dev)
     p.pair_base = torch.empty(cap, dtype=torch.int32, device=dev)
     p.pair_win = torch.full((row_cap,), -1, dtype=torch.int32, device=dev)
-    p.pair_vox = torch.full((row_cap,), -1, dtype=torch.int32, device=dev)
+    # pair_vox is only read by the ragged kernels (sync=True); the plan kernel writes every live entry
+    p.pair_vox = (torch.full if sync else torch.empty)(*(((row_cap,), -1) if sync else ((row_cap,),)),
+                                                       dtype=torch.int32, device=dev)
     p.num_rows = ws[2:3]
     t = block._tables_on(dev)
     _lib.call("mssvt_window_plan_one", *[_i(int(v)) for v in sp.spatial_shape],
