@@ -200,23 +200,25 @@ int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int nq, const
                      int win_capacity, int row_capacity, int *perm, int *num_active_dev, int *q_off,
                      float *qrow_meta, int *qrow_src, int *num_rows_dev, void *stream);
 
-/* Fused attention of ONE head group of a Block (channels [c0, c0+Cg), Cg = heads*head_dim
- * <= 64): gathers + positional MLP + MixedScaleAttention (ref mssvt_backbone.py:260-295,
- * mssvt_utils.py:112-150) for every valid query of every window.  xhat (N,C) = norm1
- * output; perm / num_active_dev / q_off / qrow_meta / qrow_src / num_rows_dev: from
- * mssvt_plan_order for the query list of this block's cbs_pattern, nq_valid = the row it
- * was built from; kmeta (cap,K,4) / wcentre (cap,4): the plan kernel's resolved metadata of
- * the key scale this group attends to; Wq (Cg,Cg), Wkv (2Cg,Cg), Wo (Cg,Cg), Wpos (C,6) +
- * biases = the module's parameters; qbuf: scratch of row_capacity x 4*ceil(heads/4)*Cg
- * floats handed between the call's three launches (queries / keys+softmax / output);
- * attn (cap*nq [+1],C): rows of valid query slots, columns [c0,c0+Cg) are written.
- * C and c0 must be multiples of 4.                                                       */
-int mssvt_block_attention_group(
-    int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
-    const float *xhat, const int *num_active_dev, const int *perm, const int *q_off, const int *nq_valid,
-    const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src, const float *kmeta,
-    const float *wcentre, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo,
-    const float *bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream);
+/* Fused attention of a Block, all head groups (group g = channels [c0[g], c0[g]+Cg[g]),
+ * Cg = heads[g]*head_dim <= 64, attends to key scale g): gathers + positional MLP +
+ * MixedScaleAttention (ref mssvt_backbone.py:260-295, mssvt_utils.py:112-150) for every valid
+ * query of every window.  xhat (N,C) = norm1 output; perm / num_active_dev / q_off / qrow_meta /
+ * qrow_src / num_rows_dev: from mssvt_plan_order for the query list of this block's cbs_pattern,
+ * nq_valid = the row it was built from; host_kmeta[g] (cap,K,4) / wcentre (cap,4): the plan
+ * kernel's resolved metadata of key scale g; host_Wq[g] (Cg,Cg), host_Wkv[g] (2Cg,Cg),
+ * host_Wo[g] (Cg,Cg) + biases, Wpos (C,6), bpos = the module's parameters (host arrays of device
+ * pointers); qbuf: scratch of row_capacity x sum_g 4*ceil(heads[g]/4)*Cg[g] floats handed between
+ * the three launches (queries / keys+softmax / output); attn (cap*nq [+1],C): rows of valid
+ * query slots are written.  Groups of equal width share the launches (grid.y = group).
+ * C and every c0 must be multiples of 4.                                                  */
+int mssvt_block_attention(
+    int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
+    int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
+    const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
+    const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
+    const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream);
 
 /* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
  * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):

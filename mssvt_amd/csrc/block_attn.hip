@@ -68,12 +68,20 @@ struct AttnArgs {
     float *attn;
 };
 
+// head groups of equal shape run in ONE launch: blockIdx.y = group (their work is independent: channel
+// slices of the same rows); a light group fills the gaps of a heavy one and launches / tails halve
+#define ATTN_MAX_GROUPS 4
+struct AttnPack {
+    AttnArgs g[ATTN_MAX_GROUPS];
+};
+
 #define MFMA4(acc, av, bv)                                                    \
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
 
 // ---- A: queries -> Qt --------------------------------------------------------------------------
 template <int CG, int HD, int HP>
-__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnArgs a) {
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnPack pack) {
+    const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, LS = CGP + 4, NH = CG / HD, QROW = HP * CG;
     extern __shared__ float4 lds4[];
     float *Wq_l = reinterpret_cast<float *>(lds4);  // [o][c]   natural nn.Linear layout, padded rows
@@ -197,7 +205,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnAr
 
 // ---- C: Xbar -> attention output rows ----------------------------------------------------------
 template <int CG, int HD, int HP>
-__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnArgs a) {
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnPack pack) {
+    const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, LS = CGP + 4, NH = CG / HD, QROW = HP * CG;
     extern __shared__ float4 lds4[];
     float *Wv_l = reinterpret_cast<float *>(lds4);  // [o][c]
@@ -312,7 +321,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnAr
 // Key slots are not compacted: masked slots score -inf (the reference adds -100: weight <= e^-100).
 // No LDS, no barriers: ~130 VGPRs, 3-4 waves per SIMD.
 template <int CG, int HD, int HP, int KT>
-__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnArgs a) {
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnPack pack) {
+    const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, NH = CG / HD, QROW = HP * CG, QPP = 16 / HP;
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = threadIdx.x / MSSVT_WAVE;
@@ -502,7 +512,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnA
 }
 
 template <int CG, int HD, int HP>
-static int launch_block_attn(AttnArgs &a, int row_capacity, hipStream_t stream) {
+static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hipStream_t stream) {
     constexpr int CGP = (CG + 15) / 16 * 16, LS = CGP + 4;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
@@ -511,53 +521,27 @@ static int launch_block_attn(AttnArgs &a, int row_capacity, hipStream_t stream) 
     // A / C: persistent over 16-row tiles, 4 workgroups of 4 waves per CU at most
     const int tiles_cap = (row_capacity + 15) / 16;
     int row_grid = (tiles_cap + ATTN_ROW_WAVES - 1) / ATTN_ROW_WAVES;
-    if (row_grid > cus * 4) row_grid = cus * 4;
+    if (row_grid > cus * 4 / ng) row_grid = cus * 4 / ng;
     if (row_grid < 1) row_grid = 1;
     const size_t lds_q = ((size_t)2 * CGP * LS + CGP * 8 + CGP) * 4, lds_o = ((size_t)2 * CGP * LS + 2 * CGP) * 4;
-    k_attn_q<CG, HD, HP><<<row_grid, ATTN_ROW_WAVES * MSSVT_WAVE, lds_q, stream>>>(a);
+    const int K = pack.g[0].K;
+    k_attn_q<CG, HD, HP><<<dim3(row_grid, ng), ATTN_ROW_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
     // B: persistent over the work order, 8 workgroups of 4 waves per CU at most (VGPR bound)
-    const int kv_grid = cus * 8;
-    if (a.K <= 16)
-        k_attn_kv<CG, HD, HP, 1><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(a);
-    else if (a.K <= 32)
-        k_attn_kv<CG, HD, HP, 2><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(a);
+    const dim3 kv_grid(cus * 8 / ng > 0 ? cus * 8 / ng : 1, ng);
+    if (K <= 16)
+        k_attn_kv<CG, HD, HP, 1><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(pack);
+    else if (K <= 32)
+        k_attn_kv<CG, HD, HP, 2><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(pack);
     else
-        k_attn_kv<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(a);
-    k_attn_o<CG, HD, HP><<<row_grid, ATTN_ROW_WAVES * MSSVT_WAVE, lds_o, stream>>>(a);
+        k_attn_kv<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(pack);
+    k_attn_o<CG, HD, HP><<<dim3(row_grid, ng), ATTN_ROW_WAVES * MSSVT_WAVE, lds_o, stream>>>(pack);
     return mssvt_launch_status();
 }
 
-extern "C" int mssvt_block_attention_group(
-    int C, int c0, int Cg, int heads, int head_dim, float scale, int nq, int key_num_sample,
-    const float *xhat, const int *num_active_dev, const int *perm, const int *q_off, const int *nq_valid,
-    const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src, const float *kmeta,
-    const float *wcentre, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo,
-    const float *bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream) {
-    if (!xhat || !num_active_dev || !perm || !q_off || !nq_valid || !num_rows_dev || !qrow_meta || !qrow_src ||
-        !kmeta || !wcentre || !Wq || !bq || !Wkv || !bkv || !Wo || !bo || !Wpos || !bpos || !qbuf || !attn ||
-        C <= 0 || Cg <= 0 || heads <= 0 || head_dim <= 0 || nq <= 0 || key_num_sample <= 0 || row_capacity <= 0)
-        return MSSVT_E_BADARG;
-    if (Cg != heads * head_dim || c0 < 0 || c0 + Cg > C) return MSSVT_E_BADARG;
-    // 16-byte row segments: channel offsets must be float4 aligned
-    if ((C & 3) || (c0 & 3)) return MSSVT_E_BADARG;
-    // one channel per lane, heads aligned to 4-float vectors, <= 8 heads per group
-    if (Cg > MSSVT_WAVE || key_num_sample > MSSVT_WAVE || (head_dim & 3) || heads > 8) return MSSVT_E_TOOLARGE;
-    AttnArgs a;
-    a.C = C; a.c0 = c0; a.heads = heads; a.hd = head_dim; a.scale = scale;
-    a.nq = nq; a.K = key_num_sample;
-    a.xhat = xhat; a.num_wins = num_active_dev; a.perm = perm; a.q_off = q_off; a.nq_valid = nq_valid;
-    a.num_rows = num_rows_dev;
-    a.qrow_meta = reinterpret_cast<const float4 *>(qrow_meta);
-    a.qrow_src = reinterpret_cast<const int2 *>(qrow_src);
-    a.kmeta = reinterpret_cast<const float4 *>(kmeta);
-    a.wcentre = reinterpret_cast<const float4 *>(wcentre);
-    a.Wq = Wq; a.bq = bq; a.Wkv = Wkv; a.bkv = bkv; a.Wo = Wo; a.bo = bo; a.Wp = Wpos; a.bp = bpos;
-    a.qbuf = qbuf;
-    a.attn = attn;
-    hipStream_t st = (hipStream_t)stream;
+static int dispatch_block_attn(const AttnPack &pack, int ng, int Cg, int head_dim, int row_capacity, hipStream_t st) {
 #define MSSVT_ATTN_CASE(cg, hd)                                   \
     if (Cg == cg && head_dim == hd)                               \
-        return launch_block_attn<cg, hd, ((cg / hd + 3) / 4) * 4>(a, row_capacity, st);
+        return launch_block_attn<cg, hd, ((cg / hd + 3) / 4) * 4>(pack, ng, row_capacity, st);
     MSSVT_ATTN_CASE(8, 8)
     MSSVT_ATTN_CASE(16, 8)
     MSSVT_ATTN_CASE(16, 16)
@@ -571,6 +555,61 @@ extern "C" int mssvt_block_attention_group(
     MSSVT_ATTN_CASE(64, 32)
     return MSSVT_E_TOOLARGE;  // shape not instantiated: the caller falls back to the operator path
 #undef MSSVT_ATTN_CASE
+}
+
+extern "C" int mssvt_block_attention(
+    int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
+    int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
+    const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
+    const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
+    const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream) {
+    if (!host_c0 || !host_cg || !host_heads || !xhat || !num_active_dev || !perm || !q_off || !nq_valid ||
+        !num_rows_dev || !qrow_meta || !qrow_src || !host_kmeta || !wcentre || !host_Wq || !host_bq || !host_Wkv ||
+        !host_bkv || !host_Wo || !host_bo || !Wpos || !bpos || !qbuf || !attn || C <= 0 || num_groups <= 0 ||
+        head_dim <= 0 || nq <= 0 || key_num_sample <= 0 || row_capacity <= 0)
+        return MSSVT_E_BADARG;
+    // 16-byte row segments: channel offsets must be float4 aligned
+    if (C & 3) return MSSVT_E_BADARG;
+    if (key_num_sample > MSSVT_WAVE || (head_dim & 3)) return MSSVT_E_TOOLARGE;
+    hipStream_t st = (hipStream_t)stream;
+    bool same = num_groups <= ATTN_MAX_GROUPS;
+    for (int g = 0; g < num_groups; ++g) same = same && host_cg[g] == host_cg[0];
+    AttnPack pack;
+    size_t qoff = 0;  // each group's region of qbuf: row_capacity x 4*ceil(heads/4)*Cg floats
+    for (int g = 0; g < num_groups; ++g) {
+        const int c0 = host_c0[g], Cg = host_cg[g], heads = host_heads[g];
+        if (!host_kmeta[g] || !host_Wq[g] || !host_bq[g] || !host_Wkv[g] || !host_bkv[g] || !host_Wo[g] || !host_bo[g])
+            return MSSVT_E_BADARG;
+        if (Cg <= 0 || heads <= 0 || Cg != heads * head_dim || c0 < 0 || c0 + Cg > C || (c0 & 3)) return MSSVT_E_BADARG;
+        // one channel per lane, <= 8 heads per group
+        if (Cg > MSSVT_WAVE || heads > 8) return MSSVT_E_TOOLARGE;
+        AttnArgs a;
+        a.C = C; a.c0 = c0; a.heads = heads; a.hd = head_dim; a.scale = scale;
+        a.nq = nq; a.K = key_num_sample;
+        a.xhat = xhat; a.num_wins = num_active_dev; a.perm = perm; a.q_off = q_off; a.nq_valid = nq_valid;
+        a.num_rows = num_rows_dev;
+        a.qrow_meta = reinterpret_cast<const float4 *>(qrow_meta);
+        a.qrow_src = reinterpret_cast<const int2 *>(qrow_src);
+        a.kmeta = reinterpret_cast<const float4 *>(host_kmeta[g]);
+        a.wcentre = reinterpret_cast<const float4 *>(wcentre);
+        a.Wq = host_Wq[g]; a.bq = host_bq[g]; a.Wkv = host_Wkv[g]; a.bkv = host_bkv[g];
+        a.Wo = host_Wo[g]; a.bo = host_bo[g]; a.Wp = Wpos; a.bp = bpos;
+        a.qbuf = qbuf + qoff;
+        a.attn = attn;
+        qoff += (size_t)row_capacity * (((heads + 3) / 4) * 4) * Cg;
+        if (same) {
+            pack.g[g] = a;
+        } else {  // unequal group widths: one launch triple per group
+            AttnPack one;
+            for (int i = 0; i < ATTN_MAX_GROUPS; ++i) one.g[i] = a;
+            const int rc = dispatch_block_attn(one, 1, Cg, head_dim, row_capacity, st);
+            if (rc) return rc;
+        }
+    }
+    if (!same) return MSSVT_OK;
+    for (int g = num_groups; g < ATTN_MAX_GROUPS; ++g) pack.g[g] = pack.g[0];
+    return dispatch_block_attn(pack, num_groups, host_cg[0], head_dim, row_capacity, st);
 }
 
 // cell centre in metres, one rounding per op like the reference's torch expression

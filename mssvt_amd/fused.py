@@ -168,11 +168,30 @@ def _work_order(block, p, nq, num_voxels):
 
 def _query_scratch(p, num_voxels, ma, dev):
     """qbuf of mssvt_block_attention_group: one row per valid query (query lists are disjoint, so at
-    most one per voxel), wide enough for the widest head group."""
-    width = max(4 * ((h + 3) // 4) * cg for h, cg in zip(ma.num_heads, ma.scale_dims))
+    most one per voxel), one region per head group."""
+    width = sum(4 * ((h + 3) // 4) * cg for h, cg in zip(ma.num_heads, ma.scale_dims))
     if p.qbuf is None or p.qbuf.shape[0] < num_voxels or p.qbuf.shape[1] < width:
         p.qbuf = torch.empty((max(num_voxels, 1), width), dtype=torch.float32, device=dev)
     return p.qbuf
+
+
+def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
+    """mssvt_block_attention for the given head groups (default: all)."""
+    ma = block.ms_attn
+    gs = list(range(len(ma.num_heads))) if groups is None else list(groups)
+    c0s = [sum(ma.scale_dims[:g]) for g in gs]
+    ia = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])  # noqa: E731
+    pa = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+    _lib.call("mssvt_block_attention", _i(C), _i(len(gs)), ia(c0s), ia([ma.scale_dims[g] for g in gs]),
+              ia([ma.num_heads[g] for g in gs]), _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(block.key_num_sample),
+              _lib.ptr(xhat), _lib.ptr(od["n_act"]), _lib.ptr(od["perm"]), _lib.ptr(od["q_off"]),
+              _lib.ptr(od["nq_valid"]), _lib.ptr(od["n_rows"]), _i(od["row_cap"]), _lib.ptr(od["row_meta"]),
+              _lib.ptr(od["row_src"]), pa([p.kmeta[g] for g in gs]), _lib.ptr(p.wcentre),
+              pa([ma.to_qs[g].weight for g in gs]), pa([ma.to_qs[g].bias for g in gs]),
+              pa([ma.to_kvs[g].weight for g in gs]), pa([ma.to_kvs[g].bias for g in gs]),
+              pa([ma.projs[g].weight for g in gs]), pa([ma.projs[g].bias for g in gs]),
+              _lib.ptr(block.pos_proj[0].weight), _lib.ptr(block.pos_proj[0].bias), _lib.ptr(qbuf), _lib.ptr(attn),
+              _lib.stream())
 
 
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
@@ -258,18 +277,7 @@ def block_forward(block, sp):
     ma = block.ms_attn
     qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
-    wpos, bpos = block.pos_proj[0].weight, block.pos_proj[0].bias
-    c0 = 0
-    for g, heads in enumerate(ma.num_heads):
-        cg = ma.scale_dims[g]
-        _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(heads), _i(ma.per_head_dim),
-                  _f(ma.scale), _i(nq), _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(od["n_act"]),
-                  _lib.ptr(od["perm"]), _lib.ptr(od["q_off"]), _lib.ptr(od["nq_valid"]), _lib.ptr(od["n_rows"]),
-                  _i(od["row_cap"]), _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]), _lib.ptr(p.kmeta[g]), _lib.ptr(p.wcentre),
-                  _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
-                  _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
-                  _lib.ptr(wpos), _lib.ptr(bpos), _lib.ptr(qbuf), _lib.ptr(attn), _lib.stream())
-        c0 += cg
+    _attention_call(block, p, od, C, nq, xhat, qbuf, attn)
     interp = 1 if block.use_feature_interpolation else 0
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
     FF = block.linear1.out_features
@@ -510,8 +518,8 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
     GEMM1 + ReLU of the FFN tail, 5 launches per frame, the largest share of GPU time), timed alone
     with HIP events through the `phases` argument of the C entry point.  It is bound by the fp32 matrix
     cores: algorithmic FLOP per launch = 2 * C * FF per voxel row.  The other
-    two heavy kernels are reported beside it: k_ffn_down (same bound) and the attention call of head
-    group 1 (3 launches; gather-latency bound, its HBM roofline is given for reference)."""
+    two heavy kernels are reported beside it: k_ffn_down (same bound) and the attention call of a
+    Block (3 launches; gather-latency bound, its HBM roofline is given for reference)."""
     import json
     from .mssvt_utils import SparseTensor
     blk = net.backbone[0]
@@ -528,25 +536,16 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
         od = _work_order(blk, p, nq, x_in.shape[0])
         ma = blk.ms_attn
         qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
-        g = 1
-        cg, c0 = ma.scale_dims[g], ma.scale_dims[0]
         vs3, mn3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3])
 
         def launch_attn():
-            _lib.call("mssvt_block_attention_group", _i(C), _i(c0), _i(cg), _i(ma.num_heads[g]),
-                      _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(blk.key_num_sample), _lib.ptr(xhat),
-                      _lib.ptr(od["n_act"]), _lib.ptr(od["perm"]), _lib.ptr(od["q_off"]), _lib.ptr(od["nq_valid"]),
-                      _lib.ptr(od["n_rows"]), _i(od["row_cap"]), _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]),
-                      _lib.ptr(p.kmeta[g]), _lib.ptr(p.wcentre),
-                      _lib.ptr(ma.to_qs[g].weight), _lib.ptr(ma.to_qs[g].bias), _lib.ptr(ma.to_kvs[g].weight),
-                      _lib.ptr(ma.to_kvs[g].bias), _lib.ptr(ma.projs[g].weight), _lib.ptr(ma.projs[g].bias),
-                      _lib.ptr(blk.pos_proj[0].weight), _lib.ptr(blk.pos_proj[0].bias), _lib.ptr(qbuf),
-                      _lib.ptr(attn), _lib.stream())
+            _attention_call(blk, p, od, C, nq, xhat, qbuf, attn)
 
         ms_attn = event_time_ms(launch_attn, 20)
         nw = int(p.num_wins.item())
         K = blk.key_num_sample
-        n_keys = int((p.k_mask[g][:nw] == 0).sum())
+        n_keys = sum(int((p.k_mask[g][:nw] == 0).sum()) for g in range(2))
+        cg = ma.scale_dims[0]
         n_q = int((q_ind[:nw] >= 0).sum())
         interp = 1 if blk.use_feature_interpolation else 0
         upd_ind, n_upd, owner = (p.ind_win1, blk.max_num_win1, p.owner_win1) if interp else (q_ind, nq, _query(blk, p)[2])
@@ -560,7 +559,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
     flop = 2.0 * C * FF * N
     tf_up = flop / (ms_up * 1e-3) / 1e12
     tf_down = flop / (ms_down * 1e-3) / 1e12
-    alg = nw * (16 + 16 * (nq + K)) + (n_keys + n_q) * 4 * cg + 3 * n_q * 16 * cg
+    alg = nw * (16 + 16 * (nq + 2 * K)) + (n_keys + 2 * n_q) * 4 * cg + 2 * 3 * n_q * 16 * cg
     gbs = alg / (ms_attn * 1e-3) / 1e9
     # HBM bytes per launch of k_ffn_up from the PMC passes committed under profiles/ (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for
@@ -579,7 +578,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
                 {"bound": "mfma", "kernel": "k_ffn_down<128,256> (GEMM2 + residual + next norm1)", "achieved": tf_down,
                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_down / MFMA_F32_PEAK_TFLOPS,
                  "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_down * 1e3},
-                {"bound": "hbm", "kernel": "mssvt_block_attention_group, group 1 (k_attn_q + k_attn_kv + k_attn_o)",
+                {"bound": "hbm", "kernel": "mssvt_block_attention, both head groups (k_attn_q + k_attn_kv + k_attn_o, grid.y = group)",
                  "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs,
                  "algorithmic_bytes_per_launch": alg, "avg_launch_us": ms_attn * 1e3,
                  "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q},
