@@ -309,23 +309,29 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnPa
     }
 }
 
-// ---- B: keys, scores, softmax, xbar (one wavefront per window, everything in registers) -----------
-// Per window the key tokens T[key][c] = xhat row + relu(pos. MLP) are held in registers in BOTH
-// matrix-core operand layouts (lane l: a = l % 16, g = l / 16):
+// ---- B: keys, scores, softmax, xbar (one wavefront per window) ------------------------------------
+// Per window the key tokens T[key][c] = xhat row + relu(pos. MLP) are needed in BOTH matrix-core
+// operand layouts (lane l: a = l % 16, g = l / 16):
 //   T1: lane (a = key % 16, g)  channels 16 S + 4 g + j   -> A operand of  S = T Qt^T   (reduce over c)
 //   T2: lane (a = c % 16,  g)   keys     16 t + 4 g + i   -> A operand of  Xbar^T = T^T P (reduce over keys)
-// The positional MLP itself is a K = 4 product (rel.x, rel.y, rel.z, 1) x (wp0, wp1, wp2, window part)
-// = one MFMA per 16 x 16 tile, computed once per layout (operands swapped).  Queries go through in
-// passes of 16 / HP (column n = query * HP + head); the softmax over keys is 8 in-lane values + two
-// cross-row shuffles, and the normalised P accumulator IS the B operand of the second product.
-// Key slots are not compacted: masked slots score -inf (the reference adds -100: weight <= e^-100).
-// No LDS, no barriers: ~130 VGPRs, 3-4 waves per SIMD.
+// T1 is gathered from HBM as 16-byte pieces of the rows and kept in registers; T2 is T1 transposed
+// through a per-wave LDS tile (row stride Cg + 4: the b128 writes and the b32 column reads are both
+// conflict free).  The positional MLP is a K = 4 product (rel.x, rel.y, rel.z, 1) x (wp0, wp1, wp2,
+// window part) = one MFMA per 16 x 16 tile.  Queries go through in passes of 16 / HP (column n =
+// query * HP + head); the softmax over keys is 8 in-lane values + two cross-row shuffles, and the
+// normalised P accumulator IS the B operand of the second product.  Key slots are not compacted:
+// masked slots score -inf (the reference adds -100: weight <= e^-100); key tiles without an unmasked
+// slot are skipped.  Software pipeline across windows: metadata two windows ahead, the feature rows
+// of the next window in flight under this window's MFMAs.
 template <int CG, int HD, int HP, int KT>
 __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnPack pack) {
     const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, NH = CG / HD, QROW = HP * CG, QPP = 16 / HP;
+    constexpr int LSK = CGP + 4;  // LDS row stride of the key tile
+    extern __shared__ float4 lds4[];
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = threadIdx.x / MSSVT_WAVE;
+    float *Tl = reinterpret_cast<float *>(lds4) + (size_t)wv * KT * 16 * LSK;
     // positional MLP operand of this lane (channel 16 u + la, input g): constant part + window part
     float wconst[NT], w3[NT], w4[NT], w5[NT];
 #pragma unroll
@@ -344,105 +350,112 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
     const int n_act = *a.num_wins;
     const int wstep = gridDim.x * ATTN_ROW_WAVES;
     const int K = a.K;
-    const int *kmeta_i = reinterpret_cast<const int *>(a.kmeta);
     int wi = blockIdx.x * ATTN_ROW_WAVES + wv;
     if (wi >= n_act) return;
-    // window metadata, loaded one window ahead (perm -> kmeta -> feature rows would otherwise be three
-    // dependent round trips per window)
-    int w_n;
-    float4 wc_n, km_n[KT];
-    int nqv_n, qbase_n, r2_n[KT][4];
+    // stage M: metadata of a window (perm -> kmeta would otherwise be dependent round trips per window)
+    float4 wc_m, km_m[KT];
+    int nqv_m, qbase_m;
 #define KV_LOAD_META(wi_)                                                                  \
     {                                                                                      \
-        w_n = a.perm[wi_];                                                                 \
-        wc_n = a.wcentre[w_n];                                                             \
-        nqv_n = a.nq_valid[w_n];                                                           \
-        qbase_n = a.q_off[w_n];                                                            \
+        const int w_ = a.perm[wi_];                                                        \
+        wc_m = a.wcentre[w_];                                                              \
+        nqv_m = a.nq_valid[w_];                                                            \
+        qbase_m = a.q_off[w_];                                                             \
+        _Pragma("unroll") for (int t = 0; t < KT; ++t)                                     \
+            km_m[t] = a.kmeta[(size_t)w_ * K + min(16 * t + la, K - 1)];                   \
+    }
+    // stage R: resolved metadata + raw feature rows of a window (T1 layout)
+    float4 wc_r;
+    int nqv_r, qbase_r;
+    float rel_r[KT];
+    unsigned vmask_r;    // bit 4 t + i: key 16 t + 4 g + i is unmasked
+    unsigned used_r;     // bit t: tile t has an unmasked key (wave-uniform)
+    f32x4 T1n[KT][NT];
+#define KV_ISSUE_ROWS()                                                                    \
+    {                                                                                      \
+        wc_r = wc_m; nqv_r = nqv_m; qbase_r = qbase_m;                                     \
+        vmask_r = 0; used_r = 0;                                                           \
         _Pragma("unroll") for (int t = 0; t < KT; ++t) {                                   \
-            km_n[t] = a.kmeta[(size_t)w_n * K + min(16 * t + la, K - 1)];                  \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
-                r2_n[t][i] = kmeta_i[((size_t)w_n * K + min(16 * t + 4 * g + i, K - 1)) * 4 + 3]; \
+            const int r_ = __builtin_bit_cast(int, km_m[t].w);                             \
+            const bool ok_ = 16 * t + la < K && r_ >= 0;                                   \
+            const unsigned long long bal_ = __ballot(ok_);  /* bits 0..15: keys 16 t + 0..15 */ \
+            vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
+            used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
+            rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
+            if (used_r >> t & 1) {                                                         \
+                const float *xr_ = a.xhat + (size_t)(ok_ ? r_ : 0) * a.C + a.c0;           \
+                _Pragma("unroll") for (int S = 0; S < NT; ++S) {                           \
+                    const int c_ = 16 * S + 4 * g;                                         \
+                    const float4 v_ = (CGP == CG || c_ < CG) ? *reinterpret_cast<const float4 *>(xr_ + c_) \
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f); \
+                    T1n[t][S] = f32x4{v_.x, v_.y, v_.z, v_.w};                             \
+                }                                                                          \
+            }                                                                              \
         }                                                                                  \
     }
     KV_LOAD_META(wi)
+    KV_ISSUE_ROWS()
+    if (wi + wstep < n_act) KV_LOAD_META(wi + wstep)
     for (; wi < n_act; wi += wstep) {
-        const float4 wc = wc_n;
-        const int nqv = nqv_n;
-        const size_t qbase = (size_t)qbase_n;
-        // key metadata in both layouts
-        float rel[KT];    // pos. MLP input g of key 16 t + la (1 for g = 3)
-        int row1[KT];     // feature row of key 16 t + la (0 when masked)
-        int row2[KT][4];  // feature row of key 16 t + 4 g + i, -1 when masked
-        bool used[KT];    // wave-uniform: any unmasked key in tile t (slot 0 is never masked)
+        // ---- this window: stage R -> working registers ------------------------------------------------
+        const float4 wc = wc_r;
+        const int nqv = nqv_r;
+        const size_t qbase = (size_t)qbase_r;
+        const unsigned vmask = vmask_r, used = used_r;
+        f32x4 T1[KT][NT];
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-            const int slot = 16 * t + la;
-            const int r = __builtin_bit_cast(int, km_n[t].w);
-            row1[t] = slot < K && r >= 0 ? r : 0;
-            rel[t] = g == 0 ? km_n[t].x : (g == 1 ? km_n[t].y : (g == 2 ? km_n[t].z : 1.0f));
-            bool any = false;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                row2[t][i] = 16 * t + 4 * g + i < K ? r2_n[t][i] : -1;
-                any = any || row2[t][i] >= 0;
-            }
-            used[t] = t == 0 || __ballot(any) != 0ull;
-        }
-        if (wi + wstep < n_act) KV_LOAD_META(wi + wstep)
-        // feature rows in both layouts
-        f32x4 T1[KT][NT], T2[KT][NT];
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            if (!used[t]) continue;
-            const float *xr = a.xhat + (size_t)row1[t] * a.C + a.c0;
-#pragma unroll
-            for (int S = 0; S < NT; ++S) {
-                const int c = 16 * S + 4 * g;
-                const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xr + c)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-                T1[t][S] = f32x4{v.x, v.y, v.z, v.w};
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float *x2 = a.xhat + (size_t)max(row2[t][i], 0) * a.C + a.c0;
-#pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    const int c = 16 * u + la;
-                    T2[t][u][i] = (CGP == CG || c < CG) ? x2[c] : 0.f;
-                }
-            }
-        }
-        // + relu(positional MLP), one MFMA per tile and layout
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            if (!used[t]) continue;
+            if (!(used >> t & 1)) continue;
+            // + relu(positional MLP): rows = channels 16 u + 4 g + i, column = key 16 t + la
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 const float wu = ((wconst[u] + w3[u] * wc.x) + w4[u] * wc.y) + w5[u] * wc.z;
-                f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f}, p2 = f32x4{0.f, 0.f, 0.f, 0.f};
-                MFMA4(p1, wu, rel[t]);  // rows = channels 16 u + 4 g + i, column = key 16 t + la
-                MFMA4(p2, rel[t], wu);  // rows = keys 16 t + 4 g + i,     column = channel 16 u + la
+                f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                MFMA4(p1, wu, rel_r[t]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    T1[t][u][i] += fmaxf(p1[i], 0.0f);
-                    T2[t][u][i] += fmaxf(p2[i], 0.0f);
-                }
+                for (int i = 0; i < 4; ++i) T1[t][u][i] = T1n[t][u][i] + fmaxf(p1[i], 0.0f);
             }
         }
-        // queries, QPP per pass: column la = query * HP + head
+        // first query pass: its Qt rows travel while the key tile is transposed
         const int hh = la % HP;
         const bool head_ok = hh < NH;
+        float *qrow = a.qbuf + (qbase + min(la / HP, nqv - 1)) * QROW + (head_ok ? hh : 0) * CG;
+        f32x4 qt[NT];
+#pragma unroll
+        for (int S = 0; S < NT; ++S) {
+            const int c = 16 * S + 4 * g;
+            const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(qrow + c)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            qt[S] = f32x4{v.x, v.y, v.z, v.w};
+        }
+        // ---- next window: rows in flight under this window's MFMAs, metadata one further ahead --------
+        if (wi + wstep < n_act) {
+            KV_ISSUE_ROWS()
+            if (wi + 2 * wstep < n_act) KV_LOAD_META(wi + 2 * wstep)
+        }
+        // key tile -> LDS (the T2 operand is read back column-wise)
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            if (!(used >> t & 1)) continue;
+#pragma unroll
+            for (int S = 0; S < NT; ++S)
+                *reinterpret_cast<float4 *>(Tl + (16 * t + la) * LSK + 16 * S + 4 * g) =
+                    make_float4(T1[t][S][0], T1[t][S][1], T1[t][S][2], T1[t][S][3]);
+        }
+        wave_lds_sync();
+        // queries, QPP per pass: column la = query * HP + head
         for (int q0 = 0; q0 < nqv; q0 += QPP) {
             const int q = q0 + la / HP;
             const bool q_ok = q < nqv && head_ok;
-            float *qrow = a.qbuf + (qbase + min(q, nqv - 1)) * QROW + (head_ok ? hh : 0) * CG;
-            f32x4 qt[NT];
+            if (q0 > 0) {
+                qrow = a.qbuf + (qbase + min(q, nqv - 1)) * QROW + (head_ok ? hh : 0) * CG;
 #pragma unroll
-            for (int S = 0; S < NT; ++S) {
-                const int c = 16 * S + 4 * g;
-                const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(qrow + c)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-                qt[S] = f32x4{v.x, v.y, v.z, v.w};
+                for (int S = 0; S < NT; ++S) {
+                    const int c = 16 * S + 4 * g;
+                    const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(qrow + c)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                    qt[S] = f32x4{v.x, v.y, v.z, v.w};
+                }
             }
             // scores: S[key][col] = sum_c T[key][c] Qt[col][c]; even / odd channel tiles accumulate
             // separately (two independent MFMA chains per key tile)
@@ -451,7 +464,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
             for (int t = 0; t < KT; ++t) sc[t] = sc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                if (!used[t]) continue;
+                if (!(used >> t & 1)) continue;
 #pragma unroll
                 for (int S = 0; S < NT; S += 2) {
 #pragma unroll
@@ -468,7 +481,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     sc[t][i] += sc2[t][i];
-                    mx = fmaxf(mx, row2[t][i] >= 0 ? sc[t][i] : -INFINITY);
+                    mx = fmaxf(mx, (vmask >> (4 * t + i) & 1) ? sc[t][i] : -INFINITY);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -477,25 +490,29 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float e = row2[t][i] >= 0 ? __expf(sc[t][i] - mx) : 0.0f;
+                    const float e = (vmask >> (4 * t + i) & 1) ? __expf(sc[t][i] - mx) : 0.0f;
                     sc[t][i] = e;
                     sum += e;
                 }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
             const float inv = __builtin_amdgcn_rcpf(sum);  // slot 0 of a list is never masked: sum >= 1
-            // Xbar^T[c][col] = sum_key T[key][c] P[key][col]
+            // Xbar^T[c][col] = sum_key T[key][c] P[key][col]; A operand = the LDS tile read column-wise
             f32x4 acc[NT];
 #pragma unroll
             for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                if (!used[t]) continue;
+                if (!(used >> t & 1)) continue;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float pv = sc[t][i] * inv;
+                    const float *col = Tl + (16 * t + 4 * g + i) * LSK + la;
+                    float tv[NT];
 #pragma unroll
-                    for (int u = 0; u < NT; ++u) MFMA4(acc[u], T2[t][u][i], pv);
+                    for (int u = 0; u < NT; ++u) tv[u] = col[16 * u];
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) MFMA4(acc[u], tv[u], pv);
                 }
             }
             if (q_ok) {
@@ -507,8 +524,10 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
                 }
             }
         }
+        wave_lds_sync();  // the next window rewrites the tile
     }
 #undef KV_LOAD_META
+#undef KV_ISSUE_ROWS
 }
 
 template <int CG, int HD, int HP>
@@ -528,12 +547,17 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hip
     k_attn_q<CG, HD, HP><<<dim3(row_grid, ng), ATTN_ROW_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
     // B: persistent over the work order, 8 workgroups of 4 waves per CU at most (VGPR bound)
     const dim3 kv_grid(cus * 8 / ng > 0 ? cus * 8 / ng : 1, ng);
+    const size_t lds_tile = (size_t)ATTN_ROW_WAVES * 16 * LS * 4;  // per key tile of 16 slots, all waves
     if (K <= 16)
-        k_attn_kv<CG, HD, HP, 1><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(pack);
+        k_attn_kv<CG, HD, HP, 1><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, lds_tile, stream>>>(pack);
     else if (K <= 32)
-        k_attn_kv<CG, HD, HP, 2><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(pack);
-    else
-        k_attn_kv<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 0, stream>>>(pack);
+        k_attn_kv<CG, HD, HP, 2><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 2 * lds_tile, stream>>>(pack);
+    else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_kv<CG, HD, HP, 4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds_tile));
+        if (e != hipSuccess) return (int)e;
+        k_attn_kv<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 4 * lds_tile, stream>>>(pack);
+    }
     k_attn_o<CG, HD, HP><<<dim3(row_grid, ng), ATTN_ROW_WAVES * MSSVT_WAVE, lds_o, stream>>>(pack);
     return mssvt_launch_status();
 }
