@@ -32,6 +32,9 @@ def lib():
     return _lib
 
 
+_NULL = ctypes.c_void_p(0)
+
+
 def check(status, what):
     if status != 0:
         raise MssvtHipError("%s failed: %s (status %d)" % (
@@ -41,16 +44,25 @@ def check(status, what):
 def ptr(t):
     """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
     if t is None:
-        return ctypes.c_void_p(0)
-    assert t.is_cuda, "mssvt_amd ops need tensors on the GPU (no CPU path)"
-    assert t.is_contiguous(), "mssvt_amd ops need contiguous tensors"
+        return _NULL
+    if not (t.is_cuda and t.is_contiguous()):
+        raise MssvtHipError("mssvt_amd ops need contiguous tensors on the GPU (no CPU path)")
     return ctypes.c_void_p(t.data_ptr())
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of torch's current HIP stream (the fast C accessor: torch.cuda.current_stream()
+    builds a Python Stream object, ~8 us per call, 20+ calls per forward)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+
+
+_fns = {}
 
 
 def call(name, *args):
-    fn = getattr(lib(), name)
-    check(fn(*args), name)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    status = fn(*args)
+    if status != 0:
+        check(status, name)
