@@ -184,7 +184,18 @@ int mssvt_window_plan_two(
     unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
     const int *indices, const float *host_voxel_size3, const float *host_range_min3,
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
-    float *kmeta2, float *wcentre, int *nq_valid, void *stream);
+    float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
+    const int *host_footprint4, const int *packed_offsets, void *stream);
+
+/* Occupancy columns of a voxel set (z_max <= 64): columns (B*x_max*y_max) 64-bit words, bit z of
+ * word (b*x_max + x)*y_max + y set when cell (b,x,y,z) holds a voxel.  Optional input of
+ * mssvt_window_plan_two (together with host_footprint4 = {min x offset, min y offset, x extent,
+ * y extent} of the four query tables and packed_offsets = the tables concatenated odd | even |
+ * win1 | win2, one word (x+64) | (y+64)<<8 | (z+64)<<16 per offset, on the device): the K3 hit test then reads one word per (x,y) column of the
+ * neighbourhood instead of probing the hash for each of its cells (ref K3 probes all of them,
+ * ms_sparse_attention_gpu.cu:193-330); the hash is only probed for the hits.               */
+int mssvt_occupancy_columns(const int *indices, int num_voxels, int batch_size, int x_max, int y_max,
+                            int z_max, unsigned long long *columns, void *stream);
 
 /* Work order and compact query rows for mssvt_block_attention_group, from one row of the
  * plan's (3,cap) nq_valid (odd / even / win1) and that list's qmeta (cap,nq,4):

@@ -54,6 +54,28 @@ __device__ __forceinline__ float half_max(float v) { v = row_max16(v); return fm
 __device__ __forceinline__ float half_sum(float v) { v = row_sum16(v); return v + __shfl_xor(v, 16); }
 __device__ __forceinline__ float wave_max(float v) { v = half_max(v); return fmaxf(v, __shfl_xor(v, 32)); }
 __device__ __forceinline__ float wave_sum(float v) { v = half_sum(v); return v + __shfl_xor(v, 32); }
+// wave-uniform reductions without LDS traffic: DPP inside the 16-lane rows, v_readlane across them
+__device__ __forceinline__ float wave_max_uniform(float v) {
+    v = row_max16(v);
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+#define DPP_MOV_U(v, ctrl) (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true)
+__device__ __forceinline__ unsigned int wave_min_u32_uniform(unsigned int v) {
+    unsigned int o;
+    o = DPP_MOV_U(v, 0xB1); v = o < v ? o : v;
+    o = DPP_MOV_U(v, 0x4E); v = o < v ? o : v;
+    o = DPP_MOV_U(v, 0x141); v = o < v ? o : v;
+    o = DPP_MOV_U(v, 0x140); v = o < v ? o : v;
+    const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 16),
+                       r2 = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned int a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
     for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
     return v;

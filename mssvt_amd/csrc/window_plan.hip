@@ -19,6 +19,7 @@
 //
 // The number of windows is read from DEVICE memory (no host round trip); the grid
 // is sized for the capacity and surplus waves exit.
+#include <stdlib.h>
 #include "common.hip.h"
 
 #define PLAN_MAX_WPB 4
@@ -47,6 +48,11 @@ struct PlanArgs {
     const int *indices;
     float vsx, vsy, vsz, minx, miny, minz, wsx, wsy, wsz;
     int lds_words_per_wave;
+    // optional occupancy columns (mssvt_occupancy_columns): one 64-bit word per (b, x, y), bit z set
+    // when the cell holds a voxel; fx0/fy0/fnx/fny = bounding box of the tables' (x, y) offsets
+    const unsigned long long *occ;
+    int fx0, fy0, fnx, fny;
+    const int *q_packed;  // with occ: the four tables concatenated, one pack_off() word per offset
 };
 
 __device__ __forceinline__ float plan_centre(int idx, float cell, float lo) {
@@ -54,6 +60,7 @@ __device__ __forceinline__ float plan_centre(int idx, float cell, float lo) {
 }
 
 #define PACK0 (64 | (64 << 8) | (64 << 16))
+#define PLAN_PRE 8  // 64-offset steps of K3 whose packed offsets are preloaded into registers
 __device__ __forceinline__ int pack_off(int ox, int oy, int oz) {
     return (ox + 64) | ((oy + 64) << 8) | ((oz + 64) << 16);
 }
@@ -163,10 +170,11 @@ __device__ __forceinline__ void fps_on_list_fast(const int *packed, int n, int n
     if (lane == 0) fps_out[0] = 0;
     for (int j = 1; j < m; ++j) {
         float x1 = 0.f, y1 = 0.f, z1 = 0.f;  // a padding slot sits at offset (0,0,0)
-        if (old < nv) {
-            x1 = __shfl(xk, old);
-            y1 = __shfl(yk, old);
-            z1 = __shfl(zk, old);
+        if (old < nv) {  // `old` is wave-uniform: v_readlane, no LDS round trip
+            const int ol = __builtin_amdgcn_readfirstlane(old);
+            x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xk), ol));
+            y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yk), ol));
+            z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zk), ol));
         }
         {
             const float dx = xk - x1, dy = yk - y1, dz = zk - z1;
@@ -180,19 +188,89 @@ __device__ __forceinline__ void fps_on_list_fast(const int *packed, int n, int n
             best = tpad;
             besti = lane + bs;
         }
-        const float M = wave_max(best);
-        const unsigned int kmin = wave_min_u32((mine && best == M) ? myrev : 0xFFFFFFFFu);
+        const float M = wave_max_uniform(best);
+        const unsigned int kmin = wave_min_u32_uniform((mine && best == M) ? myrev : 0xFFFFFFFFu);
         int pick;
         if (padgroup && (nv == 0 || tpad > M || (tpad == M && vp_rev < kmin))) {
             pick = vp;
         } else {
             const unsigned long long wm = __ballot(mine && best == M && myrev == kmin);
-            pick = __shfl(besti, __ffsll((long long)wm) - 1);
+            pick = __builtin_amdgcn_readlane(besti, __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1));
         }
         old = pick;
         if (lane == 0) fps_out[j] = old;
         if (M <= 0.f && (!padgroup || tpad <= 0.f) && !(nv < n && tpad > 0.f)) {
             // every remaining min-distance is 0: all further rounds tie completely and return slot 0
+            for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
+            if (old == 0) break;
+        }
+    }
+}
+
+// Register form of the same sampler for lists of any fill (bs <= 512, i.e. n < 1024): the reference
+// block's thread vt = lane + 64 k owns slots vt and vt + bs (n < 2 bs), both kept in registers with their
+// running min-distances -- padding slots are ordinary slots at offset (0,0,0).  Per round: update
+// 2 TPL distances, reduce the lane's TPL threads and then the wave with the tree's tie rule (among the
+// maximal values the smallest BIT-REVERSED thread id wins; inside a thread the lower slot), fetch the
+// picked slot's offset from the LDS list.  No LDS tree, no per-slot LDS traffic: ~0.5 k cycles per
+// round against ~4 k for fps_on_list (10 % of the windows of a 160k-point scene hold > 64 entries and
+// used to set the run time of the whole plan kernel).
+template <int TPL>
+__device__ __forceinline__ void fps_on_list_regs(const int *packed, int n, int m, int bs, int *fps_out, int lane) {
+    int L = 0;
+    while ((1 << L) < bs) ++L;
+    float xa[TPL], ya[TPL], za[TPL], da[TPL], xb[TPL], yb[TPL], zb[TPL], db[TPL];
+    unsigned int rev[TPL];
+    bool ea[TPL], eb[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+        const int vt = lane + MSSVT_WAVE * k;
+        ea[k] = vt < bs && vt < n;
+        eb[k] = vt < bs && vt + bs < n;
+        const int pa = packed[ea[k] ? vt : 0], pb = packed[eb[k] ? vt + bs : 0];
+        xa[k] = (float)((pa & 255) - 64); ya[k] = (float)(((pa >> 8) & 255) - 64); za[k] = (float)(((pa >> 16) & 255) - 64);
+        xb[k] = (float)((pb & 255) - 64); yb[k] = (float)(((pb >> 8) & 255) - 64); zb[k] = (float)(((pb >> 16) & 255) - 64);
+        da[k] = db[k] = 1e10f;
+        rev[k] = L ? __brev((unsigned int)vt) >> (32 - L) : 0u;
+    }
+    int old = 0;
+    if (lane == 0) fps_out[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        const int po = packed[old];
+        const float x1 = (float)((po & 255) - 64), y1 = (float)(((po >> 8) & 255) - 64),
+                    z1 = (float)(((po >> 16) & 255) - 64);
+        float bestv = -1.0f;
+        int besti = 0;
+        unsigned int bestrev = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+            if (!ea[k]) continue;
+            const int vt = lane + MSSVT_WAVE * k;
+            float dx = xa[k] - x1, dy = ya[k] - y1, dz = za[k] - z1;
+            da[k] = fminf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), da[k]);
+            float tb = da[k];
+            int ti = vt;
+            if (eb[k]) {
+                dx = xb[k] - x1; dy = yb[k] - y1; dz = zb[k] - z1;
+                db[k] = fminf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), db[k]);
+                if (db[k] > tb) {  // the later slot only on a STRICTLY larger distance
+                    tb = db[k];
+                    ti = vt + bs;
+                }
+            }
+            if (tb > bestv || (tb == bestv && rev[k] < bestrev)) {
+                bestv = tb;
+                besti = ti;
+                bestrev = rev[k];
+            }
+        }
+        const float M = wave_max_uniform(bestv);
+        const unsigned int kmin = wave_min_u32_uniform(bestv == M ? bestrev : 0xFFFFFFFFu);
+        const unsigned long long wm = __ballot(bestv == M && bestrev == kmin);
+        old = __builtin_amdgcn_readlane(besti, __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1));
+        if (lane == 0) fps_out[j] = old;
+        if (M <= 0.f) {
+            // every min-distance is 0 from here on: all further rounds tie completely -> thread 0, slot 0
             for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
             if (old == 0) break;
         }
@@ -260,74 +338,182 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
     const int e0 = a.n_odd, e1 = e0 + a.n_even, e2 = e1 + a.n_win1, total = e2 + a.n_win2;
     int cnt_odd = 0, cnt_even = 0, cnt_w1 = 0, cnt_w2 = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
-    // ---- K3: probe all offsets, 64 per step, ordered append ----------------------
-    for (int bq = 0; bq < total; bq += MSSVT_WAVE) {
-        if (cnt_w2 >= a.max_win2 && cnt_w1 >= a.max_win1 && (cnt_even >= a.max_even || bq >= e1) &&
-            (cnt_odd >= a.max_odd || bq >= e0))
-            break;
-        const int q = bq + lane;
-        const int seg = (q >= e0) + (q >= e1) + (q >= e2);
-        int sv = MSSVT_EMPTY, ox = 0, oy = 0, oz = 0;
-        if (q < total) {
-            const int *src = seg == 0 ? a.q_odd + q * 3
-                           : seg == 1 ? a.q_even + (q - e0) * 3
-                           : seg == 2 ? a.q_win1 + (q - e1) * 3
-                                      : a.q_win2 + (q - e2) * 3;
-            ox = src[0];
-            oy = src[1];
-            oz = src[2];
-            const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
-            if (!(sx >= a.x_max || sx < 0 || sy >= a.y_max || sy < 0 || sz >= a.z_max || sz < 0))
-                sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
+    if (a.occ) {
+        // ---- K3 with occupancy columns: the hit test needs no hash probe (one 64-bit word per (x, y)
+        // column of the neighbourhood, loaded once), positions come from ballots alone, and the hash is
+        // probed only for the hits -- all of them in one round instead of one dependent round per 64 offsets
+        unsigned long long *colw = reinterpret_cast<unsigned long long *>(
+            (reinterpret_cast<size_t>(bidx + bsmax) + 7) & ~(size_t)7);  // 8-byte aligned (the wave's region is)
+        int *lo_c = reinterpret_cast<int *>(colw + a.fnx * a.fny);
+        int *le_c = lo_c + a.max_odd;
+        const int ncols = a.fnx * a.fny;
+        // the first PLAN_PRE x 64 offsets travel together with the column words
+        int pre[PLAN_PRE];
+#pragma unroll
+        for (int ci = 0; ci < PLAN_PRE; ++ci) {
+            const int q = ci * MSSVT_WAVE + lane;
+            pre[ci] = q < total ? a.q_packed[q] : PACK0;
         }
-        const bool hit = sv != MSSVT_EMPTY;
-        const unsigned long long m_all = __ballot(hit);
-        if (m_all == 0) continue;
-        const unsigned long long m_odd = __ballot(hit && seg == 0);
-        const unsigned long long m_even = __ballot(hit && seg == 1);
-        const unsigned long long m_w1 = __ballot(hit && seg <= 2);
-        if (hit) {
-            const int pk = pack_off(ox, oy, oz);
-            if (seg == 0) {
-                const int p = cnt_odd + __popcll(m_odd & below);
-                if (p < a.max_odd) {
-                    a.ind_odd[(size_t)w * a.max_odd + p] = sv;
+        for (int c = lane; c < ncols; c += MSSVT_WAVE) {
+            const int sx = cx + a.fx0 + c / a.fny, sy = cy + a.fy0 + c % a.fny;
+            colw[c] = (sx >= 0 && sx < a.x_max && sy >= 0 && sy < a.y_max)
+                          ? a.occ[((size_t)wi.x * a.x_max + sx) * a.y_max + sy] : 0ull;
+        }
+        wave_lds_sync();
+        for (int bq = 0; bq < total; bq += MSSVT_WAVE) {
+            if (cnt_w2 >= a.max_win2 && cnt_w1 >= a.max_win1 && (cnt_even >= a.max_even || bq >= e1) &&
+                (cnt_odd >= a.max_odd || bq >= e0))
+                break;
+            const int q = bq + lane;
+            const int seg = (q >= e0) + (q >= e1) + (q >= e2);
+            bool hit = false;
+            const int ci = bq / MSSVT_WAVE;
+            int pk = PACK0;
+            if (ci < PLAN_PRE) {
+#pragma unroll
+                for (int u = 0; u < PLAN_PRE; ++u) pk = ci == u ? pre[u] : pk;  // ci is wave-uniform: scalar selects
+            } else if (q < total) {
+                pk = a.q_packed[q];
+            }
+            if (q < total) {
+                const int ox = (pk & 255) - 64, oy = ((pk >> 8) & 255) - 64, oz = ((pk >> 16) & 255) - 64;
+                const int sz = cz + oz, dx = ox - a.fx0, dy = oy - a.fy0;
+                // columns outside the grid are zero words; sz outside [0, z_max) has no bit set
+                if (sz >= 0 && sz < a.z_max && dx >= 0 && dx < a.fnx && dy >= 0 && dy < a.fny)
+                    hit = (colw[dx * a.fny + dy] >> sz) & 1ull;
+            }
+            const unsigned long long m_all = __ballot(hit);
+            if (m_all == 0) continue;
+            const unsigned long long m_odd = __ballot(hit && seg == 0);
+            const unsigned long long m_even = __ballot(hit && seg == 1);
+            const unsigned long long m_w1 = __ballot(hit && seg <= 2);
+            if (hit) {
+                if (seg == 0) {
+                    const int p = cnt_odd + __popcll(m_odd & below);
+                    if (p < a.max_odd) lo_c[p] = pk;
+                }
+                if (seg == 1) {
+                    const int p = cnt_even + __popcll(m_even & below);
+                    if (p < a.max_even) le_c[p] = pk;
+                }
+                if (seg <= 2) {
+                    const int p = cnt_w1 + __popcll(m_w1 & below);
+                    if (p < a.max_win1) l1_c[p] = pk;
+                }
+                const int p2 = cnt_w2 + __popcll(m_all & below);
+                if (p2 < a.max_win2) l2_c[p2] = pk;
+            }
+            cnt_odd += __popcll(m_odd);
+            cnt_even += __popcll(m_even);
+            cnt_w1 += __popcll(m_w1);
+            cnt_w2 += __popcll(m_all);
+        }
+        wave_lds_sync();
+        // the hits of all four lists, concatenated: one hash probe each, all in flight together
+        const int n0 = min(cnt_odd, a.max_odd), n1 = n0 + min(cnt_even, a.max_even),
+                  n2 = n1 + min(cnt_w1, a.max_win1), n3 = n2 + min(cnt_w2, a.max_win2);
+        for (int e = lane; e < n3; e += MSSVT_WAVE) {
+            const int lst = (e >= n0) + (e >= n1) + (e >= n2);
+            const int p = e - (lst == 0 ? 0 : lst == 1 ? n0 : lst == 2 ? n1 : n2);
+            const int pk = lst == 0 ? lo_c[p] : lst == 1 ? le_c[p] : lst == 2 ? l1_c[p] : l2_c[p];
+            const int ox = (pk & 255) - 64, oy = ((pk >> 8) & 255) - 64, oz = ((pk >> 16) & 255) - 64;
+            const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
+            const int sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
+            if (lst == 0) {
+                a.ind_odd[(size_t)w * a.max_odd + p] = sv;
+                if (sv != MSSVT_EMPTY) {
                     if (a.kmeta1)
                         a.qmeta_odd[(size_t)w * a.max_odd + p] = make_float4(
-                            plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
-                            plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
+                            plan_centre(sx, a.vsx, a.minx) - wcx, plan_centre(sy, a.vsy, a.miny) - wcy,
+                            plan_centre(sz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
                     atomicMax(a.owner_odd + vstart + sv, w * a.max_odd + p);
                 }
-            }
-            if (seg == 1) {
-                const int p = cnt_even + __popcll(m_even & below);
-                if (p < a.max_even) {
-                    a.ind_even[(size_t)w * a.max_even + p] = sv;
+            } else if (lst == 1) {
+                a.ind_even[(size_t)w * a.max_even + p] = sv;
+                if (sv != MSSVT_EMPTY) {
                     if (a.kmeta1)
                         a.qmeta_even[(size_t)w * a.max_even + p] = make_float4(
-                            plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
-                            plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
+                            plan_centre(sx, a.vsx, a.minx) - wcx, plan_centre(sy, a.vsy, a.miny) - wcy,
+                            plan_centre(sz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
                     atomicMax(a.owner_even + vstart + sv, w * a.max_even + p);
                 }
-            }
-            if (seg <= 2) {
-                const int p = cnt_w1 + __popcll(m_w1 & below);
-                if (p < a.max_win1) {
-                    l1_ind[p] = sv;
-                    l1_c[p] = pk;
-                    atomicMax(a.owner_win1 + vstart + sv, w * a.max_win1 + p);
-                }
-            }
-            const int p2 = cnt_w2 + __popcll(m_all & below);
-            if (p2 < a.max_win2) {
-                l2_ind[p2] = sv;
-                l2_c[p2] = pk;
+            } else if (lst == 2) {
+                l1_ind[p] = sv;
+                if (sv != MSSVT_EMPTY) atomicMax(a.owner_win1 + vstart + sv, w * a.max_win1 + p);
+            } else {
+                l2_ind[p] = sv;
             }
         }
-        cnt_odd += __popcll(m_odd);
-        cnt_even += __popcll(m_even);
-        cnt_w1 += __popcll(m_w1);
-        cnt_w2 += __popcll(m_all);
+    } else {
+        // ---- K3: probe all offsets, 64 per step, ordered append ----------------------
+        for (int bq = 0; bq < total; bq += MSSVT_WAVE) {
+            if (cnt_w2 >= a.max_win2 && cnt_w1 >= a.max_win1 && (cnt_even >= a.max_even || bq >= e1) &&
+                (cnt_odd >= a.max_odd || bq >= e0))
+                break;
+            const int q = bq + lane;
+            const int seg = (q >= e0) + (q >= e1) + (q >= e2);
+            int sv = MSSVT_EMPTY, ox = 0, oy = 0, oz = 0;
+            if (q < total) {
+                const int *src = seg == 0 ? a.q_odd + q * 3
+                               : seg == 1 ? a.q_even + (q - e0) * 3
+                               : seg == 2 ? a.q_win1 + (q - e1) * 3
+                                          : a.q_win2 + (q - e2) * 3;
+                ox = src[0];
+                oy = src[1];
+                oz = src[2];
+                const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
+                if (!(sx >= a.x_max || sx < 0 || sy >= a.y_max || sy < 0 || sz >= a.z_max || sz < 0))
+                    sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
+            }
+            const bool hit = sv != MSSVT_EMPTY;
+            const unsigned long long m_all = __ballot(hit);
+            if (m_all == 0) continue;
+            const unsigned long long m_odd = __ballot(hit && seg == 0);
+            const unsigned long long m_even = __ballot(hit && seg == 1);
+            const unsigned long long m_w1 = __ballot(hit && seg <= 2);
+            if (hit) {
+                const int pk = pack_off(ox, oy, oz);
+                if (seg == 0) {
+                    const int p = cnt_odd + __popcll(m_odd & below);
+                    if (p < a.max_odd) {
+                        a.ind_odd[(size_t)w * a.max_odd + p] = sv;
+                        if (a.kmeta1)
+                            a.qmeta_odd[(size_t)w * a.max_odd + p] = make_float4(
+                                plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
+                                plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
+                        atomicMax(a.owner_odd + vstart + sv, w * a.max_odd + p);
+                    }
+                }
+                if (seg == 1) {
+                    const int p = cnt_even + __popcll(m_even & below);
+                    if (p < a.max_even) {
+                        a.ind_even[(size_t)w * a.max_even + p] = sv;
+                        if (a.kmeta1)
+                            a.qmeta_even[(size_t)w * a.max_even + p] = make_float4(
+                                plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
+                                plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
+                        atomicMax(a.owner_even + vstart + sv, w * a.max_even + p);
+                    }
+                }
+                if (seg <= 2) {
+                    const int p = cnt_w1 + __popcll(m_w1 & below);
+                    if (p < a.max_win1) {
+                        l1_ind[p] = sv;
+                        l1_c[p] = pk;
+                        atomicMax(a.owner_win1 + vstart + sv, w * a.max_win1 + p);
+                    }
+                }
+                const int p2 = cnt_w2 + __popcll(m_all & below);
+                if (p2 < a.max_win2) {
+                    l2_ind[p2] = sv;
+                    l2_c[p2] = pk;
+                }
+            }
+            cnt_odd += __popcll(m_odd);
+            cnt_even += __popcll(m_even);
+            cnt_w1 += __popcll(m_w1);
+            cnt_w2 += __popcll(m_all);
+        }
     }
     wave_lds_sync();
     PSTAMP()
@@ -363,6 +549,14 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         const int nv = min(scale ? cnt_w2 : cnt_w1, n);
         if (nv <= MSSVT_WAVE && nv <= bs && bs >= 2)
             fps_on_list_fast(lc, n, nv, K, bs, fps_out, lane);
+        else if (bs <= 64)
+            fps_on_list_regs<1>(lc, n, K, bs, fps_out, lane);
+        else if (bs == 128)
+            fps_on_list_regs<2>(lc, n, K, bs, fps_out, lane);
+        else if (bs == 256)
+            fps_on_list_regs<4>(lc, n, K, bs, fps_out, lane);
+        else if (bs == 512)
+            fps_on_list_regs<8>(lc, n, K, bs, fps_out, lane);
         else
             fps_on_list(lc, n, K, bs, temp, bv, bidx, fps_out, lane);
         wave_lds_sync();
@@ -420,7 +614,8 @@ extern "C" int mssvt_window_plan_two(
     unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
     const int *indices, const float *host_voxel_size3, const float *host_range_min3,
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
-    float *kmeta2, float *wcentre, int *nq_valid, void *stream) {
+    float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
+    const int *host_footprint4, const int *packed_offsets, void *stream) {
     if (!win_indices || !num_wins_dev || !xyz_to_vidx || !v_bs_cnt || !ind_odd || !ind_even ||
         !ind_win1 || !k_ind1 || !k_ind2 || !k_mask1 || !k_mask2 || !win_vstart || !owner_win1 ||
         !owner_odd || !owner_even || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
@@ -468,8 +663,31 @@ extern "C" int mssvt_window_plan_two(
     const int nmax = max_num_win1 > max_num_win2 ? max_num_win1 : max_num_win2;
     const int bsmax = a.bs1 > a.bs2 ? a.bs1 : a.bs2;
     a.lds_words_per_wave = 2 * max_num_win1 + 2 * max_num_win2 + nmax + key_num_sample + 2 * bsmax;
-    int wpb = PLAN_MAX_WPB;  // waves (windows) per workgroup: as many as fit in 64 KiB of LDS
-    while (wpb > 1 && (size_t)a.lds_words_per_wave * 4 * wpb > 64 * 1024) wpb >>= 1;
+    a.occ = nullptr;
+    a.fx0 = a.fy0 = a.fnx = a.fny = 0;
+    a.q_packed = packed_offsets;
+    if (occ_columns && host_footprint4 && packed_offsets && z_max <= 64 && host_footprint4[2] > 0 &&
+        host_footprint4[3] > 0 && host_footprint4[2] * host_footprint4[3] <= 1024) {
+        a.occ = occ_columns;
+        a.fx0 = host_footprint4[0]; a.fy0 = host_footprint4[1];
+        a.fnx = host_footprint4[2]; a.fny = host_footprint4[3];
+        // + the column words (8-byte aligned) and the odd / even offset lists
+        a.lds_words_per_wave += 1 + 2 * a.fnx * a.fny + max_num_odd + max_num_even;
+        a.lds_words_per_wave += a.lds_words_per_wave & 1;  // keep every wave's region 8-byte aligned
+    }
+    // waves (windows) per workgroup: the count that puts the most waves on a CU (160 KiB of LDS,
+    // workgroups <= 64 KiB), ties -> larger workgroups (fewer of them to dispatch)
+    int wpb = 1, best_waves = 0;
+    for (int cand = 1; cand <= PLAN_MAX_WPB; ++cand) {
+        const size_t bytes = (size_t)a.lds_words_per_wave * 4 * cand;
+        if (bytes > 64 * 1024) break;
+        const int waves = (int)((160 * 1024) / bytes) * cand;
+        if (waves >= best_waves) {
+            best_waves = waves;
+            wpb = cand;
+        }
+    }
+    if (getenv("MSSVT_PLAN_WPB")) wpb = atoi(getenv("MSSVT_PLAN_WPB"));
     const size_t lds_bytes = (size_t)a.lds_words_per_wave * 4 * wpb;
     if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
     if (lds_bytes > 64 * 1024) {
@@ -478,6 +696,35 @@ extern "C" int mssvt_window_plan_two(
         if (e != hipSuccess) return (int)e;
     }
     k_window_plan<<<divup(win_capacity, wpb), wpb * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
+    return mssvt_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Occupancy columns of a voxel set: one 64-bit word per (b, x, y), bit z = the cell holds a voxel
+// (z_max <= 64).  1.8 MB for a 470 x 470 grid: L2 resident.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_occupancy_columns(const int *indices, int n, int batch_size, int x_max,
+                                                           int y_max, int z_max, unsigned long long *cols) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 v = reinterpret_cast<const int4 *>(indices)[i];  // [b, z, y, x]
+    if (v.x < 0 || v.x >= batch_size || v.w < 0 || v.w >= x_max || v.z < 0 || v.z >= y_max || v.y < 0 || v.y >= z_max)
+        return;
+    atomicOr(cols + ((size_t)v.x * x_max + v.w) * y_max + v.z, 1ull << v.y);
+}
+
+extern "C" int mssvt_occupancy_columns(const int *indices, int num_voxels, int batch_size, int x_max, int y_max,
+                                       int z_max, unsigned long long *columns, void *stream_) {
+    if (!columns || (!indices && num_voxels > 0) || num_voxels < 0 || batch_size <= 0 || x_max <= 0 || y_max <= 0 ||
+        z_max <= 0)
+        return MSSVT_E_BADARG;
+    if (z_max > 64) return MSSVT_E_TOOLARGE;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipError_t e = hipMemsetAsync(columns, 0, (size_t)batch_size * x_max * y_max * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return (int)e;
+    if (num_voxels > 0)
+        k_occupancy_columns<<<divup(num_voxels, 256), 256, 0, stream>>>(indices, num_voxels, batch_size, x_max, y_max,
+                                                                      z_max, columns);
     return mssvt_launch_status();
 }
 

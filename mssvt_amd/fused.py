@@ -68,6 +68,32 @@ def level_state(sp):
     return st
 
 
+def occupancy_columns(sp, st):
+    """One 64-bit word per (b, x, y) column of the level (bit z = occupied), or None when z > 64."""
+    if "occ" not in st:
+        X, Y, Z = (int(v) for v in sp.spatial_shape)
+        occ = None
+        if OCC_COLUMNS and Z <= 64:
+            occ = torch.empty(sp.batch_size * X * Y, dtype=torch.int64, device=sp.indices.device)
+            _lib.call("mssvt_occupancy_columns", _lib.ptr(sp.indices), _i(sp.indices.shape[0]), _i(sp.batch_size),
+                      _i(X), _i(Y), _i(Z), _lib.ptr(occ), _lib.stream())
+        st["occ"] = occ
+    return st["occ"]
+
+
+def _table_footprint(block, t):
+    """(min x offset, min y offset, x extent, y extent) over the four query tables (host, cached)."""
+    fp = getattr(block, "_footprint_cache", None)
+    if fp is None or fp[0] is not t['win2']:
+        allt = torch.cat([t[k].reshape(-1, 3).cpu() for k in ('odd', 'even', 'win1', 'win2')], 0)
+        lo, hi = allt.min(0).values, allt.max(0).values
+        arr = (ctypes.c_int * 4)(int(lo[0]), int(lo[1]), int(hi[0] - lo[0] + 1), int(hi[1] - lo[1] + 1))
+        a64 = allt.to(torch.int64) + 64
+        packed = (a64[:, 0] | (a64[:, 1] << 8) | (a64[:, 2] << 16)).to(torch.int32).to(t['win2'].device)
+        fp = block._footprint_cache = (t['win2'], arr, packed)
+    return fp[1], fp[2]
+
+
 @torch.no_grad()
 def two_scale_plan(block, sp):
     st = level_state(sp)
@@ -103,6 +129,7 @@ def two_scale_plan(block, sp):
     owners = torch.full((3, cap), -1, dtype=torch.int32, device=dev)
     p.owner_win1, p.owner_odd, p.owner_even = owners[0], owners[1], owners[2]
     t = block._tables_on(dev)
+    fp4, packed = _table_footprint(block, t)
     _lib.call("mssvt_window_plan_two", *[_i(int(v)) for v in sp.spatial_shape],
               *[_i(int(v)) for v in block.win1_size], _i(n_o), _i(n_e), _i(n1), _i(n2), _i(H), _i(B),
               _i(t['odd'].shape[0]), _i(t['even'].shape[0]), _i(t['win1'].shape[0]), _i(t['win2'].shape[0]),
@@ -113,7 +140,8 @@ def two_scale_plan(block, sp):
               _lib.ptr(p.win_vstart), _lib.ptr(p.owner_win1), _lib.ptr(p.owner_odd), _lib.ptr(p.owner_even),
               _lib.ptr(sp.indices), _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m),
               _lib.ptr(p.qmeta_odd), _lib.ptr(p.qmeta_even), _lib.ptr(p.qmeta_win1), _lib.ptr(p.kmeta[0]),
-              _lib.ptr(p.kmeta[1]), _lib.ptr(p.wcentre), _lib.ptr(p.nq_valid), _lib.stream())
+              _lib.ptr(p.kmeta[1]), _lib.ptr(p.wcentre), _lib.ptr(p.nq_valid), _lib.ptr(occupancy_columns(sp, st)),
+              fp4, _lib.ptr(packed), _lib.stream())
     st["plans"][key] = p
     return p
 
@@ -197,6 +225,7 @@ def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
 FFN_SPLIT = os.environ.get("MSSVT_FFN_SPLIT", "1") != "0"
 CMP_FUSED = os.environ.get("MSSVT_CMP_FUSED", "1") != "0"
+OCC_COLUMNS = os.environ.get("MSSVT_OCC_COLUMNS", "1") != "0"
 
 
 def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=None, apply_out=True, phases=3):

@@ -23,9 +23,12 @@ def _block(ws, m1, m2, K, pattern=1, C=32, heads=(2, 2)):
                                               ([[3, 3, 5], [7, 7, 7]], 6, 20, 8, 3, 30000),
                                               ([[2, 2, 2], [4, 4, 4]], 8, 64, 16, 1, 20000),
                                               ([[5, 5, 7], [11, 11, 11]], 175, 1331, 32, 1, 60000)])
-def test_window_plan_matches_oracle(ws, m1, m2, K, B, pts):
+@pytest.mark.parametrize("occ", [True, False])
+def test_window_plan_matches_oracle(ws, m1, m2, K, B, pts, occ, monkeypatch):
+    """occ: K3 hit test through the occupancy columns (default) / through hash probes (z > 64 fallback)."""
     from mssvt_amd import fused
     from mssvt_amd.mssvt_utils import SparseTensor
+    monkeypatch.setattr(fused, "OCC_COLUMNS", occ)
     H = 200003
     p_np = synthetic.make_batch_points(pts, B, 11)
     vc, _, _ = synthetic.voxelize_numpy(p_np)

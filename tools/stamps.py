@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 buf = np.zeros(64 * 16, dtype=np.uint64)
 _lib.lib().mssvt_debug_read_plan_stamps(buf.ctypes.data_as(ctypes.c_void_p))
 s = buf.reshape(64, 16).astype(np.int64)
-print("phases: start, init, K3, win1meta, fps1, out1, fps2, out2   (100 cycles)")
+print("phases: start, init, cols, phase1, K3 end, win1meta, fps1, out1, fps2, out2   (100 cycles)")
 for w in range(0, 64, 4):
     r_ = s[w]
     nz = int((r_ != 0).sum())
