@@ -279,6 +279,10 @@ __device__ __forceinline__ void fps_on_list_regs(const int *packed, int n, int m
 
 #ifdef MSSVT_STAMPS  // developer instrumentation
 __device__ unsigned long long g_plan_stamps[64 * 16];
+__device__ unsigned long long g_plan_span[32768 * 2];
+extern "C" int mssvt_debug_read_plan_span(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_plan_span), sizeof(g_plan_span));
+}
 extern "C" int mssvt_debug_read_plan_stamps(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_plan_stamps), sizeof(g_plan_stamps));
 }
@@ -295,6 +299,9 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
     int si = 0;
     (void)si;
     PSTAMP()
+#ifdef MSSVT_STAMPS
+    if (lane == 0 && w < 32768) g_plan_span[2 * w] = __builtin_readcyclecounter();
+#endif
     int *base = lds + (size_t)wv * a.lds_words_per_wave;
     int *l1_ind = base;
     int *l1_c = l1_ind + a.max_win1;
@@ -594,6 +601,9 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         wave_lds_sync();
         PSTAMP()
     }
+#ifdef MSSVT_STAMPS
+    if (lane == 0 && w < 32768) g_plan_span[2 * w + 1] = __builtin_readcyclecounter();
+#endif
 }
 
 static inline int plan_opt_n_threads(int work_size) {  // ref cuda_utils.h:10-14

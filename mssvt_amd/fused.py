@@ -405,6 +405,13 @@ def one_scale_plan(block, sp, sync=True):
               _lib.ptr(p.num_rows), _lib.stream())
     p.ws, p.N = ws, N
     if not sync:
+        # the window count is final here, ~250 us of GPU work before the block ends: copy it to pinned
+        # host memory now and wait for THAT copy later (not for the stream) -- the forward returns while
+        # the GPU still runs the block's tail and the next frame's launches queue up behind it
+        p.host_ws = torch.empty(3, dtype=torch.int32, pin_memory=True)
+        p.host_ws.copy_(ws[:3], non_blocking=True)
+        p.host_ev = torch.cuda.Event()
+        p.host_ev.record()
         return p
     status, p.nw, p.R = ws[:3].tolist()  # the forward's single host sync
     if p.disjoint:
@@ -460,7 +467,8 @@ def _compress_forward_fused(block, sp, xhat, x_in):
               _lib.ptr(ma.to_kvs[0].bias), _lib.ptr(ma.projs[0].weight), _lib.ptr(ma.projs[0].bias),
               _lib.ptr(qp), _lib.ptr(ktok), _lib.ptr(score), _lib.ptr(vp), _lib.ptr(new), _lib.stream())
     y = _ffn_tail(block, sp, new, n_rows_dev=p.num_wins, apply_out=False)  # no residual to the block input (ref :383-385)
-    status, nw, _ = p.ws[:3].tolist()  # the forward's single host sync: the output shape
+    p.host_ev.synchronize()  # the forward's single host wait: the output shape (copied out long ago)
+    status, nw, _ = p.host_ws.tolist()
     _check_plan_status(block, status, sp.hash_size)
     p.nw = nw
     pre = getattr(sp, "_xhat", None)
