@@ -211,6 +211,14 @@ int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int nq, const
                      int win_capacity, int row_capacity, int *perm, int *num_active_dev, int *q_off,
                      float *qrow_meta, int *qrow_src, int *num_rows_dev, void *stream);
 
+/* mssvt_plan_order for several query lists of one plan in ONE launch pair (host arrays of
+ * num_sets <= 4 device pointers / sizes, one entry per list).                                 */
+int mssvt_plan_order_multi(int num_sets, const int *num_wins_dev, const int *const *host_nq_valid,
+                           const int *host_nq, const float *const *host_qmeta, int win_capacity,
+                           int row_capacity, int *const *host_perm, int *const *host_num_active,
+                           int *const *host_q_off, float *const *host_qrow_meta, int *const *host_qrow_src,
+                           int *const *host_num_rows, void *stream);
+
 /* Fused attention of a Block, all head groups (group g = channels [c0[g], c0[g]+Cg[g]),
  * Cg = heads[g]*head_dim <= 64, attends to key scale g): gathers + positional MLP +
  * MixedScaleAttention (ref mssvt_backbone.py:260-295, mssvt_utils.py:112-150) for every valid
@@ -335,6 +343,15 @@ int mssvt_block_interp_table(int nq, int n_upd, int use_interpolation, const int
                              const int *owner, const float *host_voxel_size3,
                              const float *host_range_min3, int zero_row, int *tab_row, float *tab_w,
                              void *stream);
+/* mssvt_block_interp_table for several (query list, interpolation mode) variants of one plan in
+ * ONE launch (host arrays of num_sets <= 4 entries).                                          */
+int mssvt_block_interp_table_multi(int num_sets, const int *host_nq, const int *host_n_upd,
+                                   const int *host_interp, const int *indices, const int *win_ind,
+                                   const int *num_wins_dev, int win_capacity, const int *win_vstart,
+                                   const int *const *host_q_ind, const int *const *host_upd_ind,
+                                   const int *const *host_owner, const float *host_voxel_size3,
+                                   const float *host_range_min3, const int *host_zero_row,
+                                   int *const *host_tab_row, float *const *host_tab_w, void *stream);
 /* mssvt_ffn_fused fed by that table: x = tab_row[v][0] < 0 ? 2*x_in[v]
  *                                      : x_in[v] + sum_i tab_w[v][i] * attn[tab_row[v][i]].   */
 int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_in, const int *tab_row,

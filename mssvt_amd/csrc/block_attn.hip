@@ -660,8 +660,14 @@ struct ScatterArgs {
 
 #define SC_WPB 4
 #define SC_MAXQ 256
+#define SC_MAX_SETS 4
+struct ScatterPack {
+    ScatterArgs s[SC_MAX_SETS];
+};
 
-__global__ void __launch_bounds__(SC_WPB *MSSVT_WAVE) k_block_scatter(ScatterArgs a) {
+// blockIdx.y = set: the interpolation tables of all (cbs_pattern, interp) variants of a plan in one launch
+__global__ void __launch_bounds__(SC_WPB *MSSVT_WAVE) k_block_scatter(ScatterPack pack) {
+    const ScatterArgs &a = pack.s[blockIdx.y];
     __shared__ float kx[SC_WPB][SC_MAXQ], ky[SC_WPB][SC_MAXQ], kz[SC_WPB][SC_MAXQ];
     __shared__ int kvalid[SC_WPB][SC_MAXQ];
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
@@ -787,36 +793,58 @@ extern "C" int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_inte
     a.tab_row = nullptr; a.tab_w = nullptr; a.zero_row = 0;
     int grid = divup(win_capacity, SC_WPB);
     if (grid > 4096) grid = 4096;  // grid-stride over the windows actually present
-    k_block_scatter<<<grid, SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(a);
+    ScatterPack pack;
+    for (int i = 0; i < SC_MAX_SETS; ++i) pack.s[i] = a;
+    k_block_scatter<<<grid, SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(pack);
     return mssvt_launch_status();
 }
 
 // Table form of mssvt_block_interp_scatter: records, per voxel owned by a list slot, the
 // (up to) three attention rows and inverse-distance weights instead of applying them.
+extern "C" int mssvt_block_interp_table_multi(int num_sets, const int *host_nq, const int *host_n_upd,
+                                              const int *host_interp, const int *indices, const int *win_ind,
+                                              const int *num_wins_dev, int win_capacity, const int *win_vstart,
+                                              const int *const *host_q_ind, const int *const *host_upd_ind,
+                                              const int *const *host_owner, const float *host_voxel_size3,
+                                              const float *host_range_min3, const int *host_zero_row,
+                                              int *const *host_tab_row, float *const *host_tab_w, void *stream) {
+    if (num_sets <= 0 || num_sets > SC_MAX_SETS) return num_sets <= 0 ? MSSVT_E_BADARG : MSSVT_E_TOOLARGE;
+    if (!host_nq || !host_n_upd || !host_interp || !indices || !win_ind || !num_wins_dev || !win_vstart ||
+        !host_q_ind || !host_upd_ind || !host_owner || !host_voxel_size3 || !host_range_min3 || !host_zero_row ||
+        !host_tab_row || !host_tab_w)
+        return MSSVT_E_BADARG;
+    if (win_capacity <= 0) return MSSVT_OK;
+    ScatterPack pack;
+    for (int i = 0; i < SC_MAX_SETS; ++i) {
+        const int k = i < num_sets ? i : 0;
+        if (!host_q_ind[k] || !host_owner[k] || !host_tab_row[k] || !host_tab_w[k] || host_nq[k] <= 0)
+            return MSSVT_E_BADARG;
+        if (host_interp[k] && (!host_upd_ind[k] || host_n_upd[k] <= 0)) return MSSVT_E_BADARG;
+        if (host_nq[k] > SC_MAXQ) return MSSVT_E_TOOLARGE;
+        ScatterArgs &a = pack.s[i];
+        a.C = 0; a.nq = host_nq[k]; a.n1 = host_n_upd[k]; a.interp = host_interp[k];
+        a.attn = nullptr; a.x_in = nullptr; a.x_new = nullptr;
+        a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev; a.win_vstart = win_vstart;
+        a.q_ind = host_q_ind[k]; a.upd_ind = host_upd_ind[k]; a.owner = host_owner[k];
+        a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
+        a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
+        a.tab_row = reinterpret_cast<int4 *>(host_tab_row[k]);
+        a.tab_w = reinterpret_cast<float4 *>(host_tab_w[k]);
+        a.zero_row = host_zero_row[k];
+    }
+    int grid = divup(win_capacity, SC_WPB);
+    if (grid > 4096 / num_sets) grid = 4096 / num_sets;
+    k_block_scatter<<<dim3(grid, num_sets), SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(pack);
+    return mssvt_launch_status();
+}
+
 extern "C" int mssvt_block_interp_table(int nq, int n_upd, int use_interpolation, const int *indices,
                                         const int *win_ind, const int *num_wins_dev, int win_capacity,
                                         const int *win_vstart, const int *q_ind, const int *upd_ind,
                                         const int *owner, const float *host_voxel_size3,
                                         const float *host_range_min3, int zero_row, int *tab_row,
                                         float *tab_w, void *stream) {
-    if (!indices || !win_ind || !num_wins_dev || !win_vstart || !q_ind || !owner || !host_voxel_size3 ||
-        !host_range_min3 || !tab_row || !tab_w || nq <= 0)
-        return MSSVT_E_BADARG;
-    if (use_interpolation && (!upd_ind || n_upd <= 0)) return MSSVT_E_BADARG;
-    if (nq > SC_MAXQ) return MSSVT_E_TOOLARGE;
-    if (win_capacity <= 0) return MSSVT_OK;
-    ScatterArgs a;
-    a.C = 0; a.nq = nq; a.n1 = n_upd; a.interp = use_interpolation;
-    a.attn = nullptr; a.x_in = nullptr; a.x_new = nullptr;
-    a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev; a.win_vstart = win_vstart;
-    a.q_ind = q_ind; a.upd_ind = upd_ind; a.owner = owner;
-    a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
-    a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
-    a.tab_row = reinterpret_cast<int4 *>(tab_row);
-    a.tab_w = reinterpret_cast<float4 *>(tab_w);
-    a.zero_row = zero_row;
-    int grid = divup(win_capacity, SC_WPB);
-    if (grid > 4096) grid = 4096;
-    k_block_scatter<<<grid, SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(a);
-    return mssvt_launch_status();
+    return mssvt_block_interp_table_multi(1, &nq, &n_upd, &use_interpolation, indices, win_ind, num_wins_dev,
+                                          win_capacity, win_vstart, &q_ind, &upd_ind, &owner, host_voxel_size3,
+                                          host_range_min3, &zero_row, &tab_row, &tab_w, stream);
 }

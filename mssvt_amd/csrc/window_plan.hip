@@ -748,9 +748,25 @@ extern "C" int mssvt_occupancy_columns(const int *indices, int num_voxels, int b
 #define PO_WAVES 16
 #define PO_KEYS 257
 #define PO_V 8  // window batches of 64 in flight per wave (one global-load latency per PO_V batches)
-__global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE)
-    k_plan_order(const int *num_wins, const int *nq_valid, int max_key, int *perm, int *num_active, int *q_off,
-                 int *num_rows) {
+#define PO_MAX_SETS 4
+struct PlanOrderSet {
+    const int *nq_valid;
+    int max_key, nq;
+    const float4 *qmeta;
+    int *perm, *num_active, *q_off, *num_rows;
+    float4 *rmeta;
+    int2 *rsrc;
+};
+struct PlanOrderPack {
+    PlanOrderSet s[PO_MAX_SETS];
+};
+
+// one workgroup per query list (blockIdx.x): the lists of a plan are ordered in one launch
+__global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *num_wins, PlanOrderPack pack) {
+    const PlanOrderSet &ps = pack.s[blockIdx.x];
+    const int *nq_valid = ps.nq_valid;
+    const int max_key = ps.max_key;
+    int *perm = ps.perm, *num_active = ps.num_active, *q_off = ps.q_off, *num_rows = ps.num_rows;
     // per-wave histograms: copies sit PO_KEYS (odd) words apart -> different LDS banks, so the 16
     // waves' atomics on the few populated keys proceed in parallel
     __shared__ int hist[PO_WAVES][PO_KEYS];
@@ -837,8 +853,13 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE)
 
 // compact query rows: row q_off[w] + p = the p-th valid slot of window w's query list:
 // rmeta = the slot's (rel.xyz, bits(feature row)), rsrc = (window, attn row w * nq + slot)
-__global__ void __launch_bounds__(256) k_query_rows(const int *num_wins, int nq, const float4 *qmeta, const int *q_off,
-                                                    int row_capacity, float4 *rmeta, int2 *rsrc) {
+__global__ void __launch_bounds__(256) k_query_rows(const int *num_wins, int row_capacity, PlanOrderPack pack) {
+    const PlanOrderSet &ps = pack.s[blockIdx.y];
+    const int nq = ps.nq;
+    const float4 *qmeta = ps.qmeta;
+    const int *q_off = ps.q_off;
+    float4 *rmeta = ps.rmeta;
+    int2 *rsrc = ps.rsrc;
     const int nw = *num_wins, lane = lane_id();
     const int wstep = gridDim.x * (blockDim.x / MSSVT_WAVE);
     for (int w = blockIdx.x * (blockDim.x / MSSVT_WAVE) + threadIdx.x / MSSVT_WAVE; w < nw; w += wstep) {
@@ -862,18 +883,41 @@ __global__ void __launch_bounds__(256) k_query_rows(const int *num_wins, int nq,
     }
 }
 
+extern "C" int mssvt_plan_order_multi(int num_sets, const int *num_wins_dev, const int *const *host_nq_valid,
+                                      const int *host_nq, const float *const *host_qmeta, int win_capacity,
+                                      int row_capacity, int *const *host_perm, int *const *host_num_active,
+                                      int *const *host_q_off, float *const *host_qrow_meta,
+                                      int *const *host_qrow_src, int *const *host_num_rows, void *stream) {
+    if (num_sets <= 0 || num_sets > PO_MAX_SETS) return num_sets <= 0 ? MSSVT_E_BADARG : MSSVT_E_TOOLARGE;
+    if (!num_wins_dev || !host_nq_valid || !host_nq || !host_qmeta || !host_perm || !host_num_active || !host_q_off ||
+        !host_qrow_meta || !host_qrow_src || !host_num_rows || win_capacity <= 0 || row_capacity <= 0)
+        return MSSVT_E_BADARG;
+    PlanOrderPack pack;
+    for (int i = 0; i < PO_MAX_SETS; ++i) {
+        const int k = i < num_sets ? i : 0;
+        if (!host_nq_valid[k] || !host_qmeta[k] || !host_perm[k] || !host_num_active[k] || !host_q_off[k] ||
+            !host_qrow_meta[k] || !host_qrow_src[k] || !host_num_rows[k] || host_nq[k] <= 0)
+            return MSSVT_E_BADARG;
+        PlanOrderSet &ps = pack.s[i];
+        ps.nq_valid = host_nq_valid[k];
+        ps.nq = host_nq[k];
+        ps.max_key = host_nq[k] > 256 ? 256 : host_nq[k];
+        ps.qmeta = reinterpret_cast<const float4 *>(host_qmeta[k]);
+        ps.perm = host_perm[k]; ps.num_active = host_num_active[k]; ps.q_off = host_q_off[k];
+        ps.num_rows = host_num_rows[k];
+        ps.rmeta = reinterpret_cast<float4 *>(host_qrow_meta[k]);
+        ps.rsrc = reinterpret_cast<int2 *>(host_qrow_src[k]);
+    }
+    k_plan_order<<<num_sets, PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, pack);
+    int grid = (win_capacity + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    k_query_rows<<<dim3(grid, num_sets), 256, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
+    return mssvt_launch_status();
+}
+
 extern "C" int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int nq, const float *qmeta,
                                 int win_capacity, int row_capacity, int *perm, int *num_active_dev, int *q_off,
                                 float *qrow_meta, int *qrow_src, int *num_rows_dev, void *stream) {
-    if (!num_wins_dev || !nq_valid || !qmeta || !perm || !num_active_dev || !q_off || !qrow_meta || !qrow_src ||
-        !num_rows_dev || nq <= 0 || win_capacity <= 0 || row_capacity <= 0)
-        return MSSVT_E_BADARG;
-    k_plan_order<<<1, PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, nq_valid, nq > 256 ? 256 : nq,
-                                                                       perm, num_active_dev, q_off, num_rows_dev);
-    int grid = (win_capacity + 3) / 4;
-    if (grid > 4096) grid = 4096;
-    k_query_rows<<<grid, 256, 0, (hipStream_t)stream>>>(num_wins_dev, nq, reinterpret_cast<const float4 *>(qmeta),
-                                                        q_off, row_capacity, reinterpret_cast<float4 *>(qrow_meta),
-                                                        reinterpret_cast<int2 *>(qrow_src));
-    return mssvt_launch_status();
+    return mssvt_plan_order_multi(1, num_wins_dev, &nq_valid, &nq, &qmeta, win_capacity, row_capacity, &perm,
+                                  &num_active_dev, &q_off, &qrow_meta, &qrow_src, &num_rows_dev, stream);
 }

@@ -300,6 +300,10 @@ def block_forward(block, sp):
     x_in = sp.features.contiguous()
     N, C = x_in.shape
     p = two_scale_plan(block, sp)
+    group = getattr(sp, "_plan_group", None)
+    if group and not getattr(p, "group_done", False):
+        p.group_done = True
+        prepare_group([b for b in group if b.plan_key() == block.plan_key() and supported(b, sp)], sp, p)
     q_ind, nq, owner_q = _query(block, p)
     attn = _attn_buffer(p, nq, C, x_in.device)
     od = _work_order(block, p, nq, N)
@@ -329,6 +333,70 @@ def block_forward(block, sp):
 
 
 @torch.no_grad()
+@torch.no_grad()
+def prepare_group(blocks, sp, p):
+    """Work orders + interpolation tables of ALL blocks that share plan `p`, one launch (pair) per kind
+    instead of one per block: they depend on the plan only, and a single-workgroup ordering kernel per
+    query list is pure latency."""
+    dev = sp.indices.device
+    N = sp.indices.shape[0]
+    ia = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])  # noqa: E731
+    pa = lambda ts: (ctypes.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
+    # --- work orders, one per cbs_pattern
+    todo, seen = [], set(p.orders)
+    for b in blocks:
+        if b.cbs_pattern not in seen:
+            seen.add(b.cbs_pattern)
+            todo.append(b)
+    if 1 < len(todo) <= 4:
+        cap_rows = max(int(N), 1)  # the query lists of one pattern are disjoint
+        outs = []
+        for b in todo:
+            _, nq, _ = _query(b, p)
+            outs.append(dict(perm=torch.empty(p.cap, dtype=torch.int32, device=dev),
+                             n_act=torch.empty(1, dtype=torch.int32, device=dev),
+                             q_off=torch.empty(p.cap, dtype=torch.int32, device=dev),
+                             nq_valid=p.nq_valid[{1: 0, 0: 1, 2: 2}[b.cbs_pattern]],
+                             row_meta=torch.empty((cap_rows, 4), dtype=torch.float32, device=dev),
+                             row_src=torch.empty((cap_rows, 2), dtype=torch.int32, device=dev),
+                             n_rows=torch.empty(1, dtype=torch.int32, device=dev), row_cap=cap_rows, nq=nq))
+        _lib.call("mssvt_plan_order_multi", _i(len(todo)), _lib.ptr(p.num_wins), pa([o["nq_valid"] for o in outs]),
+                  ia([o["nq"] for o in outs]), pa([_qmeta(b, p) for b in todo]), _i(p.cap), _i(cap_rows),
+                  pa([o["perm"] for o in outs]), pa([o["n_act"] for o in outs]), pa([o["q_off"] for o in outs]),
+                  pa([o["row_meta"] for o in outs]), pa([o["row_src"] for o in outs]),
+                  pa([o["n_rows"] for o in outs]), _lib.stream())
+        for b, o in zip(todo, outs):
+            p.orders[b.cbs_pattern] = o
+    # --- interpolation tables, one per (cbs_pattern, interpolation)
+    tabs = getattr(p, "tables", None)
+    if tabs is None:
+        tabs = p.tables = {}
+    todo, seen = [], set(tabs)
+    for b in blocks:
+        C, FF = b.linear1.in_features, b.linear1.out_features
+        key = (b.cbs_pattern, 1 if b.use_feature_interpolation else 0)
+        if key not in seen and (C, FF) in FFN_SHAPES:
+            seen.add(key)
+            todo.append((b, key))
+    if 1 < len(todo) <= 4:
+        vs3, mn3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3])
+        # one fill for all tab_row arrays
+        rows = torch.full((len(todo), max(N, 1), 4), -1, dtype=torch.int32, device=dev)
+        ws = torch.empty((len(todo), max(N, 1), 4), dtype=torch.float32, device=dev)  # written with tab_row
+        nqs, nus, its, qis, uis, ows, zrs = [], [], [], [], [], [], []
+        for b, (pat, interp) in todo:
+            q_ind, nq, owner_q = _query(b, p)
+            upd_ind, n_upd, owner = (p.ind_win1, b.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
+            nqs.append(nq); nus.append(n_upd); its.append(interp); qis.append(q_ind); uis.append(upd_ind)
+            ows.append(owner); zrs.append(p.cap * nq)
+        _lib.call("mssvt_block_interp_table_multi", _i(len(todo)), ia(nqs), ia(nus), ia(its), _lib.ptr(sp.indices),
+                  _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), pa(qis), pa(uis),
+                  pa(ows), vs3, mn3, ia(zrs), pa([rows[i] for i in range(len(todo))]),
+                  pa([ws[i] for i in range(len(todo))]), _lib.stream())
+        for i, (b, key) in enumerate(todo):
+            tabs[key] = (rows[i], ws[i])
+
+
 def _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, mn3):
     """(tab_row (N,4) int32, tab_w (N,4) f32): where each voxel's update comes from.  Geometry
     only -> computed once per plan and (cbs_pattern, interpolation) and reused by later blocks."""

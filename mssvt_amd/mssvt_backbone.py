@@ -344,6 +344,8 @@ class MixedScaleSparseTransformer(nn.Module):
         for i, blk in enumerate(self.backbone):
             # lets a fused FFN epilogue also emit the next block's norm1 (mssvt_amd/fused.py)
             sp._next_norm1 = self.backbone[i + 1].norm1 if i + 1 < len(self.backbone) else None
+            # the Blocks from here on (fused.prepare_group orders / tabulates all that share a plan at once)
+            sp._plan_group = [b for b in self.backbone[i:] if isinstance(b, MixedScaleSparseTransformerBlock)]
             sp = blk(sp, block_idx=i)
         batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
         return batch_dict
