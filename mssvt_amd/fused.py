@@ -126,7 +126,7 @@ def two_scale_plan(block, sp):
     p.wcentre = torch.empty((cap, 4), dtype=torch.float32, device=dev)
     p.nq_valid = torch.empty((3, cap), dtype=torch.int32, device=dev)
     p.orders = {}
-    owners = torch.full((3, cap), -1, dtype=torch.int32, device=dev)
+    owners = mssvt_ops.full_neg1((3, cap), dev)
     p.owner_win1, p.owner_odd, p.owner_even = owners[0], owners[1], owners[2]
     t = block._tables_on(dev)
     fp4, packed = _table_footprint(block, t)
@@ -381,7 +381,7 @@ def prepare_group(blocks, sp, p):
     if 1 < len(todo) <= 4:
         vs3, mn3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3])
         # one fill for all tab_row arrays
-        rows = torch.full((len(todo), max(N, 1), 4), -1, dtype=torch.int32, device=dev)
+        rows = mssvt_ops.full_neg1((len(todo), max(N, 1), 4), dev)
         ws = torch.empty((len(todo), max(N, 1), 4), dtype=torch.float32, device=dev)  # written with tab_row
         nqs, nus, its, qis, uis, ows, zrs = [], [], [], [], [], [], []
         for b, (pat, interp) in todo:
@@ -407,7 +407,7 @@ def _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, m
     if key not in tabs:
         dev = sp.indices.device
         N = sp.indices.shape[0]
-        tab_row = torch.full((max(N, 1), 4), -1, dtype=torch.int32, device=dev)
+        tab_row = mssvt_ops.full_neg1((max(N, 1), 4), dev)
         tab_w = torch.empty((max(N, 1), 4), dtype=torch.float32, device=dev)  # written with tab_row
         _lib.call("mssvt_block_interp_table", _i(nq), _i(n_upd), _i(interp), _lib.ptr(sp.indices),
                   _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind),
@@ -458,7 +458,7 @@ def one_scale_plan(block, sp, sync=True):
     p.win_vstart = torch.empty(cap, dtype=torch.int32, device=dev)
     p.win_cnt = torch.empty(cap, dtype=torch.int32, device=dev)
     p.pair_base = torch.empty(cap, dtype=torch.int32, device=dev)
-    p.pair_win = torch.full((row_cap,), -1, dtype=torch.int32, device=dev)
+    p.pair_win = mssvt_ops.full_neg1((row_cap,), dev)
     # pair_vox is only read by the ragged kernels (sync=True); the plan kernel writes every live entry
     p.pair_vox = (torch.full if sync else torch.empty)(*(((row_cap,), -1) if sync else ((row_cap,),)),
                                                        dtype=torch.int32, device=dev)

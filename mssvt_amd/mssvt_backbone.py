@@ -337,15 +337,25 @@ class MixedScaleSparseTransformer(nn.Module):
 
     def forward(self, batch_dict):
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
-        sp = SparseTensor(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
-                          voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
-                          batch_size=batch_dict['batch_size'], hash_size=self.hash_size,
-                          map_table=None, gather_dict=None)
-        for i, blk in enumerate(self.backbone):
-            # lets a fused FFN epilogue also emit the next block's norm1 (mssvt_amd/fused.py)
-            sp._next_norm1 = self.backbone[i + 1].norm1 if i + 1 < len(self.backbone) else None
-            # the Blocks from here on (fused.prepare_group orders / tabulates all that share a plan at once)
-            sp._plan_group = [b for b in self.backbone[i:] if isinstance(b, MixedScaleSparseTransformerBlock)]
-            sp = blk(sp, block_idx=i)
+        # one -1 fill for all hash tables / owner arrays of the forward (sized from the previous forward)
+        arena = None
+        if feats.is_cuda and any(getattr(b, 'impl', None) == 'fused' for b in self.backbone):
+            arena = mssvt_ops.FillArena(getattr(self, '_fill_demand', 0), feats.device)
+        mssvt_ops.FillArena.current = arena
+        try:
+            sp = SparseTensor(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
+                              voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
+                              batch_size=batch_dict['batch_size'], hash_size=self.hash_size,
+                              map_table=None, gather_dict=None)
+            for i, blk in enumerate(self.backbone):
+                # lets a fused FFN epilogue also emit the next block's norm1 (mssvt_amd/fused.py)
+                sp._next_norm1 = self.backbone[i + 1].norm1 if i + 1 < len(self.backbone) else None
+                # the Blocks from here on (fused.prepare_group orders / tabulates all that share a plan at once)
+                sp._plan_group = [b for b in self.backbone[i:] if isinstance(b, MixedScaleSparseTransformerBlock)]
+                sp = blk(sp, block_idx=i)
+        finally:
+            mssvt_ops.FillArena.current = None
+            if arena is not None:
+                self._fill_demand = arena.demand
         batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
         return batch_dict

@@ -33,6 +33,41 @@ def _ints(xs):
     return [int(v) for v in xs]
 
 
+
+class FillArena(object):
+    """One -1-filled int32 buffer per forward, carved into the tables / owner arrays / list prefills the
+    path needs (each would otherwise be its own fill launch, ~4 us of GPU time and a framework call).
+    Sized from the previous forward's demand; a request that does not fit falls back to its own fill."""
+    current = None  # set by MixedScaleSparseTransformer.forward around the fused path
+
+    def __init__(self, numel, device):
+        self.buf = torch.full((max(int(numel), 1),), -1, dtype=torch.int32, device=device)
+        self.used = 0
+        self.demand = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) // 64 * 64  # keep every piece 256-byte aligned
+        self.demand += n_al
+        if self.used + n_al > self.buf.numel():
+            return None
+        out = self.buf[self.used:self.used + n].view(*shape)
+        self.used += n_al
+        return out
+
+
+def full_neg1(shape, device):
+    """int32 tensor of -1s: a slice of the current forward's FillArena when there is one."""
+    a = FillArena.current
+    if a is not None and a.buf.device == torch.device(device):
+        t = a.take(shape)
+        if t is not None:
+            return t
+    return torch.full(tuple(shape), -1, dtype=torch.int32, device=device)
+
+
 def hash_workspace(num_voxels, batch_size, device):
     n = int(_lib.lib().mssvt_hash_workspace_ints(_i(int(num_voxels)), _i(int(batch_size))))
     return torch.empty(n, dtype=torch.int32, device=device)
@@ -52,7 +87,7 @@ def build_hash_table(batch_size, hash_size, spatial_shape, voxel_indices, v_bs_c
     _check_int32(voxel_indices, "voxel_indices")
     v_bs_cnt = v_bs_cnt.to(device=voxel_indices.device, dtype=torch.int32).contiguous()
     n = voxel_indices.shape[0]
-    table = torch.full((batch_size, hash_size, 2), -1, dtype=torch.int32, device=voxel_indices.device)
+    table = full_neg1((batch_size, hash_size, 2), voxel_indices.device)
     ws = workspace if workspace is not None else hash_workspace(n, batch_size, voxel_indices.device)
     _lib.call("mssvt_build_mapping_with_hash", _i(x_max), _i(y_max), _i(z_max), _i(n),
               _i(int(hash_size)), _i(int(batch_size)), _lib.ptr(voxel_indices), _lib.ptr(v_bs_cnt),
@@ -70,7 +105,7 @@ def window_partition_device(win_size, max_num_wins, batch_size, hash_size, spati
     _check_int32(voxel_indices, "voxel_indices")
     dev = voxel_indices.device
     n = voxel_indices.shape[0]
-    table = torch.full((batch_size, hash_size, 2), -1, dtype=torch.int32, device=dev)
+    table = full_neg1((batch_size, hash_size, 2), dev)
     win = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
     vcount = torch.zeros(batch_size, dtype=torch.int32, device=dev)
     ws = workspace if workspace is not None else hash_workspace(n, batch_size, dev)
