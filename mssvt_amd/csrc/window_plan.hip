@@ -142,20 +142,40 @@ __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
     return v;
 }
 
+// Offsets are integers in [-64, 63]: every squared distance is an integer < 2^16, exact in fp32, so the
+// sampler can run on integers with the same outcome.  One 32-bit key = (distance << 11) | ((1023 -
+// bit-reversed thread id) << 1) | 1 orders candidates exactly like the reference's tree (larger
+// distance first, then the smaller bit-reversed id; 0 = no candidate): ONE wave max per round replaces a
+// float max plus a tie-break min.
+#define FPS_BIG 0xFFFFFu  // "1e10": replaced by a real distance in the first round
+__device__ __forceinline__ unsigned int fps_key(unsigned int dist, unsigned int rev) {
+    return (dist << 11) | ((1023u - rev) << 1) | 1u;
+}
+__device__ __forceinline__ unsigned int wave_max_u32_uniform(unsigned int v) {
+    unsigned int o;
+    o = DPP_MOV_U(v, 0xB1); v = o > v ? o : v;
+    o = DPP_MOV_U(v, 0x4E); v = o > v ? o : v;
+    o = DPP_MOV_U(v, 0x141); v = o > v ? o : v;
+    o = DPP_MOV_U(v, 0x140); v = o > v ? o : v;
+    const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 16),
+                       r2 = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned int a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
+}
+
 __device__ __forceinline__ void fps_on_list_fast(const int *packed, int n, int nv, int m, int bs,
                                                  int *fps_out, int lane) {
     int L = 0;
     while ((1 << L) < bs) ++L;
     const bool mine = lane < nv;
     const int pk = packed[mine ? lane : 0];
-    const float xk = (float)((pk & 255) - 64), yk = (float)(((pk >> 8) & 255) - 64),
-                zk = (float)(((pk >> 16) & 255) - 64);
-    float tk = 1e10f, tpad = 1e10f;
-    const unsigned int myrev = mine ? (__brev((unsigned int)lane) >> (32 - L)) : 0xFFFFFFFFu;
+    const int xk = (pk & 255) - 64, yk = ((pk >> 8) & 255) - 64, zk = ((pk >> 16) & 255) - 64;
+    unsigned int tk = FPS_BIG, tpad = FPS_BIG;
+    const unsigned int myrev = mine ? (__brev((unsigned int)lane) >> (32 - L)) : 0u;
     const bool has_second = mine && lane + bs < n;  // this thread's second slot (padding)
     // pure-padding threads vt in [nv, bs): the tree favours the smallest bit-reversed id
     const bool padgroup = nv < bs;
-    unsigned int vp_rev = 0xFFFFFFFFu;
+    unsigned int vp_rev = 0u;
     int vp = 0;
     if (padgroup) {
         unsigned int best = 0xFFFFFFFFu;
@@ -163,43 +183,45 @@ __device__ __forceinline__ void fps_on_list_fast(const int *packed, int n, int n
             const unsigned int r = __brev((unsigned int)vt) >> (32 - L);
             best = r < best ? r : best;
         }
-        vp_rev = wave_min_u32(best);
+        vp_rev = wave_min_u32_uniform(best);
         vp = (int)(__brev(vp_rev) >> (32 - L));  // bit reversal is an involution on L bits
     }
     int old = 0;
     if (lane == 0) fps_out[0] = 0;
     for (int j = 1; j < m; ++j) {
-        float x1 = 0.f, y1 = 0.f, z1 = 0.f;  // a padding slot sits at offset (0,0,0)
+        int x1 = 0, y1 = 0, z1 = 0;  // a padding slot sits at offset (0,0,0)
         if (old < nv) {  // `old` is wave-uniform: v_readlane, no LDS round trip
             const int ol = __builtin_amdgcn_readfirstlane(old);
-            x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xk), ol));
-            y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yk), ol));
-            z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zk), ol));
+            x1 = __builtin_amdgcn_readlane(xk, ol);
+            y1 = __builtin_amdgcn_readlane(yk, ol);
+            z1 = __builtin_amdgcn_readlane(zk, ol);
         }
         {
-            const float dx = xk - x1, dy = yk - y1, dz = zk - z1;
-            tk = fminf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), tk);
-            const float px = 0.f - x1, py = 0.f - y1, pz = 0.f - z1;
-            tpad = fminf(__builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px)), tpad);
+            const int dx = xk - x1, dy = yk - y1, dz = zk - z1;
+            const unsigned int d = (unsigned int)(__mul24(dz, dz) + __mul24(dy, dy) + __mul24(dx, dx));
+            tk = d < tk ? d : tk;
+            const unsigned int pd = (unsigned int)(x1 * x1 + y1 * y1 + z1 * z1);  // wave-uniform: scalar ALU
+            tpad = pd < tpad ? pd : tpad;
         }
-        float best = mine ? tk : -INFINITY;
+        unsigned int best = tk;
         int besti = lane;
         if (has_second && tpad > best) {
             best = tpad;
             besti = lane + bs;
         }
-        const float M = wave_max_uniform(best);
-        const unsigned int kmin = wave_min_u32_uniform((mine && best == M) ? myrev : 0xFFFFFFFFu);
+        const unsigned int key = mine ? fps_key(best, myrev) : 0u;
+        const unsigned int mkey = wave_max_u32_uniform(key);
+        const unsigned int M = mkey >> 11;  // 0 when there is no valid entry at all (nv == 0)
         int pick;
-        if (padgroup && (nv == 0 || tpad > M || (tpad == M && vp_rev < kmin))) {
+        if (padgroup && (nv == 0 || fps_key(tpad, vp_rev) > mkey)) {
             pick = vp;
         } else {
-            const unsigned long long wm = __ballot(mine && best == M && myrev == kmin);
+            const unsigned long long wm = __ballot(key == mkey);  // bit-reversed ids are unique: one lane
             pick = __builtin_amdgcn_readlane(besti, __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1));
         }
         old = pick;
         if (lane == 0) fps_out[j] = old;
-        if (M <= 0.f && (!padgroup || tpad <= 0.f) && !(nv < n && tpad > 0.f)) {
+        if (M == 0u && (!padgroup || tpad == 0u) && !(nv < n && tpad > 0u)) {
             // every remaining min-distance is 0: all further rounds tie completely and return slot 0
             for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
             if (old == 0) break;
@@ -219,8 +241,8 @@ template <int TPL>
 __device__ __forceinline__ void fps_on_list_regs(const int *packed, int n, int m, int bs, int *fps_out, int lane) {
     int L = 0;
     while ((1 << L) < bs) ++L;
-    float xa[TPL], ya[TPL], za[TPL], da[TPL], xb[TPL], yb[TPL], zb[TPL], db[TPL];
-    unsigned int rev[TPL];
+    int xa[TPL], ya[TPL], za[TPL], xb[TPL], yb[TPL], zb[TPL];
+    unsigned int da[TPL], db[TPL], rev[TPL];
     bool ea[TPL], eb[TPL];
 #pragma unroll
     for (int k = 0; k < TPL; ++k) {
@@ -228,48 +250,47 @@ __device__ __forceinline__ void fps_on_list_regs(const int *packed, int n, int m
         ea[k] = vt < bs && vt < n;
         eb[k] = vt < bs && vt + bs < n;
         const int pa = packed[ea[k] ? vt : 0], pb = packed[eb[k] ? vt + bs : 0];
-        xa[k] = (float)((pa & 255) - 64); ya[k] = (float)(((pa >> 8) & 255) - 64); za[k] = (float)(((pa >> 16) & 255) - 64);
-        xb[k] = (float)((pb & 255) - 64); yb[k] = (float)(((pb >> 8) & 255) - 64); zb[k] = (float)(((pb >> 16) & 255) - 64);
-        da[k] = db[k] = 1e10f;
+        xa[k] = (pa & 255) - 64; ya[k] = ((pa >> 8) & 255) - 64; za[k] = ((pa >> 16) & 255) - 64;
+        xb[k] = (pb & 255) - 64; yb[k] = ((pb >> 8) & 255) - 64; zb[k] = ((pb >> 16) & 255) - 64;
+        da[k] = db[k] = FPS_BIG;
         rev[k] = L ? __brev((unsigned int)vt) >> (32 - L) : 0u;
     }
     int old = 0;
     if (lane == 0) fps_out[0] = 0;
     for (int j = 1; j < m; ++j) {
         const int po = packed[old];
-        const float x1 = (float)((po & 255) - 64), y1 = (float)(((po >> 8) & 255) - 64),
-                    z1 = (float)(((po >> 16) & 255) - 64);
-        float bestv = -1.0f;
+        const int x1 = (po & 255) - 64, y1 = ((po >> 8) & 255) - 64, z1 = ((po >> 16) & 255) - 64;
+        unsigned int bestkey = 0u;  // integer keys: see fps_key
         int besti = 0;
-        unsigned int bestrev = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
             if (!ea[k]) continue;
             const int vt = lane + MSSVT_WAVE * k;
-            float dx = xa[k] - x1, dy = ya[k] - y1, dz = za[k] - z1;
-            da[k] = fminf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), da[k]);
-            float tb = da[k];
+            int dx = xa[k] - x1, dy = ya[k] - y1, dz = za[k] - z1;
+            unsigned int d = (unsigned int)(__mul24(dz, dz) + __mul24(dy, dy) + __mul24(dx, dx));
+            da[k] = d < da[k] ? d : da[k];
+            unsigned int tb = da[k];
             int ti = vt;
             if (eb[k]) {
                 dx = xb[k] - x1; dy = yb[k] - y1; dz = zb[k] - z1;
-                db[k] = fminf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), db[k]);
+                d = (unsigned int)(__mul24(dz, dz) + __mul24(dy, dy) + __mul24(dx, dx));
+                db[k] = d < db[k] ? d : db[k];
                 if (db[k] > tb) {  // the later slot only on a STRICTLY larger distance
                     tb = db[k];
                     ti = vt + bs;
                 }
             }
-            if (tb > bestv || (tb == bestv && rev[k] < bestrev)) {
-                bestv = tb;
+            const unsigned int key = fps_key(tb, rev[k]);
+            if (key > bestkey) {
+                bestkey = key;
                 besti = ti;
-                bestrev = rev[k];
             }
         }
-        const float M = wave_max_uniform(bestv);
-        const unsigned int kmin = wave_min_u32_uniform(bestv == M ? bestrev : 0xFFFFFFFFu);
-        const unsigned long long wm = __ballot(bestv == M && bestrev == kmin);
+        const unsigned int mkey = wave_max_u32_uniform(bestkey);
+        const unsigned long long wm = __ballot(bestkey == mkey);  // unique: thread ids differ
         old = __builtin_amdgcn_readlane(besti, __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1));
         if (lane == 0) fps_out[j] = old;
-        if (M <= 0.f) {
+        if ((mkey >> 11) == 0u) {
             // every min-distance is 0 from here on: all further rounds tie completely -> thread 0, slot 0
             for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
             if (old == 0) break;
