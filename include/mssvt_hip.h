@@ -379,6 +379,16 @@ int mssvt_voxelize(const float *points, int point_stride, long long num_points, 
                    int voxel_capacity, int *voxel_coords, int *point_voxel, int *num_voxels_dev,
                    int *workspace, void *stream);
 
+/* ======================================================================== *
+ * Part 4 -- dense output: SparseTensor.dense() + the view of
+ *           HeightCompression (ref mssvt_utils.py:6-19,50-62; height_compression.py:41-45) in one pass.
+ * out (B, C, Z, Y, X) f32 (= (B, C*Z, Y, X) for the BEV backbone), every element written (zeros for empty
+ * cells): out[b, c, z, y, x] = features[row(b,x,y,z), c] where the row comes from the set's hash table
+ * map_table (B,H,2) (key x*Y*Z + y*Z + z -> row within the sample; v_bs_cnt (B) rows per sample).
+ * ======================================================================== */
+int mssvt_dense_bev(const float *features, int C, const int *map_table, int hash_size, const int *v_bs_cnt,
+                    int batch_size, int x_max, int y_max, int z_max, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

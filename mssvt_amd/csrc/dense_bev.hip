@@ -1,0 +1,82 @@
+// dense_bev.hip -- sparse voxel set -> dense channel-first grid, the step right after the path.
+//
+// Replaces SparseTensor.dense() + the view of HeightCompression (ref: scatter_nd / dense,
+// pcdet/models/model_utils/mssvt_utils.py:6-19,50-62; height_compression.py:41-45):
+//     dense = zeros(B, Z, Y, X, C); dense[b, z, y, x] = features; out = dense.permute(0, 4, 1, 2, 3).contiguous()
+//     spatial_features = out.view(B, C * Z, Y, X)
+// i.e. a zero fill of the whole grid, a scatter and a 5-D permute copy (three passes over B*C*Z*Y*X floats).
+// Here the output is produced in ONE pass as a GATHER: one wavefront owns 64 consecutive x cells of a
+// (b, z, y) line, finds each cell's voxel through the set's hash table (key -> row; the table of a
+// CompressBlock output is its window table), moves the occupied cells' rows through a small LDS tile and
+// writes every channel as one coalesced 256-byte line -- zeros included, so there is no separate fill and
+// no write is ever narrower than a full line.  Pure copy: bit-exact.
+#include "common.hip.h"
+
+#define DB_WPB 4
+#define DB_CH 32  // channels per LDS tile
+
+__global__ void __launch_bounds__(DB_WPB *MSSVT_WAVE)
+    k_dense_bev(const float *features, const slot_t *table, const int *v_bs_cnt, int B, int X, int Y, int Z, int C,
+                int hash_size, float *out) {
+    __shared__ float tile[DB_WPB][DB_CH][MSSVT_WAVE + 1];
+    const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    const int xblocks = (X + MSSVT_WAVE - 1) / MSSVT_WAVE;
+    const long long lines = (long long)B * Z * Y * xblocks;
+    for (long long item = (long long)blockIdx.x * DB_WPB + wv; item < lines; item += (long long)gridDim.x * DB_WPB) {
+        const int xb = (int)(item % xblocks);
+        const int y = (int)((item / xblocks) % Y);
+        const int z = (int)((item / ((long long)xblocks * Y)) % Z);
+        const int b = (int)(item / ((long long)xblocks * Y * Z));
+        const int x = xb * MSSVT_WAVE + lane;
+        int vstart = 0;
+        for (int k = 0; k < b; ++k) vstart += v_bs_cnt[k];
+        int row = -1;
+        if (x < X) {
+            const int sv = table_find(x * Y * Z + y * Z + z, hash_size, table + (size_t)b * hash_size);  // x-major key
+            if (sv != MSSVT_EMPTY) row = vstart + sv;
+        }
+        const unsigned long long occ = __ballot(row >= 0);
+        float *dst = out + ((size_t)b * C * Z + z) * Y * X + (size_t)y * X + x;  // + c * Z*Y*X
+        const size_t cstride = (size_t)Z * Y * X;
+        for (int c0 = 0; c0 < C; c0 += DB_CH) {
+            // occupied cells' rows -> tile[channel][cell]: two cells per step (32 channels each, 128-byte reads)
+            unsigned long long m = occ;
+            while (m) {
+                const int l0 = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                int l1 = l0;
+                if (m) {
+                    l1 = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                }
+                const int src_lane = lane < DB_CH ? l0 : l1;
+                const int r = __shfl(row, src_lane);
+                const int c = c0 + (lane & (DB_CH - 1));
+                if (c < C && (lane < DB_CH || l1 != l0)) tile[wv][lane & (DB_CH - 1)][src_lane] = features[(size_t)r * C + c];
+            }
+            wave_lds_sync();
+            if (x < X) {
+#pragma unroll 8
+                for (int cc = 0; cc < DB_CH; ++cc) {
+                    if (c0 + cc >= C) break;
+                    dst[(size_t)(c0 + cc) * cstride] = row >= 0 ? tile[wv][cc][lane] : 0.0f;
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+extern "C" int mssvt_dense_bev(const float *features, int C, const int *map_table, int hash_size,
+                               const int *v_bs_cnt, int batch_size, int x_max, int y_max, int z_max, float *out,
+                               void *stream) {
+    if (!features || !map_table || !v_bs_cnt || !out || C <= 0 || hash_size <= 0 || batch_size <= 0 || x_max <= 0 ||
+        y_max <= 0 || z_max <= 0)
+        return MSSVT_E_BADARG;
+    const long long lines = (long long)batch_size * z_max * y_max * ((x_max + MSSVT_WAVE - 1) / MSSVT_WAVE);
+    long long grid = (lines + DB_WPB - 1) / DB_WPB;
+    if (grid > 65536) grid = 65536;
+    k_dense_bev<<<(int)grid, DB_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(
+        features, reinterpret_cast<const slot_t *>(map_table), v_bs_cnt, batch_size, x_max, y_max, z_max, C, hash_size, out);
+    return mssvt_launch_status();
+}

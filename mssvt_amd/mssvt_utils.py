@@ -70,6 +70,19 @@ class SparseTensor(object):
         """(B, C, Z, Y, X) (or (B, Z, Y, X, C)) dense grid.  ref: mssvt_utils.py:50-62."""
         zyx = list(self.spatial_shape[::-1])
         shape = [self.batch_size] + zyx + [self.features.shape[1]]
+        f = self.features
+        if (channels_first and f.is_cuda and f.dtype == torch.float32 and not (torch.is_grad_enabled() and f.requires_grad)
+                and self.map_table is not None and self.indices.dtype == torch.int32):
+            # one gather pass through the hash table instead of zero fill + scatter + permute copy
+            from . import _lib
+            ci = ctypes.c_int
+            X, Y, Z = (int(v) for v in self.spatial_shape)
+            out = torch.empty([self.batch_size, f.shape[1]] + zyx, dtype=torch.float32, device=f.device)
+            cnt = batch_counts(self.indices.contiguous(), self.batch_size)
+            _lib.call("mssvt_dense_bev", _lib.ptr(f.contiguous()), ci(f.shape[1]), _lib.ptr(self.map_table),
+                      ci(int(self.hash_size)), _lib.ptr(cnt), ci(int(self.batch_size)), ci(X), ci(Y), ci(Z),
+                      _lib.ptr(out), _lib.stream())
+            return out
         res = scatter_nd(self.indices.to(self.features.device).long(), self.features, shape)
         if not channels_first:
             return res

@@ -145,3 +145,20 @@ def test_layer_norm_kernel_matches_torch(C, n):
         ref = torch.nn.functional.layer_norm(x.double(), (C,), norm.weight.double(), norm.bias.double(), norm.eps)
     # fp32 LayerNorm against an fp64 reference: 1e-5 absolute on O(1) values
     assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("pts,B,C", [(20000, 2, 32), (160000, 1, 128), (300, 3, 5)])
+def test_dense_bev_matches_scatter(pts, B, C):
+    """SparseTensor.dense() through the one-pass gather kernel == zero fill + scatter + permute (pure copy)."""
+    from mssvt_amd.mssvt_utils import SparseTensor, scatter_nd
+    p_np = synthetic.make_batch_points(pts, B, 5)
+    vc, _, _ = synthetic.voxelize_numpy(p_np)
+    g = torch.Generator().manual_seed(pts)
+    feats = torch.randn(vc.shape[0], C, generator=g).to(DEV)
+    sp = SparseTensor(features=feats, indices=torch.from_numpy(vc).to(DEV), spatial_shape=synthetic.GRID_SIZE,
+                      voxel_size=synthetic.VOXEL_SIZE, point_cloud_range=synthetic.POINT_CLOUD_RANGE, batch_size=B,
+                      hash_size=200003)
+    got = sp.dense()
+    zyx = list(synthetic.GRID_SIZE[::-1])
+    want = scatter_nd(sp.indices.long(), feats, [B] + zyx + [C]).permute(0, 4, 1, 2, 3).contiguous()
+    assert got.shape == want.shape and torch.equal(got, want)
