@@ -63,7 +63,10 @@ def level_state(sp):
     """Per voxel-set (resolution level) device state shared by all plans on it."""
     st = getattr(sp, "_level", None)
     if st is None or st["indices"] is not sp.indices:
-        st = {"indices": sp.indices, "v_bs_cnt": batch_counts(sp.indices, sp.batch_size), "plans": {}}
+        cnt = getattr(sp, "v_bs_cnt", None)
+        if cnt is None or getattr(sp, "_cnt_of", None) is not sp.indices:
+            cnt = batch_counts(sp.indices, sp.batch_size)
+        st = {"indices": sp.indices, "v_bs_cnt": cnt, "plans": {}}
         sp._level = st
     return st
 
@@ -606,6 +609,7 @@ def _compress_finish(sp, p, features):
     if pre is not None:
         sp._xhat = (pre[0], pre[1], features)
     sp.indices = p.win_ind[:p.nw].contiguous()
+    sp.v_bs_cnt, sp._cnt_of = p.k_bs_cnt, sp.indices  # windows per sample = rows per sample of the output
     sp.spatial_shape = p.new_spatial_shape
     sp.voxel_size = p.win_size_m
     sp.map_table = p.win_table

@@ -107,7 +107,7 @@ def window_partition_device(win_size, max_num_wins, batch_size, hash_size, spati
     n = voxel_indices.shape[0]
     table = full_neg1((batch_size, hash_size, 2), dev)
     win = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
-    vcount = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+    vcount = torch.empty(batch_size, dtype=torch.int32, device=dev)  # every entry is written by the scan kernel
     ws = workspace if workspace is not None else hash_workspace(n, batch_size, dev)
     _lib.call("mssvt_window_partition_compact", _i(x_wgs), _i(y_wgs), _i(z_wgs), _i(x_ws), _i(y_ws),
               _i(z_ws), _i(n), _i(int(max_num_wins)), _i(int(hash_size)), _i(int(batch_size)),

@@ -58,11 +58,13 @@ class SparseTensor(object):
         self.point_cloud_range = point_cloud_range
         self.hash_size = hash_size
         self.gather_dict = gather_dict
+        self.v_bs_cnt = None
         self.map_table = self.build_map_table() if map_table is None else map_table
+        self._cnt_of = self.indices if self.v_bs_cnt is not None else None
 
     @torch.no_grad()
     def build_map_table(self):
-        cnt = batch_counts(self.indices, self.batch_size)
+        cnt = self.v_bs_cnt = batch_counts(self.indices, self.batch_size)  # kept: the plans need it too
         return mssvt_ops.build_hash_table(self.batch_size, self.hash_size, self.spatial_shape,
                                           self.indices, cnt)
 
@@ -78,7 +80,9 @@ class SparseTensor(object):
             ci = ctypes.c_int
             X, Y, Z = (int(v) for v in self.spatial_shape)
             out = torch.empty([self.batch_size, f.shape[1]] + zyx, dtype=torch.float32, device=f.device)
-            cnt = batch_counts(self.indices.contiguous(), self.batch_size)
+            cnt = getattr(self, "v_bs_cnt", None)
+            if cnt is None or getattr(self, "_cnt_of", None) is not self.indices:
+                cnt = batch_counts(self.indices.contiguous(), self.batch_size)
             _lib.call("mssvt_dense_bev", _lib.ptr(f.contiguous()), ci(f.shape[1]), _lib.ptr(self.map_table),
                       ci(int(self.hash_size)), _lib.ptr(cnt), ci(int(self.batch_size)), ci(X), ci(Y), ci(Z),
                       _lib.ptr(out), _lib.stream())
