@@ -483,8 +483,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
                     sc[t][i] += sc2[t][i];
                     mx = fmaxf(mx, (vmask >> (4 * t + i) & 1) ? sc[t][i] : -INFINITY);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = fmaxf(mx, lane_xor16(mx));
+            mx = fmaxf(mx, lane_xor32(mx));
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < KT; ++t)
@@ -494,8 +494,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
                     sc[t][i] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum += lane_xor16(sum);
+            sum += lane_xor32(sum);
             const float inv = __builtin_amdgcn_rcpf(sum);  // slot 0 of a list is never masked: sum >= 1
             // Xbar^T[c][col] = sum_key T[key][c] P[key][col]; A operand = the LDS tile read column-wise
             f32x4 acc[NT];

@@ -50,10 +50,23 @@ __device__ __forceinline__ float row_sum16(float v) {
     v += DPP_MOV(v, 0x140);
     return v;
 }
-__device__ __forceinline__ float half_max(float v) { v = row_max16(v); return fmaxf(v, __shfl_xor(v, 16)); }
-__device__ __forceinline__ float half_sum(float v) { v = row_sum16(v); return v + __shfl_xor(v, 16); }
-__device__ __forceinline__ float wave_max(float v) { v = half_max(v); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float wave_sum(float v) { v = half_sum(v); return v + __shfl_xor(v, 32); }
+// value of lane (l ^ 16) / (l ^ 32) through the gfx950 row / half swaps (VALU, no LDS round trip as
+// ds_bpermute would be): v_permlane16_swap exchanges the odd rows of its first operand with the even
+// rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second
+__device__ __forceinline__ float lane_xor16(float v) {
+    const unsigned int u = __builtin_bit_cast(unsigned int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (lane_id() & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const unsigned int u = __builtin_bit_cast(unsigned int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (lane_id() & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float half_max(float v) { v = row_max16(v); return fmaxf(v, lane_xor16(v)); }
+__device__ __forceinline__ float half_sum(float v) { v = row_sum16(v); return v + lane_xor16(v); }
+__device__ __forceinline__ float wave_max(float v) { v = half_max(v); return fmaxf(v, lane_xor32(v)); }
+__device__ __forceinline__ float wave_sum(float v) { v = half_sum(v); return v + lane_xor32(v); }
 // wave-uniform reductions without LDS traffic: DPP inside the 16-lane rows, v_readlane across them
 __device__ __forceinline__ float wave_max_uniform(float v) {
     v = row_max16(v);

@@ -275,10 +275,10 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
             part[u] = (acc[u][0] * q[u].x + acc[u][1] * q[u].y) + (acc[u][2] * q[u].z + acc[u][3] * q[u].w);
             // this lane's 4 channels 16 u + 4 g .. belong to head (16 u + 4 g) / HD
             if (HD >= 16) {
-                part[u] += __shfl_xor(part[u], 16);
-                part[u] += __shfl_xor(part[u], 32);
+                part[u] += lane_xor16(part[u]);
+                part[u] += lane_xor32(part[u]);
             } else {  // HD == 8: lanes g = 0,1 -> head 2u, g = 2,3 -> head 2u + 1
-                part[u] += __shfl_xor(part[u], 16);
+                part[u] += lane_xor16(part[u]);
             }
         }
         if (live && pw >= 0) {

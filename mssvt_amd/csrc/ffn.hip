@@ -182,8 +182,8 @@ __global__ void __launch_bounds__(FFN_NW *MSSVT_WAVE, 2) k_ffn(FfnArgs a) {
             float sum = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) sum += xn[s];
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum += lane_xor16(sum);
+            sum += lane_xor32(sum);
             const float mean = sum * (1.0f / C);
             float var = 0.f;
 #pragma unroll
@@ -191,8 +191,8 @@ __global__ void __launch_bounds__(FFN_NW *MSSVT_WAVE, 2) k_ffn(FfnArgs a) {
                 const float d = xn[s] - mean;
                 var = __builtin_fmaf(d, d, var);
             }
-            var += __shfl_xor(var, 16);
-            var += __shfl_xor(var, 32);
+            var += lane_xor16(var);
+            var += lane_xor32(var);
             const float rstd = rsqrtf(var * (1.0f / C) + a.eps);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -521,8 +521,8 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_up(FfnArgs a, float 
         float sum = 0.f;
 #pragma unroll
         for (int S = 0; S < NT; ++S) sum += (x[S][0] + x[S][1]) + (x[S][2] + x[S][3]);
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum += lane_xor16(sum);
+        sum += lane_xor32(sum);
         const float mean = sum * (1.0f / C);
         float var = 0.f;
 #pragma unroll
@@ -532,8 +532,8 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_up(FfnArgs a, float 
                 const float d = x[S][j] - mean;
                 var = __builtin_fmaf(d, d, var);
             }
-        var += __shfl_xor(var, 16);
-        var += __shfl_xor(var, 32);
+        var += lane_xor16(var);
+        var += lane_xor32(var);
         const float rstd = rsqrtf(var * (1.0f / C) + a.eps);
 #pragma unroll
         for (int S = 0; S < NT; ++S) {
@@ -695,8 +695,8 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
             for (int t = 0; t < NT; ++t) *reinterpret_cast<float4 *>(py + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
         }
         if (a.y_norm) {  // LayerNorm of y for the next block
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum += lane_xor16(sum);
+            sum += lane_xor32(sum);
             const float mean = sum * (1.0f / C);
             float var = 0.f;
 #pragma unroll
@@ -706,8 +706,8 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
                     const float d = acc[t][j] - mean;
                     var = __builtin_fmaf(d, d, var);
                 }
-            var += __shfl_xor(var, 16);
-            var += __shfl_xor(var, 32);
+            var += lane_xor16(var);
+            var += lane_xor32(var);
             const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
             if (live) {
                 float *pn = a.y_norm + (size_t)row * C + 4 * g;
