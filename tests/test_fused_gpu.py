@@ -162,3 +162,23 @@ def test_dense_bev_matches_scatter(pts, B, C):
     zyx = list(synthetic.GRID_SIZE[::-1])
     want = scatter_nd(sp.indices.long(), feats, [B] + zyx + [C]).permute(0, 4, 1, 2, 3).contiguous()
     assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("pts,B", [(20000, 2), (160000, 1), (0, 1)])
+def test_occupancy_columns_bit_exact(pts, B):
+    """One 64-bit word per (b, x, y) column, bit z = occupied (input of the K3 hit test)."""
+    import ctypes
+    from mssvt_amd import _lib
+    X, Y, Z = synthetic.GRID_SIZE
+    if pts:
+        vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(pts, B, 21))
+    else:
+        vc = np.zeros((0, 4), np.int32)
+    want = np.zeros((B, X, Y), np.uint64)
+    np.bitwise_or.at(want, (vc[:, 0], vc[:, 3], vc[:, 2]), np.uint64(1) << vc[:, 1].astype(np.uint64))
+    ind = torch.from_numpy(vc).to(DEV)
+    cols = torch.empty(B * X * Y, dtype=torch.int64, device=DEV)
+    i = ctypes.c_int
+    _lib.call("mssvt_occupancy_columns", _lib.ptr(ind) if pts else ctypes.c_void_p(0), i(vc.shape[0]), i(B), i(X), i(Y),
+              i(Z), _lib.ptr(cols), _lib.stream())
+    np.testing.assert_array_equal(cols.cpu().numpy().view(np.uint64).reshape(B, X, Y), want)
