@@ -11,8 +11,10 @@ Multi-GPU: scenes are sharded by rank (no data-path collective; weak scaling), t
 max over ranks between barriers.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  "roofline":     the dominant kernel's algorithmic HBM bytes per launch / its measured
-                  average duration (HIP events on the launching stream) vs the 8 TB/s peak;
+  "roofline":     the dominant kernel (k_ffn_up, fp32 MFMA bound): algorithmic FLOP per launch / its
+                  measured average duration (HIP events on the launching stream) vs the 157.3 TFLOP/s
+                  dense fp32 matrix-core peak, HBM traffic from the committed PMC passes; the next two
+                  kernels beside it (mssvt_amd/fused.py: roofline);
   "cpu_baseline": the CPU oracle (a port of the reference's CUDA semantics; the reference
                   has no CPU path) timed on this box's host on a bounded sample.
 """
