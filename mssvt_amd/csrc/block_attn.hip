@@ -45,6 +45,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define ATTN_ROW_WAVES 4  // waves per workgroup of the row-tiled launches
+#define AST_UN 16        // weight elements per matrix and thread in flight while staging (64 x 64 / 256 threads)
 
 struct AttnArgs {
     int C, c0, heads, hd;
@@ -88,19 +89,19 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnPa
     float *WkT_l = Wq_l + CGP * LS;                 // [c][o] = Wk[o][c]
     float *Wp_l = WkT_l + CGP * LS;                 // [c][8] = pos_proj row (6 weights, bias, 0)
     float *bq_l = Wp_l + CGP * 8;                   // [o]
-    // 8 elements of each matrix in flight per thread (a plain copy loop waits for every load before
+    // AST_UN elements of each matrix in flight per thread (a plain copy loop waits for every load before
     // its store: one global round trip per element)
-    for (int e0 = threadIdx.x; e0 < CGP * CGP; e0 += blockDim.x * 8) {
-        float vq[8], vk[8];
+    for (int e0 = threadIdx.x; e0 < CGP * CGP; e0 += blockDim.x * AST_UN) {
+        float vq[AST_UN], vk[AST_UN];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < AST_UN; ++u) {
             const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
             const bool in = e < CGP * CGP && o < CG && c < CG;
             vq[u] = in ? a.Wq[o * CG + c] : 0.f;
             vk[u] = in ? a.Wkv[o * CG + c] : 0.f;  // rows [0,CG) of to_kvs = K projection
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < AST_UN; ++u) {
             const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
             if (e < CGP * CGP) {
                 Wq_l[o * LS + c] = vq[u];
@@ -212,17 +213,17 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnPa
     float *Wv_l = reinterpret_cast<float *>(lds4);  // [o][c]
     float *Wo_l = Wv_l + CGP * LS;                  // [p][o]
     float *bv_l = Wo_l + CGP * LS, *bo_l = bv_l + CGP;
-    for (int e0 = threadIdx.x; e0 < CGP * CGP; e0 += blockDim.x * 8) {
-        float vv[8], vo[8];
+    for (int e0 = threadIdx.x; e0 < CGP * CGP; e0 += blockDim.x * AST_UN) {
+        float vv[AST_UN], vo[AST_UN];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < AST_UN; ++u) {
             const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
             const bool in = e < CGP * CGP && o < CG && c < CG;
             vv[u] = in ? a.Wkv[(size_t)(CG + o) * CG + c] : 0.f;  // rows [CG,2CG) of to_kvs = V projection
             vo[u] = in ? a.Wo[o * CG + c] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < AST_UN; ++u) {
             const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
             if (e < CGP * CGP) {
                 Wv_l[o * LS + c] = vv[u];
