@@ -252,13 +252,13 @@ extern "C" int mssvt_build_mapping_with_hash(int x_max, int y_max, int z_max, in
                                              int hash_size, int batch_size, const int *v_indices,
                                              const int *v_bs_cnt, int *xyz_to_vidx, int *workspace,
                                              void *stream_) {
-    if (!v_indices || !v_bs_cnt || !xyz_to_vidx || !workspace || hash_size <= 0 ||
+    if ((!v_indices && num_voxels > 0) || !v_bs_cnt || !xyz_to_vidx || !workspace || hash_size <= 0 ||
         batch_size <= 0 || num_voxels < 0)
         return MSSVT_E_BADARG;
     hipStream_t stream = (hipStream_t)stream_;
     hipError_t e = hipMemsetAsync(workspace, 0, WS_HDR_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
-    if (num_voxels == 0) return MSSVT_OK;
+    if (num_voxels == 0) return MSSVT_OK;  // an empty table (the caller pre-fills it with -1)
     VoxKey kf{x_max, y_max, z_max};
     slot_t *table = reinterpret_cast<slot_t *>(xyz_to_vidx);
     k_vox_insert_all<<<divup(num_voxels, TPB), TPB, 0, stream>>>(

@@ -204,10 +204,19 @@ class MixedScaleSparseTransformerBlock(nn.Module):
 
     # -- forward ---------------------------------------------------------------
     def forward(self, sp_tensor, block_idx=None, recycle_dict=None):
+        if sp_tensor.features.shape[0] == 0:  # empty scene: nothing to attend to (the reference crashes here)
+            return self._forward_empty(sp_tensor)
         if self.impl == "fused":
             from . import fused
             return fused.block_forward(self, sp_tensor)
         return self.forward_ops(sp_tensor)
+
+    def _out_channels(self, c_in):
+        return self.out_linear.out_features if hasattr(self, 'out_linear') else c_in
+
+    def _forward_empty(self, sp):
+        sp.features = sp.features.new_zeros((0, self._out_channels(sp.features.shape[1])))
+        return sp
 
     def forward_ops(self, sp):
         """Operator-level forward (ref: mssvt_backbone.py:201-346)."""
@@ -260,6 +269,13 @@ class MixedScaleSparseTransformerBlock(nn.Module):
 class MixedScaleSparseTransformerCompressBlock(MixedScaleSparseTransformerBlock):
 
     def forward(self, sp_tensor, block_idx=None, recycle_dict=None):
+        if sp_tensor.features.shape[0] == 0:  # empty scene: an empty coarser level
+            sp = self._forward_empty(sp_tensor)
+            sp.spatial_shape = [sp.spatial_shape[i] // self.win1_size[i] for i in range(3)]
+            sp.voxel_size = [sp.voxel_size[i] * self.win1_size[i] for i in range(3)]
+            sp.map_table = torch.full((sp.batch_size, sp.hash_size, 2), -1, dtype=torch.int32, device=sp.features.device)
+            sp.gather_dict = None
+            return sp
         if self.impl == "fused":
             from . import fused
             return fused.compress_forward(self, sp_tensor)

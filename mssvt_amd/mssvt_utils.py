@@ -73,6 +73,9 @@ class SparseTensor(object):
         zyx = list(self.spatial_shape[::-1])
         shape = [self.batch_size] + zyx + [self.features.shape[1]]
         f = self.features
+        if f.shape[0] == 0:
+            out_shape = [shape[0], shape[-1]] + zyx if channels_first else shape
+            return torch.zeros(out_shape, dtype=f.dtype, device=f.device)
         if (channels_first and f.is_cuda and f.dtype == torch.float32 and not (torch.is_grad_enabled() and f.requires_grad)
                 and self.map_table is not None and self.indices.dtype == torch.int32):
             # one gather pass through the hash table instead of zero fill + scatter + permute copy

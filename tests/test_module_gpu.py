@@ -168,3 +168,23 @@ def test_full_size_frame_fused_matches_operator_path():
     assert torch.equal(a.features, a2.features), "the fused path must be run-to-run deterministic"
     assert_feat_close(a.features.cpu().numpy(), b.features.cpu().numpy())
     assert list(a.spatial_shape) == list(b.spatial_shape) and torch.equal(a.dense(), a2.dense())
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_empty_and_tiny_scenes(impl):
+    """No voxels at all (the reference would crash) and a handful of isolated voxels."""
+    from mssvt_amd import config
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval().set_impl(impl)
+    for n in (0, 1, 7):
+        vc = torch.zeros((n, 4), dtype=torch.int32)
+        if n:
+            vc[:, 1] = torch.arange(n) % 32
+            vc[:, 2] = 100 + 3 * torch.arange(n)
+            vc[:, 3] = 200
+        with torch.no_grad():
+            sp = net(dict(voxel_features=torch.randn(n, 128).to(DEV), voxel_coords=vc.to(DEV), batch_size=1))[
+                "encoded_spconv_tensor"]
+        assert sp.features.shape == (n, 128) and sp.indices.shape == (n, 4)  # distinct (x, y) pillars stay distinct
+        assert list(sp.spatial_shape) == [470, 470, 1] and bool(torch.isfinite(sp.features).all())
+        assert sp.dense().shape == (1, 128, 1, 470, 470)
