@@ -379,6 +379,18 @@ int mssvt_voxelize(const float *points, int point_stride, long long num_points, 
                    int voxel_capacity, int *voxel_coords, int *point_voxel, int *num_voxels_dev,
                    int *workspace, void *stream);
 
+/* Per-voxel reductions of DynamicVFE without torch_scatter (ref dynamic_vfe.py:98,111,128-129);
+ * point_voxel (P) = unq_inv of mssvt_voxelize (-1: point outside the grid).
+ * mssvt_voxel_mean_xyz: mean3 (N,3) f32 = scatter_mean of the x,y,z columns (points rows
+ *   [b,x,y,z,...]); count (N) points per voxel; scratch_sum3: N*3 64-bit words (fixed-point
+ *   sums, 2^-20 m: order independent -> deterministic).
+ * mssvt_voxel_max: out (N,F) f32 = scatter_max of features (P,F) (voxels without a point: -inf). */
+int mssvt_voxel_mean_xyz(const float *points, int point_stride, long long num_points,
+                         const int *point_voxel, int num_voxels, float *mean3, int *count,
+                         long long *scratch_sum3, void *stream);
+int mssvt_voxel_max(const float *features, int F, long long num_points, const int *point_voxel,
+                    int num_voxels, float *out, void *stream);
+
 /* ======================================================================== *
  * Part 4 -- dense output: SparseTensor.dense() + the view of
  *           HeightCompression (ref mssvt_utils.py:6-19,50-62; height_compression.py:41-45) in one pass.

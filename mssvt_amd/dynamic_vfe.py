@@ -1,0 +1,101 @@
+"""``DynamicVFE`` for the MI355X path: points -> (voxel_features, voxel_coords) without torch_scatter.
+
+Interface-compatible with the reference's ``pcdet/models/backbones_3d/vfe/dynamic_vfe.py:12-131`` (same
+constructor, ``forward(batch_dict)`` keys, ``get_output_feature_dim`` and state-dict keys ``pfn.{i}.{0,1}.*``).
+The index part (``torch.unique`` of the merged coordinate) runs in the bitmap voxelizer
+(``csrc/voxelize.hip``), ``scatter_mean`` / ``scatter_max`` of the un-vendored torch_scatter package in
+``csrc/vfe.hip``; the tiny per-point PFN layers (Linear + BatchNorm1d + ReLU) stay torch modules.
+Inference only: the reductions carry no autograd.  Points outside the grid are kept in the arrays (their
+voxel id is -1) instead of being filtered out, so nothing is compacted or synchronised.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib, voxelize
+
+_i = ctypes.c_int
+
+
+def voxel_mean_xyz(points, point_voxel, num_voxels):
+    """scatter_mean(points[:, 1:4], point_voxel) -> (N,3) f32, points per voxel (N,) int32."""
+    P, stride = points.shape
+    dev = points.device
+    mean = torch.empty((max(num_voxels, 1), 3), dtype=torch.float32, device=dev)
+    cnt = torch.empty(max(num_voxels, 1), dtype=torch.int32, device=dev)
+    scratch = torch.empty(max(num_voxels, 1) * 3, dtype=torch.int64, device=dev)
+    _lib.call("mssvt_voxel_mean_xyz", _lib.ptr(points), _i(stride), ctypes.c_longlong(P), _lib.ptr(point_voxel),
+              _i(num_voxels), _lib.ptr(mean), _lib.ptr(cnt), _lib.ptr(scratch), _lib.stream())
+    return mean[:num_voxels], cnt[:num_voxels]
+
+
+def voxel_max(features, point_voxel, num_voxels):
+    """scatter_max(features, point_voxel)[0] -> (N,F) f32."""
+    features = features.contiguous()
+    P, F = features.shape
+    out = torch.empty((max(num_voxels, 1), F), dtype=torch.float32, device=features.device)
+    _lib.call("mssvt_voxel_max", _lib.ptr(features), _i(F), ctypes.c_longlong(P), _lib.ptr(point_voxel),
+              _i(num_voxels), _lib.ptr(out), _lib.stream())
+    return out[:num_voxels]
+
+
+class DynamicVFE(nn.Module):
+    def __init__(self, model_cfg, num_point_features, voxel_size, grid_size, point_cloud_range, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        get = model_cfg.get if hasattr(model_cfg, 'get') else (lambda k, d=None: getattr(model_cfg, k, d))
+        self.num_point_features_in = num_point_features
+        self.grid_size_l = [int(v) for v in grid_size]
+        self.voxel_size_l = [float(v) for v in voxel_size]
+        self.point_cloud_range_l = [float(v) for v in point_cloud_range]
+        # ref :29-35: voxel centre = coord * voxel_size + (voxel_size / 2 + range_min)
+        self.register_buffer('voxel_size_t', torch.tensor(self.voxel_size_l, dtype=torch.float32).view(1, 3),
+                             persistent=False)
+        self.register_buffer('xyz_offset', torch.tensor(
+            [self.voxel_size_l[k] / 2 + self.point_cloud_range_l[k] for k in range(3)], dtype=torch.float32).view(1, 3),
+            persistent=False)
+        self.with_cluster_center = get('WITH_CLUSTER_CENTER', True)
+        self.with_voxel_center = get('WITH_VOXEL_CENTER', True)
+        self.with_distance = get('WITH_DISTANCE', False)
+        in_channels = num_point_features + (3 if self.with_cluster_center else 0) + \
+            (3 if self.with_voxel_center else 0) + (1 if self.with_distance else 0)
+        self.in_channels = in_channels
+        filters = list(get('NUM_FILTERS', [64, 128]))
+        self.num_point_features = filters[-1]
+        self.pfn = nn.ModuleList([])
+        in_c = in_channels
+        for out_c in filters:
+            self.pfn.append(nn.Sequential(nn.Linear(in_c, out_c), nn.BatchNorm1d(out_c), nn.ReLU(inplace=True)))
+            in_c = out_c * 2
+
+    def get_output_feature_dim(self):
+        return self.num_point_features
+
+    @torch.no_grad()
+    def forward(self, batch_dict, **kwargs):
+        points = batch_dict['points'].contiguous()  # (P, 1 + F) rows [b, x, y, z, intensity, ...]
+        batch_size = batch_dict['batch_size']
+        voxel_coords, pv = voxelize.voxelize(points, self.point_cloud_range_l, self.voxel_size_l, self.grid_size_l,
+                                             batch_size)
+        N = voxel_coords.shape[0]
+        gather = pv.clamp(min=0).long()  # points outside the grid read voxel 0; their rows are never reduced
+        xyz = points[:, 1:4]
+        feats = [points[:, 1:self.num_point_features_in + 1]]
+        if self.with_cluster_center:
+            xyz_mean, _ = voxel_mean_xyz(points, pv, N)
+            feats.append(xyz - xyz_mean[gather] if N else torch.zeros_like(xyz))
+        if self.with_voxel_center:
+            pc = voxel_coords[gather][:, [3, 2, 1]].to(torch.float32) if N else torch.zeros_like(xyz)
+            feats.append(xyz - (pc * self.voxel_size_t + self.xyz_offset))
+        if self.with_distance:
+            feats.append(torch.norm(xyz, p=2, dim=1, keepdim=True))  # (the reference's dim=2 cannot run)
+        x = torch.cat(feats, dim=-1)
+        for i, blk in enumerate(self.pfn):
+            x = blk(x)
+            if i < len(self.pfn) - 1:
+                fea_v = voxel_max(x, pv, N)
+                x = torch.cat((x, fea_v[gather] if N else torch.zeros_like(x)), dim=-1)
+        batch_dict['voxel_features'] = voxel_max(x, pv, N).contiguous()
+        batch_dict['voxel_coords'] = voxel_coords.contiguous()
+        return batch_dict
