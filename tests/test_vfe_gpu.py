@@ -55,3 +55,20 @@ def test_voxel_reductions_edge_cases():
     f = torch.tensor([[-1.0, 5.0], [100, 100], [-3, -2], [-0.5, 4], [-2, 6], [-4, -1]], device=DEV)
     mx = voxel_max(f, pv, 3).cpu().numpy()
     np.testing.assert_array_equal(mx, [[-3, -1], [-np.inf, -np.inf], [-0.5, 6]])
+
+
+def test_points_to_bev_pipeline():
+    """points -> DynamicVFE -> MixedScaleSparseTransformer -> dense(): the path with its two neighbours, all HIP."""
+    from mssvt_amd import config
+    from mssvt_amd.dynamic_vfe import DynamicVFE
+    p = synthetic.make_batch_points(40000, 2, 9)
+    torch.manual_seed(0)
+    vfe = DynamicVFE(_Cfg(), 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.POINT_CLOUD_RANGE).to(DEV).eval()
+    net = config.build_backbone_from_cfg().to(DEV).eval()
+    with torch.no_grad():
+        bd = vfe(dict(points=torch.from_numpy(p).to(DEV), batch_size=2))
+        assert bd["voxel_features"].shape[1] == 128 == net.num_point_features
+        sp = net(bd)["encoded_spconv_tensor"]
+        bev = sp.dense()
+    assert bev.shape == (2, 128, 1, 470, 470) and bool(torch.isfinite(bev).all())
+    assert int((bev.abs().sum(1) > 0).sum()) == sp.features.shape[0]  # one occupied BEV cell per output voxel
