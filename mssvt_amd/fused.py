@@ -113,6 +113,7 @@ def two_scale_plan(block, sp):
         block.win1_size, block.max_num_wins, B, H, p.new_spatial_shape, sp.indices)
     p.num_wins = ws[1:2]  # device scalar
     p.status = ws[0:1]
+    st.setdefault("status_words", []).append(p.status)
     p.cap = cap = max(N, 1)
     n_o, n_e, n1, n2, K = (block.max_num_odd, block.max_num_even, block.max_num_win1, block.max_num_win2,
                            block.key_num_sample)
@@ -479,8 +480,12 @@ def one_scale_plan(block, sp, sync=True):
         # the window count is final here, ~250 us of GPU work before the block ends: copy it to pinned
         # host memory now and wait for THAT copy later (not for the stream) -- the forward returns while
         # the GPU still runs the block's tail and the next frame's launches queue up behind it
-        p.host_ws = torch.empty(3, dtype=torch.int32, pin_memory=True)
-        p.host_ws.copy_(ws[:3], non_blocking=True)
+        # ... together with the status words of the voxel table and of the Block plans of this level
+        words = [ws[:3]] + list(st.get("status_words", []))
+        if getattr(sp, "map_status", None) is not None:
+            words.append(sp.map_status)
+        p.host_ws = torch.empty(3 + len(words) - 1, dtype=torch.int32, pin_memory=True)
+        p.host_ws.copy_(torch.cat(words) if len(words) > 1 else ws[:3], non_blocking=True)
         p.host_ev = torch.cuda.Event()
         p.host_ev.record()
         return p
@@ -539,7 +544,10 @@ def _compress_forward_fused(block, sp, xhat, x_in):
               _lib.ptr(qp), _lib.ptr(ktok), _lib.ptr(score), _lib.ptr(vp), _lib.ptr(new), _lib.stream())
     y = _ffn_tail(block, sp, new, n_rows_dev=p.num_wins, apply_out=False)  # no residual to the block input (ref :383-385)
     p.host_ev.synchronize()  # the forward's single host wait: the output shape (copied out long ago)
-    status, nw, _ = p.host_ws.tolist()
+    host = p.host_ws.tolist()
+    status, nw = host[0], host[1]
+    for extra in host[3:]:  # voxel hash table / Block plans: overflow must not pass silently
+        status |= extra & (mssvt_ops.ST_TABLE_OVERFLOW | mssvt_ops.ST_WINDOW_OVERFLOW)
     _check_plan_status(block, status, sp.hash_size)
     p.nw = nw
     pre = getattr(sp, "_xhat", None)

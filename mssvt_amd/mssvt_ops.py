@@ -92,7 +92,11 @@ def build_hash_table(batch_size, hash_size, spatial_shape, voxel_indices, v_bs_c
     _lib.call("mssvt_build_mapping_with_hash", _i(x_max), _i(y_max), _i(z_max), _i(n),
               _i(int(hash_size)), _i(int(batch_size)), _lib.ptr(voxel_indices), _lib.ptr(v_bs_cnt),
               _lib.ptr(table), _lib.ptr(ws), _lib.stream())
+    build_hash_table.last_status = ws[0:1]  # device word: ST_* bits (read lazily by the fused path)
     return table
+
+
+build_hash_table.last_status = None
 
 
 def window_partition_device(win_size, max_num_wins, batch_size, hash_size, spatial_shape,

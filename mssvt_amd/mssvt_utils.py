@@ -65,8 +65,9 @@ class SparseTensor(object):
     @torch.no_grad()
     def build_map_table(self):
         cnt = self.v_bs_cnt = batch_counts(self.indices, self.batch_size)  # kept: the plans need it too
-        return mssvt_ops.build_hash_table(self.batch_size, self.hash_size, self.spatial_shape,
-                                          self.indices, cnt)
+        table = mssvt_ops.build_hash_table(self.batch_size, self.hash_size, self.spatial_shape, self.indices, cnt)
+        self.map_status = getattr(mssvt_ops.build_hash_table, "last_status", None)  # device status word of this table
+        return table
 
     def dense(self, channels_first=True):
         """(B, C, Z, Y, X) (or (B, Z, Y, X, C)) dense grid.  ref: mssvt_utils.py:50-62."""

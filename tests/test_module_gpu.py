@@ -188,3 +188,17 @@ def test_empty_and_tiny_scenes(impl):
         assert sp.features.shape == (n, 128) and sp.indices.shape == (n, 4)  # distinct (x, y) pillars stay distinct
         assert list(sp.spatial_shape) == [470, 470, 1] and bool(torch.isfinite(sp.features).all())
         assert sp.dense().shape == (1, 128, 1, 470, 470)
+
+
+def test_hash_overflow_is_loud():
+    """A voxel hash table that is too small for the scene must raise (the reference drops voxels silently)."""
+    from mssvt_amd import config
+    from mssvt_amd._lib import MssvtHipError
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval()
+    net.hash_size = 1000  # 20k-point scene: ~9k voxels per sample
+    pts = synthetic.make_batch_points(20000, 1, 3)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    with pytest.raises(MssvtHipError), torch.no_grad():
+        net(dict(voxel_features=torch.randn(vc.shape[0], 128, device=DEV), voxel_coords=torch.from_numpy(vc).to(DEV),
+                 batch_size=1))
