@@ -202,3 +202,27 @@ def test_hash_overflow_is_loud():
     with pytest.raises(MssvtHipError), torch.no_grad():
         net(dict(voxel_features=torch.randn(vc.shape[0], 128, device=DEV), voxel_coords=torch.from_numpy(vc).to(DEV),
                  batch_size=1))
+
+
+def test_enlarged_windows_stride1_fused_matches_operator_path():
+    """BASELINE configs[4] shape: windows [5,5,7]/[11,11,11], cbs_pattern 2 (every win1 voxel is a query)."""
+    from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
+    C, B, H = 32, 1, 200003
+    blk = dict(name="MixedScaleSparseTransformerBlock", channels=[C, 2 * C, C], num_heads=[2, 2],
+               window_size=[[5, 5, 7], [11, 11, 11]], max_num_win1=175, max_num_win2=1331, cbs_mode="odd_even",
+               cbs_pattern=2, key_num_sample=32, use_feature_interpolation=True)
+    params = [blk, dict(blk, use_feature_interpolation=False),
+              dict(name="MixedScaleSparseTransformerCompressBlock", channels=[C, 2 * C, C], num_heads=[2],
+                   window_size=[[1, 1, 32]], max_num_win1=32)]
+    pts = synthetic.make_batch_points(30000, B, 17)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], C, generator=torch.Generator().manual_seed(5))
+    torch.manual_seed(1)
+    net = MixedScaleSparseTransformer(_cfg(params, H, C), C, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
+                                      synthetic.POINT_CLOUD_RANGE).to(DEV).eval()
+    batch = lambda: dict(voxel_features=feats.to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV), batch_size=B)  # noqa: E731
+    with torch.no_grad():
+        a = net.set_impl("fused")(batch())["encoded_spconv_tensor"]
+        b = net.set_impl("ops")(batch())["encoded_spconv_tensor"]
+    assert torch.equal(a.indices, b.indices)
+    assert_feat_close(a.features.cpu().numpy(), b.features.cpu().numpy())
