@@ -6,9 +6,9 @@
 // exactly one window: pair row = voxel row, see k_window_plan_one).  Every count is read on the
 // device; the caller synchronises once, after the whole block is enqueued, to learn the output size.
 //
-//   A  k_cmp_query : rows = windows.  q_tok = channel-wise max over the window's (zero padded) key
+//   A  (k_cmp_query_keys, first workgroups) : rows = windows.  q_tok = channel-wise max over the window's (zero padded) key
 //                    features (ref :370); q' = scale (Wq q_tok + bq)                       -> qp (nw, C)
-//   B  k_cmp_keys  : rows = voxels.   h = relu(Wp1 [rel ; centre] + bp1)   (one K = 8 MFMA per tile)
+//   B  (k_cmp_query_keys, the others) : rows = voxels.   h = relu(Wp1 [rel ; centre] + bp1)   (one K = 8 MFMA per tile)
 //                    k_tok = xhat + relu(Wp2 h + bp2)                                      -> ktok (N, C)
 //   C  k_cmp_kv    : rows = voxels.   K = Wk k_tok + bk  -> score[v][head] = q'[window(v)] . K[v]
 //                                     V = Wv k_tok + bv                                    -> vp (N, C)
@@ -106,7 +106,7 @@ __device__ __forceinline__ void cf_stage_lists(int *lst, const CmpArgs &a, int t
 
 // ---- A: queries ---------------------------------------------------------------------------------
 template <int C>
-__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query(CmpArgs a) {
+__device__ __forceinline__ void cmp_query_body(const CmpArgs &a, int block_id, int num_blocks) {
     constexpr int NT = C / 16, LS = C + 4;
     extern __shared__ float4 lds4[];
     float *Wq_l = reinterpret_cast<float *>(lds4), *bq_l = Wq_l + C * LS;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query(CmpArgs a) {
     const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
     const int nw = *a.num_wins, tiles = (nw + 15) >> 4;
     for (int k = wv;; k += CF_NW) {
-        const int tile = k * gridDim.x + blockIdx.x;
+        const int tile = k * num_blocks + block_id;
         if (tile >= tiles) break;
         const int w = min(tile * 16 + la, nw - 1);
         const bool live = tile * 16 + la < nw;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query(CmpArgs a) {
 
 // ---- B: key tokens --------------------------------------------------------------------------------
 template <int C>
-__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_keys(CmpArgs a) {
+__device__ __forceinline__ void cmp_keys_body(const CmpArgs &a, int block_id, int num_blocks) {
     constexpr int NT = C / 16, LS = C + 4;
     extern __shared__ float4 lds4[];
     float *W2_l = reinterpret_cast<float *>(lds4), *b2_l = W2_l + C * LS;
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_keys(CmpArgs a) {
     __syncthreads();
     const int n = a.num_voxels, tiles = (n + 15) >> 4;
     for (int k = wv;; k += CF_NW) {
-        const int tile = k * gridDim.x + blockIdx.x;
+        const int tile = k * num_blocks + block_id;
         if (tile >= tiles) break;
         const int v = min(tile * 16 + la, n - 1);
         const bool live = tile * 16 + la < n;
@@ -231,6 +231,21 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_keys(CmpArgs a) {
                             : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+}
+
+// A and B in ONE launch: they are independent (windows -> qp, voxels -> ktok), and the query side is a
+// latency-bound walk over the window lists that hides under the key side's matrix work.
+template <int C>
+__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query_keys(CmpArgs a, int query_blocks) {
+    // roles alternate so that both kinds are resident from the start (dispatch is in block order)
+    const int key_blocks = gridDim.x - query_blocks, both = 2 * min(query_blocks, key_blocks);
+    const int b = blockIdx.x;
+    const bool query = b < both ? (b & 1) == 0 : query_blocks > key_blocks;
+    const int id = b < both ? b >> 1 : b - both / 2;
+    if (query)
+        cmp_query_body<C>(a, id, query_blocks);
+    else
+        cmp_keys_body<C>(a, id, key_blocks);
 }
 
 // ---- C: K scores + V rows ---------------------------------------------------------------------------
@@ -413,7 +428,7 @@ static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t strea
     const size_t lds1w = lds1 + (size_t)CF_NW * 16 * a.ns * 4;  // + the tile's K4 lists per wave
     if (lds1w > 160 * 1024) return MSSVT_E_TOOLARGE;
     int rc;
-    if ((rc = cf_prepare(k_cmp_query<C>, lds1w)) || (rc = cf_prepare(k_cmp_keys<C>, lds1)) ||
+    if ((rc = cf_prepare(k_cmp_query_keys<C>, lds1w)) ||
         (rc = cf_prepare(k_cmp_kv<C, HD>, lds2)) || (rc = cf_prepare(k_cmp_out<C, HD>, lds1w)))
         return rc;
     int dev = 0, cus = 256;
@@ -424,8 +439,7 @@ static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t strea
     const int per1 = (int)((160 * 1024) / lds1) > 2 ? 2 : (int)((160 * 1024) / lds1);
     const int per1w = (int)((160 * 1024) / lds1w) > 2 ? 2 : (int)((160 * 1024) / lds1w);
     const int g_w = min(cus * (per1w < 1 ? 1 : per1w), max(wt, 1)), g_v = min(cus * per1, max(vt, 1)), g_v2 = min(cus, max(vt, 1));
-    k_cmp_query<C><<<g_w, CF_NW * MSSVT_WAVE, lds1w, stream>>>(a);
-    k_cmp_keys<C><<<g_v, CF_NW * MSSVT_WAVE, lds1, stream>>>(a);
+    k_cmp_query_keys<C><<<g_w + g_v, CF_NW * MSSVT_WAVE, lds1w, stream>>>(a, g_w);
     k_cmp_kv<C, HD><<<g_v2, CF_NW * MSSVT_WAVE, lds2, stream>>>(a);
     k_cmp_out<C, HD><<<g_w, CF_NW * MSSVT_WAVE, lds1w, stream>>>(a);
     return mssvt_launch_status();

@@ -479,16 +479,18 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_up(FfnArgs a, float 
     const bool any = tile < tiles;
     // the first tile's table entry travels while the weights are staged
     FfnTab tab_cur = ffn_tab_load(a, any ? tile : 0, n, la);
+    float4 rx[SH], r1[SH], r2[SH], r3[SH];
+    f32x4 x[NT], xnext[NT];
+    // the first half of the first tile's gather is issued BEFORE the weights are staged: both are pure
+    // latency (table -> rows, L2 -> LDS) and overlap
+    FfnRowSrc cur = ffn_row_src<C, FF>(a, hidden, any ? tile : 0, n, la, g, tab_cur);
+    FFN_ISSUE(cur, 0)
     ffn_stage_weights<C, LS>(W1_l, a.W1, FF);
     for (int e = threadIdx.x; e < FF; e += blockDim.x) b1_l[e] = a.b1[e];
     for (int e = threadIdx.x; e < C; e += blockDim.x) {
         lnw_l[e] = a.ln_w[e];
         lnb_l[e] = a.ln_b[e];
     }
-    float4 rx[SH], r1[SH], r2[SH], r3[SH];
-    f32x4 x[NT], xnext[NT];
-    FfnRowSrc cur = ffn_row_src<C, FF>(a, hidden, any ? tile : 0, n, la, g, tab_cur);
-    FFN_ISSUE(cur, 0)  // in flight across the barrier
     STAMP(0)
     __syncthreads();
     STAMP(0)
