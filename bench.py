@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--points", type=int, default=160000, help="LiDAR points per scene")
     ap.add_argument("--batch", type=int, default=1, help="scenes per GPU per step")
     ap.add_argument("--impl", default=None, choices=[None, "fused", "ops"])
+    ap.add_argument("--cfg", default=None, help="backbone yaml (default: mssvt_amd/cfgs/mssvt.yaml = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -114,7 +115,8 @@ def main():
 
     from mssvt_amd import config, roofline
     torch.manual_seed(0)
-    net = config.build_backbone_from_cfg().to(dev).eval()
+    cfg = config.load_yaml(args.cfg) if args.cfg else None
+    net = config.build_backbone_from_cfg(cfg).to(dev).eval()
     if args.impl:
         net.set_impl(args.impl)
     impl = net.backbone[0].impl
@@ -139,16 +141,17 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d-point Waymo-shaped scene x batch %d per GPU, full "
-                                   "mssvt.yaml backbone (4 Blocks [3,3,5]/[7,7,7] cbs 1,0,1,0 + CompressBlock "
-                                   "[1,1,32], C=128, heads [4,4], HASH_SIZE 400000), fp32"
-                                   % (args.points, args.batch),
+            "config": {"workload": ("BASELINE configs[1]: %d-point Waymo-shaped scene x batch %d per GPU, full "
+                                    "mssvt.yaml backbone (4 Blocks [3,3,5]/[7,7,7] cbs 1,0,1,0 + CompressBlock "
+                                    "[1,1,32], C=128, heads [4,4], HASH_SIZE 400000), fp32" % (args.points, args.batch))
+                       if not args.cfg else "%s: %d-point scene x batch %d per GPU, fp32"
+                       % (os.path.basename(args.cfg), args.points, args.batch),
                        "impl": impl, "voxels_per_gpu": int(vc.shape[0]), "output_voxels": n_out,
                        "parallelism": "scenes sharded over %d GPU(s), no data-path collective" % world},
         }
-        if not args.no_roofline:
+        if not args.no_roofline and not args.cfg:
             res["roofline"] = roofline.measure(net, vc, feats, args.batch, event_time_ms, HBM_PEAK_GBS)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.cfg:
             res["cpu_baseline"] = cpu_baseline(net, vc_np, feats_np, args.batch)
         print(json.dumps(res), flush=True)
     if dist:
