@@ -312,6 +312,10 @@ extern "C" int mssvt_debug_read_plan_stamps(unsigned long long *host) {
 #define PSTAMP()
 #endif
 
+// FPS_TPL = largest "reference threads per lane" the register sampler is instantiated for in this
+// kernel (8: lists below 1024 entries; 16: below 2048, e.g. 11 x 11 x 11 windows -- a separate
+// instantiation so that the common one keeps its register footprint)
+template <int FPS_TPL>
 __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanArgs a) {
     extern __shared__ int lds[];
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
@@ -585,6 +589,8 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
             fps_on_list_regs<4>(lc, n, K, bs, fps_out, lane);
         else if (bs == 512)
             fps_on_list_regs<8>(lc, n, K, bs, fps_out, lane);
+        else if (FPS_TPL >= 16 && bs == 1024)
+            fps_on_list_regs<FPS_TPL >= 16 ? 16 : 1>(lc, n, K, bs, fps_out, lane);
         else
             fps_on_list(lc, n, K, bs, temp, bv, bidx, fps_out, lane);
         wave_lds_sync();
@@ -721,12 +727,17 @@ extern "C" int mssvt_window_plan_two(
     if (getenv("MSSVT_PLAN_WPB")) wpb = atoi(getenv("MSSVT_PLAN_WPB"));
     const size_t lds_bytes = (size_t)a.lds_words_per_wave * 4 * wpb;
     if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
+    const bool big = bsmax > 512;  // lists of 1024 .. 2047 slots: the instantiation with the 16-slot register sampler
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_plan),
+        hipError_t e = hipFuncSetAttribute(big ? reinterpret_cast<const void *>(k_window_plan<16>)
+                                               : reinterpret_cast<const void *>(k_window_plan<8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    k_window_plan<<<divup(win_capacity, wpb), wpb * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
+    if (big)
+        k_window_plan<16><<<divup(win_capacity, wpb), wpb * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
+    else
+        k_window_plan<8><<<divup(win_capacity, wpb), wpb * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
     return mssvt_launch_status();
 }
 
