@@ -229,6 +229,7 @@ def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
 FFN_SPLIT = os.environ.get("MSSVT_FFN_SPLIT", "1") != "0"
 CMP_FUSED = os.environ.get("MSSVT_CMP_FUSED", "1") != "0"
+FFN_TIMER = None  # bench.py sets this to a list to time k_ffn_up live (see _ffn_tail)
 OCC_COLUMNS = os.environ.get("MSSVT_OCC_COLUMNS", "1") != "0"
 
 
@@ -261,13 +262,26 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=No
                 _lib.ptr(nxt.bias if y_norm is not None else None),
                 _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.ptr(hidden),
                 _lib.ptr(n_rows_dev), _i(phases), _lib.stream())
-        if table is not None:
-            (tab_row, tab_w), attn = table
-            _lib.call("mssvt_ffn_fused_interp", _i(n), _i(C), _i(FF), _lib.ptr(x_in), _lib.ptr(tab_row),
-                      _lib.ptr(tab_w), _lib.ptr(attn), *tail)
+        def launch(tail_):
+            if table is not None:
+                (tab_row, tab_w), attn = table
+                _lib.call("mssvt_ffn_fused_interp", _i(n), _i(C), _i(FF), _lib.ptr(x_in), _lib.ptr(tab_row),
+                          _lib.ptr(tab_w), _lib.ptr(attn), *tail_)
+            else:
+                _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _lib.ptr(x_new), _lib.ptr(x_in),
+                          _lib.ptr(owner), *tail_)
+
+        if FFN_TIMER is not None and split and phases == 3:
+            # bench.py's live roofline: HIP events around k_ffn_up inside the timed steps (two C calls
+            # instead of one: the same two launches, the same stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch(tail[:-2] + (_i(1), tail[-1]))
+            e1.record()
+            launch(tail[:-2] + (_i(2), tail[-1]))
+            FFN_TIMER.append((e0, e1, n if n_rows_dev is None else n_rows_dev, C, FF))
         else:
-            _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
-                      *tail)
+            launch(tail)
         sp._xhat = (y_norm, nxt, y) if y_norm is not None else None
     if apply_out and hasattr(block, 'out_linear'):
         y = block.out_linear(y)
@@ -630,7 +644,17 @@ def _compress_finish(sp, p, features):
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix-core peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
 
 
-def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
+def ffn_timer_summary(samples):
+    """(launches, total FLOP, total seconds) of the k_ffn_up launches recorded through FFN_TIMER."""
+    flop, sec = 0.0, 0.0
+    for e0, e1, rows, C, FF in samples:
+        rows = int(rows.item()) if torch.is_tensor(rows) else int(rows)
+        flop += 2.0 * C * FF * rows
+        sec += e0.elapsed_time(e1) * 1e-3
+    return len(samples), flop, sec
+
+
+def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
     """Roofline of the dominant kernel of the frame on the bench inputs: k_ffn_up<128,256> (LayerNorm +
     GEMM1 + ReLU of the FFN tail, 5 launches per frame, the largest share of GPU time), timed alone
     with HIP events through the `phases` argument of the C entry point.  It is bound by the fp32 matrix
@@ -686,11 +710,27 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs):
     if os.path.exists(pmc):
         with open(pmc) as f:
             traffic = json.load(f).get("k_ffn_up<128,256>", {}).get("hbm_bytes_per_launch")
+    head = {"achieved": tf_up, "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_up * 1e3,
+            "units_per_launch": {"voxel_rows": N, "flop_per_row": 2 * C * FF},
+            "timing": "HIP events around 20 isolated launches on the bench frame"}
+    if live is not None and live[0] > 0:
+        # measured over a repeat of the K timed steps: every k_ffn_up launch (4 Block tails of N rows + the
+        # CompressBlock tail of nw rows per frame) between two HIP events on its stream
+        cnt, lflop, lsec = live
+        head = {"achieved": lflop / lsec / 1e12, "algorithmic_flop_per_launch": lflop / cnt,
+                "avg_launch_us": lsec / cnt * 1e6,
+                "units_per_launch": {"voxel_rows_mean": lflop / cnt / (2 * C * FF), "flop_per_row": 2 * C * FF,
+                                     "launches_timed": cnt},
+                "timing": "HIP events around every k_ffn_up launch of a repeat of the timed steps",
+                "isolated_launch_us_full_frame_rows": ms_up * 1e3}
     return {"bound": "mfma", "kernel": "k_ffn_up<128,256> (norm2 + GEMM1 + ReLU of the FFN tail, fp32 MFMA; input built "
                                        "from x_in + 3 attention rows)",
-            "achieved": tf_up, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_up / MFMA_F32_PEAK_TFLOPS,
-            "traffic": traffic, "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_up * 1e3,
-            "units_per_launch": {"voxel_rows": N, "flop_per_row": 2 * C * FF},
+            "achieved": head["achieved"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": head["achieved"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "algorithmic_flop_per_launch": head["algorithmic_flop_per_launch"], "avg_launch_us": head["avg_launch_us"],
+            "units_per_launch": head["units_per_launch"], "timing": head["timing"],
+            **({"isolated_launch_us_full_frame_rows": head["isolated_launch_us_full_frame_rows"]}
+               if "isolated_launch_us_full_frame_rows" in head else {}),
             "other_kernels": [
                 {"bound": "mfma", "kernel": "k_ffn_down<128,256> (GEMM2 + residual + next norm1)", "achieved": tf_down,
                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_down / MFMA_F32_PEAK_TFLOPS,

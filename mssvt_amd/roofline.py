@@ -57,9 +57,9 @@ def _gather_two_window(net, vc, batch, event_time_ms, peak_gbs):
             "units_per_launch": {"windows": nw, "probes": probes, "list_entries": written}}
 
 
-def measure(net, vc, feats, batch, event_time_ms, peak_gbs):
+def measure(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
     impl = net.backbone[0].impl
     if impl == "fused":
         from . import fused
-        return fused.roofline(net, vc, feats, batch, event_time_ms, peak_gbs)
+        return fused.roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=live)
     return _gather_two_window(net, vc, batch, event_time_ms, peak_gbs)
