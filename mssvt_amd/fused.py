@@ -710,6 +710,9 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
     if os.path.exists(pmc):
         with open(pmc) as f:
             traffic = json.load(f).get("k_ffn_up<128,256>", {}).get("hbm_bytes_per_launch")
+    if traffic is not None and live is not None and live[0] > 0:
+        # the PMC passes ran full-size launches (N rows); the live average mixes in the smaller CompressBlock tail
+        traffic = int(traffic * (live[1] / live[0] / (2.0 * C * FF)) / N)
     head = {"achieved": tf_up, "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_up * 1e3,
             "units_per_launch": {"voxel_rows": N, "flop_per_row": 2 * C * FF},
             "timing": "HIP events around 20 isolated launches on the bench frame"}
