@@ -694,17 +694,34 @@ __global__ void __launch_bounds__(SC_WPB *MSSVT_WAVE) k_block_scatter(ScatterPac
         }
         // known points = ALL nq query slots; empty slots sit at the world origin with zero
         // features (ref :302 gathers coordinates with -1 -> 0 fill) -- kept as is
-        for (int i = lane; i < a.nq; i += MSSVT_WAVE) {
-            const int v = a.q_ind[(size_t)w * a.nq + i];
+        // Candidate list for the 3-NN search, in slot order: every valid slot, and of the EMPTY slots only the
+        // first three -- all empty slots are the same point (the origin), the search keeps the first seen on
+        // ties (strict <), so a fourth one can never enter the best three.  ~5 candidates instead of nq.
+        int ncand = 0, nempty = 0;
+        for (int i0 = 0; i0 < a.nq; i0 += MSSVT_WAVE) {
+            const int i = i0 + lane;
+            int v = -1;
             float x = 0.f, y = 0.f, z = 0.f;
-            if (v >= 0) {
-                const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + v];
-                x = centre_of(vi.w, a.vsx, a.minx);
-                y = centre_of(vi.z, a.vsy, a.miny);
-                z = centre_of(vi.y, a.vsz, a.minz);
+            if (i < a.nq) {
+                v = a.q_ind[(size_t)w * a.nq + i];
+                if (v >= 0) {
+                    const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + v];
+                    x = centre_of(vi.w, a.vsx, a.minx);
+                    y = centre_of(vi.z, a.vsy, a.miny);
+                    z = centre_of(vi.y, a.vsz, a.minz);
+                }
             }
-            kx[wv][i] = x; ky[wv][i] = y; kz[wv][i] = z;
-            kvalid[wv][i] = v >= 0;
+            const bool empty = i < a.nq && v < 0;
+            const unsigned long long me = __ballot(empty);
+            const bool keep = i < a.nq && (v >= 0 || nempty + __popcll(me & ((1ull << lane) - 1ull)) < 3);
+            const unsigned long long mk = __ballot(keep);
+            if (keep) {
+                const int p = ncand + __popcll(mk & ((1ull << lane) - 1ull));
+                kx[wv][p] = x; ky[wv][p] = y; kz[wv][p] = z;
+                kvalid[wv][p] = (i << 1) | (v >= 0 ? 1 : 0);  // original slot, valid bit
+            }
+            ncand += __popcll(mk);
+            nempty += __popcll(me);
         }
         wave_lds_sync();
         for (int s0 = 0; s0 < a.n1; s0 += MSSVT_WAVE) {
@@ -720,22 +737,29 @@ __global__ void __launch_bounds__(SC_WPB *MSSVT_WAVE) k_block_scatter(ScatterPac
                 const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + v];
                 const float ux = centre_of(vi.w, a.vsx, a.minx), uy = centre_of(vi.z, a.vsy, a.miny),
                             uz = centre_of(vi.y, a.vsz, a.minz);
-                double b1 = 1e40, b2 = 1e40, b3 = 1e40;
-                for (int k = 0; k < a.nq; ++k) {
+                // the reference keeps the running bests in double (initial 1e40) and compares float distances
+                // against them: the same order as float compares against +inf
+                float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+                int c1 = -1, c2 = -1, c3 = -1;  // candidate positions
+                for (int k = 0; k < ncand; ++k) {
                     const float dx = ux - kx[wv][k], dy = uy - ky[wv][k], dz = uz - kz[wv][k];
                     const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
-                    else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
-                    else if (d < b3) { b3 = d; i3 = k; }
+                    if (d < b1) { b3 = b2; c3 = c2; b2 = b1; c2 = c1; b1 = d; c1 = k; }
+                    else if (d < b2) { b3 = b2; c3 = c2; b2 = d; c2 = k; }
+                    else if (d < b3) { b3 = d; c3 = k; }
                 }
-                const float d1 = fmaxf(sqrtf((float)b1), 1e-10f), d2 = fmaxf(sqrtf((float)b2), 1e-10f),
-                            d3 = fmaxf(sqrtf((float)b3), 1e-10f);
+                // fewer than three candidates (nq < 3): the reference leaves index 0 / distance 1e40 -> weight ~0
+                const int m1 = c1 >= 0 ? kvalid[wv][c1] : 0, m2 = c2 >= 0 ? kvalid[wv][c2] : 0,
+                          m3 = c3 >= 0 ? kvalid[wv][c3] : 0;
+                i1 = m1 >> 1; i2 = m2 >> 1; i3 = m3 >> 1;
+                const float d1 = fmaxf(c1 >= 0 ? sqrtf(b1) : INFINITY, 1e-10f), d2 = fmaxf(c2 >= 0 ? sqrtf(b2) : INFINITY, 1e-10f),
+                            d3 = fmaxf(c3 >= 0 ? sqrtf(b3) : INFINITY, 1e-10f);
                 w1 = 1.0f / d1; w2 = 1.0f / d2; w3 = 1.0f / d3;
                 const float norm = (w1 + w2) + w3;
                 w1 /= norm; w2 /= norm; w3 /= norm;
-                if (!kvalid[wv][i1]) w1 = 0.f;  // empty slots carry zero features
-                if (!kvalid[wv][i2]) w2 = 0.f;
-                if (!kvalid[wv][i3]) w3 = 0.f;
+                if (!(m1 & 1) || c1 < 0) w1 = 0.f;  // empty slots carry zero features
+                if (!(m2 & 1) || c2 < 0) w2 = 0.f;
+                if (!(m3 & 1) || c3 < 0) w3 = 0.f;
             }
             if (a.tab_row) {
                 if (v >= 0) {
@@ -834,7 +858,7 @@ extern "C" int mssvt_block_interp_table_multi(int num_sets, const int *host_nq, 
         a.zero_row = host_zero_row[k];
     }
     int grid = divup(win_capacity, SC_WPB);
-    if (grid > 4096 / num_sets) grid = 4096 / num_sets;
+    if (grid > 16384 / num_sets) grid = 16384 / num_sets;  // ~1 window per wave: the per-window chain is 3 dependent round trips
     k_block_scatter<<<dim3(grid, num_sets), SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(pack);
     return mssvt_launch_status();
 }
