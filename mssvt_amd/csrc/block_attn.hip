@@ -67,6 +67,7 @@ struct AttnArgs {
     const float *Wq, *bq, *Wkv, *bkv, *Wo, *bo, *Wp, *bp;
     float *qbuf;  // (query rows, HP*CG): Qt after A, Xbar after B
     float *attn;
+    int row_capacity;  // rows of qbuf / the compact row arrays
 };
 
 // head groups of equal shape run in ONE launch: blockIdx.y = group (their work is independent: channel
@@ -400,7 +401,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
     for (; wi < n_act; wi += wstep) {
         // ---- this window: stage R -> working registers ------------------------------------------------
         const float4 wc = wc_r;
-        const int nqv = nqv_r;
+        // a window whose rows would not fit the compact arrays is skipped (cannot happen with the caller's bound)
+        const int nqv = qbase_r + nqv_r <= a.row_capacity ? nqv_r : 0;
         const size_t qbase = (size_t)qbase_r;
         const unsigned vmask = vmask_r, used = used_r;
         f32x4 T1[KT][NT];
@@ -622,6 +624,7 @@ extern "C" int mssvt_block_attention(
         a.Wo = host_Wo[g]; a.bo = host_bo[g]; a.Wp = Wpos; a.bp = bpos;
         a.qbuf = qbuf + qoff;
         a.attn = attn;
+        a.row_capacity = row_capacity;
         qoff += (size_t)row_capacity * (((heads + 3) / 4) * 4) * Cg;
         if (same) {
             pack.g[g] = a;

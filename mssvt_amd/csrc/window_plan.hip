@@ -794,7 +794,8 @@ struct PlanOrderPack {
 };
 
 // one workgroup per query list (blockIdx.x): the lists of a plan are ordered in one launch
-__global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *num_wins, PlanOrderPack pack) {
+__global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *num_wins, int row_capacity,
+                                                                     PlanOrderPack pack) {
     const PlanOrderSet &ps = pack.s[blockIdx.x];
     const int *nq_valid = ps.nq_valid;
     const int max_key = ps.max_key;
@@ -851,7 +852,7 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
         *num_active = run;
         int rows = 0;
         for (int i = 0; i < PO_WAVES; ++i) rows += wave_q[i];
-        *num_rows = rows;
+        *num_rows = rows < row_capacity ? rows : row_capacity;  // rows past the capacity are dropped (caller's bound)
     }
     __syncthreads();
     // pass 1: q_off = exclusive scan of nq_valid in window order; perm = counting sort
@@ -940,7 +941,7 @@ extern "C" int mssvt_plan_order_multi(int num_sets, const int *num_wins_dev, con
         ps.rmeta = reinterpret_cast<float4 *>(host_qrow_meta[k]);
         ps.rsrc = reinterpret_cast<int2 *>(host_qrow_src[k]);
     }
-    k_plan_order<<<num_sets, PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, pack);
+    k_plan_order<<<num_sets, PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
     int grid = (win_capacity + 3) / 4;
     if (grid > 4096) grid = 4096;
     k_query_rows<<<dim3(grid, num_sets), 256, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);

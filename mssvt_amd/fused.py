@@ -175,6 +175,16 @@ def _qmeta(block, p):
     return {0: p.qmeta_even, 1: p.qmeta_odd, 2: p.qmeta_win1}[block.cbs_pattern]
 
 
+def _row_capacity(block, p, nq, num_voxels):
+    """Upper bound of the number of valid query slots over all windows: a voxel sits in one window's lists per
+    axis with an odd window size and in up to two per axis with an even one (the lists then cover w + 1 cells:
+    mssvt_backbone.py:94-97), and never more often than there are slots."""
+    overlap = 1
+    for w in block.win1_size:
+        overlap *= 2 if int(w) % 2 == 0 else 1
+    return max(min(int(num_voxels) * overlap, int(p.cap) * int(nq)), 1)
+
+
 @torch.no_grad()
 def _work_order(block, p, nq, num_voxels):
     """Work order + compact query rows of this cbs_pattern's query list (mssvt_plan_order): dict of
@@ -182,7 +192,7 @@ def _work_order(block, p, nq, num_voxels):
     pat = block.cbs_pattern
     if pat not in p.orders:
         dev = p.win_ind.device
-        cap_rows = max(int(num_voxels), 1)  # the query lists of one pattern are disjoint
+        cap_rows = _row_capacity(block, p, nq, num_voxels)
         o = dict(perm=torch.empty(p.cap, dtype=torch.int32, device=dev),
                  n_act=torch.empty(1, dtype=torch.int32, device=dev),
                  q_off=torch.empty(p.cap, dtype=torch.int32, device=dev),
@@ -198,12 +208,12 @@ def _work_order(block, p, nq, num_voxels):
     return p.orders[pat]
 
 
-def _query_scratch(p, num_voxels, ma, dev):
-    """qbuf of mssvt_block_attention_group: one row per valid query (query lists are disjoint, so at
-    most one per voxel), one region per head group."""
+def _query_scratch(p, rows, ma, dev):
+    """qbuf of mssvt_block_attention: one row per valid query (`rows` = the work order's row capacity), one
+    region per head group."""
     width = sum(4 * ((h + 3) // 4) * cg for h, cg in zip(ma.num_heads, ma.scale_dims))
-    if p.qbuf is None or p.qbuf.shape[0] < num_voxels or p.qbuf.shape[1] < width:
-        p.qbuf = torch.empty((max(num_voxels, 1), width), dtype=torch.float32, device=dev)
+    if p.qbuf is None or p.qbuf.shape[0] < rows or p.qbuf.shape[1] < width:
+        p.qbuf = torch.empty((max(rows, 1), width), dtype=torch.float32, device=dev)
     return p.qbuf
 
 
@@ -326,7 +336,7 @@ def block_forward(block, sp):
     attn = _attn_buffer(p, nq, C, x_in.device)
     od = _work_order(block, p, nq, N)
     ma = block.ms_attn
-    qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
+    qbuf = _query_scratch(p, od["row_cap"], ma, x_in.device)
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
     _attention_call(block, p, od, C, nq, xhat, qbuf, attn)
     interp = 1 if block.use_feature_interpolation else 0
@@ -367,7 +377,7 @@ def prepare_group(blocks, sp, p):
             seen.add(b.cbs_pattern)
             todo.append(b)
     if 1 < len(todo) <= 4:
-        cap_rows = max(int(N), 1)  # the query lists of one pattern are disjoint
+        cap_rows = max(_row_capacity(b, p, _query(b, p)[1], N) for b in todo)
         outs = []
         for b in todo:
             _, nq, _ = _query(b, p)
@@ -676,7 +686,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
         attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
         od = _work_order(blk, p, nq, x_in.shape[0])
         ma = blk.ms_attn
-        qbuf = _query_scratch(p, x_in.shape[0], ma, x_in.device)
+        qbuf = _query_scratch(p, od["row_cap"], ma, x_in.device)
         vs3, mn3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3])
 
         def launch_attn():

@@ -256,7 +256,15 @@ class MixedScaleSparseTransformerBlock(nn.Module):
         rows = (upd_ind.long() + p.win_v_start.unsqueeze(1)).reshape(-1)
         valid = (upd_ind >= 0).reshape(-1)
         feats = x_in.clone()
-        feats[rows[valid]] = upd[valid]
+        # a voxel may sit in several lists (even window sizes overlap, ref :94-97): the reference's
+        # index_put then keeps an arbitrary writer; the canonical order is "the highest flat slot wins"
+        # (DESIGN.md section 2), which the fused path's owner array and the oracle also apply
+        sel = torch.nonzero(valid, as_tuple=True)[0]
+        if sel.numel():
+            winner = torch.full((x_in.shape[0],), -1, dtype=torch.long, device=x_in.device)
+            winner.scatter_reduce_(0, rows[sel], sel, reduce="amax", include_self=True)
+            keep = sel[winner[rows[sel]] == sel]
+            feats = feats.index_copy(0, rows[keep], upd[keep])  # differentiable, no duplicate rows left
         new = self.drop_path(feats) + x_in  # untouched voxels end up as 2 * x_in (ref quirk, R12)
         new = new + self.drop_path(self.dropout1(self._ffn(new)))
         if hasattr(self, 'out_linear'):

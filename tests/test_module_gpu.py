@@ -262,3 +262,44 @@ def test_training_falls_back_to_differentiable_operator_path():
         fd = (loss_of(x.detach() + eps * d) - loss_of(x.detach() - eps * d)) / (2 * eps)
     an = (x.grad * d).sum()
     assert abs(float(fd) - float(an)) <= 2e-2 * max(1.0, abs(float(an))), (float(fd), float(an))
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("m1,pattern,interp", [(27, 1, True), (9, 1, False), (27, 2, True), (27, 0, False)])
+def test_even_window_sizes_overlapping_lists_match_oracle(impl, m1, pattern, interp):
+    """Even window sizes give (w+1)-cell win1 lists that overlap between neighbouring windows (ref quirk,
+    mssvt_backbone.py:94-97): a voxel is query / update target of up to 8 windows; the highest flat slot wins."""
+    from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
+    C, B, H = 32, 2, 40009
+    params = [dict(name="MixedScaleSparseTransformerBlock", channels=[C, 2 * C, C], num_heads=[2, 2],
+                   window_size=[[2, 2, 2], [4, 4, 4]], max_num_win1=m1, max_num_win2=64, cbs_mode="odd_even",
+                   cbs_pattern=pattern, key_num_sample=8, use_feature_interpolation=interp),
+              dict(name="MixedScaleSparseTransformerCompressBlock", channels=[C, 2 * C, C], num_heads=[2],
+                   window_size=[[1, 1, 32]], max_num_win1=32)]
+    pts = synthetic.make_batch_points(1500, B, 1)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], C, generator=torch.Generator().manual_seed(1)).numpy()
+    torch.manual_seed(1)
+    net = MixedScaleSparseTransformer(_cfg(params, H, C), C, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
+                                      synthetic.POINT_CLOUD_RANGE).eval()
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    want = block_ref.backbone_forward(sd, params, feats, vc, B, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
+                                      synthetic.POINT_CLOUD_RANGE, H)
+    net = net.to(DEV).set_impl(impl)
+    with torch.no_grad():
+        sp = net(dict(voxel_features=torch.from_numpy(feats).to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV),
+                      batch_size=B))["encoded_spconv_tensor"]
+    np.testing.assert_array_equal(sp.indices.cpu().numpy(), want.indices)
+    assert_feat_close(sp.features.cpu().numpy(), want.features)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 5, 6, 7, 12, 13, 17])
+def test_random_configurations_fused_matches_operator_path(seed):
+    """Random small backbones (window sizes incl. even ones, truncated lists, all cbs patterns, K, batch)."""
+    import subprocess
+    import sys
+    import os
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_fused_vs_ops.py")
+    r = subprocess.run([sys.executable, tool, "--one", str(seed)], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("%d " % seed)]
+    assert r.returncode == 0 and lines and lines[-1].split()[1] == "ok", (r.stdout[-400:], r.stderr[-400:])
