@@ -293,7 +293,7 @@ def test_even_window_sizes_overlapping_lists_match_oracle(impl, m1, pattern, int
     assert_feat_close(sp.features.cpu().numpy(), want.features)
 
 
-@pytest.mark.parametrize("seed", [0, 1, 5, 6, 7, 12, 13, 17])
+@pytest.mark.parametrize("seed", [0, 1, 5, 6, 7, 12, 13, 17, 1001, 1002, 1005, 1010, 1020])
 def test_random_configurations_fused_matches_operator_path(seed):
     """Random small backbones (window sizes incl. even ones, truncated lists, all cbs patterns, K, batch)."""
     import subprocess
