@@ -415,11 +415,10 @@ __device__ __forceinline__ FfnRowSrc ffn_row_src(const FfnArgs &a, float *hidden
     return r;
 }
 
-// weights -> LDS rows of LS floats, 8 float4 loads in flight per thread (a plain copy loop waits
-// for every load before its store: 17 round trips for 132 KiB)
-template <int COLS, int LS>
+// weights -> LDS rows of LS floats, UN float4 loads in flight per thread (a plain copy loop waits
+// for every load before its store: 17 round trips for 132 KiB; UN = 16 at 512 threads is ONE)
+template <int COLS, int LS, int UN = 16>
 __device__ __forceinline__ void ffn_stage_weights(float *dst, const float *src, int rows) {
-    constexpr int UN = 8;
     const int total = rows * COLS;
     for (int e0 = threadIdx.x * 4; e0 < total; e0 += blockDim.x * 4 * UN) {
         float4 v[UN];

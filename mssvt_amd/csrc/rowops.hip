@@ -8,18 +8,19 @@
 //                        emitted by the previous block's fused FFN epilogue, csrc/ffn.hip).
 #include "common.hip.h"
 
-#define BC_ROWS 16  // rows per thread
+#define BC_ROWS 16   // rows per thread
+#define BC_LDS 1024  // samples counted in LDS per workgroup
 __global__ void __launch_bounds__(256) k_batch_counts(const int *indices, int n, int batch_size, int *counts) {
     // one global atomic per (workgroup, sample present in it): single-address atomics cost ~11 ns each
-    // chip-wide, one per wavefront would be 1 161 of them for a 74k-voxel scene
-    __shared__ int first_b, first_cnt;
-    if (threadIdx.x == 0) {
-        first_b = -1;
-        first_cnt = 0;
-    }
+    // chip-wide -- one per wavefront would be 1 161 of them for a 74k-voxel scene, one per row of a
+    // workgroup that straddles a sample boundary 4 096
+    __shared__ int cnt[BC_LDS];
+    __shared__ int first_cnt;
+    for (int e = threadIdx.x; e < BC_LDS; e += 256) cnt[e] = 0;
+    if (threadIdx.x == 0) first_cnt = 0;
     __syncthreads();
     const long long base = (long long)blockIdx.x * 256 * BC_ROWS;
-    // samples are contiguous: nearly every workgroup sees one sample only -> count it in LDS
+    // samples are contiguous: nearly every workgroup sees one sample only -> count it in registers
     const int b_first = base < n ? indices[4 * base] : -1;
     int local = 0;
 #pragma unroll 4
@@ -29,13 +30,15 @@ __global__ void __launch_bounds__(256) k_batch_counts(const int *indices, int n,
         const int b = indices[4 * i];
         if (b < 0 || b >= batch_size) continue;
         if (b == b_first) ++local;
+        else if (b < BC_LDS) atomicAdd(&cnt[b], 1);
         else atomicAdd(counts + b, 1);
     }
     local = wave_sum_i(local);
     if (lane_id() == 0 && local) atomicAdd(&first_cnt, local);
     __syncthreads();
     if (threadIdx.x == 0 && first_cnt && b_first >= 0 && b_first < batch_size) atomicAdd(counts + b_first, first_cnt);
-    (void)first_b;
+    for (int e = threadIdx.x; e < BC_LDS && e < batch_size; e += 256)
+        if (cnt[e]) atomicAdd(counts + e, cnt[e]);
 }
 
 extern "C" int mssvt_batch_counts(const int *indices, int num_rows, int batch_size, int *counts, void *stream_) {
