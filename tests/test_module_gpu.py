@@ -148,26 +148,72 @@ def test_backbone_matches_oracle_on_waymo_shaped_scene(impl):
     assert_feat_close(sp.features.cpu().numpy(), want.features)
 
 
-def test_full_size_frame_fused_matches_operator_path():
-    """BASELINE configs[1] at full size (160k points, mssvt.yaml backbone, C=128): the oracle would take minutes,
-    so the property checked is agreement of the two independent HIP paths -- the fused kernels against the
-    operator-level composition (itself pinned to the oracle / goldens above) -- plus determinism."""
+@pytest.mark.parametrize("B", [1, 4])
+def test_full_size_frame_fused_matches_operator_path(B):
+    """BASELINE configs[1] (B = 1) and the per-GPU shape of configs[3] (4 scenes per GPU) at full size (160k
+    points per scene, mssvt.yaml backbone, C=128): the oracle would take minutes, so the property checked is
+    agreement of the two independent HIP paths -- the fused kernels against the operator-level composition
+    (itself pinned to the oracle / goldens above) -- plus determinism."""
     from mssvt_amd import config
     from mssvt_amd.dist import scene_seeds
-    pts = synthetic.make_batch_points(160000, 1, seed0=scene_seeds(0, 1)[0])
+    pts = synthetic.make_batch_points(160000, B, seed0=scene_seeds(0, B)[0])
     vc, _, _ = synthetic.voxelize_numpy(pts)
     feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(1000))
     torch.manual_seed(0)
     net = config.build_backbone_from_cfg().to(DEV).eval()
-    batch = lambda: dict(voxel_features=feats.to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV), batch_size=1)  # noqa: E731
+    batch = lambda: dict(voxel_features=feats.to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV), batch_size=B)  # noqa: E731
     with torch.no_grad():
         a = net.set_impl("fused")(batch())["encoded_spconv_tensor"]
         a2 = net(batch())["encoded_spconv_tensor"]
         b = net.set_impl("ops")(batch())["encoded_spconv_tensor"]
-    assert a.features.shape[0] > 30000 and torch.equal(a.indices, b.indices)
+    assert a.features.shape[0] > 30000 * B and torch.equal(a.indices, b.indices)
     assert torch.equal(a.features, a2.features), "the fused path must be run-to-run deterministic"
     assert_feat_close(a.features.cpu().numpy(), b.features.cpu().numpy())
     assert list(a.spatial_shape) == list(b.spatial_shape) and torch.equal(a.dense(), a2.dense())
+
+
+def test_scene_sharding_invariance_at_full_size():
+    """What the multi-GPU sharding relies on: a scene's output does not depend on which other scenes
+    share its batch.  Four 160k-point scenes in one batch == the same scenes one by one (rank-by-rank), bit for bit."""
+    from mssvt_amd import config
+    B = 4
+    pts = synthetic.make_batch_points(160000, B, seed0=40)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(7)).to(DEV)
+    vct = torch.from_numpy(vc).to(DEV)
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval().set_impl("fused")
+    with torch.no_grad():
+        whole = net(dict(voxel_features=feats, voxel_coords=vct, batch_size=B))["encoded_spconv_tensor"]
+        for b in range(B):
+            sel = vct[:, 0] == b
+            one_vc = vct[sel].clone()
+            one_vc[:, 0] = 0
+            one = net(dict(voxel_features=feats[sel], voxel_coords=one_vc, batch_size=1))["encoded_spconv_tensor"]
+            osel = whole.indices[:, 0] == b
+            got_idx = whole.indices[osel].clone()
+            got_idx[:, 0] = 0
+            assert torch.equal(got_idx, one.indices), "scene %d: output voxel order" % b
+            assert torch.equal(whole.features[osel], one.features), "scene %d: features" % b
+
+
+def test_dense_scene_enlarged_windows_full_size():
+    """BASELINE configs[4] at full size: 300k points, windows [5,5,7]/[11,11,11], every win1 voxel a query
+    (mssvt_amd/cfgs/mssvt_enlarged.yaml, C=128): fused kernels vs the operator-level composition."""
+    import os
+    from mssvt_amd import config
+    cfg = config.load_yaml(os.path.join(os.path.dirname(config.__file__), "cfgs", "mssvt_enlarged.yaml"))
+    pts = synthetic.make_batch_points(300000, 1, seed0=3)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(11))
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg(cfg).to(DEV).eval()
+    batch = lambda: dict(voxel_features=feats.to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV), batch_size=1)  # noqa: E731
+    with torch.no_grad():
+        a = net.set_impl("fused")(batch())["encoded_spconv_tensor"]
+        b = net.set_impl("ops")(batch())["encoded_spconv_tensor"]
+    assert a.features.shape[0] > 40000 and torch.equal(a.indices, b.indices)
+    assert_feat_close(a.features.cpu().numpy(), b.features.cpu().numpy())
 
 
 @pytest.mark.parametrize("impl", IMPLS)
