@@ -161,6 +161,21 @@ int mssvt_window_partition_compact(int x_wgs, int y_wgs, int z_wgs, int x_ws, in
                                    const int *v_indices, int *win_ind, int *xyz_to_vidx,
                                    int *vcount, int *workspace, void *stream);
 
+/* Several window partitions of ONE voxel list in the same five launches (grid.y = partition), e.g. a
+ * Block's [3,3,5] windows and the following CompressBlock's [1,1,32] pillars: both only depend on the voxel
+ * indices (ref: Block.window_partition, mssvt_backbone.py:139-152, recomputed per block there).
+ * Host arrays of num_sets (<= 4) entries: win_grid3 / win_size3 (3 ints each), max_num_wins, and the
+ * device pointers win_ind (N,4), tables (B,H,2; pre-filled with -1), vcount (B).  scratch_tables (array or
+ * entries may be NULL): a second -1-filled (B,H,2) buffer per partition for the first-occurrence pass --
+ * without it the table is its own scratch and is refilled in between.  workspaces: num_sets slices of
+ * workspace_stride_ints (>= mssvt_hash_workspace_ints) ints of one allocation; slice k holds
+ * [status, window count, ...] of partition k as in mssvt_window_partition_compact. */
+int mssvt_window_partition_multi(int num_sets, const int *host_win_grid3, const int *host_win_size3,
+                                 const int *host_max_num_wins, int num_voxels, int hash_size, int batch_size,
+                                 const int *v_indices, int *const *host_win_ind, int *const *host_tables,
+                                 int *const *host_scratch_tables, int *const *host_vcount, int *workspaces,
+                                 long long workspace_stride_ints, void *stream);
+
 /* Fused window plan of a two-scale Block: K3 + 2 x K7 + 2 x K8 + the key-mask logic
  * of ref mssvt_backbone.py:247-258 in one launch, one wavefront per window, hit lists
  * kept in LDS.  num_wins_dev: DEVICE scalar (e.g. workspace+1 of

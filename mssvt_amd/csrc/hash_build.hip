@@ -108,30 +108,48 @@ __global__ void __launch_bounds__(1024) k_vox_dup_fallback(VoxKey kf, int n, int
 }
 
 // ---- K2 ----------------------------------------------------------------------
+// Several partitions of the SAME voxel list (a Block's windows and the following CompressBlock's)
+// run in the same five launches: blockIdx.y = partition.  Per-set workspace layout:
+// [WS_HDR_INTS header | sample_base (B+1) | flags (n) | blockcnt].
+#define WP_MAX_SETS 4
+struct WinSet {
+    WinKey kf;
+    int num_windows;
+    slot_t *table;    // final table (key -> window rank)
+    slot_t *phase1;   // table of the min-insert pass: a caller-provided scratch table or `table` itself
+    int *w_indices, *win_compact, *vcount, *ws;
+};
+struct WinSets {
+    WinSet s[WP_MAX_SETS];
+};
+__device__ __forceinline__ int *ws_sample_base(int *ws) { return ws + WS_HDR_INTS; }
+__device__ __forceinline__ int *ws_flags(int *ws, int batch_size) { return ws + WS_HDR_INTS + batch_size + 1; }
+__device__ __forceinline__ int *ws_blockcnt(int *ws, int batch_size, int n) { return ws_flags(ws, batch_size) + n; }
+
 // pass 1: order-agnostic insert, value = min voxel index of the window
-__global__ void __launch_bounds__(TPB) k_win_insert_min(WinKey kf, int n, int hash_size,
-                                                        int batch_size, const int *v_indices,
-                                                        slot_t *table, int *ws) {
+__global__ void __launch_bounds__(TPB) k_win_insert_min(WinSets sets, int n, int hash_size,
+                                                        int batch_size, const int *v_indices) {
+    const WinSet &S = sets.s[blockIdx.y];
     int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     int b, key, wz, wy, wx;
-    if (!kf(v_indices, i, b, key, wz, wy, wx) || b < 0 || b >= batch_size) return;
-    if (table_insert_min(key, i, hash_size, table + (size_t)b * hash_size) < 0)
-        atomicOr(ws + WS_STATUS, ST_TABLE_OVERFLOW);
+    if (!S.kf(v_indices, i, b, key, wz, wy, wx) || b < 0 || b >= batch_size) return;
+    if (table_insert_min(key, i, hash_size, S.phase1 + (size_t)b * hash_size) < 0)
+        atomicOr(S.ws + WS_STATUS, ST_TABLE_OVERFLOW);
 }
 
 // pass 2: flag first occurrences, count them per 256-voxel block
-__global__ void __launch_bounds__(TPB) k_win_flag_count(WinKey kf, int n, int hash_size,
-                                                        int batch_size, const int *v_indices,
-                                                        const slot_t *table, int *flags,
-                                                        int *blockcnt) {
+__global__ void __launch_bounds__(TPB) k_win_flag_count(WinSets sets, int n, int hash_size,
+                                                        int batch_size, const int *v_indices) {
+    const WinSet &S = sets.s[blockIdx.y];
+    int *flags = ws_flags(S.ws, batch_size), *blockcnt = ws_blockcnt(S.ws, batch_size, n);
     __shared__ int wcnt[TPB / MSSVT_WAVE];
     int i = blockIdx.x * TPB + threadIdx.x;
     int flag = 0;
     if (i < n) {
         int b, key, wz, wy, wx;
-        if (kf(v_indices, i, b, key, wz, wy, wx) && b >= 0 && b < batch_size)
-            flag = table_find(key, hash_size, table + (size_t)b * hash_size) == i;
+        if (S.kf(v_indices, i, b, key, wz, wy, wx) && b >= 0 && b < batch_size)
+            flag = table_find(key, hash_size, S.phase1 + (size_t)b * hash_size) == i;
         flags[i] = flag;
     }
     unsigned long long m = __ballot(flag);
@@ -144,13 +162,16 @@ __global__ void __launch_bounds__(TPB) k_win_flag_count(WinKey kf, int n, int ha
     }
 }
 
-// pass 3 (one workgroup): exclusive scan of the block counts, per-sample bases.
+// pass 3 (one workgroup per partition): exclusive scan of the block counts, per-sample bases.
 // Samples are contiguous in v_indices (as every consumer of the reference
 // assumes, e.g. ref :81-87), so sample b starts at lower_bound(batch >= b).
-__global__ void __launch_bounds__(1024) k_win_scan(int n, int nblocks, int batch_size,
-                                                   int num_windows, const int *v_indices,
-                                                   const int *flags, int *blockcnt,
-                                                   int *sample_base, int *vcount, int *ws) {
+__global__ void __launch_bounds__(1024) k_win_scan(WinSets sets, int n, int nblocks, int batch_size,
+                                                   const int *v_indices) {
+    const WinSet &S = sets.s[blockIdx.y];
+    int *ws = S.ws, *sample_base = ws_sample_base(ws), *vcount = S.vcount;
+    const int *flags = ws_flags(ws, batch_size);
+    int *blockcnt = ws_blockcnt(ws, batch_size, n);
+    const int num_windows = S.num_windows;
     __shared__ int part[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -201,13 +222,13 @@ __global__ void __launch_bounds__(1024) k_win_scan(int n, int nblocks, int batch
 }
 
 // pass 4: rank first occurrences, emit window rows, ordered insert (key, rank)
-__global__ void __launch_bounds__(TPB) k_win_insert_ranked(WinKey kf, int n, int hash_size,
-                                                           int batch_size, int num_windows,
-                                                           const int *v_indices, const int *flags,
-                                                           const int *blockoff,
-                                                           const int *sample_base, slot_t *table,
-                                                           int *w_indices, int *win_compact,
-                                                           int *ws) {
+__global__ void __launch_bounds__(TPB) k_win_insert_ranked(WinSets sets, int n, int hash_size,
+                                                           int batch_size, const int *v_indices) {
+    const WinSet &S = sets.s[blockIdx.y];
+    int *ws = S.ws;
+    const int *flags = ws_flags(ws, batch_size), *blockoff = ws_blockcnt(ws, batch_size, n);
+    const int *sample_base = ws_sample_base(ws);
+    const int num_windows = S.num_windows;
     __shared__ int woff[TPB / MSSVT_WAVE];
     int i = blockIdx.x * TPB + threadIdx.x;
     int flag = i < n ? flags[i] : 0;
@@ -220,26 +241,29 @@ __global__ void __launch_bounds__(TPB) k_win_insert_ranked(WinKey kf, int n, int
     if (!flag) return;
     int r = blockoff[blockIdx.x] + before + __popcll(m & ((1ull << lane) - 1ull));
     int b, key, wz, wy, wx;
-    kf(v_indices, i, b, key, wz, wy, wx);
+    S.kf(v_indices, i, b, key, wz, wy, wx);
     int rank = r - sample_base[b];
-    if (win_compact) {  // (nw,4) rows [b,wz,wy,wx]: ref mssvt/mssvt_ops.py:45-53 done on device
-        reinterpret_cast<int4 *>(win_compact)[r] = make_int4(b, wz, wy, wx);
+    if (S.win_compact) {  // (nw,4) rows [b,wz,wy,wx]: ref mssvt/mssvt_ops.py:45-53 done on device
+        reinterpret_cast<int4 *>(S.win_compact)[r] = make_int4(b, wz, wy, wx);
     }
     if (rank >= num_windows) return;  // the reference writes out of bounds here
-    if (w_indices) {
-        int *w = w_indices + ((size_t)b * num_windows + rank) * 3;
+    if (S.w_indices) {
+        int *w = S.w_indices + ((size_t)b * num_windows + rank) * 3;
         w[0] = wz;  // ref :154-156
         w[1] = wy;
         w[2] = wx;
     }
-    int st = table_insert_ordered(key, rank, hash_size, table + (size_t)b * hash_size);
+    int st = table_insert_ordered(key, rank, hash_size, S.table + (size_t)b * hash_size);
     if (st & ST_TABLE_OVERFLOW) atomicOr(ws + WS_STATUS, ST_TABLE_OVERFLOW);
 }
 
-__global__ void k_fill_slots(slot_t *p, long long n) {
+// refill of the tables that served as their own phase-1 scratch (blockIdx.y = partition)
+__global__ void k_fill_slots_sets(WinSets sets, long long n) {
+    const WinSet &S = sets.s[blockIdx.y];
+    if (S.phase1 != S.table) return;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) p[i] = SLOT_EMPTY;
+    for (; i < n; i += stride) S.table[i] = SLOT_EMPTY;
 }
 
 // ---- host entry points --------------------------------------------------------
@@ -268,6 +292,23 @@ extern "C" int mssvt_build_mapping_with_hash(int x_max, int y_max, int z_max, in
     return mssvt_launch_status();
 }
 
+// all partitions of `sets` over one voxel list, five launches (grid.y = partition)
+static int window_partition_sets(const WinSets &sets, int num_sets, bool refill, int num_voxels, int hash_size,
+                                 int batch_size, const int *v_indices, hipStream_t stream) {
+    const int nblocks = divup(num_voxels, TPB);
+    const long long cells = (long long)batch_size * hash_size;
+    k_win_insert_min<<<dim3(nblocks, num_sets), TPB, 0, stream>>>(sets, num_voxels, hash_size, batch_size, v_indices);
+    k_win_flag_count<<<dim3(nblocks, num_sets), TPB, 0, stream>>>(sets, num_voxels, hash_size, batch_size, v_indices);
+    k_win_scan<<<dim3(1, num_sets), 1024, 0, stream>>>(sets, num_voxels, nblocks, batch_size, v_indices);
+    if (refill) {
+        long long fill_blocks = (cells + 1023) / 1024;
+        if (fill_blocks > 2048) fill_blocks = 2048;  // grid-stride the rest
+        k_fill_slots_sets<<<dim3((int)fill_blocks, num_sets), 1024, 0, stream>>>(sets, cells);
+    }
+    k_win_insert_ranked<<<dim3(nblocks, num_sets), TPB, 0, stream>>>(sets, num_voxels, hash_size, batch_size, v_indices);
+    return mssvt_launch_status();
+}
+
 // shared by the reference-shaped entry point and the compact one (fused.hip)
 int mssvt_window_partition_impl(int x_wgs, int y_wgs, int z_wgs, int x_ws, int y_ws, int z_ws,
                                 int num_voxels, int num_windows, int hash_size, int batch_size,
@@ -280,27 +321,61 @@ int mssvt_window_partition_impl(int x_wgs, int y_wgs, int z_wgs, int x_ws, int y
         e = hipMemsetAsync(vcount, 0, batch_size * sizeof(int), stream);
         return e == hipSuccess ? MSSVT_OK : (int)e;
     }
-    WinKey kf{x_wgs, y_wgs, z_wgs, x_ws, y_ws, z_ws};
-    slot_t *table = reinterpret_cast<slot_t *>(xyz_to_vidx);
-    const int nblocks = divup(num_voxels, TPB);
-    int *sample_base = workspace + WS_HDR_INTS;
-    int *flags = sample_base + (batch_size + 1);
-    int *blockcnt = flags + num_voxels;
-    const long long cells = (long long)batch_size * hash_size;
-    k_win_insert_min<<<nblocks, TPB, 0, stream>>>(kf, num_voxels, hash_size, batch_size,
-                                                   v_indices, table, workspace);
-    k_win_flag_count<<<nblocks, TPB, 0, stream>>>(kf, num_voxels, hash_size, batch_size,
-                                                   v_indices, table, flags, blockcnt);
-    k_win_scan<<<1, 1024, 0, stream>>>(num_voxels, nblocks, batch_size, num_windows, v_indices,
-                                       flags, blockcnt, sample_base, vcount, workspace);
-    long long fill_blocks = (cells + 1023) / 1024;
-    if (fill_blocks > 2048) fill_blocks = 2048;  // grid-stride the rest
-    k_fill_slots<<<(int)fill_blocks, 1024, 0, stream>>>(table, cells);
-    k_win_insert_ranked<<<nblocks, TPB, 0, stream>>>(kf, num_voxels, hash_size, batch_size,
-                                                      num_windows, v_indices, flags, blockcnt,
-                                                      sample_base, table, w_indices, win_compact,
-                                                      workspace);
-    return mssvt_launch_status();
+    WinSets sets;
+    WinSet &S = sets.s[0];
+    S.kf = WinKey{x_wgs, y_wgs, z_wgs, x_ws, y_ws, z_ws};
+    S.num_windows = num_windows;
+    S.table = S.phase1 = reinterpret_cast<slot_t *>(xyz_to_vidx);
+    S.w_indices = w_indices;
+    S.win_compact = win_compact;
+    S.vcount = vcount;
+    S.ws = workspace;
+    return window_partition_sets(sets, 1, true, num_voxels, hash_size, batch_size, v_indices, stream);
+}
+
+// Several partitions of one voxel list in the same launches (see include/mssvt_hip.h)
+extern "C" int mssvt_window_partition_multi(int num_sets, const int *host_win_grid3, const int *host_win_size3,
+                                            const int *host_max_num_wins, int num_voxels, int hash_size,
+                                            int batch_size, const int *v_indices, int *const *host_win_ind,
+                                            int *const *host_tables, int *const *host_scratch_tables,
+                                            int *const *host_vcount, int *workspaces, long long workspace_stride_ints,
+                                            void *stream_) {
+    if (num_sets < 1 || num_sets > WP_MAX_SETS || !host_win_grid3 || !host_win_size3 || !host_max_num_wins ||
+        !host_win_ind || !host_tables || !host_vcount || !workspaces || (!v_indices && num_voxels > 0) ||
+        hash_size <= 0 || batch_size <= 0 || num_voxels < 0 ||
+        workspace_stride_ints < mssvt_hash_workspace_ints(num_voxels, batch_size))
+        return MSSVT_E_BADARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    WinSets sets;
+    bool refill = false;
+    for (int k = 0; k < num_sets; ++k) {
+        const int *g = host_win_grid3 + 3 * k, *w = host_win_size3 + 3 * k;
+        if (!host_win_ind[k] || !host_tables[k] || !host_vcount[k] || w[0] <= 0 || w[1] <= 0 || w[2] <= 0)
+            return MSSVT_E_BADARG;
+        WinSet &S = sets.s[k];
+        S.kf = WinKey{g[0], g[1], g[2], w[0], w[1], w[2]};
+        S.num_windows = host_max_num_wins[k];
+        S.table = reinterpret_cast<slot_t *>(host_tables[k]);
+        S.phase1 = host_scratch_tables && host_scratch_tables[k] ? reinterpret_cast<slot_t *>(host_scratch_tables[k])
+                                                                 : S.table;
+        refill = refill || S.phase1 == S.table;
+        S.w_indices = nullptr;
+        S.win_compact = host_win_ind[k];
+        S.vcount = host_vcount[k];
+        S.ws = workspaces + (size_t)k * workspace_stride_ints;
+    }
+    // the headers of all partitions (status, window count) are cleared by ONE fill: the workspaces are
+    // slices of one allocation
+    hipError_t e = hipMemsetAsync(workspaces, 0, ((size_t)(num_sets - 1) * workspace_stride_ints + WS_HDR_INTS) * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    if (num_voxels == 0) {
+        for (int k = 0; k < num_sets; ++k) {
+            e = hipMemsetAsync(host_vcount[k], 0, batch_size * sizeof(int), stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        return MSSVT_OK;
+    }
+    return window_partition_sets(sets, num_sets, refill, num_voxels, hash_size, batch_size, v_indices, stream);
 }
 
 extern "C" int mssvt_window_with_hash(int x_wgs, int y_wgs, int z_wgs, int x_ws, int y_ws,

@@ -71,6 +71,33 @@ def level_state(sp):
     return st
 
 
+PARTITION_GROUPS = True  # a Block's window partition and the next CompressBlock's share their launches
+
+
+def _partition_key(block):
+    return (tuple(int(v) for v in block.win1_size), int(block.max_num_wins))
+
+
+def window_partition(block, sp, st):
+    """(win_ind, window table, windows per sample, workspace) of `block`'s windows on this level, cached per
+    (window size, max_num_wins).  The partition of the CompressBlock that ends the level only depends on the
+    same voxel indices, so it is computed in the same launches (`mssvt_window_partition_multi`)."""
+    parts = st.setdefault("partitions", {})
+    key = _partition_key(block)
+    if key not in parts:
+        todo = [block]
+        nxt = getattr(sp, "_next_compress", None)
+        if (PARTITION_GROUPS and nxt is not None and nxt is not block and _partition_key(nxt) not in parts
+                and _partition_key(nxt) != key):
+            todo.append(nxt)
+        shapes = [[sp.spatial_shape[i] // b.win1_size[i] for i in range(3)] for b in todo]
+        res = mssvt_ops.window_partitions_device([b.win1_size for b in todo], [b.max_num_wins for b in todo],
+                                                 sp.batch_size, sp.hash_size, shapes, sp.indices)
+        for b, r in zip(todo, res):
+            parts[_partition_key(b)] = r
+    return parts[key]
+
+
 def occupancy_columns(sp, st):
     """One 64-bit word per (b, x, y) column of the level (bit z = occupied), or None when z > 64."""
     if "occ" not in st:
@@ -109,8 +136,7 @@ def two_scale_plan(block, sp):
     p = _Plan()
     p.new_spatial_shape = [sp.spatial_shape[i] // block.win1_size[i] for i in range(3)]
     p.win_size_m = [sp.voxel_size[i] * block.win1_size[i] for i in range(3)]
-    p.win_ind, p.win_table, p.k_bs_cnt, ws = mssvt_ops.window_partition_device(
-        block.win1_size, block.max_num_wins, B, H, p.new_spatial_shape, sp.indices)
+    p.win_ind, p.win_table, p.k_bs_cnt, ws = window_partition(block, sp, st)
     p.num_wins = ws[1:2]  # device scalar
     p.status = ws[0:1]
     st.setdefault("status_words", []).append(p.status)
@@ -464,8 +490,7 @@ def one_scale_plan(block, sp, sync=True):
     p = _Plan()
     p.new_spatial_shape = [sp.spatial_shape[i] // block.win1_size[i] for i in range(3)]
     p.win_size_m = [sp.voxel_size[i] * block.win1_size[i] for i in range(3)]
-    p.win_ind, p.win_table, p.k_bs_cnt, ws = mssvt_ops.window_partition_device(
-        block.win1_size, block.max_num_wins, B, H, p.new_spatial_shape, sp.indices)
+    p.win_ind, p.win_table, p.k_bs_cnt, ws = window_partition(block, sp, st)
     p.num_wins = ws[1:2]
     cap = max(N, 1)
     ns = block.max_num_win1

@@ -376,6 +376,9 @@ class MixedScaleSparseTransformer(nn.Module):
                 sp._next_norm1 = self.backbone[i + 1].norm1 if i + 1 < len(self.backbone) else None
                 # the Blocks from here on (fused.prepare_group orders / tabulates all that share a plan at once)
                 sp._plan_group = [b for b in self.backbone[i:] if isinstance(b, MixedScaleSparseTransformerBlock)]
+                # the CompressBlock that ends this resolution level: its window partition rides along with the Blocks'
+                sp._next_compress = next((b for b in self.backbone[i:]
+                                          if isinstance(b, MixedScaleSparseTransformerCompressBlock)), None)
                 sp = blk(sp, block_idx=i)
         finally:
             mssvt_ops.FillArena.current = None

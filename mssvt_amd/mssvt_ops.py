@@ -120,6 +120,28 @@ def window_partition_device(win_size, max_num_wins, batch_size, hash_size, spati
     return win, table, vcount, ws
 
 
+def window_partitions_device(win_sizes, max_num_wins, batch_size, hash_size, spatial_shapes, voxel_indices):
+    """Several partitions of one voxel list in the same launches (``mssvt_window_partition_multi``):
+    a list of (win_ind_padded, table, k_bs_cnt, workspace) as ``window_partition_device`` returns them."""
+    k = len(win_sizes)
+    _check_int32(voxel_indices, "voxel_indices")
+    dev = voxel_indices.device
+    n = voxel_indices.shape[0]
+    tables = [full_neg1((batch_size, hash_size, 2), dev) for _ in range(k)]
+    scratch = [full_neg1((batch_size, hash_size, 2), dev) for _ in range(k)]
+    wins = [torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev) for _ in range(k)]
+    vcounts = torch.empty((k, batch_size), dtype=torch.int32, device=dev)
+    stride = int(_lib.lib().mssvt_hash_workspace_ints(_i(int(n)), _i(int(batch_size))))
+    ws = torch.empty((k, stride), dtype=torch.int32, device=dev)
+    ints = lambda rows: (ctypes.c_int * (3 * k))(*[int(v) for r in rows for v in r])  # noqa: E731
+    ptrs = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])  # noqa: E731
+    _lib.call("mssvt_window_partition_multi", _i(k), ints(spatial_shapes), ints(win_sizes),
+              (ctypes.c_int * k)(*[int(m) for m in max_num_wins]), _i(n), _i(int(hash_size)), _i(int(batch_size)),
+              _lib.ptr(voxel_indices), ptrs(wins), ptrs(tables), ptrs(scratch), ptrs([vcounts[i] for i in range(k)]),
+              _lib.ptr(ws), ctypes.c_longlong(stride), _lib.stream())
+    return [(wins[i], tables[i], vcounts[i], ws[i]) for i in range(k)]
+
+
 def get_non_empty_window_center(win_size, max_num_wins, batch_size, hash_size, spatial_shape,
                                 voxel_indices):
     """-> (win_ind (nw,4) int32 [b,wz,wy,wx], window table (B,H,2) int32).
