@@ -366,7 +366,12 @@ extern "C" int mssvt_window_partition_multi(int num_sets, const int *host_win_gr
     }
     // the headers of all partitions (status, window count) are cleared by ONE fill: the workspaces are
     // slices of one allocation
-    hipError_t e = hipMemsetAsync(workspaces, 0, ((size_t)(num_sets - 1) * workspace_stride_ints + WS_HDR_INTS) * sizeof(int), stream);
+    // (rounded up to 4 KiB inside the allocation: the runtime splits a fill whose size is not a multiple of
+    // 16 bytes into two launches; the words behind a header are scratch that is written before it is read)
+    size_t zero_bytes = ((size_t)(num_sets - 1) * workspace_stride_ints + WS_HDR_INTS) * sizeof(int);
+    const size_t all_bytes = (size_t)num_sets * workspace_stride_ints * sizeof(int);
+    if (((zero_bytes + 4095) & ~(size_t)4095) <= all_bytes) zero_bytes = (zero_bytes + 4095) & ~(size_t)4095;
+    hipError_t e = hipMemsetAsync(workspaces, 0, zero_bytes, stream);
     if (e != hipSuccess) return (int)e;
     if (num_voxels == 0) {
         for (int k = 0; k < num_sets; ++k) {

@@ -176,17 +176,42 @@ def two_scale_plan(block, sp):
     return p
 
 
-def _attn_buffer(p, nq, C, dev):
-    """(cap*nq + 1, C) rows of attention output, one per (window, query slot), shared by the
-    blocks of a plan; only rows of valid slots are ever written, the last row stays zero."""
+def _attn_buffers_alloc(p, specs, dev):
+    """Attention output rows for the (nq, C) combinations of `specs` in ONE allocation per C that ends in a
+    single zero row: buffer i is the view from its first row to the end, so the shared zero row is row
+    `total - 1 - offset_i` of it (one fill launch per plan instead of one per buffer)."""
     bufs = getattr(p, "attn_bufs", None)
     if bufs is None:
-        bufs = p.attn_bufs = {}
-    if (nq, C) not in bufs:
-        b = torch.empty((p.cap * nq + 1, C), dtype=torch.float32, device=dev)
-        b[-1].zero_()
-        bufs[(nq, C)] = b
-    return bufs[(nq, C)]
+        bufs, p.attn_zero = {}, {}
+        p.attn_bufs = bufs
+    by_c = {}
+    for nq, C in specs:
+        if (nq, C) not in bufs and (nq, C) not in by_c.setdefault(C, []):
+            by_c[C].append((nq, C))
+    for C, todo in by_c.items():
+        if not todo:
+            continue
+        total = sum(p.cap * nq for nq, _ in todo) + 1
+        big = torch.empty((total, C), dtype=torch.float32, device=dev)
+        big[-1].zero_()
+        off = 0
+        for nq, _ in todo:
+            bufs[(nq, C)] = big[off:]
+            p.attn_zero[(nq, C)] = total - 1 - off
+            off += p.cap * nq
+
+
+def _attn_buffer(p, nq, C, dev):
+    """(>= cap*nq + 1, C) rows of attention output, one per (window, query slot), shared by the blocks of a
+    plan; only rows of valid slots are ever written, row `_attn_zero_row` stays zero."""
+    if (nq, C) not in getattr(p, "attn_bufs", ()):
+        _attn_buffers_alloc(p, [(nq, C)], dev)
+    return p.attn_bufs[(nq, C)]
+
+
+def _attn_zero_row(p, nq, C, dev):
+    _attn_buffer(p, nq, C, dev)
+    return p.attn_zero[(nq, C)]
 
 
 def _query(block, p):
@@ -396,6 +421,7 @@ def prepare_group(blocks, sp, p):
     N = sp.indices.shape[0]
     ia = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])  # noqa: E731
     pa = lambda ts: (ctypes.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
+    _attn_buffers_alloc(p, [(_query(b, p)[1], b.linear1.in_features) for b in blocks], dev)
     # --- work orders, one per cbs_pattern
     todo, seen = [], set(p.orders)
     for b in blocks:
@@ -442,7 +468,7 @@ def prepare_group(blocks, sp, p):
             q_ind, nq, owner_q = _query(b, p)
             upd_ind, n_upd, owner = (p.ind_win1, b.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
             nqs.append(nq); nus.append(n_upd); its.append(interp); qis.append(q_ind); uis.append(upd_ind)
-            ows.append(owner); zrs.append(p.cap * nq)
+            ows.append(owner); zrs.append(_attn_zero_row(p, nq, b.linear1.in_features, dev))
         _lib.call("mssvt_block_interp_table_multi", _i(len(todo)), ia(nqs), ia(nus), ia(its), _lib.ptr(sp.indices),
                   _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), pa(qis), pa(uis),
                   pa(ows), vs3, mn3, ia(zrs), pa([rows[i] for i in range(len(todo))]),
@@ -465,7 +491,8 @@ def _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, m
         tab_w = torch.empty((max(N, 1), 4), dtype=torch.float32, device=dev)  # written with tab_row
         _lib.call("mssvt_block_interp_table", _i(nq), _i(n_upd), _i(interp), _lib.ptr(sp.indices),
                   _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind),
-                  _lib.ptr(upd_ind), _lib.ptr(owner), vs3, mn3, _i(p.cap * nq), _lib.ptr(tab_row),
+                  _lib.ptr(upd_ind), _lib.ptr(owner), vs3, mn3,
+                  _i(_attn_zero_row(p, nq, block.linear1.in_features, dev)), _lib.ptr(tab_row),
                   _lib.ptr(tab_w), _lib.stream())
         tabs[key] = (tab_row, tab_w)
     return tabs[key]
