@@ -176,6 +176,22 @@ int mssvt_window_partition_multi(int num_sets, const int *host_win_grid3, const 
                                  int *const *host_scratch_tables, int *const *host_vcount, int *workspaces,
                                  long long workspace_stride_ints, void *stream);
 
+/* Everything a resolution level needs before its first Block, in one call behind ONE fill:
+ * samples' voxel counts (with_bs_cnt, mssvt_backbone.py:124-130), the voxel hash table
+ * (SparseTensor.build_map_table, mssvt_utils.py:31-48 = mssvt_build_mapping_with_hash), the occupancy
+ * columns of mssvt_occupancy_columns (optional: NULL) and num_sets (0..4) window partitions as in
+ * mssvt_window_partition_multi.  zero_region / zero_bytes: one caller allocation that this function clears and
+ * that must contain v_bs_cnt (B ints), the first 4 ints of map_workspace, occ_columns (B*X*Y words) and
+ * the first 4 ints of every partition workspace (and the vcount arrays when num_voxels == 0);
+ * MSSVT_E_BADARG otherwise.  map_table and the partition tables / scratch tables are pre-filled with -1 by the
+ * caller as for the single entry points. */
+int mssvt_level_setup(int num_voxels, int batch_size, int x_max, int y_max, int z_max, int hash_size,
+                      const int *v_indices, void *zero_region, long long zero_bytes, int *v_bs_cnt, int *map_table,
+                      int *map_workspace, unsigned long long *occ_columns, int num_sets, const int *host_win_grid3,
+                      const int *host_win_size3, const int *host_max_num_wins, int *const *host_win_ind,
+                      int *const *host_tables, int *const *host_scratch_tables, int *const *host_vcount,
+                      int *workspaces, long long workspace_stride_ints, void *stream);
+
 /* Fused window plan of a two-scale Block: K3 + 2 x K7 + 2 x K8 + the key-mask logic
  * of ref mssvt_backbone.py:247-258 in one launch, one wavefront per window, hit lists
  * kept in LDS.  num_wins_dev: DEVICE scalar (e.g. workspace+1 of

@@ -25,6 +25,12 @@ static inline int mssvt_launch_status() {
 
 static inline int divup(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// launch-only halves of entry points whose output / status words must be zero on entry: the public
+// functions clear them with their own fill, mssvt_level_setup clears all of them with ONE
+int mssvt_batch_counts_launch(const int *indices, int num_rows, int batch_size, int *counts, hipStream_t stream);
+int mssvt_occupancy_columns_launch(const int *indices, int num_voxels, int batch_size, int x_max, int y_max, int z_max,
+                                   unsigned long long *columns, hipStream_t stream);
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (MSSVT_WAVE - 1); }
 
 // Ordering point for LDS traffic between lanes of ONE wave (LDS operations of a

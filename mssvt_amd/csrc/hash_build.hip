@@ -272,6 +272,10 @@ extern "C" long long mssvt_hash_workspace_ints(int num_voxels, int batch_size) {
     return WS_HDR_INTS + (batch_size + 1) + n + (n + TPB - 1) / TPB + 64;
 }
 
+static int build_mapping_launch(int x_max, int y_max, int z_max, int num_voxels, int hash_size, int batch_size,
+                                const int *v_indices, const int *v_bs_cnt, int *xyz_to_vidx, int *workspace,
+                                hipStream_t stream);
+
 extern "C" int mssvt_build_mapping_with_hash(int x_max, int y_max, int z_max, int num_voxels,
                                              int hash_size, int batch_size, const int *v_indices,
                                              const int *v_bs_cnt, int *xyz_to_vidx, int *workspace,
@@ -282,6 +286,13 @@ extern "C" int mssvt_build_mapping_with_hash(int x_max, int y_max, int z_max, in
     hipStream_t stream = (hipStream_t)stream_;
     hipError_t e = hipMemsetAsync(workspace, 0, WS_HDR_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
+    return build_mapping_launch(x_max, y_max, z_max, num_voxels, hash_size, batch_size, v_indices, v_bs_cnt,
+                                xyz_to_vidx, workspace, stream);
+}
+
+static int build_mapping_launch(int x_max, int y_max, int z_max, int num_voxels, int hash_size, int batch_size,
+                                const int *v_indices, const int *v_bs_cnt, int *xyz_to_vidx, int *workspace,
+                                hipStream_t stream) {
     if (num_voxels == 0) return MSSVT_OK;  // an empty table (the caller pre-fills it with -1)
     VoxKey kf{x_max, y_max, z_max};
     slot_t *table = reinterpret_cast<slot_t *>(xyz_to_vidx);
@@ -333,21 +344,18 @@ int mssvt_window_partition_impl(int x_wgs, int y_wgs, int z_wgs, int x_ws, int y
     return window_partition_sets(sets, 1, true, num_voxels, hash_size, batch_size, v_indices, stream);
 }
 
-// Several partitions of one voxel list in the same launches (see include/mssvt_hip.h)
-extern "C" int mssvt_window_partition_multi(int num_sets, const int *host_win_grid3, const int *host_win_size3,
-                                            const int *host_max_num_wins, int num_voxels, int hash_size,
-                                            int batch_size, const int *v_indices, int *const *host_win_ind,
-                                            int *const *host_tables, int *const *host_scratch_tables,
-                                            int *const *host_vcount, int *workspaces, long long workspace_stride_ints,
-                                            void *stream_) {
+// host arrays of mssvt_window_partition_multi -> kernel argument pack
+static int window_sets_from_host(WinSets &sets, bool &refill, int num_sets, const int *host_win_grid3,
+                                 const int *host_win_size3, const int *host_max_num_wins, int num_voxels,
+                                 int hash_size, int batch_size, const int *v_indices, int *const *host_win_ind,
+                                 int *const *host_tables, int *const *host_scratch_tables, int *const *host_vcount,
+                                 int *workspaces, long long workspace_stride_ints) {
     if (num_sets < 1 || num_sets > WP_MAX_SETS || !host_win_grid3 || !host_win_size3 || !host_max_num_wins ||
         !host_win_ind || !host_tables || !host_vcount || !workspaces || (!v_indices && num_voxels > 0) ||
         hash_size <= 0 || batch_size <= 0 || num_voxels < 0 ||
         workspace_stride_ints < mssvt_hash_workspace_ints(num_voxels, batch_size))
         return MSSVT_E_BADARG;
-    hipStream_t stream = (hipStream_t)stream_;
-    WinSets sets;
-    bool refill = false;
+    refill = false;
     for (int k = 0; k < num_sets; ++k) {
         const int *g = host_win_grid3 + 3 * k, *w = host_win_size3 + 3 * k;
         if (!host_win_ind[k] || !host_tables[k] || !host_vcount[k] || w[0] <= 0 || w[1] <= 0 || w[2] <= 0)
@@ -364,6 +372,23 @@ extern "C" int mssvt_window_partition_multi(int num_sets, const int *host_win_gr
         S.vcount = host_vcount[k];
         S.ws = workspaces + (size_t)k * workspace_stride_ints;
     }
+    return MSSVT_OK;
+}
+
+// Several partitions of one voxel list in the same launches (see include/mssvt_hip.h)
+extern "C" int mssvt_window_partition_multi(int num_sets, const int *host_win_grid3, const int *host_win_size3,
+                                            const int *host_max_num_wins, int num_voxels, int hash_size,
+                                            int batch_size, const int *v_indices, int *const *host_win_ind,
+                                            int *const *host_tables, int *const *host_scratch_tables,
+                                            int *const *host_vcount, int *workspaces, long long workspace_stride_ints,
+                                            void *stream_) {
+    WinSets sets;
+    bool refill = false;
+    int rc = window_sets_from_host(sets, refill, num_sets, host_win_grid3, host_win_size3, host_max_num_wins,
+                                   num_voxels, hash_size, batch_size, v_indices, host_win_ind, host_tables,
+                                   host_scratch_tables, host_vcount, workspaces, workspace_stride_ints);
+    if (rc != MSSVT_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
     // the headers of all partitions (status, window count) are cleared by ONE fill: the workspaces are
     // slices of one allocation
     // (rounded up to 4 KiB inside the allocation: the runtime splits a fill whose size is not a multiple of
@@ -381,6 +406,53 @@ extern "C" int mssvt_window_partition_multi(int num_sets, const int *host_win_gr
         return MSSVT_OK;
     }
     return window_partition_sets(sets, num_sets, refill, num_voxels, hash_size, batch_size, v_indices, stream);
+}
+
+// Everything a resolution level needs before its first Block, behind ONE fill (see include/mssvt_hip.h)
+extern "C" int mssvt_level_setup(int num_voxels, int batch_size, int x_max, int y_max, int z_max, int hash_size,
+                                 const int *v_indices, void *zero_region, long long zero_bytes, int *v_bs_cnt,
+                                 int *map_table, int *map_workspace, unsigned long long *occ_columns, int num_sets,
+                                 const int *host_win_grid3, const int *host_win_size3,
+                                 const int *host_max_num_wins, int *const *host_win_ind, int *const *host_tables,
+                                 int *const *host_scratch_tables, int *const *host_vcount, int *workspaces,
+                                 long long workspace_stride_ints, void *stream_) {
+    if (!zero_region || zero_bytes <= 0 || !v_bs_cnt || !map_table || !map_workspace || batch_size <= 0 ||
+        hash_size <= 0 || num_voxels < 0 || (!v_indices && num_voxels > 0) || x_max <= 0 || y_max <= 0 || z_max <= 0 ||
+        num_sets < 0)
+        return MSSVT_E_BADARG;
+    if (occ_columns && z_max > 64) return MSSVT_E_TOOLARGE;
+    WinSets sets;
+    bool refill = false;
+    if (num_sets > 0) {
+        int rc = window_sets_from_host(sets, refill, num_sets, host_win_grid3, host_win_size3, host_max_num_wins,
+                                       num_voxels, hash_size, batch_size, v_indices, host_win_ind, host_tables,
+                                       host_scratch_tables, host_vcount, workspaces, workspace_stride_ints);
+        if (rc != MSSVT_OK) return rc;
+    }
+    // every word the kernels below accumulate into must lie inside the region cleared here
+    const char *z0 = (const char *)zero_region, *z1 = z0 + zero_bytes;
+    auto inside = [&](const void *p, size_t bytes) { return (const char *)p >= z0 && (const char *)p + bytes <= z1; };
+    bool ok = inside(v_bs_cnt, (size_t)batch_size * sizeof(int)) && inside(map_workspace, WS_HDR_INTS * sizeof(int)) &&
+              (!occ_columns || inside(occ_columns, (size_t)batch_size * x_max * y_max * sizeof(unsigned long long)));
+    for (int k = 0; k < num_sets; ++k) ok = ok && inside(sets.s[k].ws, WS_HDR_INTS * sizeof(int));
+    if (num_voxels == 0)
+        for (int k = 0; k < num_sets; ++k) ok = ok && inside(host_vcount[k], (size_t)batch_size * sizeof(int));
+    if (!ok) return MSSVT_E_BADARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipError_t e = hipMemsetAsync(zero_region, 0, (size_t)zero_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    int rc = mssvt_batch_counts_launch(v_indices, num_voxels, batch_size, v_bs_cnt, stream);
+    if (rc != MSSVT_OK) return rc;
+    rc = build_mapping_launch(x_max, y_max, z_max, num_voxels, hash_size, batch_size, v_indices, v_bs_cnt, map_table,
+                              map_workspace, stream);
+    if (rc != MSSVT_OK) return rc;
+    if (occ_columns) {
+        rc = mssvt_occupancy_columns_launch(v_indices, num_voxels, batch_size, x_max, y_max, z_max, occ_columns, stream);
+        if (rc != MSSVT_OK) return rc;
+    }
+    if (num_sets > 0 && num_voxels > 0)
+        return window_partition_sets(sets, num_sets, refill, num_voxels, hash_size, batch_size, v_indices, stream);
+    return MSSVT_OK;
 }
 
 extern "C" int mssvt_window_with_hash(int x_wgs, int y_wgs, int z_wgs, int x_ws, int y_ws,

@@ -46,6 +46,10 @@ extern "C" int mssvt_batch_counts(const int *indices, int num_rows, int batch_si
     hipStream_t stream = (hipStream_t)stream_;
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)batch_size * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
+    return mssvt_batch_counts_launch(indices, num_rows, batch_size, counts, stream);
+}
+
+int mssvt_batch_counts_launch(const int *indices, int num_rows, int batch_size, int *counts, hipStream_t stream) {
     if (num_rows > 0)
         k_batch_counts<<<divup(num_rows, 256 * BC_ROWS), 256, 0, stream>>>(indices, num_rows, batch_size, counts);
     return mssvt_launch_status();

@@ -764,6 +764,11 @@ extern "C" int mssvt_occupancy_columns(const int *indices, int num_voxels, int b
     hipStream_t stream = (hipStream_t)stream_;
     hipError_t e = hipMemsetAsync(columns, 0, (size_t)batch_size * x_max * y_max * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return (int)e;
+    return mssvt_occupancy_columns_launch(indices, num_voxels, batch_size, x_max, y_max, z_max, columns, stream);
+}
+
+int mssvt_occupancy_columns_launch(const int *indices, int num_voxels, int batch_size, int x_max, int y_max, int z_max,
+                                   unsigned long long *columns, hipStream_t stream) {
     if (num_voxels > 0)
         k_occupancy_columns<<<divup(num_voxels, 256), 256, 0, stream>>>(indices, num_voxels, batch_size, x_max, y_max,
                                                                       z_max, columns);

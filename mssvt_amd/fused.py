@@ -98,6 +98,64 @@ def window_partition(block, sp, st):
     return parts[key]
 
 
+LEVEL_SETUP = True  # counts + voxel table + occupancy columns + window partitions of the input level in one call
+
+
+@torch.no_grad()
+def setup_input_level(blocks, sp_kwargs):
+    """SparseTensor of the backbone input with everything its first resolution level needs (`mssvt_level_setup`:
+    per-sample counts, voxel hash table, occupancy columns, the window partitions of the Blocks up to and
+    including the first CompressBlock) produced behind ONE fill instead of five.  None when not applicable."""
+    from .mssvt_utils import SparseTensor
+    from .mssvt_backbone import MixedScaleSparseTransformerCompressBlock as Compress
+    indices = sp_kwargs["indices"]
+    n = indices.shape[0]
+    if not (LEVEL_SETUP and indices.is_cuda and n > 0 and indices.dtype == torch.int32 and indices.is_contiguous()):
+        return None
+    dev = indices.device
+    B, H = int(sp_kwargs["batch_size"]), int(sp_kwargs["hash_size"])
+    X, Y, Z = (int(v) for v in sp_kwargs["spatial_shape"])
+    todo, keys = [], set()
+    for b in blocks:
+        k = _partition_key(b)
+        if k not in keys and len(todo) < 4:
+            keys.add(k)
+            todo.append(b)
+        if isinstance(b, Compress):
+            break
+    k = len(todo)
+    use_occ = OCC_COLUMNS and Z <= 64
+    al = lambda v: (int(v) + 63) // 64 * 64  # noqa: E731  (256-byte aligned pieces)
+    stride = al(_lib.lib().mssvt_hash_workspace_ints(_i(n), _i(B)))
+    sizes = [al(B), stride, k * stride, al(2 * B * X * Y) if use_occ else 0]
+    zero = torch.empty(sum(sizes), dtype=torch.int32, device=dev)  # cleared by the call itself
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    cnt = zero[offs[0]:offs[0] + B]
+    map_ws = zero[offs[1]:offs[1] + stride]
+    part_ws = zero[offs[2]:offs[2] + k * stride].view(k, stride) if k else None
+    occ = zero[offs[3]:offs[3] + 2 * B * X * Y].view(torch.int64) if use_occ else None
+    table = mssvt_ops.full_neg1((B, H, 2), dev)
+    tables = [mssvt_ops.full_neg1((B, H, 2), dev) for _ in range(k)]
+    scratch = [mssvt_ops.full_neg1((B, H, 2), dev) for _ in range(k)]
+    wins = [torch.empty((n, 4), dtype=torch.int32, device=dev) for _ in range(k)]
+    vcounts = torch.empty((max(k, 1), B), dtype=torch.int32, device=dev)
+    shapes = [[[X, Y, Z][i] // b.win1_size[i] for i in range(3)] for b in todo]
+    ints = lambda rows: (ctypes.c_int * max(3 * k, 1))(*[int(v) for r in rows for v in r])  # noqa: E731
+    ptrs = lambda ts: (ctypes.c_void_p * max(k, 1))(*[t.data_ptr() for t in ts])  # noqa: E731
+    _lib.call("mssvt_level_setup", _i(n), _i(B), _i(X), _i(Y), _i(Z), _i(H), _lib.ptr(indices), _lib.ptr(zero),
+              ctypes.c_longlong(zero.numel() * 4), _lib.ptr(cnt), _lib.ptr(table), _lib.ptr(map_ws), _lib.ptr(occ),
+              _i(k), ints(shapes), ints([b.win1_size for b in todo]),
+              (ctypes.c_int * max(k, 1))(*[int(b.max_num_wins) for b in todo]), ptrs(wins), ptrs(tables),
+              ptrs(scratch), ptrs([vcounts[i] for i in range(k)]), _lib.ptr(part_ws), ctypes.c_longlong(stride),
+              _lib.stream())
+    sp = SparseTensor(map_table=table, **sp_kwargs)
+    sp.v_bs_cnt, sp._cnt_of, sp.map_status = cnt, sp.indices, map_ws[0:1]
+    sp._level = {"indices": sp.indices, "v_bs_cnt": cnt, "plans": {}, "occ": occ,
+                 "partitions": {_partition_key(b): (wins[i], tables[i], vcounts[i], part_ws[i])
+                                for i, b in enumerate(todo)}}
+    return sp
+
+
 def occupancy_columns(sp, st):
     """One 64-bit word per (b, x, y) column of the level (bit z = occupied), or None when z > 64."""
     if "occ" not in st:

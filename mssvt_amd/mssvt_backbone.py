@@ -367,10 +367,15 @@ class MixedScaleSparseTransformer(nn.Module):
             arena = mssvt_ops.FillArena(getattr(self, '_fill_demand', 0), feats.device)
         mssvt_ops.FillArena.current = arena
         try:
-            sp = SparseTensor(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
-                              voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
-                              batch_size=batch_dict['batch_size'], hash_size=self.hash_size,
-                              map_table=None, gather_dict=None)
+            kw = dict(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
+                      voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
+                      batch_size=batch_dict['batch_size'], hash_size=self.hash_size, gather_dict=None)
+            sp = None
+            if arena is not None and not torch.is_grad_enabled():
+                from . import fused  # one call sets up the whole input level for the fused blocks
+                sp = fused.setup_input_level(self.backbone, kw)
+            if sp is None:
+                sp = SparseTensor(map_table=None, **kw)
             for i, blk in enumerate(self.backbone):
                 # lets a fused FFN epilogue also emit the next block's norm1 (mssvt_amd/fused.py)
                 sp._next_norm1 = self.backbone[i + 1].norm1 if i + 1 < len(self.backbone) else None

@@ -182,3 +182,38 @@ def test_occupancy_columns_bit_exact(pts, B):
     _lib.call("mssvt_occupancy_columns", _lib.ptr(ind) if pts else ctypes.c_void_p(0), i(vc.shape[0]), i(B), i(X), i(Y),
               i(Z), _lib.ptr(cols), _lib.stream())
     np.testing.assert_array_equal(cols.cpu().numpy().view(np.uint64).reshape(B, X, Y), want)
+
+
+@pytest.mark.parametrize("pts,B", [(20000, 3), (160000, 1)])
+def test_level_setup_equals_the_single_entry_points(pts, B):
+    """mssvt_level_setup (counts + voxel table + occupancy columns + the partitions of the level behind one fill)
+    against the entry points it bundles, bit for bit."""
+    from mssvt_amd import config, fused, mssvt_ops
+    from mssvt_amd.mssvt_utils import SparseTensor
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(dev).eval()
+    vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(pts, B, 33))
+    idx = torch.from_numpy(vc).to(dev)
+    kw = dict(features=torch.zeros(idx.shape[0], 128, device=dev), indices=idx, spatial_shape=net.grid_size,
+              voxel_size=net.voxel_size, point_cloud_range=net.point_cloud_range, batch_size=B,
+              hash_size=net.hash_size, gather_dict=None)
+    with torch.no_grad():
+        got = fused.setup_input_level(net.backbone, kw)
+        want = SparseTensor(map_table=None, **kw)
+    assert got is not None
+    assert torch.equal(got.v_bs_cnt, want.v_bs_cnt) and torch.equal(got.map_table, want.map_table)
+    assert int(got.map_status.item()) == 0
+    st_w = fused.level_state(want)
+    assert torch.equal(got._level["occ"], fused.occupancy_columns(want, st_w))
+    keys = list(got._level["partitions"])
+    assert len(keys) == 2  # the Blocks' [3,3,5] windows and the CompressBlock's pillars
+    for blk in net.backbone:
+        key = fused._partition_key(blk)
+        win, table, vcount, ws = got._level["partitions"][key]
+        shape = [net.grid_size[i] // blk.win1_size[i] for i in range(3)]
+        win_w, table_w, vcount_w, ws_w = mssvt_ops.window_partition_device(blk.win1_size, blk.max_num_wins, B,
+                                                                           net.hash_size, shape, idx)
+        st, nw = ws[:2].tolist()
+        assert [st, nw] == ws_w[:2].tolist() and st == 0 and nw > 0
+        assert torch.equal(win[:nw], win_w[:nw]) and torch.equal(table, table_w) and torch.equal(vcount, vcount_w)
