@@ -103,3 +103,16 @@ def test_drop_path_train_eval():
     torch.manual_seed(0)
     y = dp(x)
     assert set(y.unique().tolist()) <= {0.0, 2.0} and 300 < (y[:, 0] == 0).sum() < 700
+
+
+def test_height_compression_mirror_state_dict_and_cfg_keys():
+    """Drop-in surface of the MAP_TO_BEV consumer: reference config keys and checkpoint names."""
+    from mssvt_amd.height_compression import HeightCompression
+    m = HeightCompression(dict(NUM_BEV_FEATURES=8, COMPRESS_LAYER_NUMS=2, LAYER_STRIDES=[1, 1, 1],
+                               LAYER_DIALATIONS=[1, 2, 2], LAYER_PADDINGS=[1, 2, 2]))
+    keys = set(m.state_dict())
+    assert {"compress_layers.0.weight", "compress_layers.1.weight", "compress_layers.1.running_mean",
+            "compress_layers.3.weight", "compress_layers.4.bias"} <= keys
+    assert m.compress_layers[3].dilation == (2, 2) and m.compress_layers[3].padding == (2, 2)
+    assert HeightCompression(dict(NUM_BEV_FEATURES=8, COMPRESS_LAYER_NUMS=0)).compress_layers is None
+    assert m.num_bev_features == 8 and m.use_amp is False

@@ -349,3 +349,34 @@ def test_random_configurations_fused_matches_operator_path(seed):
     r = subprocess.run([sys.executable, tool, "--one", str(seed)], capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("%d " % seed)]
     assert r.returncode == 0 and lines and lines[-1].split()[1] == "ok", (r.stdout[-400:], r.stderr[-400:])
+
+
+@pytest.mark.parametrize("layers", [0, 3])
+def test_height_compression_on_backbone_output(layers):
+    """MAP_TO_BEV behind the backbone: gather-kernel dense() + view + library convs == the reference formulation
+    (scatter into a zero grid, permute, view: mssvt_utils.py:6-19,50-62, height_compression.py:41-50) on the CPU."""
+    from mssvt_amd import config
+    from mssvt_amd.height_compression import HeightCompression
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval()
+    pts = synthetic.make_batch_points(20000, 2, 9)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(2))
+    hc = HeightCompression(dict(NUM_BEV_FEATURES=128, COMPRESS_LAYER_NUMS=layers)).eval()
+    with torch.no_grad():
+        bd = net(dict(voxel_features=feats.to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV), batch_size=2))
+        got = hc.to(DEV)(bd)
+        sp = bd["encoded_spconv_tensor"]
+        X, Y, Z = (int(v) for v in sp.spatial_shape)
+        idx, f = sp.indices.cpu().long(), sp.features.cpu()
+        grid = torch.zeros(2, Z, Y, X, f.shape[1])
+        grid[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = f
+        want = grid.permute(0, 4, 1, 2, 3).contiguous().view(2, f.shape[1] * Z, Y, X)
+        if layers:
+            for layer in hc.cpu().compress_layers:
+                want = layer(want)
+    assert got["spatial_features"].shape == want.shape and got["spatial_features_stride"] == 1
+    if layers == 0:
+        assert torch.equal(got["spatial_features"].cpu(), want)  # pure data movement: bit exact
+    else:
+        torch.testing.assert_close(got["spatial_features"].cpu(), want, rtol=1e-3, atol=1e-3)
