@@ -25,6 +25,7 @@
 #define PLAN_MAX_WPB 4
 
 struct PlanArgs {
+    int fps_nmax, fps_bs;  // LDS sampler scratch (0: every list fits a register sampler)
     int x_max, y_max, z_max, x_ws, y_ws, z_ws;
     int max_odd, max_even, max_win1, max_win2;
     int hash_size, batch_size;
@@ -332,11 +333,13 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
     int *l1_c = l1_ind + a.max_win1;
     int *l2_ind = l1_c + a.max_win1;
     int *l2_c = l2_ind + a.max_win2;
-    const int nmax = a.max_win1 > a.max_win2 ? a.max_win1 : a.max_win2;
+    // scratch of the LDS sampler: only lists beyond the register samplers' reach get it (fps_nmax = fps_bs = 0
+    // otherwise -- half of a wave's LDS at the 7 x 7 x 7 windows, i.e. 32 instead of 22 windows per CU in flight)
+    const int nmax = a.fps_nmax;
     float *temp = reinterpret_cast<float *>(l2_c + a.max_win2);
     int *fps_out = reinterpret_cast<int *>(temp + nmax);
     float *bv = reinterpret_cast<float *>(fps_out + a.key_num_sample);
-    const int bsmax = a.bs1 > a.bs2 ? a.bs1 : a.bs2;
+    const int bsmax = a.fps_bs;
     int *bidx = reinterpret_cast<int *>(bv + bsmax);
 
     for (int k = lane; k < a.max_win1; k += MSSVT_WAVE) {
@@ -591,7 +594,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
             fps_on_list_regs<8>(lc, n, K, bs, fps_out, lane);
         else if (FPS_TPL >= 16 && bs == 1024)
             fps_on_list_regs<FPS_TPL >= 16 ? 16 : 1>(lc, n, K, bs, fps_out, lane);
-        else
+        else if (a.fps_bs)
             fps_on_list(lc, n, K, bs, temp, bv, bidx, fps_out, lane);
         wave_lds_sync();
         PSTAMP()
@@ -699,7 +702,11 @@ extern "C" int mssvt_window_plan_two(
     }
     const int nmax = max_num_win1 > max_num_win2 ? max_num_win1 : max_num_win2;
     const int bsmax = a.bs1 > a.bs2 ? a.bs1 : a.bs2;
-    a.lds_words_per_wave = 2 * max_num_win1 + 2 * max_num_win2 + nmax + key_num_sample + 2 * bsmax;
+    // the register samplers cover reference block sizes up to 512 (1024 in the <16> instantiation)
+    const bool lds_fps = bsmax > 1024;
+    a.fps_nmax = lds_fps ? nmax : 0;
+    a.fps_bs = lds_fps ? bsmax : 0;
+    a.lds_words_per_wave = 2 * max_num_win1 + 2 * max_num_win2 + a.fps_nmax + key_num_sample + 2 * a.fps_bs;
     a.occ = nullptr;
     a.fx0 = a.fy0 = a.fnx = a.fny = 0;
     a.q_packed = packed_offsets;
