@@ -109,9 +109,11 @@ def main():
     from mssvt_amd import dist as mdist
     rank, world, local_rank = mdist.env_rank_world()
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the hot path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = mdist.init("nccl", dev)
+    # MSSVT_BENCH_ONE_DEVICE=1 (debugging the N > 1 code path on a single-GPU box): every rank on cuda:0, gloo
+    one_dev = os.environ.get("MSSVT_BENCH_ONE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if one_dev else local_rank)
+    torch.cuda.set_device(dev)
+    dist = mdist.init("gloo" if one_dev else "nccl", dev)
 
     from mssvt_amd import config, roofline
     torch.manual_seed(0)
