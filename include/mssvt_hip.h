@@ -289,7 +289,8 @@ int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_interpolation, 
  * voxel row (-1 = pad) of every pair row.  disjoint_lists != 0 (no voxel in two lists: odd
  * window sizes): pair row = the voxel's feature row, pad row of window w = num_voxels + w,
  * pair_win must be pre-filled with -1, pair_base = -1.  Otherwise rows are reserved through
- * counters[0] (= rows handed out) and pair_base[w] is the window's first row.            */
+ * counters[0] (= rows handed out; cleared by this call) and pair_base[w] is the window's
+ * first row.  With disjoint lists counters[0] is not touched.                            */
 int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws,
                           int max_num_win1, int hash_size, int num_win1, const int *vox_query_win1,
                           const int *win_indices, const int *num_wins_dev, int win_capacity,

@@ -234,8 +234,10 @@ extern "C" int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, 
         max_num_win1 <= 0)
         return MSSVT_E_BADARG;
     if (win_capacity <= 0) return MSSVT_OK;
-    hipError_t e = hipMemsetAsync(counters, 0, sizeof(int), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    if (!disjoint_lists) {  // the row counter is only touched when rows have to be reserved (overlapping lists)
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(int), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
     k_window_plan_one<<<divup(win_capacity, CP_WPB), CP_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(
         x_max, y_max, z_max, x_ws, y_ws, z_ws, max_num_win1, hash_size, num_win1, vox_query_win1,
         win_indices, num_wins_dev, reinterpret_cast<const slot_t *>(xyz_to_vidx), v_bs_cnt, with_pad,
