@@ -805,25 +805,35 @@ struct PlanOrderPack {
     PlanOrderSet s[PO_MAX_SETS];
 };
 
-// one workgroup per query list (blockIdx.x): the lists of a plan are ordered in one launch
+// blockIdx.y = query list (the lists of a plan are ordered in one launch), blockIdx.x = one of G workgroups that
+// each own a contiguous run of windows.  G > 1: PHASE 0 leaves every workgroup's key histogram and row total in
+// `scratch` (G x (PO_KEYS + 1) ints, the head of the list's row array that k_query_rows only fills afterwards),
+// PHASE 1 turns the other workgroups' histograms into its offsets and then sorts its own run exactly like the
+// single workgroup does.  G == 1: PHASE 1 alone.
+template <int PHASE>
 __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *num_wins, int row_capacity,
                                                                      PlanOrderPack pack) {
-    const PlanOrderSet &ps = pack.s[blockIdx.x];
+    const PlanOrderSet &ps = pack.s[blockIdx.y];
     const int *nq_valid = ps.nq_valid;
     const int max_key = ps.max_key;
+    const int G = gridDim.x, gidx = blockIdx.x;
+    int *scratch = reinterpret_cast<int *>(ps.rsrc);
     int *perm = ps.perm, *num_active = ps.num_active, *q_off = ps.q_off, *num_rows = ps.num_rows;
     // per-wave histograms: copies sit PO_KEYS (odd) words apart -> different LDS banks, so the 16
     // waves' atomics on the few populated keys proceed in parallel
     __shared__ int hist[PO_WAVES][PO_KEYS];
     __shared__ int key_base[PO_KEYS];
     __shared__ int wave_q[PO_WAVES];
+    __shared__ int rows_before, rows_all;
     const int nw = *num_wins;
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
     for (int k = threadIdx.x; k < PO_WAVES * PO_KEYS; k += blockDim.x) (&hist[0][0])[k] = 0;
     __syncthreads();
-    // each wave owns a contiguous run of windows
-    const int per_wave = (nw + PO_WAVES - 1) / PO_WAVES;
-    const int wb = min(wv * per_wave, nw), we = min(wb + per_wave, nw);
+    // each workgroup, and inside it each wave, owns a contiguous run of windows
+    const int per_wg = (nw + G - 1) / G;
+    const int gb = min(gidx * per_wg, nw), ge = min(gb + per_wg, nw);
+    const int per_wave = (ge - gb + PO_WAVES - 1) / PO_WAVES;
+    const int wb = min(gb + wv * per_wave, ge), we = min(wb + per_wave, ge);
     // pass 0: histogram of the query counts + the run's total
     int total = 0;
     for (int base = wb; base < we; base += MSSVT_WAVE * PO_V) {
@@ -843,15 +853,48 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
     total = wave_sum_i(total);
     if (lane == 0) wave_q[wv] = total;
     __syncthreads();
-    // hist[wv][k] -> exclusive prefix over the waves, key totals -> key_base (heaviest key first)
+    if (PHASE == 0) {  // publish this workgroup's histogram and row total
+        if (threadIdx.x <= max_key) {
+            int c = 0;
+            for (int i = 0; i < PO_WAVES; ++i) c += hist[i][threadIdx.x];
+            scratch[gidx * (PO_KEYS + 1) + threadIdx.x] = c;
+        }
+        if (threadIdx.x == 0) {
+            int rows = 0;
+            for (int i = 0; i < PO_WAVES; ++i) rows += wave_q[i];
+            scratch[gidx * (PO_KEYS + 1) + PO_KEYS] = rows;
+        }
+        return;
+    }
+    // hist[wv][k] -> exclusive prefix over the earlier workgroups and the waves, key totals -> key_base
+    // (heaviest key first)
     if (threadIdx.x <= max_key) {
-        int run = 0;
+        int run = 0, all = 0;
+        for (int gg = 0; gg < G && G > 1; ++gg) {
+            const int c = scratch[gg * (PO_KEYS + 1) + threadIdx.x];
+            run += gg < gidx ? c : 0;
+            all += c;
+        }
+        int own = 0;
         for (int i = 0; i < PO_WAVES; ++i) {
             const int c = hist[i][threadIdx.x];
             hist[i][threadIdx.x] = run;
             run += c;
+            own += c;
         }
-        key_base[threadIdx.x] = run;
+        key_base[threadIdx.x] = G > 1 ? all : own;
+    }
+    if (threadIdx.x == PO_WAVES * MSSVT_WAVE - 1) {
+        int before = 0, all = 0;
+        for (int gg = 0; gg < G && G > 1; ++gg) {
+            const int c = scratch[gg * (PO_KEYS + 1) + PO_KEYS];
+            before += gg < gidx ? c : 0;
+            all += c;
+        }
+        if (G == 1)
+            for (int i = 0; i < PO_WAVES; ++i) all += wave_q[i];
+        rows_before = before;
+        rows_all = all;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -861,14 +904,14 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
             key_base[k] = run;
             run += c;
         }
-        *num_active = run;
-        int rows = 0;
-        for (int i = 0; i < PO_WAVES; ++i) rows += wave_q[i];
-        *num_rows = rows < row_capacity ? rows : row_capacity;  // rows past the capacity are dropped (caller's bound)
+        if (gidx == 0) {
+            *num_active = run;
+            *num_rows = rows_all < row_capacity ? rows_all : row_capacity;  // rows past the capacity are dropped (caller's bound)
+        }
     }
     __syncthreads();
     // pass 1: q_off = exclusive scan of nq_valid in window order; perm = counting sort
-    int carry = 0;
+    int carry = rows_before;
     for (int i = 0; i < wv; ++i) carry += wave_q[i];
     for (int base = wb; base < we; base += MSSVT_WAVE * PO_V) {
         int v[PO_V];
@@ -953,7 +996,16 @@ extern "C" int mssvt_plan_order_multi(int num_sets, const int *num_wins_dev, con
         ps.rmeta = reinterpret_cast<float4 *>(host_qrow_meta[k]);
         ps.rsrc = reinterpret_cast<int2 *>(host_qrow_src[k]);
     }
-    k_plan_order<<<num_sets, PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
+    // workgroups per list: one per ~2k windows of capacity, as long as their histograms fit the head of the row array
+    int G = win_capacity / 2048;
+    if (G > 64) G = 64;
+    while (G > 1 && (long long)G * (PO_KEYS + 1) > 2LL * row_capacity) --G;
+    if (G > 1) {
+        k_plan_order<0><<<dim3(G, num_sets), PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
+        k_plan_order<1><<<dim3(G, num_sets), PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
+    } else {
+        k_plan_order<1><<<dim3(1, num_sets), PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
+    }
     int grid = (win_capacity + 3) / 4;
     if (grid > 4096) grid = 4096;
     k_query_rows<<<dim3(grid, num_sets), 256, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
