@@ -1,5 +1,7 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
+"""Developer tool: 3000 forwards over four scenes of different sizes -- allocator footprint must stay flat and
+the output of a scene bit-identical every time it comes round."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mssvt_amd import config
 dev = torch.device("cuda", 0)

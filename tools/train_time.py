@@ -1,5 +1,7 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
+"""Developer tool: one training step (forward + backward + SGD) of the backbone on a 160k-point scene --
+autograd on means the differentiable operator path (K6 / K11 backward kernels); prints ms per step and peak memory."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mssvt_amd import config
 dev = torch.device("cuda", 0)
