@@ -99,7 +99,9 @@ __device__ __forceinline__ void cf_stage_lists(int *lst, const CmpArgs &a, int t
         const int r = e / a.ns, sl = e % a.ns;
         const int w = min(tile * 16 + r, nw - 1);
         const int cnt = a.win_cnt[w];
-        lst[e] = a.win_vstart[w] + a.k_ind[(size_t)w * a.ns + (sl < cnt ? sl : 0)];
+        // (a window whose voxels were all dropped by an overflowing hash table has cnt = 0 and slot 0 = -1: the
+        // frame ends in an error anyway, but every row read on the way must exist)
+        lst[e] = a.win_vstart[w] + max(a.k_ind[(size_t)w * a.ns + (sl < cnt ? sl : 0)], 0);
     }
     wave_lds_sync();
 }

@@ -453,7 +453,11 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
             const int pk = lst == 0 ? lo_c[p] : lst == 1 ? le_c[p] : lst == 2 ? l1_c[p] : l2_c[p];
             const int ox = (pk & 255) - 64, oy = ((pk >> 8) & 255) - 64, oz = ((pk >> 16) & 255) - 64;
             const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
-            const int sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
+            int sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
+            // an occupied cell the table does not know: only after a voxel-table overflow (status bit set, the
+            // caller raises at the end of the frame).  Until then every index downstream must stay in range and
+            // the counts must match the entries: the entry is redirected to the sample's first voxel.
+            if (sv == MSSVT_EMPTY) sv = 0;
             if (lst == 0) {
                 a.ind_odd[(size_t)w * a.max_odd + p] = sv;
                 if (sv != MSSVT_EMPTY) {

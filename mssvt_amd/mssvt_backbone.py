@@ -23,12 +23,25 @@ Two execution paths compute the same function:
 import numpy as np
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 from . import mssvt_ops, pointnet2_utils, query_table
 from .mssvt_utils import MixedScaleAttention, SparseTensor, batch_counts
 
 MAX_NUM_WINS = 90000  # ref: mssvt_backbone.py:56
 DEFAULT_IMPL = "fused"
+
+
+class PointwiseConv1d(nn.Conv1d):
+    """``nn.Conv1d(c_in, c_out, 1)`` (same parameters and state-dict entries as the reference's ``pos_proj`` layers,
+    mssvt_backbone.py:43-54) evaluated as ONE matrix product over all (window, slot) columns: the convolution
+    library treats these (nw, 6..C, <= 64) inputs as images -- 24 ms per call on MI355X, and its weight gradient
+    falls back to a naive kernel (115 ms) -- where a (nw * slots, c_in) x (c_in, c_out) GEMM takes microseconds.
+    Only the operator-level path (training, fallback shapes) runs it; the fused kernels have their own form."""
+
+    def forward(self, x):  # (B, c_in, L) -> (B, c_out, L)
+        assert self.kernel_size == (1,) and self.stride == (1,) and self.groups == 1
+        return F.linear(x.transpose(1, 2), self.weight.squeeze(-1), self.bias).transpose(1, 2)
 
 
 class DropPath(nn.Module):
@@ -85,9 +98,9 @@ class MixedScaleSparseTransformerBlock(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
         self.drop_path = DropPath(drop_path) if drop_path and drop_path > 0. else nn.Identity()
         assert len(window_size) <= 2
-        pos = [nn.Conv1d(6, in_channels, 1), nn.ReLU()]
+        pos = [PointwiseConv1d(6, in_channels, 1), nn.ReLU()]
         if len(window_size) != 2:  # single-window blocks get a second layer (ref :48-54)
-            pos += [nn.Conv1d(in_channels, in_channels, 1), nn.ReLU()]
+            pos += [PointwiseConv1d(in_channels, in_channels, 1), nn.ReLU()]
         self.pos_proj = nn.Sequential(*pos)
         self.key_num_sample = key_num_sample
         self.max_num_wins = MAX_NUM_WINS

@@ -236,18 +236,28 @@ def test_empty_and_tiny_scenes(impl):
         assert sp.dense().shape == (1, 128, 1, 470, 470)
 
 
-def test_hash_overflow_is_loud():
-    """A voxel hash table that is too small for the scene must raise (the reference drops voxels silently)."""
+@pytest.mark.parametrize("hash_size", [1000, 5000])
+@pytest.mark.parametrize("garbage", [0x7f7f7f7f, -1, 0x7fc00000])
+def test_hash_overflow_is_loud(hash_size, garbage):
+    """A hash table that is too small for the scene (1000: voxel and window tables, 5000: the voxel table only;
+    20k points = ~9k voxels, ~4k windows) must raise (the reference drops voxels silently) -- and must get there
+    without a stray access: the status is only read at the end of the frame, so every kernel in between runs
+    on tables with holes.  The allocator's free blocks are filled with garbage first (large ints / -1 / NaN bits)
+    so that anything read without having been written shows."""
     from mssvt_amd import config
     from mssvt_amd._lib import MssvtHipError
     torch.manual_seed(0)
     net = config.build_backbone_from_cfg().to(DEV).eval()
-    net.hash_size = 1000  # 20k-point scene: ~9k voxels per sample
+    net.hash_size = hash_size
     pts = synthetic.make_batch_points(20000, 1, 3)
     vc, _, _ = synthetic.voxelize_numpy(pts)
-    with pytest.raises(MssvtHipError), torch.no_grad():
-        net(dict(voxel_features=torch.randn(vc.shape[0], 128, device=DEV), voxel_coords=torch.from_numpy(vc).to(DEV),
-                 batch_size=1))
+    feats, vct = torch.randn(vc.shape[0], 128, device=DEV), torch.from_numpy(vc).to(DEV)
+    for _ in range(2):
+        junk = [torch.full((32 << 20,), garbage, dtype=torch.int32, device=DEV) for _ in range(8)]  # 1 GiB
+        del junk
+        with pytest.raises(MssvtHipError), torch.no_grad():
+            net(dict(voxel_features=feats, voxel_coords=vct, batch_size=1))
+        torch.cuda.synchronize()
 
 
 def test_enlarged_windows_stride1_fused_matches_operator_path():
@@ -380,3 +390,27 @@ def test_height_compression_on_backbone_output(layers):
         assert torch.equal(got["spatial_features"].cpu(), want)  # pure data movement: bit exact
     else:
         torch.testing.assert_close(got["spatial_features"].cpu(), want, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("garbage", [0x7fc00000, 0x7f7f7f7f, -1])
+@pytest.mark.parametrize("impl", IMPLS)
+def test_results_do_not_depend_on_stale_memory(impl, garbage):
+    """Every buffer is `torch.empty`: nothing may be read before it is written.  Same frame, first on a clean
+    allocator, then with the allocator's free blocks full of NaN bits / huge ints / -1: bit-identical."""
+    from mssvt_amd import config
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval().set_impl(impl)
+    pts = synthetic.make_batch_points(40000, 2, 21)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats, vct = torch.randn(vc.shape[0], 128, device=DEV), torch.from_numpy(vc).to(DEV)
+    run = lambda: net(dict(voxel_features=feats, voxel_coords=vct, batch_size=2))["encoded_spconv_tensor"]  # noqa: E731
+    with torch.no_grad():
+        a = run()
+        fa, ia, da = a.features.clone(), a.indices.clone(), a.dense().clone()
+        del a
+        for _ in range(2):
+            junk = [torch.full((32 << 20,), garbage, dtype=torch.int32, device=DEV) for _ in range(16)]  # 2 GiB
+            del junk
+            b = run()
+            assert torch.equal(ia, b.indices) and torch.equal(fa, b.features) and torch.equal(da, b.dense())
+            del b
