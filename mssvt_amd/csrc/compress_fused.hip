@@ -394,7 +394,9 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
         }
 #pragma unroll
         for (int S = 0; S < NT; ++S) {
-            const float inv = 1.0f / sum[S];  // every window owns >= 1 voxel
+            // every window owns >= 1 listed voxel -- except one made by a voxel outside the grid (invalid input: the
+            // voxel table skips it, K2 does not): the reference would average its padded slots, here the row is bo
+            const float inv = sum[S] > 0.f ? 1.0f / sum[S] : 0.f;
             o[S][0] *= inv; o[S][1] *= inv; o[S][2] *= inv; o[S][3] *= inv;
         }
         f32x4 acc[NT];

@@ -414,3 +414,41 @@ def test_results_do_not_depend_on_stale_memory(impl, garbage):
             b = run()
             assert torch.equal(ia, b.indices) and torch.equal(fa, b.features) and torch.equal(da, b.dense())
             del b
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_invalid_voxel_coordinates_never_fault(impl):
+    """Voxels outside the grid, negative coordinates, duplicated coordinates, batch indices out of range (no VFE
+    produces them; the reference skips them in K1 and is undefined elsewhere): the forward returns finite rows or
+    raises, on garbage-filled allocator memory, and the process survives."""
+    from mssvt_amd import config
+    from mssvt_amd._lib import MssvtHipError
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval().set_impl(impl)
+    X = synthetic.GRID_SIZE[0]
+    for case in range(6):
+        vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(20000, 2, 5))
+        vc = vc.copy()
+        n = vc.shape[0]
+        for j, r in enumerate(range(100, n, n // 50)):
+            kind = case if case < 5 else j % 5
+            if kind == 0:
+                vc[r, 3] = X + 5
+            elif kind == 1:
+                vc[r, 1] = -1
+            elif kind == 2:
+                vc[r, 1:] = vc[r - 1, 1:]
+            elif kind == 3:
+                vc[r, 0] = 7
+            else:
+                vc[r, 0] = -1
+        feats, vct = torch.randn(n, 128, device=DEV), torch.from_numpy(vc).to(DEV)
+        junk = [torch.full((32 << 20,), 0x7f7f7f7f, dtype=torch.int32, device=DEV) for _ in range(8)]
+        del junk
+        try:
+            with torch.no_grad():
+                out = net(dict(voxel_features=feats, voxel_coords=vct, batch_size=2))["encoded_spconv_tensor"]
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(out.features).all()), "case %d" % case
+        except MssvtHipError:
+            torch.cuda.synchronize()
