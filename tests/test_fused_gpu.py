@@ -217,3 +217,21 @@ def test_level_setup_equals_the_single_entry_points(pts, B):
         st, nw = ws[:2].tolist()
         assert [st, nw] == ws_w[:2].tolist() and st == 0 and nw > 0
         assert torch.equal(win[:nw], win_w[:nw]) and torch.equal(table, table_w) and torch.equal(vcount, vcount_w)
+
+
+def test_voxelizer_drops_non_finite_and_foreign_points():
+    """NaN / inf / far coordinates and batch indices outside [0, B) never reach a voxel (the reference's
+    float -> int conversion of a NaN is implementation defined; here it is 'dropped')."""
+    from mssvt_amd import voxelize
+    p = synthetic.make_batch_points(20000, 2, 1).copy()
+    bad = [10, 11, 12, 13, 14, 15]
+    p[10, 1], p[11, 2], p[12, 3], p[13, 1], p[14, 0], p[15, 0] = np.nan, np.inf, -np.inf, 1e30, 5, -1
+    good = np.ones(p.shape[0], bool)
+    good[bad] = False
+    want_vc, want_inv, kept = synthetic.voxelize_numpy(p[good])
+    vc, pv = voxelize.voxelize(torch.from_numpy(p).to(DEV), synthetic.POINT_CLOUD_RANGE, synthetic.VOXEL_SIZE,
+                               synthetic.GRID_SIZE, 2)
+    pv = pv.cpu().numpy()
+    assert (pv[bad] == -1).all()
+    np.testing.assert_array_equal(vc.cpu().numpy(), want_vc)
+    np.testing.assert_array_equal(pv[good][kept], want_inv)
