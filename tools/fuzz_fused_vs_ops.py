@@ -57,8 +57,15 @@ for seed in seeds:
         vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(pts, B, seed))
         f = torch.randn(vc.shape[0], C, generator=torch.Generator().manual_seed(seed)).to(dev)
         bd = lambda: dict(voxel_features=f, voxel_coords=torch.from_numpy(vc).to(dev), batch_size=B)
+        def junk():  # MSSVT_FUZZ_GARBAGE=1: the allocator's free blocks hold garbage (reads of unwritten memory show)
+            if os.environ.get("MSSVT_FUZZ_GARBAGE", "0") == "1":
+                j = [torch.full((32 << 20,), rng.choice([0x7f7f7f7f, -1, 0x7fc00000]), dtype=torch.int32, device=dev)
+                     for _ in range(8)]
+                del j
         with torch.no_grad():
+            junk()
             a = net.set_impl("fused")(bd())["encoded_spconv_tensor"]
+            junk()
             b = net.set_impl("ops")(bd())["encoded_spconv_tensor"]
         ok = torch.equal(a.indices, b.indices)
         err = float(((a.features - b.features).abs() / b.features.abs().clamp(min=1.0)).max()) if ok else float("nan")
