@@ -16,6 +16,7 @@ What is pinned:
 The fixtures hold data only (inputs, weights, intermediates, outputs).
 """
 import os
+import sys
 
 import numpy as np
 import torch
@@ -228,9 +229,30 @@ def gen_backbone(mods):
     print("backbone out", sp.features.shape, "dense", tuple(dense.shape))
 
 
+def gen_even_windows(mods):
+    """Even window sizes: (w+1)-cell overlapping win1 lists (ref mssvt_backbone.py:94-97), a voxel in the lists of
+    several windows; the reference's scatter `select_v[win1_ind.flatten()] = ...` (:320-322) then has duplicate
+    rows -- on the CPU the last (highest flat slot) write wins, which is the canonical order of DESIGN.md."""
+    WE = [[2, 2, 2], [4, 4, 4]]
+    # torch documents an index_put with duplicate indices as undefined; its CPU kernel splits the rows over the
+    # intra-op threads, so the winner depends on the thread count.  ONE thread = sequential execution = the
+    # last (highest flat slot) write wins: the canonical order the oracle and the HIP paths implement.
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        run_block(mods, "block_evenwin_odd_interp", "block", WE, [2, 2], 27, 64, 1, True, seed=30)
+        run_block(mods, "block_evenwin_all_nointerp", "block", WE, [1, 3], 27, 64, 2, False, seed=31, key_num_sample=16)
+        run_block(mods, "block_evenwin_trunc", "block", WE, [2, 2], 9, 40, 0, True, seed=32)
+    finally:
+        torch.set_num_threads(nthreads)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_import.load()
+    if "--even-only" in sys.argv:  # add the even-window cases without touching the committed files
+        gen_even_windows(mods)
+        return
     gen_attention(mods)
     gen_query_tables(mods)
     W2 = [[3, 3, 5], [7, 7, 7]]
@@ -243,6 +265,7 @@ def main():
               key_num_sample=8)
     run_block(mods, "compress_1x1x16", "compress", [[1, 1, 16]], [4], 16, None, 1, True, seed=20, Cout=48)
     run_block(mods, "compress_3x3x5", "compress", [[3, 3, 5]], [2, 2], 45, None, 1, True, seed=21)
+    gen_even_windows(mods)
     gen_backbone(mods)
 
 

@@ -60,7 +60,8 @@ def build_block(d, sd, cls):
     return blk.to(DEV).eval()
 
 
-BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc"]
+BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc",
+          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc"]
 
 
 @pytest.mark.parametrize("impl", IMPLS)

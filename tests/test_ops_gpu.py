@@ -242,7 +242,7 @@ def test_gather_points_three_nn_group_points():
 def test_ops_reproduce_reference_run_intermediates(golden_dir):
     """HIP ops vs the index intermediates recorded while the REFERENCE's Block.forward ran."""
     ops, pn2 = _ops()
-    for name in ("block_odd_interp", "block_trunc"):
+    for name in ("block_odd_interp", "block_trunc", "block_evenwin_odd_interp"):
         z = np.load(os.path.join(golden_dir, name + ".npz"))
         B, H = int(z["batch_size"]), int(z["hash_size"])
         vc = z["voxel_coords"]

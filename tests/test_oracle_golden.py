@@ -61,7 +61,8 @@ def _state(d):
                                  int(d["batch_size"]), int(d["hash_size"]))
 
 
-BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc"]
+BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc",
+          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc"]
 
 
 @pytest.mark.parametrize("name", BLOCKS)
