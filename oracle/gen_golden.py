@@ -243,6 +243,9 @@ def gen_even_windows(mods):
         run_block(mods, "block_evenwin_odd_interp", "block", WE, [2, 2], 27, 64, 1, True, seed=30)
         run_block(mods, "block_evenwin_all_nointerp", "block", WE, [1, 3], 27, 64, 2, False, seed=31, key_num_sample=16)
         run_block(mods, "block_evenwin_trunc", "block", WE, [2, 2], 9, 40, 0, True, seed=32)
+        # CompressBlocks with even windows: a voxel is a key of up to 8 windows
+        run_block(mods, "compress_2x2x4", "compress", [[2, 2, 4]], [4], 45, None, 1, True, seed=33, Cout=48)
+        run_block(mods, "compress_2x2x2_groups", "compress", [[2, 2, 2]], [2, 2], 27, None, 1, True, seed=34)
     finally:
         torch.set_num_threads(nthreads)
 

@@ -76,7 +76,7 @@ def test_block_matches_reference_golden(golden_dir, name, impl):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5"])
+@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups"])
 def test_compress_matches_reference_golden(golden_dir, name, impl):
     d, sd = load(golden_dir, name)
     blk = build_block(d, sd, "compress")

@@ -85,7 +85,7 @@ def test_block_forward_matches_reference(golden_dir, name):
     np.testing.assert_allclose(sp.features, d["out_features"], **TOL)
 
 
-@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5"])
+@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups"])
 def test_compress_forward_matches_reference(golden_dir, name):
     d, sd = load(golden_dir, name)
     sp = _state(d)
