@@ -36,8 +36,10 @@ def sd_to_np(sd, prefix="sd."):
     return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
-def toy_scene(batch_size, pts_per_scene, seed0, C):
+def toy_scene(batch_size, pts_per_scene, seed0, C, empty_sample=None):
     pts = synthetic.make_batch_points(pts_per_scene, batch_size, seed0)
+    if empty_sample is not None:  # a sample of the batch without a single point
+        pts = pts[pts[:, 0] != empty_sample]
     vc, _, _ = synthetic.voxelize_numpy(pts, PC_RANGE, VOXEL, GRID)
     g = torch.Generator().manual_seed(1234 + seed0)
     feats = torch.randn(vc.shape[0], C, generator=g)
@@ -151,9 +153,9 @@ def gen_query_tables(mods):
 
 
 def run_block(mods, name, cls, window_size, heads, max1, max2, cbs_pattern, interp, seed,
-              C=32, ff=64, Cout=32, B=2, pts=1500, key_num_sample=32):
+              C=32, ff=64, Cout=32, B=2, pts=1500, key_num_sample=32, empty_sample=None):
     bb, utils, _, _ = mods
-    vc, feats = toy_scene(B, pts, seed, C)
+    vc, feats = toy_scene(B, pts, seed, C, empty_sample)
     torch.manual_seed(100 + seed)
     blk = make_block(bb, cls, C, ff, Cout, heads, window_size, max1, max2, cbs_pattern, interp,
                      key_num_sample)
@@ -248,6 +250,11 @@ def gen_even_windows(mods):
         run_block(mods, "compress_2x2x2_groups", "compress", [[2, 2, 2]], [2, 2], 27, None, 1, True, seed=34)
     finally:
         torch.set_num_threads(nthreads)
+    # a batch of three whose middle sample is empty (per-sample loops, sample offsets, hash tables)
+    run_block(mods, "block_empty_sample", "block", [[3, 3, 5], [7, 7, 7]], [2, 2], 45, 343, 1, True, seed=35, B=3,
+              pts=1000, empty_sample=1)
+    run_block(mods, "compress_empty_sample", "compress", [[1, 1, 16]], [4], 16, None, 1, True, seed=36, B=3, pts=1000,
+              empty_sample=1, Cout=48)
 
 
 def main():

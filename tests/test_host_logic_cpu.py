@@ -34,7 +34,8 @@ def test_block_ops_path_matches_reference_golden(golden_dir, name):
     assert_feat_close(out.features.numpy(), d["out_features"], tol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups"])
+@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups",
+                                  "compress_empty_sample"])
 def test_compress_ops_path_matches_reference_golden(golden_dir, name):
     d, sd = load(golden_dir, name)
     blk = build_block(d, sd, "compress")

@@ -61,7 +61,7 @@ def build_block(d, sd, cls):
 
 
 BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc",
-          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc"]
+          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc", "block_empty_sample"]
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -76,7 +76,8 @@ def test_block_matches_reference_golden(golden_dir, name, impl):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups"])
+@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups",
+                                  "compress_empty_sample"])
 def test_compress_matches_reference_golden(golden_dir, name, impl):
     d, sd = load(golden_dir, name)
     blk = build_block(d, sd, "compress")

@@ -62,7 +62,7 @@ def _state(d):
 
 
 BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc",
-          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc"]
+          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc", "block_empty_sample"]
 
 
 @pytest.mark.parametrize("name", BLOCKS)
@@ -85,7 +85,8 @@ def test_block_forward_matches_reference(golden_dir, name):
     np.testing.assert_allclose(sp.features, d["out_features"], **TOL)
 
 
-@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups"])
+@pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups",
+                                  "compress_empty_sample"])
 def test_compress_forward_matches_reference(golden_dir, name):
     d, sd = load(golden_dir, name)
     sp = _state(d)
