@@ -190,10 +190,10 @@ def run_block(mods, name, cls, window_size, heads, max1, max2, cbs_pattern, inte
           "out", out.features.shape)
 
 
-def gen_backbone(mods):
+def gen_backbone(mods, name="backbone", params=None, out_features=48, seed=40):
     bb, utils, _, _ = mods
     C = 32
-    params = [
+    params = params or [
         dict(name="MixedScaleSparseTransformerBlock", channels=[C, 64, C], num_heads=[2, 2],
              window_size=[[3, 3, 5], [7, 7, 7]], max_num_win1=45, max_num_win2=343,
              cbs_mode="odd_even", cbs_pattern=1, key_num_sample=32, use_feature_interpolation=True),
@@ -203,10 +203,10 @@ def gen_backbone(mods):
         dict(name="MixedScaleSparseTransformerCompressBlock", channels=[C, 64, 48], num_heads=[4],
              window_size=[[1, 1, 16]], max_num_win1=16),
     ]
-    cfg = ref_import.AttrDict.wrap(dict(HASH_SIZE=HASH, NUM_OUTPUT_FEATURES=48, PARAMS=params))
+    cfg = ref_import.AttrDict.wrap(dict(HASH_SIZE=HASH, NUM_OUTPUT_FEATURES=out_features, PARAMS=params))
     B = 2
-    vc, feats = toy_scene(B, 1500, 40, C)
-    torch.manual_seed(4040)
+    vc, feats = toy_scene(B, 1500, seed, C)
+    torch.manual_seed(4000 + seed)
     net = bb.MixedScaleSparseTransformer(cfg, C, list(GRID), list(VOXEL), list(PC_RANGE)).eval()
     with torch.no_grad():
         for p in net.parameters():
@@ -227,8 +227,9 @@ def gen_backbone(mods):
     d.update(sd_to_np(net.state_dict()))
     import json
     d["params_json"] = json.dumps(params)
-    np.savez_compressed(os.path.join(OUT, "backbone.npz"), **d)
-    print("backbone out", sp.features.shape, "dense", tuple(dense.shape))
+    d["out_features_dim"] = out_features
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "out", sp.features.shape, "dense", tuple(dense.shape))
 
 
 def gen_even_windows(mods):
@@ -255,6 +256,24 @@ def gen_even_windows(mods):
               pts=1000, empty_sample=1)
     run_block(mods, "compress_empty_sample", "compress", [[1, 1, 16]], [4], 16, None, 1, True, seed=36, B=3, pts=1000,
               empty_sample=1, Cout=48)
+    # more keys than list slots (FPS runs past the list: repeated-0 picks), head dimension 8
+    run_block(mods, "block_k64_heads44", "block", [[3, 3, 5], [7, 7, 7]], [4, 4], 45, 343, 1, True, seed=37, C=64, ff=128,
+              Cout=64, key_num_sample=64)
+    # enlarged windows, every win1 voxel a query (BASELINE configs[4] shape)
+    run_block(mods, "block_enlarged_stride1", "block", [[5, 5, 7], [11, 11, 11]], [2, 2], 175, 1331, 2, True, seed=38,
+              pts=2500)
+    # two resolution levels: a Block on the output of a CompressBlock (window table -> voxel table, scaled voxels)
+    C = 32
+    blk = dict(name="MixedScaleSparseTransformerBlock", channels=[C, 64, C], num_heads=[2, 2],
+               window_size=[[3, 3, 5], [7, 7, 7]], max_num_win1=45, max_num_win2=343, cbs_mode="odd_even",
+               key_num_sample=32, use_feature_interpolation=True)
+    gen_backbone(mods, "backbone_two_levels", [
+        dict(blk, cbs_pattern=1),
+        dict(name="MixedScaleSparseTransformerCompressBlock", channels=[C, 64, C], num_heads=[4],
+             window_size=[[2, 2, 4]], max_num_win1=45),
+        dict(blk, cbs_pattern=0, window_size=[[3, 3, 3], [5, 5, 5]], max_num_win1=27, max_num_win2=125),
+        dict(name="MixedScaleSparseTransformerCompressBlock", channels=[C, 64, 48], num_heads=[2, 2],
+             window_size=[[1, 1, 8]], max_num_win1=8)], out_features=48, seed=41)
 
 
 def main():

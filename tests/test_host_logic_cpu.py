@@ -46,9 +46,10 @@ def test_compress_ops_path_matches_reference_golden(golden_dir, name):
     assert_feat_close(out.features.numpy(), d["out_features"], tol=1e-4)
 
 
-def test_backbone_ops_path_and_state_dict_keys(golden_dir):
+@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels"])
+def test_backbone_ops_path_and_state_dict_keys(golden_dir, name):
     from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
-    d, sd = load(golden_dir, "backbone")
+    d, sd = load(golden_dir, name)
     params = json.loads(str(d["params_json"]))
     net = MixedScaleSparseTransformer(_cfg(params, int(d["hash_size"]), 48), 32, d["grid_size"].tolist(),
                                       d["voxel_size"].tolist(), d["point_cloud_range"].tolist())

@@ -61,7 +61,8 @@ def build_block(d, sd, cls):
 
 
 BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc",
-          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc", "block_empty_sample"]
+          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc", "block_empty_sample",
+          "block_k64_heads44", "block_enlarged_stride1"]
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -97,9 +98,10 @@ def _cfg(params, hash_size, nout):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-def test_backbone_matches_reference_golden(golden_dir, impl):
+@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels"])
+def test_backbone_matches_reference_golden(golden_dir, name, impl):
     from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
-    d, sd = load(golden_dir, "backbone")
+    d, sd = load(golden_dir, name)
     params = json.loads(str(d["params_json"]))
     net = MixedScaleSparseTransformer(_cfg(params, int(d["hash_size"]), 48), 32, d["grid_size"].tolist(),
                                       d["voxel_size"].tolist(), d["point_cloud_range"].tolist())

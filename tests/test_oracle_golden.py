@@ -62,7 +62,8 @@ def _state(d):
 
 
 BLOCKS = ["block_odd_interp", "block_even_interp", "block_all_interp", "block_odd_nointerp", "block_trunc",
-          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc", "block_empty_sample"]
+          "block_evenwin_odd_interp", "block_evenwin_all_nointerp", "block_evenwin_trunc", "block_empty_sample",
+          "block_k64_heads44", "block_enlarged_stride1"]
 
 
 @pytest.mark.parametrize("name", BLOCKS)
@@ -101,8 +102,9 @@ def test_compress_forward_matches_reference(golden_dir, name):
     np.testing.assert_allclose(sp.features, d["out_features"], **TOL)
 
 
-def test_backbone_forward_matches_reference(golden_dir):
-    d, sd = load(golden_dir, "backbone")
+@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels"])
+def test_backbone_forward_matches_reference(golden_dir, name):
+    d, sd = load(golden_dir, name)
     params = json.loads(str(d["params_json"]))
     # the reference built its tables with torch.sort on CPU; the oracle's stable order must give
     # the same features here because no list in this fixture is truncated (order-invariant sets),
