@@ -1,6 +1,9 @@
 """Generate tests/golden/*.npz by running the REFERENCE's own Python (BUILD CONTAINER ONLY).
 
-    python -m oracle.gen_golden            # from /root/repo
+    python -m oracle.gen_golden               # from /root/repo: everything
+    python -m oracle.gen_golden --even-only   # only the cases added after the first set (even windows, empty
+                                              # sample, K = 64, enlarged windows, two-level backbone): the
+                                              # committed files of the first set stay byte-identical
 
 What is pinned:
   * attention_block.npz / attention_compress.npz -- true reference arithmetic of
@@ -8,7 +11,7 @@ What is pinned:
     and key masks (Block) and sequence-first nq=1 with a key mask (CompressBlock);
   * query_tables.npz -- ``get_vox_query_table`` (mssvt_backbone.py:73-122) for four
     window configurations (tie order = this CPU run's torch.sort; F7c);
-  * block_*.npz / compress.npz / backbone.npz -- the reference's
+  * block_*.npz / compress_*.npz / backbone*.npz -- the reference's
     ``MixedScaleSparseTransformerBlock/CompressBlock/MixedScaleSparseTransformer``
     ``forward`` executed unmodified with the C oracle underneath (oracle/ref_import.py),
     with every index intermediate recorded.
