@@ -1,0 +1,98 @@
+"""Generate tests/golden/dynamic_vfe*.npz by running the REFERENCE's own ``DynamicVFE.forward``
+(pcdet/models/backbones_3d/vfe/dynamic_vfe.py:71-131) on the CPU (BUILD CONTAINER ONLY).
+
+    python -m oracle.gen_golden_vfe            # from /root/repo
+
+The one thing the reference's VFE needs that is absent here is the third-party library ``torch_scatter``
+(un-vendored, no version pinned in the reference's requirements.txt / setup.py).  It is replaced by a restatement
+of the two functions the VFE calls, with their published semantics (torch_scatter 2.x documentation):
+
+  * ``scatter_mean(src, index, dim=0)``: out[i] = mean of the rows of src with index == i, out has
+    ``index.max() + 1`` rows (sum / count, count clamped to >= 1);
+  * ``scatter_max(src, index, dim=0)``: (out, argmax) with out[i] = element-wise max over those rows
+    (0 for a group without rows -- there is none here: every index comes from ``torch.unique``).
+
+Everything else -- range mask, voxel keys, ``torch.unique``, the cluster / voxel-centre feature augmentation,
+the PFN stack with BatchNorm and the repeated max + concat, the coordinate decode -- is the reference's code,
+executed unmodified.  So the goldens pin the VFE to the reference up to the library, whose two reductions the
+oracle (oracle/vfe_ref.py) and the HIP kernels restate.  Data only is written (points, weights, outputs).
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+from mssvt_amd import synthetic
+from . import ref_import
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _torch_scatter_restatement():
+    mod = types.ModuleType("torch_scatter")
+
+    def scatter_mean(src, index, dim=0):
+        assert dim == 0 and index.dim() == 1
+        n = int(index.max()) + 1
+        out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
+        cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+        return out / cnt.clamp(min=1).view(-1, *([1] * (src.dim() - 1)))
+
+    def scatter_max(src, index, dim=0):
+        assert dim == 0 and index.dim() == 1
+        n = int(index.max()) + 1
+        idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+        out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).scatter_reduce_(0, idx, src, "amax",
+                                                                                         include_self=False)
+        return out, None  # the VFE only takes [0]
+
+    mod.scatter_mean, mod.scatter_max = scatter_mean, scatter_max
+    return mod
+
+
+def load_reference_vfe():
+    ref_import.load()  # CPU redirections (.cuda() -> identity) + the pcdet namespace stubs
+    sys.modules["torch_scatter"] = _torch_scatter_restatement()
+    name = "pcdet.models.backbones_3d.vfe"
+    if name not in sys.modules:
+        ns = types.ModuleType(name)
+        ns.__path__ = [os.path.join(ref_import.REFERENCE_ROOT, "pcdet/models/backbones_3d/vfe")]
+        sys.modules[name] = ns
+    return importlib.import_module(name + ".dynamic_vfe")
+
+
+def run(mod, name, filters, pts, B, seed, cluster=True, centre=True):
+    p = synthetic.make_batch_points(pts, B, seed)  # rows [b, x, y, z, intensity, elongation]
+    p[::53, 1] += 500.0  # points outside the range are dropped by the reference
+    cfg = ref_import.AttrDict.wrap(dict(NUM_FILTERS=filters, WITH_CLUSTER_CENTER=cluster, WITH_VOXEL_CENTER=centre))
+    torch.manual_seed(700 + seed)
+    vfe = mod.DynamicVFE(cfg, 5, list(synthetic.VOXEL_SIZE), list(synthetic.GRID_SIZE),
+                         list(synthetic.POINT_CLOUD_RANGE)).eval()
+    with torch.no_grad():
+        for m in vfe.modules():  # non-trivial BatchNorm statistics and affine
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+        out = vfe(dict(points=torch.from_numpy(p), batch_size=B))
+    d = dict(points=p, batch_size=B, num_filters=np.array(filters), with_cluster_center=cluster, with_voxel_center=centre,
+             voxel_features=out["voxel_features"].numpy(), voxel_coords=out["voxel_coords"].numpy(),
+             voxel_size=np.array(synthetic.VOXEL_SIZE), grid_size=np.array(synthetic.GRID_SIZE),
+             point_cloud_range=np.array(synthetic.POINT_CLOUD_RANGE), num_point_features=vfe.get_output_feature_dim())
+    d.update({"sd." + k: v.numpy() for k, v in vfe.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "points", p.shape[0], "voxels", d["voxel_coords"].shape[0], "features", d["voxel_features"].shape)
+
+
+def main():
+    mod = load_reference_vfe()
+    run(mod, "dynamic_vfe_64_128", [64, 128], 6000, 2, 50)
+    run(mod, "dynamic_vfe_16", [16], 1500, 3, 51)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,10 +1,11 @@
 """CPU restatement of DynamicVFE.forward (test infrastructure only).
 
-ref: pcdet/models/backbones_3d/vfe/dynamic_vfe.py:71-131.  The reference cannot be imported here: it needs
-the un-vendored, un-pinned ``torch_scatter`` package (SURVEY.md F-list), so this file restates its published
-semantics -- ``scatter_mean`` = per-index arithmetic mean, ``scatter_max(...)[0]`` = per-index maximum -- with
-numpy; parity of the VFE features against real torch_scatter output is therefore UNPINNED (the voxel
-indices are pinned through ``torch.unique`` semantics, tests/test_fused_gpu.py::test_voxelizer_bit_exact).
+ref: pcdet/models/backbones_3d/vfe/dynamic_vfe.py:71-131.  The reference's VFE needs the un-vendored, un-pinned
+``torch_scatter`` package (SURVEY.md F-list); this file restates the published semantics of the two functions it
+calls -- ``scatter_mean`` = per-index arithmetic mean, ``scatter_max(...)[0]`` = per-index maximum -- with numpy.
+Pinned: tests/golden/dynamic_vfe_*.npz are runs of the reference's own ``DynamicVFE.forward`` on the CPU with
+exactly those two reductions restated (oracle/gen_golden_vfe.py); this restatement must reproduce them
+(tests/test_oracle_vfe_cpu.py).  Parity against the real torch_scatter binaries stays UNPINNED.
 """
 import numpy as np
 import torch

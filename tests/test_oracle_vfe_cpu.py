@@ -22,3 +22,22 @@ def test_vfe_restatement_known_answer():
     want0 = [0.75, 0.25, 0.25, 3.0, 0.25, 0.0, 0.0, 0.25, 0.0, 0.0]
     want1 = [2.5, 1.5, 1.5, 2.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
     np.testing.assert_allclose(vf, [want0, want1], atol=1e-6)
+
+
+import os  # noqa: E402
+
+import pytest  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["dynamic_vfe_64_128", "dynamic_vfe_16"])
+def test_vfe_restatement_matches_the_reference_run(name):
+    """oracle/vfe_ref.py against the reference's own DynamicVFE.forward (oracle/gen_golden_vfe.py: the reference
+    code on the CPU, torch_scatter's two reductions restated): voxel coordinates bit-exact, features 1e-5."""
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sd = {k[3:]: d[k] for k in d.files if k.startswith("sd.")}
+    vf, vc = vfe_ref.dynamic_vfe_forward(sd, d["points"], 5, d["voxel_size"].tolist(), d["grid_size"].tolist(),
+                                         d["point_cloud_range"].tolist(), len(d["num_filters"]))
+    np.testing.assert_array_equal(vc, d["voxel_coords"])
+    np.testing.assert_allclose(vf, d["voxel_features"], rtol=1e-5, atol=1e-5)

@@ -72,3 +72,21 @@ def test_points_to_bev_pipeline():
         bev = sp.dense()
     assert bev.shape == (2, 128, 1, 470, 470) and bool(torch.isfinite(bev).all())
     assert int((bev.abs().sum(1) > 0).sum()) == sp.features.shape[0]  # one occupied BEV cell per output voxel
+
+
+@pytest.mark.parametrize("name", ["dynamic_vfe_64_128", "dynamic_vfe_16"])
+def test_dynamic_vfe_matches_the_reference_run(name):
+    """The HIP DynamicVFE against the reference's own DynamicVFE.forward run (oracle/gen_golden_vfe.py): same
+    state-dict keys (loaded strictly), voxel coordinates bit-exact, features within 1e-4."""
+    import os
+    from mssvt_amd.dynamic_vfe import DynamicVFE
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    vfe = DynamicVFE(_Cfg(NUM_FILTERS=d["num_filters"].tolist()), 5, d["voxel_size"].tolist(), d["grid_size"].tolist(),
+                     d["point_cloud_range"].tolist()).eval()
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd.")}
+    vfe.load_state_dict(sd, strict=True)
+    assert vfe.get_output_feature_dim() == int(d["num_point_features"])
+    out = vfe.to(DEV)(dict(points=torch.from_numpy(d["points"]).to(DEV), batch_size=int(d["batch_size"])))
+    np.testing.assert_array_equal(out["voxel_coords"].cpu().numpy(), d["voxel_coords"])
+    got, want = out["voxel_features"].cpu().numpy(), d["voxel_features"]
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
