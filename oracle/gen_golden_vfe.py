@@ -1,5 +1,6 @@
-"""Generate tests/golden/dynamic_vfe*.npz by running the REFERENCE's own ``DynamicVFE.forward``
-(pcdet/models/backbones_3d/vfe/dynamic_vfe.py:71-131) on the CPU (BUILD CONTAINER ONLY).
+"""Generate tests/golden/dynamic_vfe*.npz and height_compression_*.npz by running the REFERENCE's own modules either
+side of the backbone -- ``DynamicVFE.forward`` (pcdet/models/backbones_3d/vfe/dynamic_vfe.py:71-131) and
+``HeightCompression`` (pcdet/models/backbones_2d/map_to_bev/height_compression.py) -- on the CPU (BUILD CONTAINER ONLY).
 
     python -m oracle.gen_golden_vfe            # from /root/repo
 
@@ -92,6 +93,46 @@ def main():
     mod = load_reference_vfe()
     run(mod, "dynamic_vfe_64_128", [64, 128], 6000, 2, 50)
     run(mod, "dynamic_vfe_16", [16], 1500, 3, 51)
+    gen_height_compression()
+
+
+
+
+def gen_height_compression():
+    """The reference's HeightCompression (pcdet/models/backbones_2d/map_to_bev/height_compression.py:5-50) on the
+    output of the backbone golden: SparseTensor.dense() (mssvt_utils.py:50-62) + view + the 3x3 conv stack."""
+    _, utils, _, _ = ref_import.load()
+    name = "pcdet.models.backbones_2d"
+    for n_, rel in ((name, "pcdet/models/backbones_2d"), (name + ".map_to_bev", "pcdet/models/backbones_2d/map_to_bev")):
+        if n_ not in sys.modules:
+            ns = types.ModuleType(n_)
+            ns.__path__ = [os.path.join(ref_import.REFERENCE_ROOT, rel)]
+            sys.modules[n_] = ns
+    hc_mod = importlib.import_module(name + ".map_to_bev.height_compression")
+    b = np.load(os.path.join(OUT, "backbone_two_levels.npz"))
+    feats, idx = torch.from_numpy(b["out_features"]), torch.from_numpy(b["out_indices"])
+    shape = b["out_spatial_shape"].tolist()
+    B = int(b["batch_size"])
+    sp = utils.SparseTensor(features=feats, indices=idx, spatial_shape=shape, voxel_size=[1.0, 1.0, 1.0],
+                            point_cloud_range=[0, 0, 0, 1, 1, 1], batch_size=B, hash_size=int(b["hash_size"]))
+    C, D = feats.shape[1], shape[2]
+    for tag, layers in (("plain", 0), ("convs", 2)):
+        cfg = ref_import.AttrDict.wrap(dict(NUM_BEV_FEATURES=C * D, COMPRESS_LAYER_NUMS=layers, LAYER_STRIDES=[1, 1],
+                                            LAYER_DIALATIONS=[1, 2], LAYER_PADDINGS=[1, 2]))
+        torch.manual_seed(900 + layers)
+        hc = hc_mod.HeightCompression(cfg).eval()
+        with torch.no_grad():
+            for m in hc.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.3)
+                    m.running_var.uniform_(0.5, 1.5)
+            out = hc(dict(encoded_spconv_tensor=sp, encoded_spconv_tensor_stride=1))
+        d = dict(features=b["out_features"], indices=b["out_indices"], spatial_shape=np.array(shape), batch_size=B,
+                 hash_size=int(b["hash_size"]), num_bev_features=C * D, layers=layers,
+                 spatial_features=out["spatial_features"].numpy(), stride=out["spatial_features_stride"])
+        d.update({"sd." + k: v.numpy() for k, v in hc.state_dict().items()})
+        np.savez_compressed(os.path.join(OUT, "height_compression_%s.npz" % tag), **d)
+        print("height_compression_" + tag, tuple(out["spatial_features"].shape))
 
 
 if __name__ == "__main__":

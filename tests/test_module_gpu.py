@@ -513,3 +513,28 @@ def test_random_configurations_match_the_oracle(impl, seed):
                       batch_size=B))["encoded_spconv_tensor"]
     np.testing.assert_array_equal(sp.indices.cpu().numpy(), want.indices)
     assert_feat_close(sp.features.cpu().numpy(), want.features)
+
+
+@pytest.mark.parametrize("tag", ["plain", "convs"])
+def test_height_compression_matches_the_reference_run(golden_dir, tag):
+    """mssvt_amd.height_compression.HeightCompression (gather-kernel dense() + view + library convs) against a run of
+    the reference's own HeightCompression on the two-level backbone golden (oracle/gen_golden_vfe.py): same
+    state-dict keys (strict load); the conv-free form bit-exact, the conv stack within 1e-4."""
+    from mssvt_amd.height_compression import HeightCompression
+    from mssvt_amd.mssvt_utils import SparseTensor
+    d = np.load(os.path.join(golden_dir, "height_compression_%s.npz" % tag))
+    layers = int(d["layers"])
+    hc = HeightCompression(dict(NUM_BEV_FEATURES=int(d["num_bev_features"]), COMPRESS_LAYER_NUMS=layers,
+                                LAYER_STRIDES=[1, 1], LAYER_DIALATIONS=[1, 2], LAYER_PADDINGS=[1, 2])).eval()
+    hc.load_state_dict({k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd.")}, strict=True)
+    sp = SparseTensor(features=torch.from_numpy(d["features"]).to(DEV), indices=torch.from_numpy(d["indices"]).to(DEV),
+                      spatial_shape=d["spatial_shape"].tolist(), voxel_size=[1.0, 1.0, 1.0],
+                      point_cloud_range=[0, 0, 0, 1, 1, 1], batch_size=int(d["batch_size"]), hash_size=int(d["hash_size"]))
+    with torch.no_grad():
+        out = hc.to(DEV)(dict(encoded_spconv_tensor=sp, encoded_spconv_tensor_stride=1))
+    got, want = out["spatial_features"].cpu().numpy(), d["spatial_features"]
+    assert out["spatial_features_stride"] == int(d["stride"]) and got.shape == want.shape
+    if layers == 0:
+        np.testing.assert_array_equal(got, want)
+    else:
+        assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
