@@ -282,6 +282,9 @@ def gen_even_windows(mods):
 def main():
     os.makedirs(OUT, exist_ok=True)
     mods = ref_import.load()
+    if "--grad-only" in sys.argv:
+        gen_gradients(mods)
+        return
     if "--even-only" in sys.argv:  # add the even-window cases without touching the committed files
         gen_even_windows(mods)
         return
@@ -298,7 +301,50 @@ def main():
     run_block(mods, "compress_1x1x16", "compress", [[1, 1, 16]], [4], 16, None, 1, True, seed=20, Cout=48)
     run_block(mods, "compress_3x3x5", "compress", [[3, 3, 5]], [2, 2], 45, None, 1, True, seed=21)
     gen_even_windows(mods)
+    gen_gradients(mods)
     gen_backbone(mods)
+
+
+
+
+def gen_gradients(mods):
+    """Backward of the reference's Block / CompressBlock (its autograd Functions GroupingOperation / GatherOperation /
+    pointnet2 GroupingOperation, mssvt_ops.py:172-190, pointnet2_utils.py:53-73,180-197, with the C oracle's K6 / K11
+    underneath): gradients of a fixed linear functional of the output w.r.t. the input features and every
+    parameter.  Pins row R15 (backward) of the scope table."""
+    bb, utils, _, _ = mods
+    C = 32
+    cases = [("grad_block_odd_interp", "block", [[3, 3, 5], [7, 7, 7]], [2, 2], 45, 343, 1, True, 60),
+             ("grad_block_even_nointerp", "block", [[3, 3, 5], [7, 7, 7]], [1, 3], 45, 343, 0, False, 61),
+             ("grad_compress_1x1x16", "compress", [[1, 1, 16]], [4], 16, None, 1, True, 62)]
+    for name, cls, ws, heads, m1, m2, pattern, interp, seed in cases:
+        vc, feats = toy_scene(2, 1200, seed, C)
+        torch.manual_seed(100 + seed)
+        blk = make_block(bb, cls, C, 64, C, heads, ws, m1, m2, pattern, interp, 32)
+        with torch.no_grad():
+            for p in blk.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+        x = torch.from_numpy(feats).clone().requires_grad_(True)
+        sp = utils.SparseTensor(features=x, indices=torch.from_numpy(vc), spatial_shape=list(GRID),
+                                voxel_size=list(VOXEL), point_cloud_range=list(PC_RANGE), batch_size=2, hash_size=HASH)
+        out = blk(sp)
+        g = torch.Generator().manual_seed(seed)
+        w = torch.randn(out.features.shape, generator=g)
+        (out.features * w).sum().backward()
+        d = dict(voxel_coords=vc, voxel_features=feats, loss_weights=w.numpy(), out_features=out.features.detach().numpy(),
+                 grad_input=x.grad.numpy(), window_size=np.array(ws), num_heads=np.array(heads),
+                 max_num_win1=m1, max_num_win2=-1 if m2 is None else m2, cbs_pattern=pattern,
+                 use_feature_interpolation=interp, channels=np.array([C, 64, C]), batch_size=2, hash_size=HASH,
+                 grid_size=np.array(GRID), voxel_size=np.array(VOXEL), point_cloud_range=np.array(PC_RANGE),
+                 key_num_sample=32)
+        for k, v in blk.vox_query_table.items():
+            d["qt." + k] = v.numpy()
+        d.update(sd_to_np(blk.state_dict()))
+        for k, p in blk.named_parameters():
+            d["grad." + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        print(name, "N=%d" % vc.shape[0], "|grad_input|", float(x.grad.abs().mean()))
 
 
 if __name__ == "__main__":

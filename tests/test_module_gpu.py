@@ -538,3 +538,32 @@ def test_height_compression_matches_the_reference_run(golden_dir, tag):
         np.testing.assert_array_equal(got, want)
     else:
         assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("name,cls", [("grad_block_odd_interp", "block"), ("grad_block_even_nointerp", "block"),
+                                      ("grad_compress_1x1x16", "compress")])
+def test_backward_matches_the_reference_run(golden_dir, name, cls):
+    """Row R15: gradients of a fixed linear functional of the block output w.r.t. the input features and every
+    parameter, against the reference's own backward (its autograd Functions with K6 / K11 of the C oracle underneath,
+    run on the CPU: oracle/gen_golden.py::gen_gradients).  With autograd on, the module runs the differentiable
+    operator path (HIP K5 / K6 / K8 / K10 / K11 kernels + torch)."""
+    from mssvt_amd.mssvt_utils import SparseTensor
+    d, sd = load(golden_dir, name)
+    blk = build_block(d, sd, cls)
+    x = torch.from_numpy(d["voxel_features"]).to(DEV).requires_grad_(True)
+    sp = SparseTensor(features=x, indices=torch.from_numpy(d["voxel_coords"]).to(DEV),
+                      spatial_shape=d["grid_size"].tolist(), voxel_size=d["voxel_size"].tolist(),
+                      point_cloud_range=d["point_cloud_range"].tolist(), batch_size=int(d["batch_size"]),
+                      hash_size=int(d["hash_size"]))
+    out = blk(sp)
+    assert_feat_close(out.features.detach().cpu().numpy(), d["out_features"])
+    (out.features * torch.from_numpy(d["loss_weights"]).to(DEV)).sum().backward()
+
+    def close(got, want, what):
+        got, want = got.detach().cpu().numpy().astype(np.float64), want.astype(np.float64)
+        scale = max(1.0, np.abs(want).max())
+        assert np.abs(got - want).max() <= 1e-3 * scale, "%s: %.3e vs scale %.3e" % (what, np.abs(got - want).max(), scale)
+
+    close(x.grad, d["grad_input"], "input")
+    for k, p in blk.named_parameters():
+        close(p.grad if p.grad is not None else torch.zeros_like(p), d["grad." + k], k)
