@@ -193,9 +193,8 @@ def run_block(mods, name, cls, window_size, heads, max1, max2, cbs_pattern, inte
           "out", out.features.shape)
 
 
-def gen_backbone(mods, name="backbone", params=None, out_features=48, seed=40):
+def gen_backbone(mods, name="backbone", params=None, out_features=48, seed=40, C=32, pts=1500):
     bb, utils, _, _ = mods
-    C = 32
     params = params or [
         dict(name="MixedScaleSparseTransformerBlock", channels=[C, 64, C], num_heads=[2, 2],
              window_size=[[3, 3, 5], [7, 7, 7]], max_num_win1=45, max_num_win2=343,
@@ -208,7 +207,7 @@ def gen_backbone(mods, name="backbone", params=None, out_features=48, seed=40):
     ]
     cfg = ref_import.AttrDict.wrap(dict(HASH_SIZE=HASH, NUM_OUTPUT_FEATURES=out_features, PARAMS=params))
     B = 2
-    vc, feats = toy_scene(B, 1500, seed, C)
+    vc, feats = toy_scene(B, pts, seed, C)
     torch.manual_seed(4000 + seed)
     net = bb.MixedScaleSparseTransformer(cfg, C, list(GRID), list(VOXEL), list(PC_RANGE)).eval()
     with torch.no_grad():
@@ -231,6 +230,7 @@ def gen_backbone(mods, name="backbone", params=None, out_features=48, seed=40):
     import json
     d["params_json"] = json.dumps(params)
     d["out_features_dim"] = out_features
+    d["in_channels"] = C
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
     print(name, "out", sp.features.shape, "dense", tuple(dense.shape))
 
@@ -265,6 +265,17 @@ def gen_even_windows(mods):
     # enlarged windows, every win1 voxel a query (BASELINE configs[4] shape)
     run_block(mods, "block_enlarged_stride1", "block", [[5, 5, 7], [11, 11, 11]], [2, 2], 175, 1331, 2, True, seed=38,
               pts=2500)
+    # the benchmark configuration's shapes (mssvt_amd/cfgs/mssvt.yaml: C = 128, FF = 256, heads [4,4] / [8]): the
+    # kernel instantiations bench.py runs, on a toy scene
+    gen_backbone(mods, "backbone_c128", [
+        dict(name="MixedScaleSparseTransformerBlock", channels=[128, 256, 128], num_heads=[4, 4],
+             window_size=[[3, 3, 5], [7, 7, 7]], max_num_win1=45, max_num_win2=343, cbs_mode="odd_even",
+             cbs_pattern=1, key_num_sample=32, use_feature_interpolation=True),
+        dict(name="MixedScaleSparseTransformerBlock", channels=[128, 256, 128], num_heads=[4, 4],
+             window_size=[[3, 3, 5], [7, 7, 7]], max_num_win1=45, max_num_win2=343, cbs_mode="odd_even",
+             cbs_pattern=0, key_num_sample=32, use_feature_interpolation=True),
+        dict(name="MixedScaleSparseTransformerCompressBlock", channels=[128, 256, 128], num_heads=[8],
+             window_size=[[1, 1, 32]], max_num_win1=32)], out_features=128, seed=42, C=128, pts=1000)
     # two resolution levels: a Block on the output of a CompressBlock (window table -> voxel table, scaled voxels)
     C = 32
     blk = dict(name="MixedScaleSparseTransformerBlock", channels=[C, 64, C], num_heads=[2, 2],

@@ -46,19 +46,20 @@ def test_compress_ops_path_matches_reference_golden(golden_dir, name):
     assert_feat_close(out.features.numpy(), d["out_features"], tol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels"])
+@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels", "backbone_c128"])
 def test_backbone_ops_path_and_state_dict_keys(golden_dir, name):
     from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
     d, sd = load(golden_dir, name)
     params = json.loads(str(d["params_json"]))
-    net = MixedScaleSparseTransformer(_cfg(params, int(d["hash_size"]), 48), 32, d["grid_size"].tolist(),
+    c_in, c_out = int(d.get("in_channels", 32)), int(d.get("out_features_dim", 48))
+    net = MixedScaleSparseTransformer(_cfg(params, int(d["hash_size"]), c_out), c_in, d["grid_size"].tolist(),
                                       d["voxel_size"].tolist(), d["point_cloud_range"].tolist())
     assert sorted(net.state_dict().keys()) == sorted(sd.keys())  # the reference's key names, exactly
     for k, v in net.state_dict().items():
         assert tuple(v.shape) == tuple(sd[k].shape), k
     net.load_state_dict(sd, strict=True)
     net.eval().set_impl("ops")
-    assert net.num_point_features == 48
+    assert net.num_point_features == c_out
     with torch.no_grad():
         bd = net(dict(voxel_features=torch.from_numpy(d["voxel_features"]),
                       voxel_coords=torch.from_numpy(d["voxel_coords"]).float(), batch_size=int(d["batch_size"])))

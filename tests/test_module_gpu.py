@@ -98,12 +98,13 @@ def _cfg(params, hash_size, nout):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels"])
+@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels", "backbone_c128"])
 def test_backbone_matches_reference_golden(golden_dir, name, impl):
     from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
     d, sd = load(golden_dir, name)
     params = json.loads(str(d["params_json"]))
-    net = MixedScaleSparseTransformer(_cfg(params, int(d["hash_size"]), 48), 32, d["grid_size"].tolist(),
+    c_in, c_out = int(d.get("in_channels", 32)), int(d.get("out_features_dim", 48))
+    net = MixedScaleSparseTransformer(_cfg(params, int(d["hash_size"]), c_out), c_in, d["grid_size"].tolist(),
                                       d["voxel_size"].tolist(), d["point_cloud_range"].tolist())
     net.load_state_dict(sd, strict=True)
     net = net.to(DEV).eval().set_impl(impl)

@@ -102,7 +102,7 @@ def test_compress_forward_matches_reference(golden_dir, name):
     np.testing.assert_allclose(sp.features, d["out_features"], **TOL)
 
 
-@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels"])
+@pytest.mark.parametrize("name", ["backbone", "backbone_two_levels", "backbone_c128"])
 def test_backbone_forward_matches_reference(golden_dir, name):
     d, sd = load(golden_dir, name)
     params = json.loads(str(d["params_json"]))
