@@ -835,6 +835,15 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
         attn_pmc = {k: {"hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"),
                         "mfma_busy_frac": v.get("mfma_busy_frac_of_gpu_active")}
                     for k, v in counters.items() if isinstance(v, dict) and k.startswith("k_attn_")}
+    # what the box delivers on bare loops (tools/peaks/run.py; `peak` below stays the guide's number)
+    ceilings = None
+    cpath = os.path.join(os.path.dirname(pmc), "r01_measured_ceilings.json")
+    if os.path.exists(cpath):
+        with open(cpath) as f:
+            mc = json.load(f)
+        ceilings = {"mfma_f32_tflops": max(mc.get("mfma_f32_tflops", {}).values(), default=None),
+                    "hbm_copy_gbs": max((v for k, v in mc.get("hbm_gbs", {}).items() if k.startswith("copy")), default=None),
+                    "hbm_read_gbs": max((v for k, v in mc.get("hbm_gbs", {}).items() if k.startswith("read")), default=None)}
     if traffic is not None and live is not None and live[0] > 0:
         # the PMC passes ran full-size launches (N rows); the live average mixes in the smaller CompressBlock tail
         traffic = int(traffic * (live[1] / live[0] / (2.0 * C * FF)) / N)
@@ -854,7 +863,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
     return {"bound": "mfma", "kernel": "k_ffn_up<128,256> (norm2 + GEMM1 + ReLU of the FFN tail, fp32 MFMA; input built "
                                        "from x_in + 3 attention rows)",
             "achieved": head["achieved"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": head["achieved"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "frac": head["achieved"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "measured_ceilings": ceilings,
             "algorithmic_flop_per_launch": head["algorithmic_flop_per_launch"], "avg_launch_us": head["avg_launch_us"],
             "units_per_launch": head["units_per_launch"], "timing": head["timing"],
             **({"isolated_launch_us_full_frame_rows": head["isolated_launch_us_full_frame_rows"]}
