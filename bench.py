@@ -1,26 +1,32 @@
-"""bench.py -- frames/s of the MsSVT backbone forward on MI355X (BASELINE.json metric).
+"""bench.py -- frames/s of the MsSVT backbone on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points 160000] [--batch 1]
+                    [--attn-dtype f32|bf16] [--train] [--cfg yaml]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one backbone forward (voxel_coords, voxel_features -> encoded SparseTensor,
-eval mode, fp32) over one batch of synthetic Waymo-shaped scenes that are already resident
-in HBM.  Workload at N=1: BASELINE.json configs[1] -- one 160k-point scene, the full
-mssvt.yaml backbone ("W": 4 Blocks + 1 CompressBlock, C=128, windows [3,3,5]/[7,7,7]).
-Multi-GPU: scenes are sharded by rank (no data-path collective; weak scaling), timing is the
-max over ranks between barriers.
+A "step" is one backbone forward (voxel_coords, voxel_features -> encoded SparseTensor, eval mode)
+over one batch of synthetic Waymo-shaped scenes already resident in HBM; with ``--train`` one
+DistributedDataParallel training step (forward + backward + gradient all-reduce over RCCL + SGD).
+Workload at N=1: BASELINE.json configs[1] -- one 160k-point scene, the full mssvt.yaml backbone
+("W": 4 Blocks + 1 CompressBlock, C=128, windows [3,3,5]/[7,7,7]), fp32.  ``--batch 8 --attn-dtype
+bf16`` is configs[2]; ``--gpus 8 --batch 4`` the per-GPU shape of configs[3].
+
+``--gpus N`` with N > 1 and no torchrun environment: this process starts N ranks itself
+(``python -m torch.distributed.run``, one per GPU, RCCL) BEFORE it makes any GPU call, relays their
+output and exits with their status.  Scenes are sharded by rank (no data-path collective; weak
+scaling); the time is the max over ranks between barriers.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  "roofline":     the dominant kernel (k_ffn_up, fp32 MFMA bound): algorithmic FLOP per launch / its
-                  measured average duration (HIP events on the launching stream) vs the 157.3 TFLOP/s
-                  dense fp32 matrix-core peak, HBM traffic from the committed PMC passes; the next two
-                  kernels beside it (mssvt_amd/fused.py: roofline);
-  "cpu_baseline": the CPU oracle (a port of the reference's CUDA semantics; the reference
-                  has no CPU path) timed on this box's host on a bounded sample.
+  "timing":       median / p10 / p90 of >= 50 steps timed one by one with HIP events;
+  "roofline":     the dominant kernel (k_ffn_up, fp32 MFMA bound) measured live with HIP events, and
+                  "frame": the whole frame's algorithmic bytes / FLOP against both roofs;
+  "cpu_baseline": the CPU oracle (a port of the reference's CUDA semantics; the reference has no CPU
+                  path) timed on this box's host: the whole forward on all cores and on one thread.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,7 +39,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.3 TB/s achievable)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -41,10 +47,32 @@ def parse():
     ap.add_argument("--points", type=int, default=160000, help="LiDAR points per scene")
     ap.add_argument("--batch", type=int, default=1, help="scenes per GPU per step")
     ap.add_argument("--impl", default=None, choices=[None, "fused", "ops"])
+    ap.add_argument("--attn-dtype", default="f32", choices=["f32", "bf16"],
+                    help="operand type of the window-attention matrix products (accumulation and softmax stay fp32)")
+    ap.add_argument("--train", action="store_true", help="DDP training step instead of the inference forward")
     ap.add_argument("--cfg", default=None, help="backbone yaml (default: mssvt_amd/cfgs/mssvt.yaml = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """--gpus N without a torchrun environment: start the N ranks as children (nothing in this process
+    has touched the GPU yet, and nothing will), relay their stdout / stderr, return their exit status."""
+    import socket
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.call(cmd, env=env)
 
 
 def make_inputs(points, batch, rank, device):
@@ -71,70 +99,165 @@ def event_time_ms(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def cpu_baseline(net, vc_np, feats_np, batch):
-    """Oracle on the host: Block 0 + the CompressBlock of the SAME frame(s), scaled to a whole
-    forward as 4 x Block + Compress (the four Blocks do identical work)."""
-    from mssvt_amd import config, synthetic
-    from oracle import block_ref
-    nthreads = torch.get_num_threads()
-    torch.set_num_threads(1)  # the C oracle is scalar; keep the torch-CPU parts scalar too
+def per_step_times_ms(step, iters):
+    """Each step between two HIP events on the launching stream (the library launches on torch's current
+    stream); returns the sorted list."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    torch.cuda.synchronize()
+    for e0, e1 in evs:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize()
+    return sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+
+
+def cpu_model():
     try:
-        cfg = config.load_yaml(config.DEFAULT_CFG)
-        params = [dict(p) for p in cfg.MODEL.BACKBONE_3D.PARAMS]
-        sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
-        sp = block_ref.SparseState(feats_np, vc_np, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
-                                   synthetic.POINT_CLOUD_RANGE, batch, 400000)
-        p0, pc = params[0], params[-1]
-        t0 = time.perf_counter()
-        sp = block_ref.block_forward(sd, "backbone.0.", sp, p0["window_size"], p0["num_heads"],
-                                     p0["max_num_win1"], p0["max_num_win2"], p0["cbs_pattern"],
-                                     p0["key_num_sample"], p0["use_feature_interpolation"])
-        t1 = time.perf_counter()
-        block_ref.compress_forward(sd, "backbone.%d." % (len(params) - 1), sp, pc["window_size"],
-                                   pc["num_heads"], pc["max_num_win1"])
-        t2 = time.perf_counter()
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo, capped by this process's affinity mask."""
+    cores = set()
+    try:
+        pkg = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    pkg = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if pkg is not None and core is not None:
+                        cores.add((pkg, core))
+                    pkg = core = None
+    except OSError:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return max(n, 1)
+
+
+def cpu_baseline(net, cfg, vc_np, feats_np, batch, gpu_out=None):
+    """The oracle's WHOLE forward of the same frame(s) on the host, first on all physical cores (OpenMP
+    loops of the C oracle + torch-CPU dense math), then on one thread.  Its output doubles as a parity check of
+    the frame just benchmarked (outside the timed region; the oracle is the checker, never the product)."""
+    import numpy as np
+    from mssvt_amd import synthetic
+    from oracle import block_ref, cref
+    params = [dict(p) for p in cfg.MODEL.BACKBONE_3D.PARAMS]
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    keep = torch.get_num_threads()
+    cores = physical_cores()
+    runs = {}
+    want = None
+    try:
+        for tag, nt in (("all_cores", cores), ("one_thread", 1)):
+            torch.set_num_threads(nt)
+            cref.set_num_threads(nt)
+            t0 = time.perf_counter()
+            want = block_ref.backbone_forward(sd, params, feats_np, vc_np, batch, synthetic.GRID_SIZE,
+                                              synthetic.VOXEL_SIZE, synthetic.POINT_CLOUD_RANGE,
+                                              int(cfg.MODEL.BACKBONE_3D.HASH_SIZE))
+            runs[tag] = time.perf_counter() - t0
     finally:
-        torch.set_num_threads(nthreads)
-    n_blocks = sum(p["name"].endswith("TransformerBlock") for p in params)
-    est = n_blocks * (t1 - t0) + (t2 - t1)
-    return {"value": batch / est, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "CPU oracle (C + torch-CPU port of the reference CUDA semantics; the reference has "
-                      "no CPU path) on the same %d frame(s): Block 0 (%.1f s) + CompressBlock (%.1f s), "
-                      "scaled as %d x Block + Compress" % (batch, t1 - t0, t2 - t1, n_blocks),
-            "host_cpus": os.cpu_count()}
+        torch.set_num_threads(keep)
+        cref.set_num_threads(0)
+    res = {"value": batch / runs["all_cores"], "unit": "frames/s", "cores": cores, "kind": "port",
+           "one_thread_value": batch / runs["one_thread"], "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+           "sample": "CPU oracle (C/OpenMP + torch-CPU port of the reference CUDA semantics; the reference has no CPU "
+                     "path): the WHOLE forward of the same %d frame(s), %.1f s on %d cores (the numpy glue between the "
+                     "kernels is single-threaded), %.1f s on one thread" % (batch, runs["all_cores"], cores,
+                                                                            runs["one_thread"])}
+    if gpu_out is not None and want is not None:
+        got = gpu_out.features.float().cpu().numpy()
+        same_idx = bool(np.array_equal(gpu_out.indices.cpu().numpy(), want.indices))
+        err = float((np.abs(got - want.features) / np.maximum(1.0, np.abs(want.features))).max()) if same_idx else None
+        res["parity_of_the_benchmarked_frame"] = {"indices_bit_exact": same_idx, "max_scaled_feature_err": err}
+    return res
+
+
+def workload_name(args, cfg_given):
+    if cfg_given:
+        return "%s: %d-point scene x batch %d per GPU" % (os.path.basename(args.cfg), args.points, args.batch)
+    base = ("%d-point Waymo-shaped scene x batch %d per GPU, full mssvt.yaml backbone (4 Blocks [3,3,5]/[7,7,7] cbs "
+            "1,0,1,0 + CompressBlock [1,1,32], C=128, heads [4,4], HASH_SIZE 400000)" % (args.points, args.batch))
+    if args.train:
+        return "BASELINE configs[3] (DDP training reading): " + base + ", fp32, forward + backward + all-reduce + SGD"
+    if args.attn_dtype == "bf16":
+        tag = "BASELINE configs[2]" if (args.batch == 8 and args.points == 160000) else "configs[2] kernels"
+        return tag + ": " + base + ", bf16-operand MFMA window attention (fp32 accumulate / softmax / FFN)"
+    if args.gpus > 1 and args.batch == 4:
+        return "BASELINE configs[3]: " + base + ", fp32"
+    return "BASELINE configs[1]: " + base + ", fp32"
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # before any GPU call of this process
     from mssvt_amd import dist as mdist
     rank, world, local_rank = mdist.env_rank_world()
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the hot path has no CPU fallback)"
     # MSSVT_BENCH_ONE_DEVICE=1 (debugging the N > 1 code path on a single-GPU box): every rank on cuda:0, gloo
     one_dev = os.environ.get("MSSVT_BENCH_ONE_DEVICE", "0") == "1"
     dev = torch.device("cuda", 0 if one_dev else local_rank)
     torch.cuda.set_device(dev)
-    dist = mdist.init("gloo" if one_dev else "nccl", dev)
+    backend = "gloo" if one_dev else "nccl"
+    dist = mdist.init(backend, dev)
+    seen_world = dist.get_world_size() if dist else 1
 
     from mssvt_amd import config, roofline
     torch.manual_seed(0)
-    cfg = config.load_yaml(args.cfg) if args.cfg else None
-    net = config.build_backbone_from_cfg(cfg).to(dev).eval()
+    cfg = config.load_yaml(args.cfg) if args.cfg else config.load_yaml(config.DEFAULT_CFG)
+    net = config.build_backbone_from_cfg(cfg).to(dev)
     if args.impl:
         net.set_impl(args.impl)
-    impl = net.backbone[0].impl
+    net.set_attn_dtype(args.attn_dtype)
     vc_np, feats_np, vc, feats = make_inputs(args.points, args.batch, rank, dev)
 
-    def step():
-        with torch.no_grad():
-            return net(dict(voxel_features=feats, voxel_coords=vc, batch_size=args.batch))
+    if args.train:
+        net.train()
+        ddp = net
+        if dist:
+            ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=None if one_dev else [dev.index])
+        opt = torch.optim.SGD(net.parameters(), lr=1e-4)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = ddp(dict(voxel_features=feats, voxel_coords=vc, batch_size=args.batch))
+            out["encoded_spconv_tensor"].features.square().mean().backward()  # gradients all-reduced here
+            opt.step()
+            return out
+    else:
+        net.eval()
+
+        def step():
+            with torch.no_grad():
+                return net(dict(voxel_features=feats, voxel_coords=vc, batch_size=args.batch))
+    impl = net.backbone[0].impl
 
     for _ in range(args.warmup):
         step()
     elapsed, out = mdist.timed_steps(step, args.steps, dist, dev)
+    # SURVEY 8(d) protocol beside the driver's K-step clock: every step between two HIP events
+    times = per_step_times_ms(step, max(50, args.steps)) if rank == 0 else None
     # live roofline: the same K steps once more on rank 0 with HIP events around every launch of the
     # dominant kernel (kept out of the timed region above: the event markers cost ~3 % of the frame rate)
     live = None
-    if rank == 0 and impl == "fused" and not args.no_roofline and not args.cfg:
+    std = rank == 0 and impl == "fused" and not args.cfg and not args.train
+    if std and not args.no_roofline:
         from mssvt_amd import fused
         fused.FFN_TIMER = []
         for _ in range(args.steps):
@@ -143,29 +266,34 @@ def main():
         live = fused.ffn_timer_summary(fused.FFN_TIMER)
         fused.FFN_TIMER = None
 
-    res = None
     if rank == 0:
-        n_out = int(out["encoded_spconv_tensor"].features.shape[0])
+        sp_out = out["encoded_spconv_tensor"]
+        ms = 1e3 * elapsed / args.steps
         res = {
-            "metric": "frames/sec (MsSVT backbone forward, synthetic Waymo-shaped scenes)",
+            "metric": "frames/sec (MsSVT backbone %s, synthetic Waymo-shaped scenes)"
+                      % ("DDP training step" if args.train else "forward"),
             "value": world * args.batch * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: %d-point Waymo-shaped scene x batch %d per GPU, full "
-                                    "mssvt.yaml backbone (4 Blocks [3,3,5]/[7,7,7] cbs 1,0,1,0 + CompressBlock "
-                                    "[1,1,32], C=128, heads [4,4], HASH_SIZE 400000), fp32" % (args.points, args.batch))
-                       if not args.cfg else "%s: %d-point scene x batch %d per GPU, fp32"
-                       % (os.path.basename(args.cfg), args.points, args.batch),
-                       "impl": impl, "voxels_per_gpu": int(vc.shape[0]), "output_voxels": n_out,
-                       "parallelism": "scenes sharded over %d GPU(s), no data-path collective" % world},
+            "dtype": "bf16" if args.attn_dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": workload_name(args, bool(args.cfg)),
+                       "impl": impl, "attn_dtype": args.attn_dtype, "voxels_per_gpu": int(vc.shape[0]),
+                       "output_voxels": int(sp_out.features.shape[0]),
+                       "parallelism": "scenes sharded over %d GPU(s), %s" % (
+                           world, "DDP gradient all-reduce (%s)" % backend if args.train else "no data-path collective"),
+                       "process_group": {"backend": backend if dist else None, "world_size": seen_world}},
+            "timing": {"protocol": "each of %d further steps between two HIP events on the launching stream" % len(times),
+                       "median_ms": times[len(times) // 2], "p10_ms": times[len(times) // 10],
+                       "p90_ms": times[(len(times) * 9) // 10], "frames_per_s_at_median":
+                           args.batch / (times[len(times) // 2] * 1e-3)},
         }
-        if not args.no_roofline and not args.cfg:
-            res["roofline"] = roofline.measure(net, vc, feats, args.batch, event_time_ms, HBM_PEAK_GBS, live=live)
-        if not args.no_cpu_baseline and world == 1 and not args.cfg:
-            res["cpu_baseline"] = cpu_baseline(net, vc_np, feats_np, args.batch)
+        if std and not args.no_roofline:
+            res["roofline"] = roofline.measure(net, vc, feats, args.batch, event_time_ms, HBM_PEAK_GBS, live=live,
+                                               ms_per_step=ms)
+        if std and not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(net, cfg, vc_np, feats_np, args.batch, gpu_out=sp_out)
         print(json.dumps(res), flush=True)
     if dist:
         dist.barrier()

@@ -668,6 +668,9 @@ extern "C" int mssvt_window_plan_two(
     if (win_capacity <= 0) return MSSVT_OK;
     // offsets are packed into bytes (|offset| <= 63) -- far beyond any window in use
     if (x_ws > 60 || y_ws > 60 || z_ws > 60 || key_num_sample > 1024) return MSSVT_E_TOOLARGE;
+    // the register samplers examine slots [0, 2 bs) with bs = min(2^floor(log2 n), 1024) (the reference's block
+    // size): lists of 2048 slots or more (e.g. 13 x 13 x 13 windows) are not covered -> the caller's operator path
+    if (max_num_win1 >= 2048 || max_num_win2 >= 2048) return MSSVT_E_TOOLARGE;
     PlanArgs a;
     a.x_max = x_max; a.y_max = y_max; a.z_max = z_max;
     a.x_ws = x_ws; a.y_ws = y_ws; a.z_ws = z_ws;

@@ -74,6 +74,12 @@ class DynamicVFE(nn.Module):
 
     @torch.no_grad()
     def forward(self, batch_dict, **kwargs):
+        if self.training:
+            # inference-only drop-in: the per-voxel reductions carry no autograd and BatchNorm1d would see the
+            # out-of-grid rows the reference filters out before the PFN (dynamic_vfe.py:89-91) -- a training
+            # pipeline must not silently freeze the PFN weights / skew the running statistics
+            raise RuntimeError("mssvt_amd DynamicVFE is forward-only (eval mode); call .eval() -- "
+                               "training the PFN layers is not supported by this drop-in")
         points = batch_dict['points'].contiguous()  # (P, 1 + F) rows [b, x, y, z, intensity, ...]
         batch_size = batch_dict['batch_size']
         voxel_coords, pv = voxelize.voxelize(points, self.point_cloud_range_l, self.voxel_size_l, self.grid_size_l,

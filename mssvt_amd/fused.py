@@ -55,6 +55,9 @@ def supported(block, sp):
     if block.win2_size is None or len(attn.num_heads) != 2:
         return False
     nq = {0: block.max_num_even, 1: block.max_num_odd, 2: block.max_num_win1}[block.cbs_pattern]
+    # plan kernel limits (csrc/window_plan.hip): offsets packed into bytes (|offset| <= 63), FPS lists < 2048 slots
+    if max(block.max_num_win1, block.max_num_win2) >= 2048 or max(block.win2_size) > 120:
+        return False
     return nq <= 256 and max(block.win1_size) <= 60
 
 
@@ -512,7 +515,7 @@ def prepare_group(blocks, sp, p):
     todo, seen = [], set(tabs)
     for b in blocks:
         C, FF = b.linear1.in_features, b.linear1.out_features
-        key = (b.cbs_pattern, 1 if b.use_feature_interpolation else 0)
+        key = (b.cbs_pattern, 1 if b.use_feature_interpolation else 0, _query(b, p)[1], C)
         if key not in seen and (C, FF) in FFN_SHAPES:
             seen.add(key)
             todo.append((b, key))
@@ -522,7 +525,7 @@ def prepare_group(blocks, sp, p):
         rows = mssvt_ops.full_neg1((len(todo), max(N, 1), 4), dev)
         ws = torch.empty((len(todo), max(N, 1), 4), dtype=torch.float32, device=dev)  # written with tab_row
         nqs, nus, its, qis, uis, ows, zrs = [], [], [], [], [], [], []
-        for b, (pat, interp) in todo:
+        for b, (pat, interp, _, _) in todo:
             q_ind, nq, owner_q = _query(b, p)
             upd_ind, n_upd, owner = (p.ind_win1, b.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
             nqs.append(nq); nus.append(n_upd); its.append(interp); qis.append(q_ind); uis.append(upd_ind)
@@ -538,7 +541,8 @@ def prepare_group(blocks, sp, p):
 def _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, mn3):
     """(tab_row (N,4) int32, tab_w (N,4) f32): where each voxel's update comes from.  Geometry
     only -> computed once per plan and (cbs_pattern, interpolation) and reused by later blocks."""
-    key = (block.cbs_pattern, interp)
+    # the table embeds the zero row of this (nq, C) attention buffer: part of the key
+    key = (block.cbs_pattern, interp, nq, block.linear1.in_features)
     tabs = getattr(p, "tables", None)
     if tabs is None:
         tabs = p.tables = {}
@@ -623,12 +627,40 @@ def one_scale_plan(block, sp, sync=True):
         p.host_ev = torch.cuda.Event()
         p.host_ev.record()
         return p
-    status, p.nw, p.R = ws[:3].tolist()  # the forward's single host sync
+    # the forward's single host sync; the status words of the voxel table and of this level's Block plans
+    # ride along (an overflow there must not pass silently either)
+    words = [ws[:3]] + list(st.get("status_words", []))
+    if getattr(sp, "map_status", None) is not None:
+        words.append(sp.map_status)
+    host = (torch.cat(words) if len(words) > 1 else ws[:3]).tolist()
+    status, p.nw, p.R = host[:3]
+    for extra in host[3:]:
+        status |= extra & (mssvt_ops.ST_TABLE_OVERFLOW | mssvt_ops.ST_WINDOW_OVERFLOW)
     if p.disjoint:
         p.R = N + (p.nw if p.with_pad else 0)  # rows = voxel rows (+ one pad row per window)
         p.num_rows = torch.full((1,), p.R, dtype=torch.int32, device=dev)
     _check_plan_status(block, status, H)
     return p
+
+
+def check_level_status(sp, max_num_wins=None):
+    """Overflow words of the level's voxel table and Block plans when no fused CompressBlock read them with
+    its output shape (operator-path CompressBlock, or a backbone that ends on a Block): one host sync."""
+    st = getattr(sp, "_level", None)
+    words = list(st.get("status_words", [])) if st else []
+    if getattr(sp, "map_status", None) is not None:
+        words.append(sp.map_status)
+    if not words or (st is not None and st.get("status_checked")):
+        return
+    status = 0
+    for w in torch.cat(words).tolist():
+        status |= w & (mssvt_ops.ST_TABLE_OVERFLOW | mssvt_ops.ST_WINDOW_OVERFLOW)
+    if st is not None:
+        st["status_checked"] = True
+    if status & mssvt_ops.ST_WINDOW_OVERFLOW:
+        raise _lib.MssvtHipError("a sample has more windows than max_num_wins")
+    if status & mssvt_ops.ST_TABLE_OVERFLOW:
+        raise _lib.MssvtHipError("hash table overflow (hash_size=%d)" % sp.hash_size)
 
 
 def _check_plan_status(block, status, H):
@@ -697,6 +729,7 @@ def _compress_forward_fused(block, sp, xhat, x_in):
 def compress_forward(block, sp):
     """Fused forward of a MixedScaleSparseTransformerCompressBlock (eval / no-grad)."""
     if not compress_supported(block, sp):
+        check_level_status(sp)
         return block.forward_ops(sp)
     xhat = _norm1(block, sp, sp.features)
     x_in = sp.features.contiguous()
@@ -820,7 +853,9 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
     flop = 2.0 * C * FF * N
     tf_up = flop / (ms_up * 1e-3) / 1e12
     tf_down = flop / (ms_down * 1e-3) / 1e12
-    alg = nw * (16 + 16 * (nq + 2 * K)) + (n_keys + 2 * n_q) * 4 * cg + 2 * 3 * n_q * 16 * cg
+    # window metadata + valid key rows (Cg wide) + query rows in and attention rows out (C wide); the Q~ / Xbar
+    # hand-off between the three launches is NOT algorithmic (it is this implementation's own traffic)
+    alg = nw * (16 + 16 * (nq + 2 * K)) + n_keys * 4 * cg + 2 * n_q * 4 * C
     gbs = alg / (ms_attn * 1e-3) / 1e9
     # HBM bytes per launch of k_ffn_up from the PMC passes committed under profiles/ (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for
@@ -877,5 +912,5 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
                  "algorithmic_bytes_per_launch": alg, "avg_launch_us": ms_attn * 1e3,
                  "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q},
                  "pmc": attn_pmc,
-                 "note": "gather-latency / MFMA-issue bound, not bandwidth bound (DESIGN.md section 4); pmc = HBM bytes "
+                 "note": "algorithmic bytes exclude the Q~ / Xbar hand-off between the launches; pmc = HBM bytes "
                          "(2 FETCH + WRITE) and MFMA-pipe busy fraction per launch from profiles/pmc_traffic.json"}]}

@@ -117,6 +117,7 @@ class MixedScaleSparseTransformerBlock(nn.Module):
             self.win1_size, self.win2_size, self.cbs_mode)
         self.set_vox_query_table(tables)
         self.impl = DEFAULT_IMPL
+        self.attn_dtype = "f32"
 
     # -- query tables -------------------------------------------------------
     def get_vox_query_table(self, win1_size, win2_size=None, cbs_mode=None):
@@ -372,6 +373,16 @@ class MixedScaleSparseTransformer(nn.Module):
             blk.impl = impl
         return self
 
+    def set_attn_dtype(self, attn_dtype):
+        """Operand type of the window-attention matrix products of the fused Blocks: "f32" (default; the parity path,
+        exact fp32 MFMA) or "bf16" (bf16 operands on the bf16 matrix cores, fp32 accumulation and softmax: the
+        BASELINE configs[2] variant, an extension of this build -- the reference computes in fp32,
+        mssvt_utils.py:112-150).  The FFN, LayerNorm, interpolation and the CompressBlock stay fp32."""
+        assert attn_dtype in ("f32", "bf16")
+        for blk in self.backbone:
+            blk.attn_dtype = attn_dtype
+        return self
+
     def forward(self, batch_dict):
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         # one -1 fill for all hash tables / owner arrays of the forward (sized from the previous forward)
@@ -398,6 +409,9 @@ class MixedScaleSparseTransformer(nn.Module):
                 sp._next_compress = next((b for b in self.backbone[i:]
                                           if isinstance(b, MixedScaleSparseTransformerCompressBlock)), None)
                 sp = blk(sp, block_idx=i)
+            if getattr(sp, "_level", None) is not None and arena is not None:
+                from . import fused  # a level that no fused CompressBlock closed: read its overflow words now
+                fused.check_level_status(sp)
         finally:
             mssvt_ops.FillArena.current = None
             if arena is not None:

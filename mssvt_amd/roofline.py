@@ -57,9 +57,81 @@ def _gather_two_window(net, vc, batch, event_time_ms, peak_gbs):
             "units_per_launch": {"windows": nw, "probes": probes, "list_entries": written}}
 
 
-def measure(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
+def frame_algorithmic(net, vc, feats, batch):
+    """Algorithmic HBM bytes and FLOP of ONE backbone forward on this input, SURVEY.md section 8(d), with the
+    valid (unpadded) counts measured on the input.  Per Block: 4C N (features read) + 4C N (written) + 16 N (indices)
+    + 8 Q nw (one hash slot per probed offset) + gathered rows (4C per valid query row in and out, 4 Cg per
+    unmasked key row: a key set only feeds its head group's channel slice) + 4C per covered voxel (interpolated rows);
+    hash build once per level: 24 N + 8 B H; the CompressBlock likewise with one query per window.  FLOP: the
+    reference's products on valid slots (Wq, Wkv, QK^T, PV, Wo per head group, positional MLP) + the FFN's 4 N C FF."""
+    from . import fused
+    from .mssvt_backbone import MixedScaleSparseTransformerBlock as Blk, MixedScaleSparseTransformerCompressBlock as Cmp
+    from .mssvt_utils import SparseTensor
+    B, H = batch, net.hash_size
+    N = int(vc.shape[0])
+    by, fl = 0.0, 0.0
+    by += 24.0 * N + 8.0 * B * H  # K1
+    plan_cache = {}
+    with torch.no_grad():
+        sp = SparseTensor(features=feats, indices=vc.int().contiguous(), spatial_shape=net.grid_size,
+                          voxel_size=net.voxel_size, point_cloud_range=net.point_cloud_range, batch_size=B,
+                          hash_size=H)
+        for blk in net.backbone:
+            C, FF = blk.linear1.in_features, blk.linear1.out_features
+            ma = blk.ms_attn
+            if isinstance(blk, Cmp):
+                t = blk._tables_on(vc.device)
+                ws = blk.win1_size
+                key = (vc[:, 0].long() * 4096 + vc[:, 3].long() // ws[0]) * 4096 + vc[:, 2].long() // ws[1]
+                key = key * 64 + vc[:, 1].long() // ws[2]
+                nw = int(torch.unique(key).numel())
+                keys = N  # every voxel sits in exactly one window of a non-overlapping partition
+                Q = int(t['win1'].shape[0])
+                by += 4.0 * C * N + 4.0 * C * nw + 16.0 * N + 8.0 * B * H + 8.0 * Q * nw + 4.0 * C * keys
+                fl += nw * 4.0 * C * C + keys * (4.0 * C * C + 4.0 * C) + keys * (12.0 * C + 2.0 * C * C)
+                fl += 4.0 * nw * C * FF
+                N = nw
+                continue
+            assert isinstance(blk, Blk)
+            k = blk.plan_key()
+            if k not in plan_cache:
+                p = fused.two_scale_plan(blk, sp)
+                nw = int(p.num_wins.item())
+                nqv = p.nq_valid[:, :nw].long()
+                kv = [(p.k_mask[g][:nw] == 0).sum(1) for g in range(2)]
+                plan_cache[k] = dict(nw=nw, nq={1: nqv[0], 0: nqv[1], 2: nqv[2]}, kv=kv,
+                                     n1=int((p.ind_win1[:nw] >= 0).sum()),
+                                     Q=sum(int(v.shape[0]) for v in blk._tables_on(vc.device).values()))
+            c = plan_cache[k]
+            nq = c["nq"][blk.cbs_pattern].double()
+            by += 8.0 * C * N + 16.0 * N + 8.0 * B * H + 8.0 * c["Q"] * c["nw"] + 8.0 * C * float(nq.sum())
+            by += 4.0 * C * (c["n1"] if blk.use_feature_interpolation else float(nq.sum()))
+            for g, cg in enumerate(ma.scale_dims):
+                kg = c["kv"][g].double()
+                by += 4.0 * cg * float(kg.sum())
+                fl += float((4.0 * nq * cg * cg + 4.0 * kg * cg * cg + 4.0 * nq * kg * cg).sum())
+                fl += 12.0 * cg * float((nq + kg).sum())
+            fl += 4.0 * N * C * FF
+    return by, fl
+
+
+def frame_roofline(net, vc, feats, batch, peak_gbs, ms_per_step):
+    from .fused import MFMA_F32_PEAK_TFLOPS
+    by, fl = frame_algorithmic(net, vc, feats, batch)
+    hbm_us, mfma_us = by / (peak_gbs * 1e9) * 1e6, fl / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e6
+    floor = hbm_us + mfma_us
+    return {"algorithmic_bytes": by, "algorithmic_flop": fl, "hbm_floor_us": hbm_us, "mfma_f32_floor_us": mfma_us,
+            "floor_us": floor, "measured_us": ms_per_step * 1e3, "frac": floor / (ms_per_step * 1e3),
+            "note": "sum of algorithmic bytes / 8 TB/s + sum of algorithmic FLOP / 157.3 TFLOP/s (fp32 matrix cores) "
+                    "against ms_per_step; SURVEY.md 8(d) accounting with the valid counts of this input"}
+
+
+def measure(net, vc, feats, batch, event_time_ms, peak_gbs, live=None, ms_per_step=None):
     impl = net.backbone[0].impl
     if impl == "fused":
         from . import fused
-        return fused.roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=live)
+        res = fused.roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=live)
+        if ms_per_step:
+            res["frame"] = frame_roofline(net, vc, feats, batch, peak_gbs, ms_per_step)
+        return res
     return _gather_two_window(net, vc, batch, event_time_ms, peak_gbs)

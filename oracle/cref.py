@@ -44,6 +44,15 @@ def lib():
     return _lib
 
 
+def set_num_threads(n):
+    """Threads of the OpenMP loops of the C oracle (0: the OpenMP default = all cores)."""
+    lib().orc_set_num_threads(int(n))
+
+
+def max_threads():
+    return int(lib().orc_get_max_threads())
+
+
 def _ip(a):
     assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))

@@ -1,6 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE's own Python (BUILD CONTAINER ONLY).
 
     python -m oracle.gen_golden               # from /root/repo: everything
+    python -m oracle.gen_golden --backbone-only  # tests/golden/backbone.npz alone
     python -m oracle.gen_golden --even-only   # only the cases added after the first set (even windows, empty
                                               # sample, K = 64, enlarged windows, two-level backbone): the
                                               # committed files of the first set stay byte-identical
@@ -295,6 +296,9 @@ def main():
     mods = ref_import.load()
     if "--grad-only" in sys.argv:
         gen_gradients(mods)
+        return
+    if "--backbone-only" in sys.argv:  # the 3-block backbone alone (metadata keys added after the first set)
+        gen_backbone(mods)
         return
     if "--even-only" in sys.argv:  # add the even-window cases without touching the committed files
         gen_even_windows(mods)

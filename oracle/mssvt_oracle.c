@@ -1,8 +1,14 @@
 /*
  * mssvt_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
  *
- * A plain-C, single-threaded restatement of the CUDA kernels on MsSVT's
- * mixed-scale sparse-voxel attention hot path.
+ * A plain-C restatement of the CUDA kernels on MsSVT's mixed-scale
+ * sparse-voxel attention hot path.  The loops
+ * over windows / rows (one CUDA thread or block each in the reference, no
+ * interaction between iterations) carry an OpenMP `parallel for`; the results
+ * do not depend on the thread count (tests/test_oracle_golden.py asserts it).
+ * K1 / K2 stay sequential: their insertion ORDER is the canonical order.  The
+ * gradient kernels (K6, K11) stay sequential too: their sum order is fixed.
+ * orc_set_num_threads(1) gives the scalar port bench.py also reports.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; the product path (mssvt_amd/) never does.
  *
@@ -29,6 +35,21 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* threads used by the parallel loops below (0 / negative: the OpenMP default) */
+static int g_threads = 0;
+void orc_set_num_threads(int n) { g_threads = n; }
+int orc_get_max_threads(void) {
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+#define ORC_THREADS (orc_get_max_threads())
 
 #define EMPTY_KEY (-1) /* mssvt/src/ms_cuda_utils.h:9 */
 
@@ -192,6 +213,7 @@ int orc_gather_two_window_voxels(
     int *vox_coord_win1, int *vox_coord_win2, const int *vox_query_odd,
     const int *vox_query_even, const int *vox_query_win1,
     const int *vox_query_win2, const int *win_indices, const int *table) {
+#pragma omp parallel for schedule(dynamic, 64) num_threads(ORC_THREADS)
     for (int t = 0; t < num_wins; ++t) {
         int b = win_indices[t * 4 + 0];
         int wz = win_indices[t * 4 + 1];
@@ -244,6 +266,7 @@ int orc_gather_one_window_voxels(int x_max, int y_max, int z_max, int x_ws,
                                  int *vox_ind_win1, int *vox_coord_win1,
                                  const int *vox_query_win1,
                                  const int *win_indices, const int *table) {
+#pragma omp parallel for schedule(dynamic, 64) num_threads(ORC_THREADS)
     for (int t = 0; t < num_wins; ++t) {
         int b = win_indices[t * 4 + 0];
         int wz = win_indices[t * 4 + 1];
@@ -267,6 +290,7 @@ int orc_gather_one_window_voxels(int x_max, int y_max, int z_max, int x_ws,
 int orc_group_features(int B, int M, int C, int nsample, const float *features,
                        const int *features_batch_cnt, const int *idx,
                        const int *idx_batch_cnt, float *out) {
+#pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
     for (int pt = 0; pt < M; ++pt) {
         int bs_idx = 0, pt_cnt = idx_batch_cnt[0]; /* :91-96 */
         for (int k = 1; k < B; k++) {
@@ -332,8 +356,11 @@ int orc_farthest_point_sampling(int b, int n, int m, const float *dataset,
                                 float *temp, int *idxs) {
     if (m <= 0) return 0;
     int bs = orc_opt_n_threads(n);
-    float *dists = (float *)malloc(sizeof(float) * (size_t)bs);
+#pragma omp parallel num_threads(ORC_THREADS)
+    {
+    float *dists = (float *)malloc(sizeof(float) * (size_t)bs); /* one "shared memory" per thread */
     int *dists_i = (int *)malloc(sizeof(int) * (size_t)bs);
+#pragma omp for schedule(dynamic, 16)
     for (int bi = 0; bi < b; ++bi) {
         const float *d = dataset + (size_t)bi * n * 3;
         float *tmp = temp + (size_t)bi * n;
@@ -374,6 +401,7 @@ int orc_farthest_point_sampling(int b, int n, int m, const float *dataset,
     }
     free(dists);
     free(dists_i);
+    }
     return 0;
 }
 
@@ -381,6 +409,7 @@ int orc_farthest_point_sampling(int b, int n, int m, const float *dataset,
  * idx (B,M) -> out (B,C,M)                                                   */
 int orc_gather_points(int b, int c, int n, int m, const float *points,
                       const int *idx, float *out) {
+#pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
     for (int bi = 0; bi < b; ++bi)
         for (int ci = 0; ci < c; ++ci)
             for (int p = 0; p < m; ++p)
@@ -407,6 +436,7 @@ int orc_gather_points_grad(int b, int c, int n, int m, const float *grad_out,
  * explicit fmaf() keeps the oracle and the HIP kernel bit-identical.        */
 int orc_three_nn(int b, int n, int m, const float *unknown, const float *known,
                  float *dist2, int *idx) {
+#pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
     for (int bi = 0; bi < b; ++bi)
         for (int p = 0; p < n; ++p) {
             const float *u = unknown + ((size_t)bi * n + p) * 3;
@@ -442,6 +472,7 @@ int orc_three_nn(int b, int n, int m, const float *unknown, const float *known,
  * points (B,C,N), idx (B,npoints,nsample) -> out (B,C,npoints,nsample)       */
 int orc_group_points(int b, int c, int n, int npoints, int nsample,
                      const float *points, const int *idx, float *out) {
+#pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
     for (int bi = 0; bi < b; ++bi)
         for (int ci = 0; ci < c; ++ci)
             for (int p = 0; p < npoints; ++p)

@@ -1,0 +1,45 @@
+"""bench.py end to end on the GPU box: the --gpus N launcher (this process starts the ranks itself), the DDP
+training step and the configs[2] flags.  A 1-GPU box runs the N > 1 code path with every rank on cuda:0 over gloo
+(MSSVT_BENCH_ONE_DEVICE=1); on the 8-GPU node the driver runs the same code over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--points",
+                        "20000", "--no-cpu-baseline", "--no-roofline"] + list(flags), capture_output=True, text=True,
+                       timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-800:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    res = _bench("--gpus", "2", "--batch", "2", env={"MSSVT_BENCH_ONE_DEVICE": "1"})
+    assert res["n_gpus"] == 2 and res["config"]["process_group"]["world_size"] == 2
+    assert res["value"] > 0 and res["scaling"] == "weak" and res["dtype"] == "f32"
+    # whole-job aggregate: both ranks' scenes over the max-over-ranks time
+    assert abs(res["value"] - 2 * 2 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]
+
+
+def test_bench_ddp_training_step_two_ranks():
+    res = _bench("--gpus", "2", "--train", env={"MSSVT_BENCH_ONE_DEVICE": "1"})
+    assert res["n_gpus"] == 2 and "DDP" in res["config"]["parallelism"] and res["value"] > 0
+
+
+def test_bench_configs2_flags():
+    res = _bench("--batch", "2", "--attn-dtype", "bf16")
+    assert res["dtype"] == "bf16" and res["config"]["attn_dtype"] == "bf16" and res["n_gpus"] == 1
+    assert res["timing"]["p10_ms"] <= res["timing"]["median_ms"] <= res["timing"]["p90_ms"]

@@ -59,3 +59,19 @@ def test_single_process_is_a_noop_group():
     assert mdist.init("gloo") is None
     el, out = mdist.timed_steps(lambda: 7, 2, None, None, sync=lambda: None)
     assert out == 7 and el >= 0
+
+
+def test_bench_launcher_starts_ranks_before_any_gpu_call_and_relays_failure():
+    """`bench.py --gpus 2` without a torchrun environment starts the two ranks itself (torch.distributed.run);
+    on this GPU-less box every rank stops at its "needs an MI355X" assert -- the parent must come back non-zero
+    (and cannot have touched a GPU itself: there is none, and it would have failed before spawning)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        return  # on the GPU box tests/test_bench_gpu.py runs the launcher for real
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr and r.stderr.count("needs an MI355X") >= 2  # both ranks ran

@@ -1,7 +1,9 @@
 """Module-level parity on the MI355X: the drop-in ``MixedScaleSparseTransformer*`` classes
 against (a) the outputs of the reference's own Python (tests/golden) and (b) the travelling
-oracle on seeded synthetic scenes.  Feature tolerance: 1e-3 relative (BASELINE north star),
-asserted here as |err| <= 1e-3 * max(1, |ref|) elementwise; indices bit-exact."""
+oracle on seeded synthetic scenes.  Indices bit-exact.  Feature tolerance: the contract's ceiling is
+1e-3 relative (BASELINE north star); what is asserted is 100x tighter, elementwise
+|err| <= 1e-5 * max(1, max|ref|) + 1e-4 * |ref| (observed ~1e-6: fp32 re-association only), so a
+regression of the arithmetic shows long before it reaches the ceiling."""
 import json
 import os
 
@@ -19,11 +21,23 @@ if os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(_
     IMPLS.append("fused")
 
 
-def assert_feat_close(got, want, tol=1e-3):
+RTOL, ATOL, CEILING = 1e-4, 1e-5, 1e-3
+
+
+def assert_feat_close(got, want, rtol=RTOL, atol=ATOL):
+    """|err| <= atol * max(1, max|ref|) + rtol * |ref| elementwise (a true relative form with an absolute floor that
+    follows the tensor's scale: an fp32 sum of terms of magnitude S carries ~1e-7 S whatever it cancels to), and the
+    contract's 1e-3 ceiling on top."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape
-    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
-    assert err.max() <= tol, "max scaled err %.3e at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
+    if got.size == 0:
+        return
+    err = np.abs(got - want)
+    bound = atol * max(1.0, float(np.abs(want).max())) + rtol * np.abs(want)
+    worst = (err / bound).max()
+    assert worst <= 1.0, "max err / bound = %.3f (err %.3e) at %s" % (
+        worst, err.flat[(err / bound).argmax()], np.unravel_index((err / bound).argmax(), err.shape))
+    assert (err / np.maximum(1.0, np.abs(want))).max() <= CEILING
 
 
 def load(golden_dir, name):
@@ -175,6 +189,34 @@ def test_full_size_frame_fused_matches_operator_path(B):
     assert torch.equal(a.features, a2.features), "the fused path must be run-to-run deterministic"
     assert_feat_close(a.features.cpu().numpy(), b.features.cpu().numpy())
     assert list(a.spatial_shape) == list(b.spatial_shape) and torch.equal(a.dense(), a2.dense())
+
+
+@pytest.mark.parametrize("impl", ["fused"])
+def test_full_size_frame_matches_the_oracle(impl):
+    """BASELINE configs[1] pinned to the oracle at the benchmark size: the 160k-point frame bench.py runs (same
+    seeds), C = 128, the mssvt.yaml backbone (heads [4,4] / [8], FF 256), through the CPU oracle's whole forward
+    (oracle/block_ref.py::backbone_forward on all host cores, tens of seconds) -- output voxel indices bit-exact,
+    features within the tolerance above."""
+    from mssvt_amd import config
+    from mssvt_amd.dist import scene_seeds
+    from oracle import cref
+    pts = synthetic.make_batch_points(160000, 1, seed0=scene_seeds(0, 1)[0])
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(1000))
+    torch.manual_seed(0)
+    cfg = config.load_yaml(config.DEFAULT_CFG)
+    net = config.build_backbone_from_cfg(cfg).eval()
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    cref.set_num_threads(0)
+    want = block_ref.backbone_forward(sd, [dict(p) for p in cfg.MODEL.BACKBONE_3D.PARAMS], feats.numpy(), vc, 1,
+                                      synthetic.GRID_SIZE, synthetic.VOXEL_SIZE, synthetic.POINT_CLOUD_RANGE, 400000)
+    net = net.to(DEV).set_impl(impl)
+    with torch.no_grad():
+        sp = net(dict(voxel_features=feats.to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV), batch_size=1))[
+            "encoded_spconv_tensor"]
+    assert want.features.shape[0] > 30000
+    np.testing.assert_array_equal(sp.indices.cpu().numpy(), want.indices)
+    assert_feat_close(sp.features.cpu().numpy(), want.features)
 
 
 def test_scene_sharding_invariance_at_full_size():

@@ -119,3 +119,41 @@ def test_backbone_forward_matches_reference(golden_dir, name):
     np.testing.assert_allclose(sp.features, d["out_features"], **TOL)
     np.testing.assert_allclose(dense[0, :, 0], d["dense_b0_z0"], **TOL)
     np.testing.assert_allclose(dense.sum(), float(d["dense_sum"]), rtol=1e-4)
+
+
+def test_oracle_results_do_not_depend_on_the_thread_count():
+    """The OpenMP loops of the C oracle (one iteration = one CUDA thread / block of the reference, no interaction)
+    give bit-identical results on one thread and on all cores -- bench.py's cpu_baseline times both."""
+    import torch
+    from mssvt_amd import synthetic
+    from oracle import cref
+    C, B, H = 32, 2, 40009
+    blk = dict(name="MixedScaleSparseTransformerBlock", channels=[C, 2 * C, C], num_heads=[2, 2],
+               window_size=[[3, 3, 5], [7, 7, 7]], max_num_win1=45, max_num_win2=343, cbs_mode="odd_even",
+               key_num_sample=32, use_feature_interpolation=True)
+    params = [dict(blk, cbs_pattern=1), dict(blk, cbs_pattern=2, use_feature_interpolation=False),
+              dict(name="MixedScaleSparseTransformerCompressBlock", channels=[C, 2 * C, C], num_heads=[4],
+                   window_size=[[1, 1, 32]], max_num_win1=32)]
+    vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(3000, B, 77))
+    feats = torch.randn(vc.shape[0], C, generator=torch.Generator().manual_seed(3)).numpy()
+    from mssvt_amd.config import Config
+    from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
+    torch.manual_seed(5)
+    net = MixedScaleSparseTransformer(Config.wrap(dict(HASH_SIZE=H, NUM_OUTPUT_FEATURES=C, PARAMS=params)), C,
+                                      synthetic.GRID_SIZE, synthetic.VOXEL_SIZE, synthetic.POINT_CLOUD_RANGE)
+    sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    outs = []
+    keep = torch.get_num_threads()
+    try:
+        for nt in (1, 4, 0):
+            cref.set_num_threads(nt)
+            torch.set_num_threads(1)  # torch's CPU GEMMs may re-associate with the thread count; the C loops must not
+            outs.append(block_ref.backbone_forward(sd, params, feats, vc, B, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
+                                                   synthetic.POINT_CLOUD_RANGE, H))
+    finally:
+        cref.set_num_threads(0)
+        torch.set_num_threads(keep)
+    assert cref.max_threads() >= 1
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o.indices, outs[0].indices)
+        np.testing.assert_array_equal(o.features, outs[0].features)
