@@ -252,7 +252,8 @@ def main():
         step()
     elapsed, out = mdist.timed_steps(step, args.steps, dist, dev)
     # SURVEY 8(d) protocol beside the driver's K-step clock: every step between two HIP events
-    times = per_step_times_ms(step, max(50, args.steps)) if rank == 0 else None
+    # (a training step is collective -- every rank takes part; the forward is not, rank 0 measures alone)
+    times = per_step_times_ms(step, max(50, args.steps)) if (rank == 0 or args.train) else None
     # live roofline: the same K steps once more on rank 0 with HIP events around every launch of the
     # dominant kernel (kept out of the timed region above: the event markers cost ~3 % of the frame rate)
     live = None

@@ -270,6 +270,20 @@ int mssvt_block_attention(
     const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
     const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream);
 
+/* mssvt_block_attention with bf16 matrix-core operands (BASELINE configs[2]; an extension of this build -- the
+ * reference's MixedScaleAttention computes in fp32, ref mssvt_utils.py:112-150): ONE launch, one wavefront per
+ * (window, head group); keys and values are projected inside the kernel (v_mfma_f32_16x16x32_bf16), so there is
+ * no qbuf hand-off.  Tokens, weights, Q', K', V', P and O are rounded to bf16 as MFMA operands; accumulation,
+ * softmax, biases, the positional MLP and the attention rows written stay fp32.  Same arguments as
+ * mssvt_block_attention minus qbuf.  MSSVT_E_TOOLARGE: shape not instantiated (use the fp32 entry point).   */
+int mssvt_block_attention_bf16(
+    int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
+    int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
+    const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
+    const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
+    const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *attn, void *stream);
+
 /* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
  * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):
  * x_new[v] = interp(v) + x_in[v] for every voxel v owned by a list slot; rows of other

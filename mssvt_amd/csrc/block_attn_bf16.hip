@@ -1,0 +1,476 @@
+// block_attn_bf16.hip -- window attention of one MsSVT Block with bf16 matrix-core operands
+// (BASELINE configs[2]; an extension of this build: the reference computes in fp32,
+// ref: pcdet/models/model_utils/mssvt_utils.py:112-150, pcdet/models/backbones_3d/mssvt_backbone.py:260-295).
+//
+// ONE launch, one wavefront per (window, head group), nothing handed over through HBM: with the bf16 matrix
+// rate (16x the fp32 one) the keys ARE projected in the kernel -- the re-association the fp32 path uses to
+// keep its matrix work small (block_attn.hip: keys never projected, 1 KiB per query and group exchanged
+// between three launches) is not needed.  Per window and group, Cg = heads * head_dim channels:
+//   T   = xhat rows of the <= K key slots + relu(positional MLP)              (fp32, K = 4 fp32 MFMA)
+//   Kp^T = Wk T^T,  Vp = T Wv^T                                               (bf16 16x16x32)
+//   per pass of 16 / HP queries (column = query * HP + head):
+//   Q'^T = Wq Xq^T + bq, scaled, masked to the column's head                  (bf16)
+//   S    = Kp Q'm^T  -> softmax over the unmasked keys (fp32, in registers)
+//   O^T  = Vp^T P + bv, masked to the column's head                           (bf16)
+//   out^T = Wo O^T summed over the HP columns of a query (DPP) + bo -> attention rows (fp32)
+// Accumulation, softmax, biases, the positional MLP and every output stay fp32; only MFMA operands are rounded
+// to bf16 (tokens, weights, Q', K', V', P, O).  bk cancels in the softmax and is never read.
+//
+// Operand layouts (v_mfma_f32_16x16x32_bf16; lane l: la = l % 16, g = l / 16): A lane holds A[row la][k-slot g*8+j],
+// B lane holds B[k-slot g*8+j][col la], j < 8; C/D lane holds rows 4 g + i of column la.  The k index of a step is
+// only a LABEL both operands must agree on: k-step s covers the two 16-channel tiles 2s and 2s+1, slot (g, j) <->
+// channel 16 (2s + j / 4) + 4 g + j % 4.  With that labelling an fp32 accumulator (lane (col, g): rows 16 n + 4 g + i)
+// IS, after conversion, the operand of the next product over its row index -- no shuffle, no LDS round trip --
+// and 4 consecutive channels of a row are one 16-byte global load.  The weight matrices sit in LDS as ready
+// fragments [matrix][tile n][step s][lane] x 16 bytes (one conflict-free ds_read_b128 per MFMA operand).
+#include "common.hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BA_WAVES 4
+#define BA_MAX_GROUPS 4
+
+struct AttnBfArgs {
+    int C, c0, heads, hd;
+    float scale;
+    int nq, K;
+    const float *xhat;
+    const int *num_wins, *perm, *q_off, *nq_valid, *num_rows;
+    const float4 *qrow_meta;
+    const int2 *qrow_src;
+    const float4 *kmeta, *wcentre;
+    const float *Wq, *bq, *Wkv, *bkv, *Wo, *bo, *Wp, *bp;
+    float *attn;
+    int row_capacity;
+};
+struct AttnBfPack {
+    AttnBfArgs g[BA_MAX_GROUPS];
+};
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4 lo, const f32x4 hi) {
+    bf16x8 r;
+    r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
+    r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+    return r;
+}
+#define MFMA_BF(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16((av), (bv), acc, 0, 0, 0)
+#define MFMA_F4(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
+
+template <int CG, int HD, int KT>
+__global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_bf16(AttnBfPack pack) {
+    const AttnBfArgs &a = pack.g[blockIdx.y];
+    constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, NS = (NT + 1) / 2, KS = (KT + 1) / 2;
+    constexpr int NH = CG / HD, HP = NH <= 1 ? 1 : (NH <= 2 ? 2 : (NH <= 4 ? 4 : 8)), QPP = 16 / HP;
+    constexpr f32x4 Z4 = {0.f, 0.f, 0.f, 0.f};
+    extern __shared__ float4 lds4[];
+    bf16x8 *Wf = reinterpret_cast<bf16x8 *>(lds4);                       // [4][NT][NS][64] fragments
+    float *bias_l = reinterpret_cast<float *>(Wf + 4 * NT * NS * 64);    // [3][CGP]: bq, bv, bo
+    // ---- stage the four matrices as bf16 fragments (mat 0 Wq, 1 Wk, 2 Wv, 3 Wo) -------------------------
+    {
+        constexpr int NF = 4 * NT * NS * 64, PER = (NF + BA_WAVES * MSSVT_WAVE - 1) / (BA_WAVES * MSSVT_WAVE);
+        float4 lo[PER], hi[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int f = threadIdx.x + u * BA_WAVES * MSSVT_WAVE;
+            const int fl = f & 63, fs = (f >> 6) % NS, fn = ((f >> 6) / NS) % NT, mat = (f >> 6) / (NS * NT);
+            const int row = 16 * fn + (fl & 15), fg = fl >> 4;
+            const float *W = mat == 0 ? a.Wq : (mat == 1 ? a.Wkv : (mat == 2 ? a.Wkv + (size_t)CG * CG : a.Wo));
+            const int cl = 16 * (2 * fs) + 4 * fg, ch = 16 * (2 * fs + 1) + 4 * fg;
+            const bool ok = f < NF && mat < 4 && row < CG;
+            lo[u] = ok && cl < CG ? *reinterpret_cast<const float4 *>(W + (size_t)row * CG + cl)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            hi[u] = ok && ch < CG ? *reinterpret_cast<const float4 *>(W + (size_t)row * CG + ch)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int f = threadIdx.x + u * BA_WAVES * MSSVT_WAVE;
+            if (f < NF)
+                Wf[f] = pack8(f32x4{lo[u].x, lo[u].y, lo[u].z, lo[u].w}, f32x4{hi[u].x, hi[u].y, hi[u].z, hi[u].w});
+        }
+        for (int e = threadIdx.x; e < 3 * CGP; e += blockDim.x) {
+            const int which = e / CGP, c = e % CGP;
+            bias_l[e] = c < CG ? (which == 0 ? a.bq[c] : (which == 1 ? a.bkv[CG + c] : a.bo[c])) : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    // positional MLP operand of this lane (channel 16 u + la, input g): constant part + window part
+    float wconst[NT], w3[NT], w4[NT], w5[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int c = 16 * u + la;
+        const bool in = CGP == CG || c < CG;
+        const float *wp = a.Wp + (size_t)(a.c0 + (in ? c : 0)) * 6;
+        wconst[u] = in ? (g < 3 ? wp[g] : a.bp[a.c0 + c]) : 0.f;
+        w3[u] = in && g == 3 ? wp[3] : 0.f;
+        w4[u] = in && g == 3 ? wp[4] : 0.f;
+        w5[u] = in && g == 3 ? wp[5] : 0.f;
+    }
+    const int hh = la % HP, ql = la / HP;  // this column's head and query of the pass
+    const int n_act = *a.num_wins;
+    const int wstep = gridDim.x * BA_WAVES;
+    const int K = a.K;
+    int wi = blockIdx.x * BA_WAVES + wv;
+    if (wi >= n_act) return;
+    // stage M: metadata of a window, two windows ahead
+    float4 wc_m, km_m[KT];
+    int nqv_m, qbase_m;
+#define BF_LOAD_META(wi_)                                                                  \
+    {                                                                                      \
+        const int w_ = a.perm[wi_];                                                        \
+        wc_m = a.wcentre[w_];                                                              \
+        nqv_m = a.nq_valid[w_];                                                            \
+        qbase_m = a.q_off[w_];                                                             \
+        _Pragma("unroll") for (int t = 0; t < KT; ++t)                                     \
+            km_m[t] = a.kmeta[(size_t)w_ * K + min(16 * t + la, K - 1)];                   \
+    }
+    // stage R: raw key rows (+ the first pass's query metadata) of a window, one window ahead
+    float4 wc_r, qm_r;
+    int2 qs_r;
+    int nqv_r, qbase_r;
+    float rel_r[KT];
+    unsigned vmask_r, used_r;
+    f32x4 T1n[KT][NT];
+#define BF_ISSUE_ROWS()                                                                    \
+    {                                                                                      \
+        wc_r = wc_m; qbase_r = qbase_m;                                                    \
+        nqv_r = qbase_m + nqv_m <= a.row_capacity ? nqv_m : 0;                             \
+        vmask_r = 0; used_r = 0;                                                           \
+        _Pragma("unroll") for (int t = 0; t < KT; ++t) {                                   \
+            const int r_ = __builtin_bit_cast(int, km_m[t].w);                             \
+            const bool ok_ = 16 * t + la < K && r_ >= 0;                                   \
+            const unsigned long long bal_ = __ballot(ok_);                                 \
+            vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
+            used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
+            rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
+            if (used_r >> t & 1) {                                                         \
+                const float *xr_ = a.xhat + (size_t)(ok_ ? r_ : 0) * a.C + a.c0;           \
+                _Pragma("unroll") for (int S = 0; S < NT; ++S) {                           \
+                    const int c_ = 16 * S + 4 * g;                                         \
+                    const float4 v_ = (CGP == CG || c_ < CG) ? *reinterpret_cast<const float4 *>(xr_ + c_) \
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f); \
+                    T1n[t][S] = f32x4{v_.x, v_.y, v_.z, v_.w};                             \
+                }                                                                          \
+            }                                                                              \
+        }                                                                                  \
+        const int qr_ = qbase_r + min(ql, max(nqv_r, 1) - 1);                              \
+        qm_r = a.qrow_meta[min(qr_, a.row_capacity - 1)];                                  \
+        qs_r = a.qrow_src[min(qr_, a.row_capacity - 1)];                                   \
+    }
+    BF_LOAD_META(wi)
+    BF_ISSUE_ROWS()
+    if (wi + wstep < n_act) BF_LOAD_META(wi + wstep)
+    for (; wi < n_act; wi += wstep) {
+        const float4 wc = wc_r;
+        const int nqv = nqv_r, qbase = qbase_r;
+        const unsigned vmask = vmask_r, used = used_r;
+        float4 qm = qm_r;
+        int2 qs = qs_r;
+        // the first pass's query rows travel under the key projections
+        f32x4 xq[NT];
+        {
+            const float *xr = a.xhat + (size_t)__builtin_bit_cast(int, qm.w) * a.C + a.c0;
+#pragma unroll
+            for (int S = 0; S < NT; ++S) {
+                const int c = 16 * S + 4 * g;
+                const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xr + c)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                xq[S] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+        // key tokens: + relu(positional MLP), rounded to bf16 operands (A of Vp = T Wv^T, B of Kp^T = Wk T^T)
+        float wu[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) wu[u] = ((wconst[u] + w3[u] * wc.x) + w4[u] * wc.y) + w5[u] * wc.z;
+        bf16x8 Tb[KT][NS];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            if (!(used >> t & 1)) continue;
+            f32x4 tk[2 * NS];
+#pragma unroll
+            for (int u = 0; u < 2 * NS; ++u) {
+                tk[u] = Z4;
+                if (u < NT) {
+                    f32x4 p1 = Z4;
+                    MFMA_F4(p1, wu[u], rel_r[t]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tk[u][i] = T1n[t][u][i] + fmaxf(p1[i], 0.0f);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Tb[t][s] = pack8(tk[2 * s], tk[2 * s + 1]);
+        }
+        // ---- next window: rows in flight under this window's MFMAs, metadata one further ahead --------
+        if (wi + wstep < n_act) {
+            BF_ISSUE_ROWS()
+            if (wi + 2 * wstep < n_act) BF_LOAD_META(wi + 2 * wstep)
+        }
+        // ---- key / value projections ---------------------------------------------------------------------
+        bf16x8 Kb[KT][NS];  // A operand of S = Kp Q'm^T: lane (key la, g), k-slots = Kp channels
+        bf16x8 Vb[NT][KS];  // A operand of O^T = Vp^T P: lane (channel la of tile n, g), k-slots = keys
+        {
+            f32x4 vacc[NT][2 * KS];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int t = 0; t < 2 * KS; ++t) vacc[n][t] = Z4;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                if (!(used >> t & 1)) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) Kb[t][s] = pack8(Z4, Z4);
+                    continue;
+                }
+                f32x4 kacc[2 * NS];
+#pragma unroll
+                for (int n = 0; n < 2 * NS; ++n) kacc[n] = Z4;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        MFMA_BF(kacc[n], Wf[((1 * NT + n) * NS + s) * 64 + lane], Tb[t][s]);
+                        MFMA_BF(vacc[n][t], Tb[t][s], Wf[((2 * NT + n) * NS + s) * 64 + lane]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of later tiles from being hoisted
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) Kb[t][s] = pack8(kacc[2 * s], kacc[2 * s + 1]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) Vb[n][s] = pack8(vacc[n][2 * s], vacc[n][2 * s + 1]);
+        }
+        // ---- queries, QPP per pass: column la = query * HP + head ----------------------------------------
+        for (int q0 = 0; q0 < nqv; q0 += QPP) {
+            if (q0 > 0) {
+                const int qr = qbase + min(q0 + ql, nqv - 1);
+                qm = a.qrow_meta[qr];
+                qs = a.qrow_src[qr];
+                const float *xr = a.xhat + (size_t)__builtin_bit_cast(int, qm.w) * a.C + a.c0;
+#pragma unroll
+                for (int S = 0; S < NT; ++S) {
+                    const int c = 16 * S + 4 * g;
+                    const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xr + c)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                    xq[S] = f32x4{v.x, v.y, v.z, v.w};
+                }
+            }
+            // query tokens: + relu(positional MLP) -> B operand of Q'^T = Wq Xq^T
+            const float qrel = g == 0 ? qm.x : (g == 1 ? qm.y : (g == 2 ? qm.z : 1.0f));
+            bf16x8 Xb[NS];
+            {
+                f32x4 tk[2 * NS];
+#pragma unroll
+                for (int u = 0; u < 2 * NS; ++u) {
+                    tk[u] = Z4;
+                    if (u < NT) {
+                        f32x4 p1 = Z4;
+                        MFMA_F4(p1, wu[u], qrel);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) tk[u][i] = xq[u][i] + fmaxf(p1[i], 0.0f);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) Xb[s] = pack8(tk[2 * s], tk[2 * s + 1]);
+            }
+            // Q'^T[o][col] = sum_c Wq[o][c] xq[col][c] + bq[o]; scaled; rows outside the column's head -> 0
+            bf16x8 Qb[NS];
+            {
+                f32x4 qa[2 * NS];
+#pragma unroll
+                for (int n = 0; n < 2 * NS; ++n) {
+                    qa[n] = Z4;
+                    if (n < NT) {
+                        const float4 b = *reinterpret_cast<const float4 *>(bias_l + 16 * n + 4 * g);
+                        qa[n] = f32x4{b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) MFMA_BF(qa[n], Wf[((0 * NT + n) * NS + s) * 64 + lane], Xb[s]);
+                        const bool mine = (16 * n + 4 * g) / HD == hh;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) qa[n][i] = mine ? qa[n][i] * a.scale : 0.f;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) Qb[s] = pack8(qa[2 * s], qa[2 * s + 1]);
+            }
+            // scores S[key][col] = sum_o Kp[key][o] Q'm[col][o]
+            f32x4 sc[2 * KS];
+#pragma unroll
+            for (int t = 0; t < 2 * KS; ++t) sc[t] = Z4;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                if (!(used >> t & 1)) continue;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) MFMA_BF(sc[t], Kb[t][s], Qb[s]);
+            }
+            // softmax over the unmasked keys: lane (col, g) holds keys 16 t + 4 g + i
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, (vmask >> (4 * t + i) & 1) ? sc[t][i] : -INFINITY);
+            mx = fmaxf(mx, lane_xor16(mx));
+            mx = fmaxf(mx, lane_xor32(mx));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2 * KS; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = (t < KT && (vmask >> (4 * t + i) & 1)) ? __expf(sc[t][i] - mx) : 0.0f;
+                    sc[t][i] = e;
+                    sum += e;
+                }
+            sum += lane_xor16(sum);
+            sum += lane_xor32(sum);
+            const float inv = __builtin_amdgcn_rcpf(sum);  // slot 0 of a list is never masked: sum >= 1
+            bf16x8 Pb[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                f32x4 p0, p1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    p0[i] = sc[2 * s][i] * inv;
+                    p1[i] = sc[2 * s + 1][i] * inv;
+                }
+                Pb[s] = pack8(p0, p1);
+            }
+            // O^T[o][col] = sum_key Vp[key][o] P[key][col] + bv[o]; rows outside the column's head -> 0
+            bf16x8 Ob[NS];
+            {
+                f32x4 oa[2 * NS];
+#pragma unroll
+                for (int n = 0; n < 2 * NS; ++n) {
+                    oa[n] = Z4;
+                    if (n < NT) {
+                        const float4 b = *reinterpret_cast<const float4 *>(bias_l + CGP + 16 * n + 4 * g);
+                        oa[n] = f32x4{b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) MFMA_BF(oa[n], Vb[n][s], Pb[s]);
+                        const bool mine = (16 * n + 4 * g) / HD == hh;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) oa[n][i] = mine ? oa[n][i] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) Ob[s] = pack8(oa[2 * s], oa[2 * s + 1]);
+            }
+            // out^T[p][col] = sum_{o in head(col)} Wo[p][o] O[col][o]; summed over the HP columns of the query
+            const bool q_ok = q0 + ql < nqv;
+            float *dst = a.attn + (size_t)qs.y * a.C + a.c0;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x4 acc = Z4;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) MFMA_BF(acc, Wf[((3 * NT + n) * NS + s) * 64 + lane], Ob[s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[i];
+                    if (HP >= 2) v += DPP_MOV(v, 0xB1);   // lane ^ 1
+                    if (HP >= 4) v += DPP_MOV(v, 0x4E);   // lane ^ 2
+                    if (HP >= 8) v += DPP_MOV(v, 0x141);  // the other quad of the 8-lane group
+                    acc[i] = v;
+                }
+                if (q_ok && (n % HP) == hh && (CGP == CG || 16 * n + 4 * g < CG)) {
+                    const float4 b = *reinterpret_cast<const float4 *>(bias_l + 2 * CGP + 16 * n + 4 * g);
+                    *reinterpret_cast<float4 *>(dst + 16 * n + 4 * g) =
+                        make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#undef BF_LOAD_META
+#undef BF_ISSUE_ROWS
+}
+
+template <int CG, int HD>
+static int launch_attn_bf16(const AttnBfPack &pack, int ng, hipStream_t stream) {
+    constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, NS = (NT + 1) / 2;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int K = pack.g[0].K;
+    // persistent over the work order: 2 workgroups of 4 waves per CU (VGPR bound)
+    const dim3 grid(cus * 2 / ng > 0 ? cus * 2 / ng : 1, ng);
+    const size_t lds = (size_t)4 * NT * NS * 64 * 16 + (size_t)3 * CGP * 4;
+    if (K <= 16)
+        k_attn_bf16<CG, HD, 1><<<grid, BA_WAVES * MSSVT_WAVE, lds, stream>>>(pack);
+    else if (K <= 32)
+        k_attn_bf16<CG, HD, 2><<<grid, BA_WAVES * MSSVT_WAVE, lds, stream>>>(pack);
+    else
+        k_attn_bf16<CG, HD, 4><<<grid, BA_WAVES * MSSVT_WAVE, lds, stream>>>(pack);
+    return mssvt_launch_status();
+}
+
+static int dispatch_attn_bf16(const AttnBfPack &pack, int ng, int Cg, int head_dim, hipStream_t st) {
+#define MSSVT_ATTN_BF_CASE(cg, hd) \
+    if (Cg == cg && head_dim == hd) return launch_attn_bf16<cg, hd>(pack, ng, st);
+    MSSVT_ATTN_BF_CASE(16, 8)
+    MSSVT_ATTN_BF_CASE(16, 16)
+    MSSVT_ATTN_BF_CASE(32, 8)
+    MSSVT_ATTN_BF_CASE(32, 16)
+    MSSVT_ATTN_BF_CASE(32, 32)
+    MSSVT_ATTN_BF_CASE(48, 16)
+    MSSVT_ATTN_BF_CASE(64, 8)
+    MSSVT_ATTN_BF_CASE(64, 16)
+    MSSVT_ATTN_BF_CASE(64, 32)
+    return MSSVT_E_TOOLARGE;  // shape not instantiated: the caller uses the fp32 kernels
+#undef MSSVT_ATTN_BF_CASE
+}
+
+extern "C" int mssvt_block_attention_bf16(
+    int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
+    int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
+    const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
+    const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
+    const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *attn, void *stream) {
+    if (!host_c0 || !host_cg || !host_heads || !xhat || !num_active_dev || !perm || !q_off || !nq_valid ||
+        !num_rows_dev || !qrow_meta || !qrow_src || !host_kmeta || !wcentre || !host_Wq || !host_bq || !host_Wkv ||
+        !host_bkv || !host_Wo || !host_bo || !Wpos || !bpos || !attn || C <= 0 || num_groups <= 0 ||
+        head_dim <= 0 || nq <= 0 || key_num_sample <= 0 || row_capacity <= 0)
+        return MSSVT_E_BADARG;
+    if (C & 3) return MSSVT_E_BADARG;
+    if (key_num_sample > MSSVT_WAVE || (head_dim & 3)) return MSSVT_E_TOOLARGE;
+    hipStream_t st = (hipStream_t)stream;
+    bool same = num_groups <= BA_MAX_GROUPS;
+    for (int g = 0; g < num_groups; ++g) same = same && host_cg[g] == host_cg[0];
+    AttnBfPack pack;
+    for (int g = 0; g < num_groups; ++g) {
+        const int c0 = host_c0[g], Cg = host_cg[g], heads = host_heads[g];
+        if (!host_kmeta[g] || !host_Wq[g] || !host_bq[g] || !host_Wkv[g] || !host_bkv[g] || !host_Wo[g] || !host_bo[g])
+            return MSSVT_E_BADARG;
+        if (Cg <= 0 || heads <= 0 || Cg != heads * head_dim || c0 < 0 || c0 + Cg > C || (c0 & 3)) return MSSVT_E_BADARG;
+        if (Cg > MSSVT_WAVE || heads > 8) return MSSVT_E_TOOLARGE;
+        AttnBfArgs a;
+        a.C = C; a.c0 = c0; a.heads = heads; a.hd = head_dim; a.scale = scale;
+        a.nq = nq; a.K = key_num_sample;
+        a.xhat = xhat; a.num_wins = num_active_dev; a.perm = perm; a.q_off = q_off; a.nq_valid = nq_valid;
+        a.num_rows = num_rows_dev;
+        a.qrow_meta = reinterpret_cast<const float4 *>(qrow_meta);
+        a.qrow_src = reinterpret_cast<const int2 *>(qrow_src);
+        a.kmeta = reinterpret_cast<const float4 *>(host_kmeta[g]);
+        a.wcentre = reinterpret_cast<const float4 *>(wcentre);
+        a.Wq = host_Wq[g]; a.bq = host_bq[g]; a.Wkv = host_Wkv[g]; a.bkv = host_bkv[g];
+        a.Wo = host_Wo[g]; a.bo = host_bo[g]; a.Wp = Wpos; a.bp = bpos;
+        a.attn = attn;
+        a.row_capacity = row_capacity;
+        if (same) {
+            pack.g[g] = a;
+        } else {  // unequal group widths: one launch per group
+            AttnBfPack one;
+            for (int i = 0; i < BA_MAX_GROUPS; ++i) one.g[i] = a;
+            const int rc = dispatch_attn_bf16(one, 1, Cg, head_dim, st);
+            if (rc) return rc;
+        }
+    }
+    if (!same) return MSSVT_OK;
+    for (int g = num_groups; g < BA_MAX_GROUPS; ++g) pack.g[g] = pack.g[0];
+    return dispatch_attn_bf16(pack, num_groups, host_cg[0], head_dim, st);
+}

@@ -329,13 +329,36 @@ def _query_scratch(p, rows, ma, dev):
     return p.qbuf
 
 
+# (channels per head group, head dim) pairs instantiated in csrc/block_attn_bf16.hip
+ATTN_BF16_SHAPES = {(16, 8), (16, 16), (32, 8), (32, 16), (32, 32), (48, 16), (64, 8), (64, 16), (64, 32)}
+
+
+def attn_uses_bf16(block):
+    """The bf16-operand kernel runs when the module asks for it (`attn_dtype == "bf16"`) and the shape is
+    instantiated; anything else runs the fp32 kernels."""
+    ma = block.ms_attn
+    return (getattr(block, "attn_dtype", "f32") == "bf16" and block.key_num_sample <= 64
+            and all((cg, ma.per_head_dim) in ATTN_BF16_SHAPES for cg in ma.scale_dims))
+
+
 def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
-    """mssvt_block_attention for the given head groups (default: all)."""
+    """mssvt_block_attention (or its bf16-operand form) for the given head groups (default: all)."""
     ma = block.ms_attn
     gs = list(range(len(ma.num_heads))) if groups is None else list(groups)
     c0s = [sum(ma.scale_dims[:g]) for g in gs]
     ia = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])  # noqa: E731
     pa = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+    if attn_uses_bf16(block):
+        _lib.call("mssvt_block_attention_bf16", _i(C), _i(len(gs)), ia(c0s), ia([ma.scale_dims[g] for g in gs]),
+                  ia([ma.num_heads[g] for g in gs]), _i(ma.per_head_dim), _f(ma.scale), _i(nq),
+                  _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(od["n_act"]), _lib.ptr(od["perm"]),
+                  _lib.ptr(od["q_off"]), _lib.ptr(od["nq_valid"]), _lib.ptr(od["n_rows"]), _i(od["row_cap"]),
+                  _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]), pa([p.kmeta[g] for g in gs]),
+                  _lib.ptr(p.wcentre), pa([ma.to_qs[g].weight for g in gs]), pa([ma.to_qs[g].bias for g in gs]),
+                  pa([ma.to_kvs[g].weight for g in gs]), pa([ma.to_kvs[g].bias for g in gs]),
+                  pa([ma.projs[g].weight for g in gs]), pa([ma.projs[g].bias for g in gs]),
+                  _lib.ptr(block.pos_proj[0].weight), _lib.ptr(block.pos_proj[0].bias), _lib.ptr(attn), _lib.stream())
+        return
     _lib.call("mssvt_block_attention", _i(C), _i(len(gs)), ia(c0s), ia([ma.scale_dims[g] for g in gs]),
               ia([ma.num_heads[g] for g in gs]), _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(block.key_num_sample),
               _lib.ptr(xhat), _lib.ptr(od["n_act"]), _lib.ptr(od["perm"]), _lib.ptr(od["q_off"]),

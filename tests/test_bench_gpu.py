@@ -19,7 +19,7 @@ def _bench(*flags, env=None):
     e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--points",
                         "20000", "--no-cpu-baseline", "--no-roofline"] + list(flags), capture_output=True, text=True,
-                       timeout=900, env=e, cwd=ROOT)
+                       timeout=420, env=e, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-800:]  # ONE JSON line, from rank 0
