@@ -57,6 +57,16 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4 lo, const f32x4 hi) {
 #define MFMA_BF(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16((av), (bv), acc, 0, 0, 0)
 #define MFMA_F4(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
 
+#ifdef MSSVT_STAMPS  // developer instrumentation: cycles per phase, summed per wave (first 64 workgroups, group 0)
+__device__ unsigned long long g_attn_bf_stamps[64 * BA_WAVES * 8];
+extern "C" int mssvt_debug_read_attn_bf_stamps(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_bf_stamps), sizeof(g_attn_bf_stamps));
+}
+#define BSTAMP(k_) { const unsigned long long now_ = __builtin_readcyclecounter(); ph[k_] += now_ - tlast; tlast = now_; }
+#else
+#define BSTAMP(k_)
+#endif
+
 template <int CG, int HD, int KT>
 __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_bf16(AttnBfPack pack) {
     const AttnBfArgs &a = pack.g[blockIdx.y];
@@ -66,6 +76,7 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
     extern __shared__ float4 lds4[];
     bf16x8 *Wf = reinterpret_cast<bf16x8 *>(lds4);                       // [4][NT][NS][64] fragments
     float *bias_l = reinterpret_cast<float *>(Wf + 4 * NT * NS * 64);    // [3][CGP]: bq, bv, bo
+    float4 *wpc_l = reinterpret_cast<float4 *>(bias_l + 3 * CGP);        // [CGP]: (wp3, wp4, wp5, bp) of the channel
     // ---- stage the four matrices as bf16 fragments (mat 0 Wq, 1 Wk, 2 Wv, 3 Wo) -------------------------
     {
         constexpr int NF = 4 * NT * NS * 64, PER = (NF + BA_WAVES * MSSVT_WAVE - 1) / (BA_WAVES * MSSVT_WAVE);
@@ -93,41 +104,68 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
             const int which = e / CGP, c = e % CGP;
             bias_l[e] = c < CG ? (which == 0 ? a.bq[c] : (which == 1 ? a.bkv[CG + c] : a.bo[c])) : 0.f;
         }
+        for (int c = threadIdx.x; c < CGP; c += blockDim.x) {
+            const float *wp = a.Wp + (size_t)(a.c0 + (c < CG ? c : 0)) * 6;
+            wpc_l[c] = c < CG ? make_float4(wp[3], wp[4], wp[5], a.bp[a.c0 + c]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __syncthreads();
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = threadIdx.x / MSSVT_WAVE;
-    // positional MLP operand of this lane (channel 16 u + la, input g): constant part + window part
-    float wconst[NT], w3[NT], w4[NT], w5[NT];
+    // positional MLP operand of this lane (channel 16 u + la, input g): lanes g < 3 hold the weight of rel. coordinate g;
+    // lanes g == 3 the window part (bp + wp3..5 . centre), rebuilt per window from LDS
+    float wrel[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const int c = 16 * u + la;
-        const bool in = CGP == CG || c < CG;
-        const float *wp = a.Wp + (size_t)(a.c0 + (in ? c : 0)) * 6;
-        wconst[u] = in ? (g < 3 ? wp[g] : a.bp[a.c0 + c]) : 0.f;
-        w3[u] = in && g == 3 ? wp[3] : 0.f;
-        w4[u] = in && g == 3 ? wp[4] : 0.f;
-        w5[u] = in && g == 3 ? wp[5] : 0.f;
+        const bool in = (CGP == CG || c < CG) && g < 3;
+        wrel[u] = in ? a.Wp[(size_t)(a.c0 + c) * 6 + g] : 0.f;
     }
     const int hh = la % HP, ql = la / HP;  // this column's head and query of the pass
-    const int n_act = *a.num_wins;
+    // per-lane multipliers that keep a column's own head: rows 16 n + 4 g .. of tile n belong to head (16 n + 4 g) / HD.
+    // The softmax runs on base-2 exponentials: log2(e) rides on the query scale.
+    float qmul[NT], omul[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const bool mine = (16 * n + 4 * g) / HD == hh;
+        qmul[n] = mine ? a.scale * 1.4426950408889634f : 0.f;
+        omul[n] = mine ? 1.0f : 0.f;
+    }
+    // gathers go through buffer descriptors: 32-bit lane offsets, no 64-bit address arithmetic per load (xhat rows:
+    // row * C * 4 + this lane's 16-byte piece; the immediate offset walks the channel tiles)
+    const __amdgpu_buffer_rsrc_t xr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.xhat), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t km_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(a.kmeta), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qm_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(a.qrow_meta), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qs_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int2 *>(a.qrow_src), 0, -1, 0x00020000);
+    const unsigned row_bytes = (unsigned)a.C * 4u, lane_off = ((unsigned)a.c0 + 4u * g) * 4u;
+#define BF_ROW4(off_, S_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_rs, (off_) + 64u * (S_), 0, 0))
+    const int n_act = __builtin_amdgcn_readfirstlane(*a.num_wins);
     const int wstep = gridDim.x * BA_WAVES;
     const int K = a.K;
-    int wi = blockIdx.x * BA_WAVES + wv;
+    int wi = __builtin_amdgcn_readfirstlane(blockIdx.x * BA_WAVES + wv);  // wave-uniform: the metadata below is scalar
     if (wi >= n_act) return;
-    // stage M: metadata of a window, two windows ahead
+#ifdef MSSVT_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+    // Software pipeline over this wave's windows, every load of the loop body UNCONDITIONAL (indices clamped to the
+    // last window): a guarded load makes the wait counts path dependent and the compiler falls back to vmcnt(0),
+    // which drains the prefetches.  vmcnt retires in order, so a wait for a load also waits for every load issued
+    // before it -- hence the order of the stages inside a step:
+    //   stage P  window id (scalar load)                         three steps ahead
+    //   stage M  its metadata: centre / counts (scalar), key slots (vector)   two steps ahead
+    //   stage R  raw key rows + the first pass's query metadata   one step ahead
+    int w_p;
     float4 wc_m, km_m[KT];
     int nqv_m, qbase_m;
-#define BF_LOAD_META(wi_)                                                                  \
+#define BF_LOAD_META()                                                                     \
     {                                                                                      \
-        const int w_ = a.perm[wi_];                                                        \
-        wc_m = a.wcentre[w_];                                                              \
-        nqv_m = a.nq_valid[w_];                                                            \
-        qbase_m = a.q_off[w_];                                                             \
+        wc_m = a.wcentre[w_p];                                                             \
+        nqv_m = a.nq_valid[w_p];                                                           \
+        qbase_m = a.q_off[w_p];                                                            \
         _Pragma("unroll") for (int t = 0; t < KT; ++t)                                     \
-            km_m[t] = a.kmeta[(size_t)w_ * K + min(16 * t + la, K - 1)];                   \
+            km_m[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(    \
+                km_rs, ((unsigned)w_p * (unsigned)K + (unsigned)min(16 * t + la, K - 1)) * 16u, 0, 0)); \
     }
-    // stage R: raw key rows (+ the first pass's query metadata) of a window, one window ahead
     float4 wc_r, qm_r;
     int2 qs_r;
     int nqv_r, qbase_r;
@@ -146,45 +184,39 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
             vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
             used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
             rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
-            if (used_r >> t & 1) {                                                         \
-                const float *xr_ = a.xhat + (size_t)(ok_ ? r_ : 0) * a.C + a.c0;           \
-                _Pragma("unroll") for (int S = 0; S < NT; ++S) {                           \
-                    const int c_ = 16 * S + 4 * g;                                         \
-                    const float4 v_ = (CGP == CG || c_ < CG) ? *reinterpret_cast<const float4 *>(xr_ + c_) \
-                                                             : make_float4(0.f, 0.f, 0.f, 0.f); \
-                    T1n[t][S] = f32x4{v_.x, v_.y, v_.z, v_.w};                             \
-                }                                                                          \
-            }                                                                              \
+            /* rows of empty slots / unused tiles read row 0 (never used; a guarded load would cost the pipeline) */ \
+            const unsigned ro_ = (unsigned)__umul24((unsigned)(ok_ ? r_ : 0), row_bytes) + lane_off; \
+            _Pragma("unroll") for (int S = 0; S < NT; ++S)                                 \
+                T1n[t][S] = (CGP == CG || 16 * S + 4 * g < CG) ? BF_ROW4(ro_, S) : Z4;     \
         }                                                                                  \
-        const int qr_ = qbase_r + min(ql, max(nqv_r, 1) - 1);                              \
-        qm_r = a.qrow_meta[min(qr_, a.row_capacity - 1)];                                  \
-        qs_r = a.qrow_src[min(qr_, a.row_capacity - 1)];                                   \
+        const unsigned qr_ = (unsigned)min(qbase_r + min(ql, max(nqv_r, 1) - 1), a.row_capacity - 1); \
+        qm_r = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(qm_rs, qr_ * 16u, 0, 0)); \
+        qs_r = __builtin_bit_cast(int2, __builtin_amdgcn_raw_buffer_load_b64(qs_rs, qr_ * 8u, 0, 0)); \
     }
-    BF_LOAD_META(wi)
+    const int w_last = n_act - 1;
+    w_p = a.perm[wi];
+    BF_LOAD_META()
+    w_p = a.perm[min(wi + wstep, w_last)];
     BF_ISSUE_ROWS()
-    if (wi + wstep < n_act) BF_LOAD_META(wi + wstep)
+    BF_LOAD_META()
+    w_p = a.perm[min(wi + 2 * wstep, w_last)];
+    BSTAMP(0)
     for (; wi < n_act; wi += wstep) {
+#ifdef MSSVT_STAMPS
+        ph[7] += 1;
+#endif
         const float4 wc = wc_r;
         const int nqv = nqv_r, qbase = qbase_r;
         const unsigned vmask = vmask_r, used = used_r;
         float4 qm = qm_r;
         int2 qs = qs_r;
-        // the first pass's query rows travel under the key projections
-        f32x4 xq[NT];
-        {
-            const float *xr = a.xhat + (size_t)__builtin_bit_cast(int, qm.w) * a.C + a.c0;
-#pragma unroll
-            for (int S = 0; S < NT; ++S) {
-                const int c = 16 * S + 4 * g;
-                const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xr + c)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-                xq[S] = f32x4{v.x, v.y, v.z, v.w};
-            }
-        }
         // key tokens: + relu(positional MLP), rounded to bf16 operands (A of Vp = T Wv^T, B of Kp^T = Wk T^T)
         float wu[NT];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) wu[u] = ((wconst[u] + w3[u] * wc.x) + w4[u] * wc.y) + w5[u] * wc.z;
+        for (int u = 0; u < NT; ++u) {
+            const float4 pc = wpc_l[16 * u + la];
+            wu[u] = g == 3 ? ((pc.w + pc.x * wc.x) + pc.y * wc.y) + pc.z * wc.z : wrel[u];
+        }
         bf16x8 Tb[KT][NS];
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
@@ -203,62 +235,94 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
 #pragma unroll
             for (int s = 0; s < NS; ++s) Tb[t][s] = pack8(tk[2 * s], tk[2 * s + 1]);
         }
-        // ---- next window: rows in flight under this window's MFMAs, metadata one further ahead --------
-        if (wi + wstep < n_act) {
-            BF_ISSUE_ROWS()
-            if (wi + 2 * wstep < n_act) BF_LOAD_META(wi + 2 * wstep)
+        BSTAMP(1)
+        // the first pass's query rows: requested only now -- the wait for the key rows above must not cover them
+        f32x4 xq[NT];
+        {
+            const unsigned ro = (unsigned)__umul24((unsigned)__builtin_bit_cast(int, qm.w), row_bytes) + lane_off;
+#pragma unroll
+            for (int S = 0; S < NT; ++S) xq[S] = (CGP == CG || 16 * S + 4 * g < CG) ? BF_ROW4(ro, S) : Z4;
         }
+        // ---- next window: rows in flight under this window's MFMAs, metadata one further ahead (past the end of
+        // the work list the last window is fetched again: unconditional loads keep the wait counts exact) --------
+        BF_ISSUE_ROWS()
+        BF_LOAD_META()  // id loaded one step ago
+        w_p = a.perm[min(wi + 3 * wstep, w_last)];
+        BSTAMP(2)
         // ---- key / value projections ---------------------------------------------------------------------
+        // tile n of the outputs at a time, for every used key tile: the weight fragments of tile n + 1 are read
+        // from LDS while tile n multiplies (an unpipelined ds_read -> MFMA pair exposes ~100 cycles per group)
         bf16x8 Kb[KT][NS];  // A operand of S = Kp Q'm^T: lane (key la, g), k-slots = Kp channels
         bf16x8 Vb[NT][KS];  // A operand of O^T = Vp^T P: lane (channel la of tile n, g), k-slots = keys
         {
-            f32x4 vacc[NT][2 * KS];
+            bf16x8 wk[NS], wv[NS], wkn[NS], wvn[NS];
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int s = 0; s < NS; ++s) {
+                wk[s] = Wf[((1 * NT + 0) * NS + s) * 64 + lane];
+                wv[s] = Wf[((2 * NT + 0) * NS + s) * 64 + lane];
+            }
+            f32x4 kacc[KT][2];
 #pragma unroll
-                for (int t = 0; t < 2 * KS; ++t) vacc[n][t] = Z4;
+            for (int n = 0; n < 2 * NS; ++n) {
+                if (n < NT) {
+                    if (n + 1 < NT) {
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                if (!(used >> t & 1)) {
+                        for (int s = 0; s < NS; ++s) {
+                            wkn[s] = Wf[((1 * NT + n + 1) * NS + s) * 64 + lane];
+                            wvn[s] = Wf[((2 * NT + n + 1) * NS + s) * 64 + lane];
+                        }
+                    }
+                    f32x4 vacc[2 * KS];
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) Kb[t][s] = pack8(Z4, Z4);
-                    continue;
-                }
-                f32x4 kacc[2 * NS];
+                    for (int t = 0; t < 2 * KS; ++t) vacc[t] = Z4;
 #pragma unroll
-                for (int n = 0; n < 2 * NS; ++n) kacc[n] = Z4;
+                    for (int t = 0; t < KT; ++t) {
+                        kacc[t][n & 1] = Z4;
+                        if (!(used >> t & 1)) continue;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
+                        for (int s = 0; s < NS; ++s) {
+                            MFMA_BF(kacc[t][n & 1], wk[s], Tb[t][s]);
+                            MFMA_BF(vacc[t], Tb[t][s], wv[s]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) Vb[n][s] = pack8(vacc[2 * s], vacc[2 * s + 1]);
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        MFMA_BF(kacc[n], Wf[((1 * NT + n) * NS + s) * 64 + lane], Tb[t][s]);
-                        MFMA_BF(vacc[n][t], Tb[t][s], Wf[((2 * NT + n) * NS + s) * 64 + lane]);
+                        wk[s] = wkn[s];
+                        wv[s] = wvn[s];
                     }
-                    __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of later tiles from being hoisted
+                } else {
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) kacc[t][n & 1] = Z4;
                 }
+                if (n & 1) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) Kb[t][s] = pack8(kacc[2 * s], kacc[2 * s + 1]);
+                    for (int t = 0; t < KT; ++t) Kb[t][n >> 1] = pack8(kacc[t][0], kacc[t][1]);
+                }
             }
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) Vb[n][s] = pack8(vacc[n][2 * s], vacc[n][2 * s + 1]);
         }
         // ---- queries, QPP per pass: column la = query * HP + head ----------------------------------------
+        BSTAMP(3)
+        float4 qm_n = qm;
+        int2 qs_n = qs;
         for (int q0 = 0; q0 < nqv; q0 += QPP) {
+            // the next pass's query metadata is requested now, its rows once this pass has consumed xq: both round
+            // trips of a further pass run under this pass's products
+            const bool more = q0 + QPP < nqv;
             if (q0 > 0) {
-                const int qr = qbase + min(q0 + ql, nqv - 1);
-                qm = a.qrow_meta[qr];
-                qs = a.qrow_src[qr];
-                const float *xr = a.xhat + (size_t)__builtin_bit_cast(int, qm.w) * a.C + a.c0;
-#pragma unroll
-                for (int S = 0; S < NT; ++S) {
-                    const int c = 16 * S + 4 * g;
-                    const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xr + c)
-                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-                    xq[S] = f32x4{v.x, v.y, v.z, v.w};
-                }
+                qm = qm_n;
+                qs = qs_n;
             }
+            if (more) {
+                const unsigned qr = (unsigned)(qbase + min(q0 + QPP + ql, nqv - 1));
+                qm_n = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(qm_rs, qr * 16u, 0, 0));
+                qs_n = __builtin_bit_cast(int2, __builtin_amdgcn_raw_buffer_load_b64(qs_rs, qr * 8u, 0, 0));
+            }
+            bf16x8 wq[NS], wqn[NS];  // Wq fragments of output tile 0: in flight under the positional MLP
+#pragma unroll
+            for (int s = 0; s < NS; ++s) wq[s] = Wf[((0 * NT + 0) * NS + s) * 64 + lane];
             // query tokens: + relu(positional MLP) -> B operand of Q'^T = Wq Xq^T
             const float qrel = g == 0 ? qm.x : (g == 1 ? qm.y : (g == 2 ? qm.z : 1.0f));
             bf16x8 Xb[NS];
@@ -277,26 +341,36 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
 #pragma unroll
                 for (int s = 0; s < NS; ++s) Xb[s] = pack8(tk[2 * s], tk[2 * s + 1]);
             }
+            if (more) {  // xq is dead: the next pass's rows travel from here on
+                const unsigned ro = (unsigned)__umul24((unsigned)__builtin_bit_cast(int, qm_n.w), row_bytes) + lane_off;
+#pragma unroll
+                for (int S = 0; S < NT; ++S) xq[S] = (CGP == CG || 16 * S + 4 * g < CG) ? BF_ROW4(ro, S) : Z4;
+            }
+            BSTAMP(4)
             // Q'^T[o][col] = sum_c Wq[o][c] xq[col][c] + bq[o]; scaled; rows outside the column's head -> 0
             bf16x8 Qb[NS];
             {
-                f32x4 qa[2 * NS];
+                f32x4 qa[2];
 #pragma unroll
                 for (int n = 0; n < 2 * NS; ++n) {
-                    qa[n] = Z4;
+                    qa[n & 1] = Z4;
                     if (n < NT) {
+                        if (n + 1 < NT) {
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) wqn[s] = Wf[((0 * NT + n + 1) * NS + s) * 64 + lane];
+                        }
                         const float4 b = *reinterpret_cast<const float4 *>(bias_l + 16 * n + 4 * g);
-                        qa[n] = f32x4{b.x, b.y, b.z, b.w};
+                        qa[n & 1] = f32x4{b.x, b.y, b.z, b.w};
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) MFMA_BF(qa[n], Wf[((0 * NT + n) * NS + s) * 64 + lane], Xb[s]);
-                        const bool mine = (16 * n + 4 * g) / HD == hh;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) qa[n][i] = mine ? qa[n][i] * a.scale : 0.f;
+                        for (int s = 0; s < NS; ++s) MFMA_BF(qa[n & 1], wq[s], Xb[s]);
                         __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
 #pragma unroll
-                for (int s = 0; s < NS; ++s) Qb[s] = pack8(qa[2 * s], qa[2 * s + 1]);
+                        for (int i = 0; i < 4; ++i) qa[n & 1][i] *= qmul[n];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) wq[s] = wqn[s];
+                    }
+                    if (n & 1) Qb[n >> 1] = pack8(qa[0], qa[1]);
+                }
             }
             // scores S[key][col] = sum_o Kp[key][o] Q'm[col][o]
             f32x4 sc[2 * KS];
@@ -309,11 +383,15 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
                 for (int s = 0; s < NS; ++s) MFMA_BF(sc[t], Kb[t][s], Qb[s]);
             }
             // softmax over the unmasked keys: lane (col, g) holds keys 16 t + 4 g + i
+            // masked slots and unused tiles score -inf: exp2(-inf) = 0, no branch (slot 0 is never masked)
             float mx = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < KT; ++t)
+            for (int t = 0; t < 2 * KS; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, (vmask >> (4 * t + i) & 1) ? sc[t][i] : -INFINITY);
+                for (int i = 0; i < 4; ++i) {
+                    sc[t][i] = (t < KT && (vmask >> (4 * t + i) & 1)) ? sc[t][i] : -INFINITY;
+                    mx = fmaxf(mx, sc[t][i]);
+                }
             mx = fmaxf(mx, lane_xor16(mx));
             mx = fmaxf(mx, lane_xor32(mx));
             float sum = 0.f;
@@ -321,7 +399,7 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
             for (int t = 0; t < 2 * KS; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float e = (t < KT && (vmask >> (4 * t + i) & 1)) ? __expf(sc[t][i] - mx) : 0.0f;
+                    const float e = __builtin_amdgcn_exp2f(sc[t][i] - mx);
                     sc[t][i] = e;
                     sum += e;
                 }
@@ -339,6 +417,9 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
                 }
                 Pb[s] = pack8(p0, p1);
             }
+            bf16x8 wo[NS], won[NS];  // Wo fragments of output tile 0: in flight under the PV product
+#pragma unroll
+            for (int s = 0; s < NS; ++s) wo[s] = Wf[((3 * NT + 0) * NS + s) * 64 + lane];
             // O^T[o][col] = sum_key Vp[key][o] P[key][col] + bv[o]; rows outside the column's head -> 0
             bf16x8 Ob[NS];
             {
@@ -351,9 +432,8 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
                         oa[n] = f32x4{b.x, b.y, b.z, b.w};
 #pragma unroll
                         for (int s = 0; s < KS; ++s) MFMA_BF(oa[n], Vb[n][s], Pb[s]);
-                        const bool mine = (16 * n + 4 * g) / HD == hh;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) oa[n][i] = mine ? oa[n][i] : 0.f;
+                        for (int i = 0; i < 4; ++i) oa[n][i] *= omul[n];
                     }
                 }
 #pragma unroll
@@ -364,9 +444,14 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
             float *dst = a.attn + (size_t)qs.y * a.C + a.c0;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
+                if (n + 1 < NT) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) won[s] = Wf[((3 * NT + n + 1) * NS + s) * 64 + lane];
+                }
                 f32x4 acc = Z4;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) MFMA_BF(acc, Wf[((3 * NT + n) * NS + s) * 64 + lane], Ob[s]);
+                for (int s = 0; s < NS; ++s) MFMA_BF(acc, wo[s], Ob[s]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float v = acc[i];
@@ -380,12 +465,20 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
                     *reinterpret_cast<float4 *>(dst + 16 * n + 4 * g) =
                         make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) wo[s] = won[s];
             }
+            BSTAMP(5)
         }
     }
+#ifdef MSSVT_STAMPS
+    if (lane == 0 && blockIdx.x < 64 && blockIdx.y == 0) {
+        for (int k = 0; k < 8; ++k) g_attn_bf_stamps[(blockIdx.x * BA_WAVES + wv) * 8 + k] = ph[k];
+    }
+#endif
 #undef BF_LOAD_META
 #undef BF_ISSUE_ROWS
+#undef BF_ROW4
 }
 
 template <int CG, int HD>
@@ -398,7 +491,7 @@ static int launch_attn_bf16(const AttnBfPack &pack, int ng, hipStream_t stream) 
     const int K = pack.g[0].K;
     // persistent over the work order: 2 workgroups of 4 waves per CU (VGPR bound)
     const dim3 grid(cus * 2 / ng > 0 ? cus * 2 / ng : 1, ng);
-    const size_t lds = (size_t)4 * NT * NS * 64 * 16 + (size_t)3 * CGP * 4;
+    const size_t lds = (size_t)4 * NT * NS * 64 * 16 + (size_t)3 * CGP * 4 + (size_t)CGP * 16;
     if (K <= 16)
         k_attn_bf16<CG, HD, 1><<<grid, BA_WAVES * MSSVT_WAVE, lds, stream>>>(pack);
     else if (K <= 32)

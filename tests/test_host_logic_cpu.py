@@ -31,7 +31,7 @@ def test_block_ops_path_matches_reference_golden(golden_dir, name):
     blk.impl = "ops"
     with torch.no_grad():
         out = blk(_sp(d))
-    assert_feat_close(out.features.numpy(), d["out_features"], tol=1e-4)
+    assert_feat_close(out.features.numpy(), d["out_features"])
 
 
 @pytest.mark.parametrize("name", ["compress_1x1x16", "compress_3x3x5", "compress_2x2x4", "compress_2x2x2_groups",
@@ -43,7 +43,7 @@ def test_compress_ops_path_matches_reference_golden(golden_dir, name):
     with torch.no_grad():
         out = blk(_sp(d))
     np.testing.assert_array_equal(out.indices.numpy(), d["out_indices"])
-    assert_feat_close(out.features.numpy(), d["out_features"], tol=1e-4)
+    assert_feat_close(out.features.numpy(), d["out_features"])
 
 
 @pytest.mark.parametrize("name", ["backbone", "backbone_two_levels", "backbone_c128"])
@@ -65,8 +65,8 @@ def test_backbone_ops_path_and_state_dict_keys(golden_dir, name):
                       voxel_coords=torch.from_numpy(d["voxel_coords"]).float(), batch_size=int(d["batch_size"])))
     sp = bd["encoded_spconv_tensor"]
     np.testing.assert_array_equal(sp.indices.numpy(), d["out_indices"])
-    assert_feat_close(sp.features.numpy(), d["out_features"], tol=1e-4)
-    assert_feat_close(sp.dense()[0, :, 0].numpy(), d["dense_b0_z0"], tol=1e-4)
+    assert_feat_close(sp.features.numpy(), d["out_features"])
+    assert_feat_close(sp.dense()[0, :, 0].numpy(), d["dense_b0_z0"])
 
 
 @pytest.mark.parametrize("name", ["w335_777", "w222_444", "w557_bbb", "w115", "w3316"])
