@@ -447,6 +447,24 @@ int mssvt_voxel_max(const float *features, int F, long long num_points, const in
 int mssvt_dense_bev(const float *features, int C, const int *map_table, int hash_size, const int *v_bs_cnt,
                     int batch_size, int x_max, int y_max, int z_max, float *out, void *stream);
 
+/* Deterministic segmented row sum -- replaces the atomicAdd accumulation of the reference's gather backward passes
+ * (ref: group_features_grad_kernel_stack, pcdet/ops/mssvt/src/group_features_gpu.cu:15-47;
+ * gather_points_grad_kernel_fast, pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:53-90;
+ * group_points_grad_kernel_fast, .../group_points_gpu.cu:14-50), whose sum order changes run to run:
+ *   dst[d][0..C) = sum over e in [csr_off[d], csr_off[d+1]) of (csr_w ? csr_w[e] : 1) * src[csr_idx[e]][0..C),
+ * added in ascending e (an inverted index of the gather, built once per index set), so gradients are bit-identical
+ * from run to run.  csr_off (n_dst+1) int32, csr_idx (nnz) int32 rows of src, csr_w (nnz) f32 or NULL,
+ * src (R,C) f32, dst (n_dst,C) f32 (every row written; C % 4 == 0).  Also the forward of a weighted row gather. */
+int mssvt_segment_sum_rows(int C, int n_dst, const int *csr_off, const int *csr_idx, const float *csr_w,
+                           const float *src, float *dst, void *stream);
+
+/* The same sum over explicit entry ranges [seg_start[d], seg_end[d]) (an empty range writes a zero row): lets the
+ * caller cut a destination with thousands of contributions -- e.g. voxel 0 of a sample, the target of every FPS-picked
+ * empty slot (ref mssvt_backbone.py:253-256) -- into fixed chunks summed by separate lane groups, and add the chunk
+ * sums in chunk order with a second call: the order stays fixed, no lane group runs for the whole launch.       */
+int mssvt_segment_sum_rows_ranges(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
+                                  const float *csr_w, const float *src, float *dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

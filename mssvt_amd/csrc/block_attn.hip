@@ -349,22 +349,33 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
     // static round-robin over the heaviest-first work order: wave i takes entries i, i + T, i + 2T ...
     // (T = waves in the grid), i.e. one window of every weight tier -- as balanced as dynamic tickets
     // without their atomics (a drained single-address ticket costs ~11 ns chip-wide, x 8192 waves)
-    const int n_act = *a.num_wins;
+    const int n_act = __builtin_amdgcn_readfirstlane(*a.num_wins);
     const int wstep = gridDim.x * ATTN_ROW_WAVES;
     const int K = a.K;
-    int wi = blockIdx.x * ATTN_ROW_WAVES + wv;
+    int wi = __builtin_amdgcn_readfirstlane(blockIdx.x * ATTN_ROW_WAVES + wv);  // wave-uniform: scalar metadata loads
     if (wi >= n_act) return;
+    // gathers through buffer descriptors: 32-bit lane offsets instead of 64-bit address arithmetic per load
+    const __amdgpu_buffer_rsrc_t xr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.xhat), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t km_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(a.kmeta), 0, -1, 0x00020000);
+    const unsigned row_bytes = (unsigned)a.C * 4u, lane_off = ((unsigned)a.c0 + 4u * g) * 4u;
+#define KV_ROW4(off_, S_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_rs, (off_) + 64u * (S_), 0, 0))
+    // Software pipeline over the wave's windows with every load of the loop body UNCONDITIONAL (indices clamped
+    // to the last window; rows of empty slots read row 0): a guarded load makes the wait counts path dependent and
+    // the compiler falls back to vmcnt(0), which drains the prefetches.  vmcnt retires in order -- a wait for a
+    // load also waits for every load issued before it -- hence window ids three steps ahead (stage P, scalar),
+    // metadata two (stage M: centre / counts scalar, key slots vector), raw rows one (stage R).
+    int w_p;
     // stage M: metadata of a window (perm -> kmeta would otherwise be dependent round trips per window)
     float4 wc_m, km_m[KT];
     int nqv_m, qbase_m;
-#define KV_LOAD_META(wi_)                                                                  \
+#define KV_LOAD_META()                                                                     \
     {                                                                                      \
-        const int w_ = a.perm[wi_];                                                        \
-        wc_m = a.wcentre[w_];                                                              \
-        nqv_m = a.nq_valid[w_];                                                            \
-        qbase_m = a.q_off[w_];                                                             \
+        wc_m = a.wcentre[w_p];                                                             \
+        nqv_m = a.nq_valid[w_p];                                                           \
+        qbase_m = a.q_off[w_p];                                                            \
         _Pragma("unroll") for (int t = 0; t < KT; ++t)                                     \
-            km_m[t] = a.kmeta[(size_t)w_ * K + min(16 * t + la, K - 1)];                   \
+            km_m[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(    \
+                km_rs, ((unsigned)w_p * (unsigned)K + (unsigned)min(16 * t + la, K - 1)) * 16u, 0, 0)); \
     }
     // stage R: resolved metadata + raw feature rows of a window (T1 layout)
     float4 wc_r;
@@ -384,20 +395,18 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
             vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
             used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
             rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
-            if (used_r >> t & 1) {                                                         \
-                const float *xr_ = a.xhat + (size_t)(ok_ ? r_ : 0) * a.C + a.c0;           \
-                _Pragma("unroll") for (int S = 0; S < NT; ++S) {                           \
-                    const int c_ = 16 * S + 4 * g;                                         \
-                    const float4 v_ = (CGP == CG || c_ < CG) ? *reinterpret_cast<const float4 *>(xr_ + c_) \
-                                                             : make_float4(0.f, 0.f, 0.f, 0.f); \
-                    T1n[t][S] = f32x4{v_.x, v_.y, v_.z, v_.w};                             \
-                }                                                                          \
-            }                                                                              \
+            const unsigned ro_ = (unsigned)__umul24((unsigned)(ok_ ? r_ : 0), row_bytes) + lane_off; \
+            _Pragma("unroll") for (int S = 0; S < NT; ++S)                                 \
+                T1n[t][S] = (CGP == CG || 16 * S + 4 * g < CG) ? KV_ROW4(ro_, S) : f32x4{0.f, 0.f, 0.f, 0.f}; \
         }                                                                                  \
     }
-    KV_LOAD_META(wi)
+    const int w_last = n_act - 1;
+    w_p = a.perm[wi];
+    KV_LOAD_META()
+    w_p = a.perm[min(wi + wstep, w_last)];
     KV_ISSUE_ROWS()
-    if (wi + wstep < n_act) KV_LOAD_META(wi + wstep)
+    KV_LOAD_META()
+    w_p = a.perm[min(wi + 2 * wstep, w_last)];
     for (; wi < n_act; wi += wstep) {
         // ---- this window: stage R -> working registers ------------------------------------------------
         const float4 wc = wc_r;
@@ -431,11 +440,11 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
             qt[S] = f32x4{v.x, v.y, v.z, v.w};
         }
-        // ---- next window: rows in flight under this window's MFMAs, metadata one further ahead --------
-        if (wi + wstep < n_act) {
-            KV_ISSUE_ROWS()
-            if (wi + 2 * wstep < n_act) KV_LOAD_META(wi + 2 * wstep)
-        }
+        // ---- next window: rows in flight under this window's MFMAs, metadata one further ahead (past the end
+        // of the work list the last window is fetched again) ------------------------------------------------
+        KV_ISSUE_ROWS()
+        KV_LOAD_META()
+        w_p = a.perm[min(wi + 3 * wstep, w_last)];
         // key tile -> LDS (the T2 operand is read back column-wise)
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
@@ -531,6 +540,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
     }
 #undef KV_LOAD_META
 #undef KV_ISSUE_ROWS
+#undef KV_ROW4
 }
 
 template <int CG, int HD, int HP>

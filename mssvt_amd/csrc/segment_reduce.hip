@@ -1,0 +1,88 @@
+// segment_reduce.hip -- deterministic replacement of the reference's atomic scatter-adds in the backward pass.
+//
+// The reference accumulates gradients of its row gathers with atomicAdd, one thread per gathered element:
+//   K6   group_features_grad_kernel_stack   (ref: pcdet/ops/mssvt/src/group_features_gpu.cu:15-47)
+//   K11a gather_points_grad_kernel_fast     (ref: pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:53-90)
+//   K11b group_points_grad_kernel_fast      (ref: .../group_points_gpu.cu:14-50)
+// so the sum order -- and with it the low bits of every gradient -- changes from run to run.  Here the gather is
+// inverted ONCE per index set (an "inverted index" in CSR form: for every destination row the list of the
+// contribution rows that add into it, in ascending contribution order; mssvt_amd/train_path.py builds it with a
+// stable sort) and every destination row is then summed by one group of lanes in that fixed order:
+//
+//     dst[d][:] = sum_{e in [off[d], off[d+1])}  w[e] * src[idx[e]][:]          (w optional)
+//
+// No atomics, no dependence on scheduling: bit-identical gradients run to run.  The same kernel is the forward
+// of a weighted row gather (3-NN interpolation: three contribution rows per voxel, ref mssvt_backbone.py:298-311)
+// and the backward of every plain gather of the training path.  HBM-bound: 4 C bytes per contribution row read
+// once (whole rows, 16 bytes per lane), 4 C bytes per destination row written once.
+#include "common.hip.h"
+
+template <int LPR>  // lanes per row (power of two <= 64): 64 / LPR destination rows per wavefront
+__global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, const int *seg_start, const int *seg_end,
+                                                          const int *idx, const float *w, const float *src, float *dst) {
+    constexpr int RPW = MSSVT_WAVE / LPR;
+    const int lane = lane_id(), sub = lane / LPR, l = lane % LPR;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / MSSVT_WAVE;
+    const int d = wave * RPW + sub;
+    if (d >= n_dst) return;
+    const int e0 = seg_start[d], e1 = seg_end[d];
+    for (int c = 4 * l; c < C; c += 4 * LPR) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // two contribution rows in flight; the ADD order stays e0, e0 + 1, ... (fixed)
+        int e = e0;
+        for (; e + 1 < e1; e += 2) {
+            const int r0 = idx[e], r1 = idx[e + 1];
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)r0 * C + c);
+            const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)r1 * C + c);
+            const float w0 = w ? w[e] : 1.0f, w1 = w ? w[e + 1] : 1.0f;
+            acc.x = __builtin_fmaf(w0, v0.x, acc.x); acc.y = __builtin_fmaf(w0, v0.y, acc.y);
+            acc.z = __builtin_fmaf(w0, v0.z, acc.z); acc.w = __builtin_fmaf(w0, v0.w, acc.w);
+            acc.x = __builtin_fmaf(w1, v1.x, acc.x); acc.y = __builtin_fmaf(w1, v1.y, acc.y);
+            acc.z = __builtin_fmaf(w1, v1.z, acc.z); acc.w = __builtin_fmaf(w1, v1.w, acc.w);
+        }
+        if (e < e1) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)idx[e] * C + c);
+            const float w0 = w ? w[e] : 1.0f;
+            acc.x = __builtin_fmaf(w0, v0.x, acc.x); acc.y = __builtin_fmaf(w0, v0.y, acc.y);
+            acc.z = __builtin_fmaf(w0, v0.z, acc.z); acc.w = __builtin_fmaf(w0, v0.w, acc.w);
+        }
+        *reinterpret_cast<float4 *>(dst + (size_t)d * C + c) = acc;
+    }
+}
+
+// A destination with thousands of contribution rows (the reference's "(x + 0.1).int()" quirk turns every FPS-picked
+// empty slot into voxel 0 of the sample: ~one contribution per window) would keep ONE lane group busy for the whole
+// launch.  The caller therefore sums such lists in fixed chunks of a few hundred entries (this entry point on
+// explicit [start, end) ranges) and adds the chunk sums in chunk order in a second call -- still a fixed order.
+extern "C" int mssvt_segment_sum_rows_ranges(int C, int n_dst, const int *seg_start, const int *seg_end,
+                                             const int *csr_idx, const float *csr_w, const float *src, float *dst,
+                                             void *stream);
+
+extern "C" int mssvt_segment_sum_rows(int C, int n_dst, const int *csr_off, const int *csr_idx, const float *csr_w,
+                                      const float *src, float *dst, void *stream) {
+    if (!csr_off) return MSSVT_E_BADARG;
+    return mssvt_segment_sum_rows_ranges(C, n_dst, csr_off, csr_off + 1, csr_idx, csr_w, src, dst, stream);
+}
+
+extern "C" int mssvt_segment_sum_rows_ranges(int C, int n_dst, const int *seg_start, const int *seg_end,
+                                             const int *csr_idx, const float *csr_w, const float *src, float *dst,
+                                             void *stream) {
+    const int *csr_off = seg_start;
+    if (!seg_start || !seg_end || !csr_idx || !src || !dst || C <= 0 || n_dst < 0) return MSSVT_E_BADARG;
+    if (C & 3) return MSSVT_E_BADARG;  // 16-byte row pieces
+    if (n_dst == 0) return MSSVT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int q = C / 4;
+#define SEG_LAUNCH(lpr)                                                                                    \
+    {                                                                                                      \
+        const int rpw = MSSVT_WAVE / lpr, waves = divup(n_dst, rpw);                                        \
+        k_segment_sum_rows<lpr><<<divup(waves, 4), 256, 0, st>>>(C, n_dst, csr_off, seg_end, csr_idx, csr_w, src, dst); \
+    }
+    if (q <= 4) SEG_LAUNCH(4)
+    else if (q <= 8) SEG_LAUNCH(8)
+    else if (q <= 16) SEG_LAUNCH(16)
+    else if (q <= 32) SEG_LAUNCH(32)
+    else SEG_LAUNCH(64)
+#undef SEG_LAUNCH
+    return mssvt_launch_status();
+}

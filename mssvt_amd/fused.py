@@ -43,6 +43,13 @@ ATTN_SHAPES = {(8, 8), (16, 8), (16, 16), (24, 8), (32, 8), (32, 16), (32, 32), 
                (64, 32)}
 
 
+TRAIN_COMPACT = os.environ.get("MSSVT_TRAIN_COMPACT", "1") != "0"  # 0: training through the padded operator path
+
+
+def _needs_grad(block, sp):
+    return torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters()))
+
+
 def supported(block, sp):
     """Shapes the v1 fused kernels cover; anything else runs the operator-level path."""
     if torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters())):
@@ -458,6 +465,9 @@ def layer_norm(x, norm):
 def block_forward(block, sp):
     """Fused forward of a MixedScaleSparseTransformerBlock (eval / no-grad)."""
     if not supported(block, sp):
+        if _needs_grad(block, sp) and TRAIN_COMPACT:
+            from . import train_path  # differentiable compact path (deterministic segmented-sum backward)
+            return train_path.block_forward(block, sp)
         return block.forward_ops(sp)
     xhat = _norm1(block, sp, sp.features)
     x_in = sp.features.contiguous()
@@ -752,6 +762,9 @@ def _compress_forward_fused(block, sp, xhat, x_in):
 def compress_forward(block, sp):
     """Fused forward of a MixedScaleSparseTransformerCompressBlock (eval / no-grad)."""
     if not compress_supported(block, sp):
+        if _needs_grad(block, sp) and TRAIN_COMPACT:
+            from . import train_path
+            return train_path.compress_forward(block, sp)
         check_level_status(sp)
         return block.forward_ops(sp)
     xhat = _norm1(block, sp, sp.features)

@@ -1,0 +1,376 @@
+"""Differentiable COMPACT path of the MsSVT blocks (training).
+
+With autograd on, the reference -- and this package's operator-level ``forward_ops`` -- materialise padded
+``(windows, C, slots)`` tensors for every gather (``grouping_operation`` x7 per Block, ref mssvt_backbone.py:260-268) and
+accumulate their gradients with atomicAdd (K6 / K11: ref group_features_gpu.cu:15-47, sampling_gpu.cu:53-90,
+group_points_gpu.cu:14-50): ~15 GB and ~200 ms per 160k-point training step here, and gradients whose low bits change
+from run to run.  This path computes the same function on COMPACT rows:
+
+* index work = the fused path's device-resident plan (``fused.two_scale_plan`` / ``one_scale_plan``: hand-written HIP,
+  no padded lists), shared by the Blocks of a level;
+* valid query rows ``R``, valid key rows per scale, (query, key) pairs of a window as flat index arrays -- nothing padded;
+* every gather and its gradient through ``mssvt_segment_sum_rows`` (csrc/segment_reduce.hip): a segmented sum over an
+  inverted index built once per index set, fixed summation order -> **bit-identical gradients run to run**;
+* dense math (LayerNorm, the projections, FFN) as library GEMMs through torch autograd; softmax over the pairs of a
+  query with ``torch.segment_reduce`` (contiguous segments, deterministic).
+
+Same arithmetic as the reference up to re-association: masked key slots (additive -100 in the reference, weight <= e^-100)
+and empty query slots are dropped instead of padded; the interpolation uses the plan's 3-NN table (weights are geometry only).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, fused, mssvt_ops
+
+_i = ctypes.c_int
+
+
+# ---------------------------------------------------------------------------------------------------------
+# segmented sums
+# ---------------------------------------------------------------------------------------------------------
+
+CHUNK = 256  # entries per partial sum of a long contribution list
+
+
+def _ranges_sum(src, start, end, idx, w, n_dst):
+    src = src.contiguous()
+    C = src.shape[1]
+    dst = torch.empty((n_dst, C), dtype=torch.float32, device=src.device)
+    if n_dst:
+        _lib.call("mssvt_segment_sum_rows_ranges", _i(C), _i(n_dst), _lib.ptr(start), _lib.ptr(end), _lib.ptr(idx),
+                  _lib.ptr(w), _lib.ptr(src), _lib.ptr(dst), _lib.stream())
+    return dst
+
+
+class Segments(object):
+    """Entry ranges of a segmented sum ``dst[d] = sum_{e in [off[d], off[d+1])} w[e] src[idx[e]]`` (ascending e).
+    Destinations with more than CHUNK entries are cut into fixed chunks (summed by separate lane groups, then added in
+    chunk order): the order is fixed either way, and no lane group serialises a whole launch."""
+
+    def __init__(self, off, idx, w):
+        self.idx, self.w, self.n_dst = idx, w, off.numel() - 1
+        counts = off[1:] - off[:-1]
+        heavy = counts > CHUNK
+        self.start = off[:-1].contiguous()
+        self.heavy = None
+        if self.n_dst and bool(heavy.any()):  # (one host sync per index set; the sets are cached per plan)
+            self.end = torch.where(heavy, self.start, off[1:]).contiguous()  # heavy rows: empty here, filled below
+            hd = torch.nonzero(heavy, as_tuple=True)[0]
+            hs, hc = self.start[hd].long(), counts[hd].long()
+            nch = (hc + CHUNK - 1) // CHUNK
+            M2 = int(nch.sum().item())
+            which = torch.repeat_interleave(torch.arange(hd.numel(), device=idx.device), nch, output_size=M2)
+            first = torch.cumsum(nch, 0) - nch
+            j = torch.arange(M2, device=idx.device) - first[which]
+            c_start = (hs[which] + j * CHUNK)
+            c_end = torch.minimum(c_start + CHUNK, hs[which] + hc[which])
+            self.heavy = dict(rows=hd, c_start=c_start.int().contiguous(), c_end=c_end.int().contiguous(),
+                              p_start=first.int().contiguous(), p_end=(first + nch).int().contiguous(),
+                              p_idx=torch.arange(M2, dtype=torch.int32, device=idx.device), n_chunks=M2)
+        else:
+            self.end = off[1:].contiguous()
+
+    def sum(self, src):
+        dst = _ranges_sum(src, self.start, self.end, self.idx, self.w, self.n_dst)
+        h = self.heavy
+        if h is not None:
+            part = _ranges_sum(src, h["c_start"], h["c_end"], self.idx, self.w, h["n_chunks"])
+            dst[h["rows"]] = _ranges_sum(part, h["p_start"], h["p_end"], h["p_idx"], None, h["rows"].numel())
+        return dst
+
+
+def segment_sum_rows(src, off, idx, w, n_dst):
+    """dst[d] = sum_{e in [off[d], off[d+1])} w[e] * src[idx[e]] in ascending e (HIP, deterministic)."""
+    return _ranges_sum(src, off[:-1].contiguous(), off[1:].contiguous(), idx, w, n_dst)
+
+
+class Csr(object):
+    """A (weighted) gather ``dst[d] = sum_e w[e] src[idx[e]]`` with its transpose (the inverted index that turns the
+    gradient scatter-add into a segmented sum).  Built once per index set and reused by every block sharing the plan.
+    `drop_src`: a source row whose gradient is not needed (the constant zero row): its list is left empty."""
+
+    def __init__(self, off, idx, w, n_src, drop_src=None):
+        self.off, self.idx, self.w, self.n_src = off, idx, w, int(n_src)
+        self.n_dst = off.numel() - 1
+        nnz = idx.numel()
+        counts = (off[1:] - off[:-1]).long()
+        dst_of = torch.repeat_interleave(torch.arange(self.n_dst, device=idx.device), counts, output_size=nnz)
+        key = idx.long()
+        keep = None
+        if drop_src is not None:
+            keep = torch.nonzero(key != drop_src, as_tuple=True)[0]
+            key, dst_of = key[keep], dst_of[keep]
+        order = torch.sort(key, stable=True).indices  # contributions of a source row in ascending entry order
+        t_idx = dst_of[order].int().contiguous()
+        wk = None if w is None else (w if keep is None else w[keep])
+        t_w = None if wk is None else wk[order].contiguous()
+        per_src = torch.bincount(key, minlength=self.n_src)
+        t_off = torch.zeros(self.n_src + 1, dtype=torch.int32, device=idx.device)
+        t_off[1:] = torch.cumsum(per_src, 0)
+        self.fwd = Segments(off, idx, w)
+        self.bwd = Segments(t_off, t_idx, t_w)
+        self.t_off, self.t_idx, self.t_w = t_off, t_idx, t_w
+
+    @staticmethod
+    def gather(idx, n_src):
+        """Plain row gather dst[i] = src[idx[i]]."""
+        idx = idx.int().contiguous()
+        off = torch.arange(idx.numel() + 1, dtype=torch.int32, device=idx.device)
+        return Csr(off, idx, None, n_src)
+
+
+class _SegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, csr):
+        ctx.csr = csr
+        return csr.fwd.sum(src)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ctx.csr.bwd.sum(grad), None
+
+
+def gather_sum(src, csr):
+    """Differentiable ``dst[d] = sum_e w[e] src[idx[e]]``; forward and backward are both segmented sums."""
+    return _SegmentSum.apply(src, csr)
+
+
+class _RepeatRows(torch.autograd.Function):
+    """x (R, ...) -> rows repeated `lengths[r]` times (contiguous segments); the gradient is a segmented sum in row
+    order (torch's own repeat_interleave backward is an atomic index_add)."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, total):
+        ctx.lengths = lengths
+        return torch.repeat_interleave(x, lengths, dim=0, output_size=total)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return torch.segment_reduce(grad.contiguous(), "sum", lengths=ctx.lengths, unsafe=True), None, None
+
+
+def repeat_rows(x, lengths, total):
+    return _RepeatRows.apply(x, lengths, total)
+
+
+class _SegAttention(torch.autograd.Function):
+    """Softmax of the scores S (P, H) over the contiguous segments `lengths` (the keys of one query), then
+    O[r] = sum_p prob[p] V[p] -> (R, H, hd).  Backward written out with segmented reductions only (fixed order)."""
+
+    @staticmethod
+    def forward(ctx, S, V, lengths):
+        P = S.shape[0]
+        rep = lambda t: torch.repeat_interleave(t, lengths, dim=0, output_size=P)  # noqa: E731
+        m = torch.segment_reduce(S, "max", lengths=lengths, unsafe=True)
+        e = torch.exp(S - rep(m))
+        prob = e / rep(torch.segment_reduce(e, "sum", lengths=lengths, unsafe=True))
+        ctx.save_for_backward(prob, V)
+        ctx.lengths = lengths
+        return torch.segment_reduce(prob.unsqueeze(-1) * V, "sum", lengths=lengths, unsafe=True)
+
+    @staticmethod
+    def backward(ctx, dO):
+        prob, V = ctx.saved_tensors
+        lengths = ctx.lengths
+        P = prob.shape[0]
+        rep = lambda t: torch.repeat_interleave(t, lengths, dim=0, output_size=P)  # noqa: E731
+        dOp = rep(dO.contiguous())  # (P, H, hd)
+        dV = prob.unsqueeze(-1) * dOp
+        dp = (dOp * V).sum(-1)  # (P, H)
+        dS = prob * (dp - rep(torch.segment_reduce(prob * dp, "sum", lengths=lengths, unsafe=True)))
+        return dS, dV, None
+
+
+def _seg_softmax_weighted_sum(S, V, lengths):
+    return _SegAttention.apply(S.contiguous(), V.contiguous(), lengths)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Block
+# ---------------------------------------------------------------------------------------------------------
+
+def block_supported(block, sp):
+    ma = block.ms_attn
+    return (sp.features.is_cuda and sp.features.dtype == torch.float32 and block.win2_size is not None
+            and len(ma.num_heads) == 2 and sp.features.shape[1] % 4 == 0 and all(d % 4 == 0 for d in ma.scale_dims)
+            and max(block.max_num_win1, block.max_num_win2) < 2048 and max(block.win2_size) <= 120
+            and max(block.win1_size) <= 60)
+
+
+@torch.no_grad()
+def _block_index_sets(block, sp, p):
+    """Compact index sets of (plan, cbs_pattern): cached on the plan, shared by the Blocks that use it."""
+    cache = getattr(p, "train_sets", None)
+    if cache is None:
+        cache = p.train_sets = {}
+    key = (block.cbs_pattern, 1 if block.use_feature_interpolation else 0)
+    if key in cache:
+        return cache[key]
+    dev = sp.indices.device
+    N = sp.indices.shape[0]
+    q_ind, nq, owner_q = fused._query(block, p)
+    od = fused._work_order(block, p, nq, N)
+    nw, R = int(p.num_wins.item()), int(od["n_rows"].item())  # host values: one sync per (plan, pattern)
+    s = {"nw": nw, "R": R, "nq": nq}
+    meta = od["row_meta"][:R]
+    s["q_rows"] = meta[:, 3].contiguous().view(torch.int32)
+    s["q_rel"] = meta[:, :3].contiguous()
+    s["q_win"] = od["row_src"][:R, 0].long()
+    s["q_csr"] = Csr.gather(s["q_rows"], N)
+    s["centre"] = p.wcentre[:nw, :3].contiguous()
+    # valid key slots of each scale, window-major (FPS pick order inside a window)
+    s["keys"] = []
+    for g in range(2):
+        km = p.kmeta[g][:nw]
+        rows = km[..., 3].contiguous().view(torch.int32)
+        valid = rows >= 0
+        k_win = torch.nonzero(valid, as_tuple=True)[0]
+        nk = valid.sum(1)  # keys per window
+        koff = torch.cumsum(nk, 0) - nk
+        k_rows = rows[valid]
+        # (query, key) pairs: every valid query of a window against every valid key of that window
+        plen = nk[s["q_win"]]  # pairs per query
+        P = int(plen.sum().item())
+        pair_q = torch.repeat_interleave(torch.arange(R, device=dev), plen, output_size=P)
+        pstart = torch.cumsum(plen, 0) - plen
+        pair_k = koff[s["q_win"]][pair_q] + (torch.arange(P, device=dev) - pstart[pair_q])
+        s["keys"].append(dict(k_rows=k_rows, k_rel=km[..., :3][valid].contiguous(), k_win=k_win, plen=plen,
+                              k_csr=Csr.gather(k_rows, N), pair_q=pair_q,
+                              pair_csr=Csr.gather(pair_k, k_rows.numel())))
+    # interpolation / scatter table: 3 compact attention rows + weights per voxel (row R = the zero row)
+    interp = key[1]
+    upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
+    zero_row = p.cap * nq  # a virtual row of the (never allocated) padded attention buffer
+    tab_row = torch.full((max(N, 1), 4), -1, dtype=torch.int32, device=dev)
+    tab_w = torch.zeros((max(N, 1), 4), dtype=torch.float32, device=dev)
+    _lib.call("mssvt_block_interp_table", _i(nq), _i(n_upd), _i(interp), _lib.ptr(sp.indices), _lib.ptr(p.win_ind),
+              _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind), _lib.ptr(upd_ind),
+              _lib.ptr(owner), fused._f3(sp.voxel_size), fused._f3(sp.point_cloud_range[0:3]), _i(zero_row),
+              _lib.ptr(tab_row), _lib.ptr(tab_w), _lib.stream())
+    inv = torch.full((zero_row + 1,), R, dtype=torch.int32, device=dev)  # padded attention row -> compact row
+    inv[od["row_src"][:R, 1].long()] = torch.arange(R, dtype=torch.int32, device=dev)
+    owned = tab_row[:N, 0] >= 0
+    idx3 = inv[tab_row[:N, :3].clamp(min=0).long()]
+    idx3 = torch.where(owned.unsqueeze(1), idx3, torch.full_like(idx3, R))
+    w3 = torch.where(owned.unsqueeze(1), tab_w[:N, :3], torch.zeros_like(tab_w[:N, :3]))
+    off3 = torch.arange(0, 3 * N + 1, 3, dtype=torch.int32, device=dev)
+    s["interp_csr"] = Csr(off3, idx3.reshape(-1).contiguous(), w3.reshape(-1).contiguous(), R + 1, drop_src=R)
+    s["owned"] = owned
+    cache[key] = s
+    return s
+
+
+def _pos6(conv, rel, centre, c0=None, c1=None):
+    """relu(Conv1d(6 -> C, 1)([rel ; centre])) on compact rows (ref pos_proj, mssvt_backbone.py:43-47)."""
+    w, b = conv.weight.squeeze(-1), conv.bias
+    if c0 is not None:
+        w, b = w[c0:c1], b[c0:c1]
+    return F.relu(F.linear(torch.cat([rel, centre], dim=1), w, b))
+
+
+def block_forward(block, sp):
+    """Differentiable forward of a MixedScaleSparseTransformerBlock on compact rows (ref mssvt_backbone.py:201-346)."""
+    if not block_supported(block, sp) or sp.features.shape[0] == 0:
+        return block.forward_ops(sp)
+    x_in = sp.features
+    N, C = x_in.shape
+    xhat = block.norm1(x_in)
+    p = fused.two_scale_plan(block, sp)
+    s = _block_index_sets(block, sp, p)
+    R, ma = s["R"], block.ms_attn
+    hd = ma.per_head_dim
+    if R > 0:
+        cq = s["centre"][s["q_win"]]
+        tok_q = gather_sum(xhat, s["q_csr"]) + _pos6(block.pos_proj[0], s["q_rel"], cq)
+        outs, c0 = [], 0
+        for g, (heads, cg) in enumerate(zip(ma.num_heads, ma.scale_dims)):
+            c1 = c0 + cg
+            ks = s["keys"][g]
+            tok_k = gather_sum(xhat[:, c0:c1].contiguous(), ks["k_csr"]) + _pos6(
+                block.pos_proj[0], ks["k_rel"], s["centre"][ks["k_win"]], c0, c1)
+            q = ma.to_qs[g](tok_q[:, c0:c1]) * ma.scale  # (R, cg)
+            kv = ma.to_kvs[g](tok_k)  # (Kg, 2 cg) = [K | V]
+            kvp = gather_sum(kv, ks["pair_csr"])  # (P, 2 cg): the keys of every (query, key) pair
+            qp = repeat_rows(q, ks["plen"], kvp.shape[0])
+            S = (qp.view(-1, heads, hd) * kvp[:, :cg].reshape(-1, heads, hd)).sum(-1)  # (P, heads)
+            o = _seg_softmax_weighted_sum(S, kvp[:, cg:].reshape(-1, heads, hd), ks["plen"])  # (R, heads, hd)
+            outs.append(ma.projs[g](o.reshape(R, cg)))
+            c0 = c1
+        attn = torch.cat(outs + [x_in.new_zeros((R, C - c0))] if c0 < C else outs, dim=1)
+    else:
+        attn = x_in.new_zeros((0, C))
+    attn_ext = torch.cat([attn, attn.new_zeros((1, C))], dim=0)  # row R = zeros (empty slots, zero weights)
+    upd = gather_sum(attn_ext, s["interp_csr"])  # (N, C): interpolated / scattered update of every owned voxel
+    feats = torch.where(s["owned"].unsqueeze(1), upd, x_in)  # untouched voxels keep x_in (ref :317-338)
+    new = block.drop_path(feats) + x_in
+    new = new + block.drop_path(block.dropout1(block._ffn(new)))
+    if hasattr(block, "out_linear"):
+        new = block.out_linear(new)
+    sp.features = new
+    sp.gather_dict = None
+    sp._xhat = None
+    return sp
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CompressBlock
+# ---------------------------------------------------------------------------------------------------------
+
+def compress_supported(block, sp):
+    ma = block.ms_attn
+    return (sp.features.is_cuda and sp.features.dtype == torch.float32 and ma.num_head_groups == 1
+            and sp.features.shape[1] % 4 == 0 and len(block.pos_proj) >= 3)
+
+
+@torch.no_grad()
+def _compress_index_sets(block, sp, p):
+    dev = sp.indices.device
+    N, nw, ns = sp.indices.shape[0], p.nw, block.max_num_win1
+    k = p.k_ind[:nw]
+    valid = k >= 0
+    pair_win = torch.nonzero(valid, as_tuple=True)[0]
+    pair_vox = (k[valid].long() + p.win_vstart[:nw].long()[pair_win]).int().contiguous()
+    cnt = valid.sum(1)
+    vox_xyz = _metric(sp.indices, sp.point_cloud_range, sp.voxel_size)
+    centre = _metric(p.win_ind[:nw], sp.point_cloud_range, p.win_size_m)
+    return dict(pair_win=pair_win, cnt=cnt, vox_csr=Csr.gather(pair_vox, N), centre=centre,
+                rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(), full=(cnt >= ns))
+
+
+def _metric(indices, point_cloud_range, cell):
+    from .mssvt_backbone import metric_centres
+    return metric_centres(indices, point_cloud_range, cell)
+
+
+def compress_forward(block, sp):
+    """Differentiable forward of a MixedScaleSparseTransformerCompressBlock (ref mssvt_backbone.py:351-398)."""
+    if not compress_supported(block, sp) or sp.features.shape[0] == 0:
+        return block.forward_ops(sp)
+    x = block.norm1(sp.features)
+    C = x.shape[1]
+    p = fused.one_scale_plan(block, sp)  # K2 + K4 on the device, one host sync (the output shape)
+    s = _compress_index_sets(block, sp, p)
+    ma = block.ms_attn
+    heads, hd = ma.num_heads[0], ma.per_head_dim
+    xk = gather_sum(x, s["vox_csr"])  # (P, C) window-major key features
+    # query = channel-wise max over the zero padded list (ref :370): the zeros take part unless the list is full
+    q_tok = torch.segment_reduce(xk, "max", lengths=s["cnt"], unsafe=True)
+    q_tok = torch.where(s["full"].unsqueeze(1), q_tok, torch.clamp(q_tok, min=0.0))
+    pos = F.relu(F.linear(torch.cat([s["rel"], s["centre"][s["pair_win"]]], dim=1),
+                          block.pos_proj[0].weight.squeeze(-1), block.pos_proj[0].bias))
+    pos = F.relu(F.linear(pos, block.pos_proj[2].weight.squeeze(-1), block.pos_proj[2].bias))
+    tok_k = xk + pos
+    q = ma.to_qs[0](q_tok) * ma.scale  # (nw, C)
+    kv = ma.to_kvs[0](tok_k)  # (P, 2C)
+    qp = repeat_rows(q, s["cnt"], kv.shape[0])
+    S = (qp.view(-1, heads, hd) * kv[:, :C].reshape(-1, heads, hd)).sum(-1)
+    o = _seg_softmax_weighted_sum(S, kv[:, C:].reshape(-1, heads, hd), s["cnt"])
+    new = ma.projs[0](o.reshape(-1, C))
+    new = new + block.dropout1(block._ffn(new))  # no residual to the block input (ref :383-385)
+    if hasattr(block, "out_linear"):
+        new = block.out_linear(new)
+    sp.features = new
+    sp._xhat = None
+    return fused._compress_finish(sp, p, new)

@@ -1,23 +1,42 @@
-"""Developer tool: one training step (forward + backward + SGD) of the backbone on a 160k-point scene --
-autograd on means the differentiable operator path (K6 / K11 backward kernels); prints ms per step and peak memory."""
-import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-from mssvt_amd import config
+"""Time a training step (forward + backward + SGD) of the backbone on the bench scene, compact path vs operator
+path, with peak memory (investigation helper; usage: python tools/train_time.py [batch] [points])."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from mssvt_amd import config, fused  # noqa: E402
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+points = int(sys.argv[2]) if len(sys.argv) > 2 else 160000
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = config.build_backbone_from_cfg().to(dev).train()
-_, _, vc, feats = bench.make_inputs(160000, 1, 0, dev)
-feats = feats.clone().requires_grad_(True)
+_, _, vc, feats = bench.make_inputs(points, batch, 0, dev)
 opt = torch.optim.SGD(net.parameters(), lr=1e-4)
+
+
 def step():
     opt.zero_grad(set_to_none=True)
-    out = net(dict(voxel_features=feats, voxel_coords=vc, batch_size=1))["encoded_spconv_tensor"].features
-    loss = out.square().mean()
-    loss.backward()
+    out = net(dict(voxel_features=feats, voxel_coords=vc, batch_size=batch))["encoded_spconv_tensor"].features
+    out.square().mean().backward()
     opt.step()
-    return float(loss)
-for _ in range(2): step()
-torch.cuda.synchronize(); t=time.perf_counter()
-for _ in range(5): l=step()
-torch.cuda.synchronize(); print("train step ms", (time.perf_counter()-t)/5*1e3, "loss", l, "peak GB", torch.cuda.max_memory_allocated()/2**30)
+
+
+for compact in ((True,) if os.environ.get("MSSVT_TRAIN_ONLY_COMPACT") else (True, False)):
+    fused.TRAIN_COMPACT = compact
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    print("%s path: %.1f ms / training step, peak memory %.2f GB" % (
+        "compact" if compact else "operator", (time.perf_counter() - t0) / n * 1e3, torch.cuda.max_memory_allocated() / 2**30))
