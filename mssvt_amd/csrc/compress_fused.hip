@@ -23,7 +23,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define CF_NW 8  // waves per workgroup
+// waves per workgroup: ONE workgroup per CU (the 66 KiB weight matrix is staged once per CU; two 8-wave workgroups do
+// not fit beside the per-wave window lists), as many waves as the registers allow
+#define CFQ_NW 12  // k_cmp_query_keys (<= 168 VGPRs)
+#define CFK_NW 12  // k_cmp_kv
+#define CFO_NW 16  // k_cmp_out (<= 128 VGPRs)
 #define MFMA4(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
 
 struct CmpArgs {
@@ -118,7 +122,7 @@ __device__ __forceinline__ void cmp_query_body(const CmpArgs &a, int block_id, i
     __syncthreads();
     const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
     const int nw = *a.num_wins, tiles = (nw + 15) >> 4;
-    for (int k = wv;; k += CF_NW) {
+    for (int k = wv;; k += CFQ_NW) {
         const int tile = k * num_blocks + block_id;
         if (tile >= tiles) break;
         const int w = min(tile * 16 + la, nw - 1);
@@ -189,7 +193,7 @@ __device__ __forceinline__ void cmp_keys_body(const CmpArgs &a, int block_id, in
     }
     __syncthreads();
     const int n = a.num_voxels, tiles = (n + 15) >> 4;
-    for (int k = wv;; k += CF_NW) {
+    for (int k = wv;; k += CFQ_NW) {
         const int tile = k * num_blocks + block_id;
         if (tile >= tiles) break;
         const int v = min(tile * 16 + la, n - 1);
@@ -238,7 +242,7 @@ __device__ __forceinline__ void cmp_keys_body(const CmpArgs &a, int block_id, in
 // A and B in ONE launch: they are independent (windows -> qp, voxels -> ktok), and the query side is a
 // latency-bound walk over the window lists that hides under the key side's matrix work.
 template <int C>
-__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query_keys(CmpArgs a, int query_blocks) {
+__global__ void __launch_bounds__(CFQ_NW *MSSVT_WAVE) k_cmp_query_keys(CmpArgs a, int query_blocks) {
     // roles alternate so that both kinds are resident from the start (dispatch is in block order)
     const int key_blocks = gridDim.x - query_blocks, both = 2 * min(query_blocks, key_blocks);
     const int b = blockIdx.x;
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_query_keys(CmpArgs a,
 
 // ---- C: K scores + V rows ---------------------------------------------------------------------------
 template <int C, int HD>
-__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
+__global__ void __launch_bounds__(CFK_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
     constexpr int NT = C / 16, LS = C + 4, NH = C / HD;
     static_assert(HD == 8 || HD == 16 || HD == 32, "head dims instantiated: 8, 16, 32");
     extern __shared__ float4 lds4[];
@@ -262,7 +266,7 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
     __syncthreads();
     const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
     const int n = a.num_voxels, tiles = (n + 15) >> 4;
-    for (int k = wv;; k += CF_NW) {
+    for (int k = wv;; k += CFK_NW) {
         const int tile = k * gridDim.x + blockIdx.x;
         if (tile >= tiles) break;
         const int v = min(tile * 16 + la, n - 1);
@@ -335,7 +339,7 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
 
 // ---- D: softmax, weighted V sum, output projection --------------------------------------------------
 template <int C, int HD>
-__global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
+__global__ void __launch_bounds__(CFO_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
     constexpr int NT = C / 16, LS = C + 4, NH = C / HD;
     extern __shared__ float4 lds4[];
     float *Wo_l = reinterpret_cast<float *>(lds4), *bo_l = Wo_l + C * LS;
@@ -345,7 +349,7 @@ __global__ void __launch_bounds__(CF_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
     __syncthreads();
     const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
     const int nw = *a.num_wins, tiles = (nw + 15) >> 4;
-    for (int k = wv;; k += CF_NW) {
+    for (int k = wv;; k += CFO_NW) {
         const int tile = k * gridDim.x + blockIdx.x;
         if (tile >= tiles) break;
         const int w = min(tile * 16 + la, nw - 1);
@@ -429,23 +433,28 @@ template <int C, int HD>
 static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t stream) {
     constexpr int LS = C + 4;
     const size_t lds1 = ((size_t)C * LS + C) * 4, lds2 = ((size_t)2 * C * LS + 2 * C) * 4;
-    const size_t lds1w = lds1 + (size_t)CF_NW * 16 * a.ns * 4;  // + the tile's K4 lists per wave
-    if (lds1w > 160 * 1024) return MSSVT_E_TOOLARGE;
+    // + the tile's K4 lists per wave
+    const size_t lds_q = lds1 + (size_t)CFQ_NW * 16 * a.ns * 4, lds_o = lds1 + (size_t)CFO_NW * 16 * a.ns * 4;
+    if (lds_q > 160 * 1024 || lds_o > 160 * 1024) return MSSVT_E_TOOLARGE;
     int rc;
-    if ((rc = cf_prepare(k_cmp_query_keys<C>, lds1w)) ||
-        (rc = cf_prepare(k_cmp_kv<C, HD>, lds2)) || (rc = cf_prepare(k_cmp_out<C, HD>, lds1w)))
+    if ((rc = cf_prepare(k_cmp_query_keys<C>, lds_q)) ||
+        (rc = cf_prepare(k_cmp_kv<C, HD>, lds2)) || (rc = cf_prepare(k_cmp_out<C, HD>, lds_o)))
         return rc;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
     const int vt = (a.num_voxels + 15) / 16, wt = (win_capacity + 15) / 16;
-    const int per1 = (int)((160 * 1024) / lds1) > 2 ? 2 : (int)((160 * 1024) / lds1);
-    const int per1w = (int)((160 * 1024) / lds1w) > 2 ? 2 : (int)((160 * 1024) / lds1w);
-    const int g_w = min(cus * (per1w < 1 ? 1 : per1w), max(wt, 1)), g_v = min(cus * per1, max(vt, 1)), g_v2 = min(cus, max(vt, 1));
-    k_cmp_query_keys<C><<<g_w + g_v, CF_NW * MSSVT_WAVE, lds1w, stream>>>(a, g_w);
-    k_cmp_kv<C, HD><<<g_v2, CF_NW * MSSVT_WAVE, lds2, stream>>>(a);
-    k_cmp_out<C, HD><<<g_w, CF_NW * MSSVT_WAVE, lds1w, stream>>>(a);
+    // every workgroup resident at once (blocks per CU by LDS), the roles of the first launch split ~1 : 2 (a key tile
+    // carries a C x C product on top of its positional layer, a query tile mostly waits for its list walk)
+    const int per_q = (int)((160 * 1024) / lds_q) < 1 ? 1 : (int)((160 * 1024) / lds_q);
+    const int per_o = (int)((160 * 1024) / lds_o) < 1 ? 1 : (int)((160 * 1024) / lds_o);
+    const int slots = cus * per_q;
+    int g_w = min(max(slots / 3, 1), max(wt, 1)), g_v = min(max(slots - g_w, 1), max(vt, 1));
+    const int g_v2 = min(cus, max(vt, 1)), g_o = min(cus * per_o, max(wt, 1));
+    k_cmp_query_keys<C><<<g_w + g_v, CFQ_NW * MSSVT_WAVE, lds_q, stream>>>(a, g_w);
+    k_cmp_kv<C, HD><<<g_v2, CFK_NW * MSSVT_WAVE, lds2, stream>>>(a);
+    k_cmp_out<C, HD><<<g_o, CFO_NW * MSSVT_WAVE, lds_o, stream>>>(a);
     return mssvt_launch_status();
 }
 
