@@ -465,6 +465,19 @@ int mssvt_segment_sum_rows(int C, int n_dst, const int *csr_off, const int *csr_
 int mssvt_segment_sum_rows_ranges(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
                                   const float *csr_w, const float *src, float *dst, void *stream);
 
+/* ========================================================================
+ * Post-processing behind the backbone: rotated BEV NMS of CenterHead's boxes.
+ * ref: iou3d_nms_cuda.nms_gpu, pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:90-135 (host loop) +
+ * iou3d_nms_kernel.cu:107-278 (box_overlap / iou_bev / nms_kernel).  boxes_sorted (N,7) f32
+ * [x,y,z,dx,dy,dz,heading] in descending score order (the caller sorts, as the reference's Python does,
+ * iou3d_nms_utils.py:83-98); a box suppresses every later box whose BEV IoU exceeds thresh (strict).
+ * keep (N) int32 receives the kept positions (ascending), *num_keep_dev their count -- the greedy walk runs
+ * on the device, nothing but these is read back.  workspace: mssvt_nms_workspace_bytes(N) bytes. N <= 16384.
+ * ======================================================================== */
+long long mssvt_nms_workspace_bytes(int num_boxes);
+int mssvt_nms_bev(int num_boxes, const float *boxes_sorted, float thresh, void *workspace, int *keep,
+                  int *num_keep_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
