@@ -44,7 +44,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define ATTN_ROW_WAVES 4  // waves per workgroup of the row-tiled launches
+#define ATTN_ROW_WAVES 4  // waves per workgroup of the per-window launch
+// waves per workgroup of the row-tiled launches (q, o): ONE workgroup per CU and head group -- the weights are staged
+// once per CU (two Cg x Cg matrices, 37 KiB) instead of once per 4-wave workgroup (four of them per CU: 148 KiB at the
+// ~11 B/clk a CU fills at = the larger part of a launch on 8k query rows); 66-71 VGPRs leave room for 4 waves / SIMD
+#define ATTN_QO_WAVES 16
 #define AST_UN 16        // weight elements per matrix and thread in flight while staging (64 x 64 / 256 threads)
 
 struct AttnArgs {
@@ -80,9 +84,23 @@ struct AttnPack {
 #define MFMA4(acc, av, bv)                                                    \
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
 
+// Store of the Q~ / Xbar hand-off rows.  (Measured: written through with `sc1` instead of left dirty for the
+// write-back at the kernel boundary, the 67 MB per launch cost the same ~11 us -- k_attn_q 20.6 -> 19.2 us,
+// k_attn_kv 46.0 -> 47.2 us: it is the bytes, not when they leave the L2.)
+__device__ __forceinline__ void store_handoff(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+#ifdef MSSVT_STAMPS
+__device__ unsigned long long g_attn_q_stamps[64 * 8];
+extern "C" int mssvt_debug_read_attn_q_stamps(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_q_stamps), sizeof(g_attn_q_stamps));
+}
+#define QSTAMP(k_) if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0) g_attn_q_stamps[blockIdx.x * 8 + (k_)] = __builtin_readcyclecounter();
+#else
+#define QSTAMP(k_)
+#endif
 // ---- A: queries -> Qt --------------------------------------------------------------------------
 template <int CG, int HD, int HP>
-__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnPack pack) {
+__global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_q(AttnPack pack) {
     const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, LS = CGP + 4, NH = CG / HD, QROW = HP * CG;
     extern __shared__ float4 lds4[];
@@ -90,6 +108,19 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnPa
     float *WkT_l = Wq_l + CGP * LS;                 // [c][o] = Wk[o][c]
     float *Wp_l = WkT_l + CGP * LS;                 // [c][8] = pos_proj row (6 weights, bias, 0)
     float *bq_l = Wp_l + CGP * 8;                   // [o]
+    // tile k * grid + block -> wave k % waves: a short row list is spread over all CUs; a workgroup without a tile
+    // leaves before it stages anything
+    QSTAMP(0)
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    if ((int)blockIdx.x >= tiles) return;
+    QSTAMP(1)
+    // the first tile's row metadata travels while the weights are staged, its feature rows while the workgroup
+    // meets at the barrier: metadata -> rows -> products is a chain of round trips as long as the staging itself
+    int tile = wv * gridDim.x + blockIdx.x;
+    float4 rm = a.qrow_meta[min(tile * 16 + r, rows - 1)];
+    int2 src = a.qrow_src[min(tile * 16 + r, rows - 1)];
     // AST_UN elements of each matrix in flight per thread (a plain copy loop waits for every load before
     // its store: one global round trip per element)
     for (int e0 = threadIdx.x; e0 < CGP * CGP; e0 += blockDim.x * AST_UN) {
@@ -115,24 +146,30 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnPa
         Wp_l[e] = c < CG ? (t < 6 ? a.Wp[(size_t)(a.c0 + c) * 6 + t] : (t == 6 ? a.bp[a.c0 + c] : 0.f)) : 0.f;
     }
     for (int e = threadIdx.x; e < CGP; e += blockDim.x) bq_l[e] = e < CG ? a.bq[e] : 0.f;
+    QSTAMP(2)
+    float4 wc = a.wcentre[src.x];
+    f32x4 xq[NT];
+#define ATTN_Q_ROWS()                                                                                     \
+    {                                                                                                     \
+        const float *xrow_ = a.xhat + (size_t)__builtin_bit_cast(int, rm.w) * a.C + a.c0;                 \
+        _Pragma("unroll") for (int S = 0; S < NT; ++S) {                                                  \
+            const int c_ = 16 * S + 4 * g;                                                                \
+            const float4 v_ = (CGP == CG || c_ < CG) ? *reinterpret_cast<const float4 *>(xrow_ + c_)      \
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);                   \
+            xq[S] = f32x4{v_.x, v_.y, v_.z, v_.w};                                                        \
+        }                                                                                                 \
+    }
+    ATTN_Q_ROWS()
     __syncthreads();
-    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
-    const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
-    const int wv = threadIdx.x / MSSVT_WAVE;
-    for (int tile = blockIdx.x * ATTN_ROW_WAVES + wv; tile < tiles; tile += gridDim.x * ATTN_ROW_WAVES) {
+    QSTAMP(3)
+    for (bool first = true; tile < tiles; tile += gridDim.x * ATTN_QO_WAVES, first = false) {
         const int row = min(tile * 16 + r, rows - 1);
-        const float4 rm = a.qrow_meta[row];
-        const int2 src = a.qrow_src[row];
-        const float4 wc = a.wcentre[src.x];
-        const float *xrow = a.xhat + (size_t)__builtin_bit_cast(int, rm.w) * a.C + a.c0;
-        // B operand of GEMM1: this lane's 4 channels 16 S + 4 g + j of its query token
-        f32x4 xq[NT];
-#pragma unroll
-        for (int S = 0; S < NT; ++S) {
-            const int c = 16 * S + 4 * g;
-            const float4 v = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xrow + c)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            xq[S] = f32x4{v.x, v.y, v.z, v.w};
+        if (!first) {
+            rm = a.qrow_meta[row];
+            src = a.qrow_src[row];
+            wc = a.wcentre[src.x];
+            // B operand of GEMM1: this lane's 4 channels 16 S + 4 g + j of its query token
+            ATTN_Q_ROWS()
         }
 #pragma unroll
         for (int S = 0; S < NT; ++S) {
@@ -198,22 +235,41 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_q(AttnPa
             for (int u = 0; u < NT; ++u) {
                 const int c = 16 * u + 4 * g;
                 if (row_ok && (CGP == CG || c < CG))
-                    *reinterpret_cast<float4 *>(dst + h * CG + c) =
-                        make_float4(acc[u][0] * a.scale, acc[u][1] * a.scale, acc[u][2] * a.scale, acc[u][3] * a.scale);
+                    store_handoff(dst + h * CG + c,
+                                  f32x4{acc[u][0] * a.scale, acc[u][1] * a.scale, acc[u][2] * a.scale, acc[u][3] * a.scale});
             }
         }
     }
+    QSTAMP(4)
 }
 
 // ---- C: Xbar -> attention output rows ----------------------------------------------------------
 template <int CG, int HD, int HP>
-__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnPack pack) {
+__global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_o(AttnPack pack) {
     const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, LS = CGP + 4, NH = CG / HD, QROW = HP * CG;
     extern __shared__ float4 lds4[];
     float *Wv_l = reinterpret_cast<float *>(lds4);  // [o][c]
     float *Wo_l = Wv_l + CGP * LS;                  // [p][o]
     float *bv_l = Wo_l + CGP * LS, *bo_l = bv_l + CGP;
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    if ((int)blockIdx.x >= tiles) return;
+    // the first tile's Xbar rows of head 0 travel while the weights are staged
+    int tile = wv * gridDim.x + blockIdx.x;
+    f32x4 x[NT], xn[NT];
+#define ATTN_O_ROWS(dst_, row_, h_)                                                                       \
+    {                                                                                                     \
+        const float *xb_ = a.qbuf + (size_t)(row_) * QROW + (h_) * CG;                                    \
+        _Pragma("unroll") for (int S = 0; S < NT; ++S) {                                                  \
+            const int c_ = 16 * S + 4 * g;                                                                \
+            const float4 t4_ = (CGP == CG || c_ < CG) ? *reinterpret_cast<const float4 *>(xb_ + c_)       \
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);                  \
+            dst_[S] = f32x4{t4_.x, t4_.y, t4_.z, t4_.w};                                                  \
+        }                                                                                                 \
+    }
+    ATTN_O_ROWS(x, min(tile * 16 + r, rows - 1), 0)
     for (int e0 = threadIdx.x; e0 < CGP * CGP; e0 += blockDim.x * AST_UN) {
         float vv[AST_UN], vo[AST_UN];
 #pragma unroll
@@ -237,14 +293,11 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnPa
         bo_l[e] = e < CG ? a.bo[e] : 0.f;
     }
     __syncthreads();
-    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
-    const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
-    const int wv = threadIdx.x / MSSVT_WAVE;
-    for (int tile = blockIdx.x * ATTN_ROW_WAVES + wv; tile < tiles; tile += gridDim.x * ATTN_ROW_WAVES) {
+    for (bool first = true; tile < tiles; tile += gridDim.x * ATTN_QO_WAVES, first = false) {
         const int row = min(tile * 16 + r, rows - 1);
         const bool row_ok = tile * 16 + r < rows;
         const int dest = a.qrow_src[row].y;
-        const float *xb = a.qbuf + (size_t)row * QROW;
+        if (!first) ATTN_O_ROWS(x, row, 0)
         // GEMM3^T: V^T[o][row] = sum_c Wv[o][c] Xbar_{head(o)}[row][c] + bv[o]
         f32x4 v[NT];
 #pragma unroll
@@ -254,14 +307,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnPa
         }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            f32x4 x[NT];
-#pragma unroll
-            for (int S = 0; S < NT; ++S) {
-                const int c = 16 * S + 4 * g;
-                const float4 t4 = (CGP == CG || c < CG) ? *reinterpret_cast<const float4 *>(xb + h * CG + c)
-                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-                x[S] = f32x4{t4.x, t4.y, t4.z, t4.w};
-            }
+            if (h + 1 < NH) ATTN_O_ROWS(xn, row, h + 1)  // the next head's rows under this head's products
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (16 * t >= (h + 1) * HD || 16 * (t + 1) <= h * HD) continue;
@@ -278,6 +324,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_o(AttnPa
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int S = 0; S < NT; ++S) x[S] = xn[S];
         }
         // GEMM4^T: out^T[p][row] = sum_o Wo[p][o] V[row][o] + bo[p]
         f32x4 out[NT];
@@ -532,12 +580,14 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
                 for (int u = 0; u < NT; ++u) {
                     const int c = 16 * u + 4 * g;
                     if (CGP == CG || c < CG)  // xbar replaces qt in place (this lane's own 16 bytes)
-                        *reinterpret_cast<float4 *>(qrow + c) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+                        store_handoff(qrow + c, acc[u]);
                 }
             }
         }
         wave_lds_sync();  // the next window rewrites the tile
     }
+#undef ATTN_Q_ROWS
+#undef ATTN_O_ROWS
 #undef KV_LOAD_META
 #undef KV_ISSUE_ROWS
 #undef KV_ROW4
@@ -550,14 +600,14 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hip
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    // A / C: persistent over 16-row tiles, 4 workgroups of 4 waves per CU at most
+    // A / C: persistent over 16-row tiles, one 16-wave workgroup per CU and head group at most
     const int tiles_cap = (row_capacity + 15) / 16;
-    int row_grid = (tiles_cap + ATTN_ROW_WAVES - 1) / ATTN_ROW_WAVES;
-    if (row_grid > cus * 4 / ng) row_grid = cus * 4 / ng;
+    int row_grid = tiles_cap;
+    if (row_grid > cus * 2 / ng) row_grid = cus * 2 / ng;
     if (row_grid < 1) row_grid = 1;
     const size_t lds_q = ((size_t)2 * CGP * LS + CGP * 8 + CGP) * 4, lds_o = ((size_t)2 * CGP * LS + 2 * CGP) * 4;
     const int K = pack.g[0].K;
-    k_attn_q<CG, HD, HP><<<dim3(row_grid, ng), ATTN_ROW_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
+    k_attn_q<CG, HD, HP><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
     // B: persistent over the work order, 8 workgroups of 4 waves per CU at most (VGPR bound)
     const dim3 kv_grid(cus * 8 / ng > 0 ? cus * 8 / ng : 1, ng);
     const size_t lds_tile = (size_t)ATTN_ROW_WAVES * 16 * LS * 4;  // per key tile of 16 slots, all waves
@@ -571,7 +621,7 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hip
         if (e != hipSuccess) return (int)e;
         k_attn_kv<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 4 * lds_tile, stream>>>(pack);
     }
-    k_attn_o<CG, HD, HP><<<dim3(row_grid, ng), ATTN_ROW_WAVES * MSSVT_WAVE, lds_o, stream>>>(pack);
+    k_attn_o<CG, HD, HP><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_o, stream>>>(pack);
     return mssvt_launch_status();
 }
 
