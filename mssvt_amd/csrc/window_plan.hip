@@ -316,12 +316,19 @@ extern "C" int mssvt_debug_read_plan_stamps(unsigned long long *host) {
 // FPS_TPL = largest "reference threads per lane" the register sampler is instantiated for in this
 // kernel (8: lists below 1024 entries; 16: below 2048, e.g. 11 x 11 x 11 windows -- a separate
 // instantiation so that the common one keeps its register footprint)
-template <int FPS_TPL>
-__global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanArgs a) {
+// MODE 0: one launch does everything.  MODE 1 ("light") + MODE 2 ("heavy"): the register samplers for lists with more
+// than 64 entries set the register footprint of the whole kernel (127 VGPRs = 4 waves / SIMD) although ~10 % of the
+// windows need them, and the kernel is a chain of dependent round trips that lives on occupancy.  The light launch
+// holds only the samplers of the common case (<= 64 valid entries) and leaves a window that needs more after its
+// list phase, flagged through a NEGATIVE win_vstart entry (-1 - vstart); the heavy launch runs the full code for
+// the flagged windows only (they redo their list phase: 10 % of the windows) and restores the entry.
+template <int FPS_TPL, int MODE>
+__global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, MODE == 1 ? 2 : 1) k_window_plan(PlanArgs a) {
     extern __shared__ int lds[];
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
     const int w = blockIdx.x * (blockDim.x / MSSVT_WAVE) + wv;
     if (w >= *a.num_wins) return;  // wave-uniform
+    if (MODE == 2 && a.win_vstart[w] >= 0) return;  // the light launch finished this window
     int si = 0;
     (void)si;
     PSTAMP()
@@ -556,6 +563,22 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
     }
     wave_lds_sync();
     PSTAMP()
+    if (MODE == 1) {
+        // does either scale need a register sampler beyond <1> (reference block > 64 threads and > 64 valid entries,
+        // or more valid entries than block threads)?  -> the heavy launch takes this window
+        bool heavy = false;
+        for (int scale = 0; scale < 2; ++scale) {
+            const int n = scale ? a.max_win2 : a.max_win1, bs = scale ? a.bs2 : a.bs1;
+            const int nv = min(scale ? cnt_w2 : cnt_w1, n);
+            const bool fast = nv <= MSSVT_WAVE && nv <= bs && bs >= 2;
+            heavy = heavy || (!fast && bs > 64);
+        }
+        if (heavy) {
+            if (lane == 0) a.win_vstart[w] = -1 - vstart;
+            return;
+        }
+    }
+    if (MODE == 2 && lane == 0) a.win_vstart[w] = vstart;
     if (a.kmeta1 && lane == 0) {
         a.nq_valid[w] = min(cnt_odd, a.max_odd);
         a.nq_valid[a.win_capacity + w] = min(cnt_even, a.max_even);
@@ -590,7 +613,9 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
             fps_on_list_fast(lc, n, nv, K, bs, fps_out, lane);
         else if (bs <= 64)
             fps_on_list_regs<1>(lc, n, K, bs, fps_out, lane);
-        else if (bs == 128)
+        else if (MODE == 1) {
+            // unreachable: such a window left for the heavy launch above
+        } else if (bs == 128)
             fps_on_list_regs<2>(lc, n, K, bs, fps_out, lane);
         else if (bs == 256)
             fps_on_list_regs<4>(lc, n, K, bs, fps_out, lane);
@@ -742,16 +767,33 @@ extern "C" int mssvt_window_plan_two(
     const size_t lds_bytes = (size_t)a.lds_words_per_wave * 4 * wpb;
     if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
     const bool big = bsmax > 512;  // lists of 1024 .. 2047 slots: the instantiation with the 16-slot register sampler
+    // light + heavy launch pair: MEASURED SLOWER than the single launch (160k points: 68 + 54 us against 93 us; batch 8:
+    // 561 + 244 against 772 us) -- at 8 waves / SIMD the light launch turns VALU-issue bound (the single launch already
+    // issues vector instructions 61 % of the time at 4 waves / SIMD) and the heavy windows form a tail-bound launch of
+    // their own.  Kept behind MSSVT_PLAN_SPLIT=1 (the -m gpu suite passes either way).
+    const bool split = bsmax > 64 && !a.fps_bs && getenv("MSSVT_PLAN_SPLIT") && atoi(getenv("MSSVT_PLAN_SPLIT")) == 1;
+    const void *kernels[4] = {reinterpret_cast<const void *>(k_window_plan<8, 0>), reinterpret_cast<const void *>(k_window_plan<16, 0>),
+                              reinterpret_cast<const void *>(k_window_plan<8, 1>), nullptr};
+    kernels[3] = big ? reinterpret_cast<const void *>(k_window_plan<16, 2>) : reinterpret_cast<const void *>(k_window_plan<8, 2>);
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(big ? reinterpret_cast<const void *>(k_window_plan<16>)
-                                               : reinterpret_cast<const void *>(k_window_plan<8>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
     }
-    if (big)
-        k_window_plan<16><<<divup(win_capacity, wpb), wpb * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
-    else
-        k_window_plan<8><<<divup(win_capacity, wpb), wpb * MSSVT_WAVE, lds_bytes, (hipStream_t)stream>>>(a);
+    const dim3 grid(divup(win_capacity, wpb)), block(wpb * MSSVT_WAVE);
+    hipStream_t st = (hipStream_t)stream;
+    if (split) {
+        k_window_plan<8, 1><<<grid, block, lds_bytes, st>>>(a);
+        if (big)
+            k_window_plan<16, 2><<<grid, block, lds_bytes, st>>>(a);
+        else
+            k_window_plan<8, 2><<<grid, block, lds_bytes, st>>>(a);
+    } else if (big) {
+        k_window_plan<16, 0><<<grid, block, lds_bytes, st>>>(a);
+    } else {
+        k_window_plan<8, 0><<<grid, block, lds_bytes, st>>>(a);
+    }
     return mssvt_launch_status();
 }
 
