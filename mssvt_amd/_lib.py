@@ -51,6 +51,12 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def ptr_fast(t):
+    """`ptr` without the device / contiguity checks: for buffers the fused path allocated itself and for module
+    parameters (the frame's front is launch bound: ~200 pointer conversions per frame)."""
+    return _NULL if t is None else ctypes.c_void_p(t.data_ptr())
+
+
 def stream():
     """Raw handle of torch's current HIP stream (the fast C accessor: torch.cuda.current_stream()
     builds a Python Stream object, ~8 us per call, 20+ calls per forward)."""

@@ -28,6 +28,7 @@ from . import _lib, mssvt_ops
 from .mssvt_utils import batch_counts
 
 _i, _f = ctypes.c_int, ctypes.c_float
+_P = _lib.ptr_fast  # every tensor handed over here is a contiguous device buffer (allocated below, or a parameter)
 
 
 def _f3(xs):
@@ -152,11 +153,11 @@ def setup_input_level(blocks, sp_kwargs):
     shapes = [[[X, Y, Z][i] // b.win1_size[i] for i in range(3)] for b in todo]
     ints = lambda rows: (ctypes.c_int * max(3 * k, 1))(*[int(v) for r in rows for v in r])  # noqa: E731
     ptrs = lambda ts: (ctypes.c_void_p * max(k, 1))(*[t.data_ptr() for t in ts])  # noqa: E731
-    _lib.call("mssvt_level_setup", _i(n), _i(B), _i(X), _i(Y), _i(Z), _i(H), _lib.ptr(indices), _lib.ptr(zero),
-              ctypes.c_longlong(zero.numel() * 4), _lib.ptr(cnt), _lib.ptr(table), _lib.ptr(map_ws), _lib.ptr(occ),
+    _lib.call("mssvt_level_setup", _i(n), _i(B), _i(X), _i(Y), _i(Z), _i(H), _P(indices), _P(zero),
+              ctypes.c_longlong(zero.numel() * 4), _P(cnt), _P(table), _P(map_ws), _P(occ),
               _i(k), ints(shapes), ints([b.win1_size for b in todo]),
               (ctypes.c_int * max(k, 1))(*[int(b.max_num_wins) for b in todo]), ptrs(wins), ptrs(tables),
-              ptrs(scratch), ptrs([vcounts[i] for i in range(k)]), _lib.ptr(part_ws), ctypes.c_longlong(stride),
+              ptrs(scratch), ptrs([vcounts[i] for i in range(k)]), _P(part_ws), ctypes.c_longlong(stride),
               _lib.stream())
     sp = SparseTensor(map_table=table, **sp_kwargs)
     sp.v_bs_cnt, sp._cnt_of, sp.map_status = cnt, sp.indices, map_ws[0:1]
@@ -173,8 +174,8 @@ def occupancy_columns(sp, st):
         occ = None
         if OCC_COLUMNS and Z <= 64:
             occ = torch.empty(sp.batch_size * X * Y, dtype=torch.int64, device=sp.indices.device)
-            _lib.call("mssvt_occupancy_columns", _lib.ptr(sp.indices), _i(sp.indices.shape[0]), _i(sp.batch_size),
-                      _i(X), _i(Y), _i(Z), _lib.ptr(occ), _lib.stream())
+            _lib.call("mssvt_occupancy_columns", _P(sp.indices), _i(sp.indices.shape[0]), _i(sp.batch_size),
+                      _i(X), _i(Y), _i(Z), _P(occ), _lib.stream())
         st["occ"] = occ
     return st["occ"]
 
@@ -231,15 +232,15 @@ def two_scale_plan(block, sp):
     _lib.call("mssvt_window_plan_two", *[_i(int(v)) for v in sp.spatial_shape],
               *[_i(int(v)) for v in block.win1_size], _i(n_o), _i(n_e), _i(n1), _i(n2), _i(H), _i(B),
               _i(t['odd'].shape[0]), _i(t['even'].shape[0]), _i(t['win1'].shape[0]), _i(t['win2'].shape[0]),
-              _lib.ptr(t['odd']), _lib.ptr(t['even']), _lib.ptr(t['win1']), _lib.ptr(t['win2']), _i(K),
-              _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(cap), _lib.ptr(sp.map_table),
-              _lib.ptr(st["v_bs_cnt"]), _lib.ptr(p.ind_odd), _lib.ptr(p.ind_even), _lib.ptr(p.ind_win1),
-              _lib.ptr(p.k_ind[0]), _lib.ptr(p.k_ind[1]), _lib.ptr(p.k_mask[0]), _lib.ptr(p.k_mask[1]),
-              _lib.ptr(p.win_vstart), _lib.ptr(p.owner_win1), _lib.ptr(p.owner_odd), _lib.ptr(p.owner_even),
-              _lib.ptr(sp.indices), _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m),
-              _lib.ptr(p.qmeta_odd), _lib.ptr(p.qmeta_even), _lib.ptr(p.qmeta_win1), _lib.ptr(p.kmeta[0]),
-              _lib.ptr(p.kmeta[1]), _lib.ptr(p.wcentre), _lib.ptr(p.nq_valid), _lib.ptr(occupancy_columns(sp, st)),
-              fp4, _lib.ptr(packed), _lib.stream())
+              _P(t['odd']), _P(t['even']), _P(t['win1']), _P(t['win2']), _i(K),
+              _P(p.win_ind), _P(p.num_wins), _i(cap), _P(sp.map_table),
+              _P(st["v_bs_cnt"]), _P(p.ind_odd), _P(p.ind_even), _P(p.ind_win1),
+              _P(p.k_ind[0]), _P(p.k_ind[1]), _P(p.k_mask[0]), _P(p.k_mask[1]),
+              _P(p.win_vstart), _P(p.owner_win1), _P(p.owner_odd), _P(p.owner_even),
+              _P(sp.indices), _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m),
+              _P(p.qmeta_odd), _P(p.qmeta_even), _P(p.qmeta_win1), _P(p.kmeta[0]),
+              _P(p.kmeta[1]), _P(p.wcentre), _P(p.nq_valid), _P(occupancy_columns(sp, st)),
+              fp4, _P(packed), _lib.stream())
     st["plans"][key] = p
     return p
 
@@ -319,9 +320,9 @@ def _work_order(block, p, nq, num_voxels):
                  row_meta=torch.empty((cap_rows, 4), dtype=torch.float32, device=dev),
                  row_src=torch.empty((cap_rows, 2), dtype=torch.int32, device=dev),
                  n_rows=torch.empty(1, dtype=torch.int32, device=dev), row_cap=cap_rows)
-        _lib.call("mssvt_plan_order", _lib.ptr(p.num_wins), _lib.ptr(o["nq_valid"]), _i(nq),
-                  _lib.ptr(_qmeta(block, p)), _i(p.cap), _i(cap_rows), _lib.ptr(o["perm"]), _lib.ptr(o["n_act"]),
-                  _lib.ptr(o["q_off"]), _lib.ptr(o["row_meta"]), _lib.ptr(o["row_src"]), _lib.ptr(o["n_rows"]),
+        _lib.call("mssvt_plan_order", _P(p.num_wins), _P(o["nq_valid"]), _i(nq),
+                  _P(_qmeta(block, p)), _i(p.cap), _i(cap_rows), _P(o["perm"]), _P(o["n_act"]),
+                  _P(o["q_off"]), _P(o["row_meta"]), _P(o["row_src"]), _P(o["n_rows"]),
                   _lib.stream())
         p.orders[pat] = o
     return p.orders[pat]
@@ -348,34 +349,40 @@ def attn_uses_bf16(block):
             and all((cg, ma.per_head_dim) in ATTN_BF16_SHAPES for cg in ma.scale_dims))
 
 
+def _attn_refs(block, groups):
+    """Constant pieces of the attention call of `block` (channel offsets, widths, head counts as ctypes arrays; the
+    parameter tensors of the chosen head groups), built once: indexing nn.ModuleLists and nn.Module attributes per
+    frame costs more host time than the launch itself."""
+    ma = block.ms_attn
+    gs = tuple(range(len(ma.num_heads))) if groups is None else tuple(groups)
+    cache = block.__dict__.setdefault("_attn_ref_cache", {})
+    r = cache.get(gs)
+    if r is None or r["Wq"][0] is not ma.to_qs[gs[0]].weight or r["Wp"] is not block.pos_proj[0].weight:
+        ia = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])  # noqa: E731
+        r = cache[gs] = dict(
+            gs=gs, n=len(gs), c0=ia([sum(ma.scale_dims[:g]) for g in gs]), cg=ia([ma.scale_dims[g] for g in gs]),
+            heads=ia([ma.num_heads[g] for g in gs]), hd=int(ma.per_head_dim), scale=float(ma.scale),
+            Wq=[ma.to_qs[g].weight for g in gs], bq=[ma.to_qs[g].bias for g in gs],
+            Wkv=[ma.to_kvs[g].weight for g in gs], bkv=[ma.to_kvs[g].bias for g in gs],
+            Wo=[ma.projs[g].weight for g in gs], bo=[ma.projs[g].bias for g in gs],
+            Wp=block.pos_proj[0].weight, bp=block.pos_proj[0].bias, K=int(block.key_num_sample),
+            bf16_ok=all((cg, ma.per_head_dim) in ATTN_BF16_SHAPES for cg in ma.scale_dims) and block.key_num_sample <= 64)
+    return r
+
+
 def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
     """mssvt_block_attention (or its bf16-operand form) for the given head groups (default: all)."""
-    ma = block.ms_attn
-    gs = list(range(len(ma.num_heads))) if groups is None else list(groups)
-    c0s = [sum(ma.scale_dims[:g]) for g in gs]
-    ia = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])  # noqa: E731
-    pa = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
-    if attn_uses_bf16(block):
-        _lib.call("mssvt_block_attention_bf16", _i(C), _i(len(gs)), ia(c0s), ia([ma.scale_dims[g] for g in gs]),
-                  ia([ma.num_heads[g] for g in gs]), _i(ma.per_head_dim), _f(ma.scale), _i(nq),
-                  _i(block.key_num_sample), _lib.ptr(xhat), _lib.ptr(od["n_act"]), _lib.ptr(od["perm"]),
-                  _lib.ptr(od["q_off"]), _lib.ptr(od["nq_valid"]), _lib.ptr(od["n_rows"]), _i(od["row_cap"]),
-                  _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]), pa([p.kmeta[g] for g in gs]),
-                  _lib.ptr(p.wcentre), pa([ma.to_qs[g].weight for g in gs]), pa([ma.to_qs[g].bias for g in gs]),
-                  pa([ma.to_kvs[g].weight for g in gs]), pa([ma.to_kvs[g].bias for g in gs]),
-                  pa([ma.projs[g].weight for g in gs]), pa([ma.projs[g].bias for g in gs]),
-                  _lib.ptr(block.pos_proj[0].weight), _lib.ptr(block.pos_proj[0].bias), _lib.ptr(attn), _lib.stream())
-        return
-    _lib.call("mssvt_block_attention", _i(C), _i(len(gs)), ia(c0s), ia([ma.scale_dims[g] for g in gs]),
-              ia([ma.num_heads[g] for g in gs]), _i(ma.per_head_dim), _f(ma.scale), _i(nq), _i(block.key_num_sample),
-              _lib.ptr(xhat), _lib.ptr(od["n_act"]), _lib.ptr(od["perm"]), _lib.ptr(od["q_off"]),
-              _lib.ptr(od["nq_valid"]), _lib.ptr(od["n_rows"]), _i(od["row_cap"]), _lib.ptr(od["row_meta"]),
-              _lib.ptr(od["row_src"]), pa([p.kmeta[g] for g in gs]), _lib.ptr(p.wcentre),
-              pa([ma.to_qs[g].weight for g in gs]), pa([ma.to_qs[g].bias for g in gs]),
-              pa([ma.to_kvs[g].weight for g in gs]), pa([ma.to_kvs[g].bias for g in gs]),
-              pa([ma.projs[g].weight for g in gs]), pa([ma.projs[g].bias for g in gs]),
-              _lib.ptr(block.pos_proj[0].weight), _lib.ptr(block.pos_proj[0].bias), _lib.ptr(qbuf), _lib.ptr(attn),
-              _lib.stream())
+    r = _attn_refs(block, groups)
+    n = r["n"]
+    pa = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+    head = (_i(C), _i(n), r["c0"], r["cg"], r["heads"], _i(r["hd"]), _f(r["scale"]), _i(nq), _i(r["K"]), _P(xhat),
+            _P(od["n_act"]), _P(od["perm"]), _P(od["q_off"]), _P(od["nq_valid"]), _P(od["n_rows"]), _i(od["row_cap"]),
+            _P(od["row_meta"]), _P(od["row_src"]), pa([p.kmeta[g] for g in r["gs"]]), _P(p.wcentre), pa(r["Wq"]),
+            pa(r["bq"]), pa(r["Wkv"]), pa(r["bkv"]), pa(r["Wo"]), pa(r["bo"]), _P(r["Wp"]), _P(r["bp"]))
+    if getattr(block, "attn_dtype", "f32") == "bf16" and r["bf16_ok"]:
+        _lib.call("mssvt_block_attention_bf16", *head, _P(attn), _lib.stream())
+    else:
+        _lib.call("mssvt_block_attention", *head, _P(qbuf), _P(attn), _lib.stream())
 
 
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
@@ -385,11 +392,23 @@ FFN_TIMER = None  # bench.py sets this to a list to time k_ffn_up live (see _ffn
 OCC_COLUMNS = os.environ.get("MSSVT_OCC_COLUMNS", "1") != "0"
 
 
+def _ffn_refs(block):
+    """The FFN tail's parameter tensors and sizes of `block`, looked up once (see _attn_refs)."""
+    r = block.__dict__.get("_ffn_ref_cache")
+    if r is None or r["W1"] is not block.linear1.weight:
+        r = block.__dict__["_ffn_ref_cache"] = dict(
+            C=int(block.linear1.in_features), FF=int(block.linear1.out_features), W1=block.linear1.weight,
+            b1=block.linear1.bias, W2=block.linear2.weight, b2=block.linear2.bias, lnw=block.norm2.weight,
+            lnb=block.norm2.bias, eps=float(block.norm2.eps), has_out=hasattr(block, 'out_linear'))
+    return r
+
+
 def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=None, apply_out=True, phases=3):
     """y = x + linear2(relu(linear1(norm2(x)))) (+ out_linear) with x = x_new, or 2*x_in on rows
     no list slot owns.  One fused MFMA kernel when the shape is instantiated; it also emits the
     NEXT block's norm1(y) (sp._xhat) so that LayerNorm never runs as a launch of its own."""
-    C, FF = block.linear1.in_features, block.linear1.out_features
+    fr = _ffn_refs(block)
+    C, FF = fr["C"], fr["FF"]
     if table is not None:
         x_new = x_in  # shapes / dtype template only
     if (C, FF) not in FFN_SHAPES:
@@ -400,28 +419,26 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=No
         n = x_new.shape[0]
         y = torch.empty_like(x_new)
         nxt = getattr(sp, "_next_norm1", None)
-        has_out = hasattr(block, 'out_linear')
+        has_out = fr["has_out"]
         y_norm = None
         if nxt is not None and not has_out and nxt.normalized_shape[0] == C:
             y_norm = torch.empty_like(x_new)
         # two launches with LDS-resident weights; the hidden activations go through this scratch
         split = FFN_SPLIT or n_rows_dev is not None  # a device-side row count needs the two-launch form
         hidden = torch.empty((n, FF), dtype=torch.float32, device=x_new.device) if split else None
-        tail = (_lib.ptr(block.norm2.weight), _lib.ptr(block.norm2.bias), _f(block.norm2.eps),
-                _lib.ptr(block.linear1.weight), _lib.ptr(block.linear1.bias), _lib.ptr(block.linear2.weight),
-                _lib.ptr(block.linear2.bias), _lib.ptr(y),
-                _lib.ptr(nxt.weight if y_norm is not None else None),
-                _lib.ptr(nxt.bias if y_norm is not None else None),
-                _f(nxt.eps if y_norm is not None else 0.0), _lib.ptr(y_norm), _lib.ptr(hidden),
-                _lib.ptr(n_rows_dev), _i(phases), _lib.stream())
+        tail = (_P(fr["lnw"]), _P(fr["lnb"]), _f(fr["eps"]), _P(fr["W1"]), _P(fr["b1"]), _P(fr["W2"]), _P(fr["b2"]), _P(y),
+                _P(nxt.weight if y_norm is not None else None),
+                _P(nxt.bias if y_norm is not None else None),
+                _f(nxt.eps if y_norm is not None else 0.0), _P(y_norm), _P(hidden),
+                _P(n_rows_dev), _i(phases), _lib.stream())
         def launch(tail_):
             if table is not None:
                 (tab_row, tab_w), attn = table
-                _lib.call("mssvt_ffn_fused_interp", _i(n), _i(C), _i(FF), _lib.ptr(x_in), _lib.ptr(tab_row),
-                          _lib.ptr(tab_w), _lib.ptr(attn), *tail_)
+                _lib.call("mssvt_ffn_fused_interp", _i(n), _i(C), _i(FF), _P(x_in), _P(tab_row),
+                          _P(tab_w), _P(attn), *tail_)
             else:
-                _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _lib.ptr(x_new), _lib.ptr(x_in),
-                          _lib.ptr(owner), *tail_)
+                _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _P(x_new), _P(x_in),
+                          _P(owner), *tail_)
 
         if FFN_TIMER is not None and split and phases == 3:
             # bench.py's live roofline: HIP events around k_ffn_up inside the timed steps (two C calls
@@ -435,7 +452,7 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=No
         else:
             launch(tail)
         sp._xhat = (y_norm, nxt, y) if y_norm is not None else None
-    if apply_out and hasattr(block, 'out_linear'):
+    if apply_out and fr["has_out"]:
         y = block.out_linear(y)
     return y
 
@@ -457,8 +474,8 @@ def layer_norm(x, norm):
         return F.layer_norm(x, (C,), norm.weight, norm.bias, norm.eps)
     x = x.contiguous()
     y = torch.empty_like(x)
-    _lib.call("mssvt_layer_norm", _lib.ptr(x), _i(x.shape[0]), _i(C), _lib.ptr(norm.weight), _lib.ptr(norm.bias),
-              _f(norm.eps), _lib.ptr(y), _lib.stream())
+    _lib.call("mssvt_layer_norm", _P(x), _i(x.shape[0]), _i(C), _P(norm.weight), _P(norm.bias),
+              _f(norm.eps), _P(y), _lib.stream())
     return y
 
 
@@ -496,9 +513,9 @@ def block_forward(block, sp):
         # rows no list slot owns are never written here: the FFN reads them as 2 * x_in
         # (features + shortcut, ref quirk R12) through the owner array
         new = torch.empty_like(x_in)
-        _lib.call("mssvt_block_interp_scatter", _i(C), _i(nq), _i(n_upd), _i(interp), _lib.ptr(attn),
-                  _lib.ptr(x_in), _lib.ptr(new), _lib.ptr(sp.indices), _lib.ptr(p.win_ind), _lib.ptr(p.num_wins),
-                  _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind), _lib.ptr(upd_ind), _lib.ptr(owner), vs3,
+        _lib.call("mssvt_block_interp_scatter", _i(C), _i(nq), _i(n_upd), _i(interp), _P(attn),
+                  _P(x_in), _P(new), _P(sp.indices), _P(p.win_ind), _P(p.num_wins),
+                  _i(p.cap), _P(p.win_vstart), _P(q_ind), _P(upd_ind), _P(owner), vs3,
                   mn3, _lib.stream())
         sp.features = _ffn_tail(block, sp, new, x_in, owner)
     sp.gather_dict = None
@@ -534,7 +551,7 @@ def prepare_group(blocks, sp, p):
                              row_meta=torch.empty((cap_rows, 4), dtype=torch.float32, device=dev),
                              row_src=torch.empty((cap_rows, 2), dtype=torch.int32, device=dev),
                              n_rows=torch.empty(1, dtype=torch.int32, device=dev), row_cap=cap_rows, nq=nq))
-        _lib.call("mssvt_plan_order_multi", _i(len(todo)), _lib.ptr(p.num_wins), pa([o["nq_valid"] for o in outs]),
+        _lib.call("mssvt_plan_order_multi", _i(len(todo)), _P(p.num_wins), pa([o["nq_valid"] for o in outs]),
                   ia([o["nq"] for o in outs]), pa([_qmeta(b, p) for b in todo]), _i(p.cap), _i(cap_rows),
                   pa([o["perm"] for o in outs]), pa([o["n_act"] for o in outs]), pa([o["q_off"] for o in outs]),
                   pa([o["row_meta"] for o in outs]), pa([o["row_src"] for o in outs]),
@@ -563,8 +580,8 @@ def prepare_group(blocks, sp, p):
             upd_ind, n_upd, owner = (p.ind_win1, b.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
             nqs.append(nq); nus.append(n_upd); its.append(interp); qis.append(q_ind); uis.append(upd_ind)
             ows.append(owner); zrs.append(_attn_zero_row(p, nq, b.linear1.in_features, dev))
-        _lib.call("mssvt_block_interp_table_multi", _i(len(todo)), ia(nqs), ia(nus), ia(its), _lib.ptr(sp.indices),
-                  _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), pa(qis), pa(uis),
+        _lib.call("mssvt_block_interp_table_multi", _i(len(todo)), ia(nqs), ia(nus), ia(its), _P(sp.indices),
+                  _P(p.win_ind), _P(p.num_wins), _i(p.cap), _P(p.win_vstart), pa(qis), pa(uis),
                   pa(ows), vs3, mn3, ia(zrs), pa([rows[i] for i in range(len(todo))]),
                   pa([ws[i] for i in range(len(todo))]), _lib.stream())
         for i, (b, key) in enumerate(todo):
@@ -584,11 +601,11 @@ def _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, m
         N = sp.indices.shape[0]
         tab_row = mssvt_ops.full_neg1((max(N, 1), 4), dev)
         tab_w = torch.empty((max(N, 1), 4), dtype=torch.float32, device=dev)  # written with tab_row
-        _lib.call("mssvt_block_interp_table", _i(nq), _i(n_upd), _i(interp), _lib.ptr(sp.indices),
-                  _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(p.cap), _lib.ptr(p.win_vstart), _lib.ptr(q_ind),
-                  _lib.ptr(upd_ind), _lib.ptr(owner), vs3, mn3,
-                  _i(_attn_zero_row(p, nq, block.linear1.in_features, dev)), _lib.ptr(tab_row),
-                  _lib.ptr(tab_w), _lib.stream())
+        _lib.call("mssvt_block_interp_table", _i(nq), _i(n_upd), _i(interp), _P(sp.indices),
+                  _P(p.win_ind), _P(p.num_wins), _i(p.cap), _P(p.win_vstart), _P(q_ind),
+                  _P(upd_ind), _P(owner), vs3, mn3,
+                  _i(_attn_zero_row(p, nq, block.linear1.in_features, dev)), _P(tab_row),
+                  _P(tab_w), _lib.stream())
         tabs[key] = (tab_row, tab_w)
     return tabs[key]
 
@@ -640,12 +657,12 @@ def one_scale_plan(block, sp, sync=True):
     p.num_rows = ws[2:3]
     t = block._tables_on(dev)
     _lib.call("mssvt_window_plan_one", *[_i(int(v)) for v in sp.spatial_shape],
-              *[_i(int(v)) for v in block.win1_size], _i(ns), _i(H), _i(t['win1'].shape[0]), _lib.ptr(t['win1']),
-              _lib.ptr(p.win_ind), _lib.ptr(p.num_wins), _i(cap), _lib.ptr(sp.map_table),
-              _lib.ptr(st["v_bs_cnt"]), _i(p.with_pad), _i(p.disjoint), _i(N), _lib.ptr(p.k_ind),
-              _lib.ptr(p.win_vstart),
-              _lib.ptr(p.win_cnt), _lib.ptr(p.pair_base), _lib.ptr(p.pair_win), _lib.ptr(p.pair_vox),
-              _lib.ptr(p.num_rows), _lib.stream())
+              *[_i(int(v)) for v in block.win1_size], _i(ns), _i(H), _i(t['win1'].shape[0]), _P(t['win1']),
+              _P(p.win_ind), _P(p.num_wins), _i(cap), _P(sp.map_table),
+              _P(st["v_bs_cnt"]), _i(p.with_pad), _i(p.disjoint), _i(N), _P(p.k_ind),
+              _P(p.win_vstart),
+              _P(p.win_cnt), _P(p.pair_base), _P(p.pair_win), _P(p.pair_vox),
+              _P(p.num_rows), _lib.stream())
     p.ws, p.N = ws, N
     if not sync:
         # the window count is final here, ~250 us of GPU work before the block ends: copy it to pinned
@@ -733,14 +750,14 @@ def _compress_forward_fused(block, sp, xhat, x_in):
     f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
     qp, ktok, score, vp, new = f32(cap_w, C), f32(max(N, 1), C), f32(max(N, 1), C // ma.per_head_dim), \
         f32(max(N, 1), C), f32(cap_w, C)
-    _lib.call("mssvt_compress_fused", _i(C), _i(ma.per_head_dim), _f(ma.scale), _i(ns), _i(N), _lib.ptr(p.num_wins),
-              _i(cap_w), _lib.ptr(p.win_ind), _lib.ptr(sp.indices), _lib.ptr(p.k_ind), _lib.ptr(p.win_vstart),
-              _lib.ptr(p.win_cnt), _lib.ptr(p.pair_win), vs3, mn3, ws3, _lib.ptr(xhat),
-              _lib.ptr(block.pos_proj[0].weight), _lib.ptr(block.pos_proj[0].bias),
-              _lib.ptr(block.pos_proj[2].weight), _lib.ptr(block.pos_proj[2].bias),
-              _lib.ptr(ma.to_qs[0].weight), _lib.ptr(ma.to_qs[0].bias), _lib.ptr(ma.to_kvs[0].weight),
-              _lib.ptr(ma.to_kvs[0].bias), _lib.ptr(ma.projs[0].weight), _lib.ptr(ma.projs[0].bias),
-              _lib.ptr(qp), _lib.ptr(ktok), _lib.ptr(score), _lib.ptr(vp), _lib.ptr(new), _lib.stream())
+    _lib.call("mssvt_compress_fused", _i(C), _i(ma.per_head_dim), _f(ma.scale), _i(ns), _i(N), _P(p.num_wins),
+              _i(cap_w), _P(p.win_ind), _P(sp.indices), _P(p.k_ind), _P(p.win_vstart),
+              _P(p.win_cnt), _P(p.pair_win), vs3, mn3, ws3, _P(xhat),
+              _P(block.pos_proj[0].weight), _P(block.pos_proj[0].bias),
+              _P(block.pos_proj[2].weight), _P(block.pos_proj[2].bias),
+              _P(ma.to_qs[0].weight), _P(ma.to_qs[0].bias), _P(ma.to_kvs[0].weight),
+              _P(ma.to_kvs[0].bias), _P(ma.projs[0].weight), _P(ma.projs[0].bias),
+              _P(qp), _P(ktok), _P(score), _P(vp), _P(new), _lib.stream())
     y = _ffn_tail(block, sp, new, n_rows_dev=p.num_wins, apply_out=False)  # no residual to the block input (ref :383-385)
     p.host_ev.synchronize()  # the forward's single host wait: the output shape (copied out long ago)
     host = p.host_ws.tolist()
@@ -781,15 +798,15 @@ def compress_forward(block, sp):
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
     # key tokens, one row per valid (window, slot) pair: feature + 2-layer positional MLP
     rows = torch.empty((max(R, 1), C), dtype=torch.float32, device=dev)
-    _lib.call("mssvt_compress_pos1", _i(C), _lib.ptr(p.num_rows), _i(R), _lib.ptr(p.pair_win),
-              _lib.ptr(p.pair_vox), _lib.ptr(sp.indices), _lib.ptr(p.win_ind), vs3, mn3, ws3,
-              _lib.ptr(block.pos_proj[0].weight), _lib.ptr(block.pos_proj[0].bias), _lib.ptr(rows), _lib.stream())
+    _lib.call("mssvt_compress_pos1", _i(C), _P(p.num_rows), _i(R), _P(p.pair_win),
+              _P(p.pair_vox), _P(sp.indices), _P(p.win_ind), vs3, mn3, ws3,
+              _P(block.pos_proj[0].weight), _P(block.pos_proj[0].bias), _P(rows), _lib.stream())
     k_tok = F.relu(F.linear(rows, block.pos_proj[2].weight.view(C, C), block.pos_proj[2].bias))
-    _lib.call("mssvt_compress_add_features", _i(C), _lib.ptr(p.num_rows), _i(R), _lib.ptr(p.pair_vox),
-              _lib.ptr(xhat), _lib.ptr(k_tok), _lib.stream())
+    _lib.call("mssvt_compress_add_features", _i(C), _P(p.num_rows), _i(R), _P(p.pair_vox),
+              _P(xhat), _P(k_tok), _lib.stream())
     q_tok = torch.empty((max(nw, 1), C), dtype=torch.float32, device=dev)
-    _lib.call("mssvt_compress_pool", _i(C), _i(ns), _lib.ptr(p.num_wins), _i(nw), _lib.ptr(p.k_ind),
-              _lib.ptr(p.win_vstart), _lib.ptr(p.win_cnt), _lib.ptr(xhat), _lib.ptr(q_tok), _lib.stream())
+    _lib.call("mssvt_compress_pool", _i(C), _i(ns), _P(p.num_wins), _i(nw), _P(p.k_ind),
+              _P(p.win_vstart), _P(p.win_cnt), _P(xhat), _P(q_tok), _lib.stream())
     G = ma.num_head_groups
     nk = ns // G
     pre = torch.empty_like(q_tok)
@@ -801,9 +818,9 @@ def compress_forward(block, sp):
         qp[:, c0:c0 + cg] = ma.to_qs[g](q_tok[:, c0:c0 + cg])
         kv = ma.to_kvs[g](k_tok[:, c0:c0 + cg]).contiguous()  # (R, 2*cg) = [K | V]
         _lib.call("mssvt_compress_attention_group", _i(C), _i(c0), _i(cg), _i(ma.per_head_dim), _f(ma.scale),
-                  _i(nk), _i(g), _i(p.with_pad), _i(ns), _i(p.N), _lib.ptr(p.num_wins), _i(nw),
-                  _lib.ptr(p.win_cnt), _lib.ptr(p.pair_base), _lib.ptr(p.k_ind), _lib.ptr(p.win_vstart),
-                  _lib.ptr(qp), _lib.ptr(kv), _lib.ptr(pre), _lib.stream())
+                  _i(nk), _i(g), _i(p.with_pad), _i(ns), _i(p.N), _P(p.num_wins), _i(nw),
+                  _P(p.win_cnt), _P(p.pair_base), _P(p.k_ind), _P(p.win_vstart),
+                  _P(qp), _P(kv), _P(pre), _lib.stream())
         c0 += cg
     c0 = 0
     for g in range(G):

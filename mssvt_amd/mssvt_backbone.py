@@ -140,8 +140,12 @@ class MixedScaleSparseTransformerBlock(nn.Module):
         return t
 
     def plan_key(self):
-        return (tuple(map(tuple, self.window_size)), self.max_num_odd, self.max_num_even,
-                self.max_num_win1, self.max_num_win2, self.key_num_sample, self._table_sig)
+        k = self.__dict__.get("_plan_key_cache")
+        if k is None or k[-1] != self._table_sig or k[3] != self.max_num_win1 or k[5] != self.key_num_sample:
+            k = self.__dict__["_plan_key_cache"] = (
+                tuple(map(tuple, self.window_size)), self.max_num_odd, self.max_num_even, self.max_num_win1,
+                self.max_num_win2, self.key_num_sample, self._table_sig)
+        return k
 
     # -- helpers shared with the reference's API ------------------------------
     @torch.no_grad()
@@ -367,6 +371,23 @@ class MixedScaleSparseTransformer(nn.Module):
         self.num_point_features = model_cfg.get('NUM_OUTPUT_FEATURES') if hasattr(model_cfg, 'get') \
             else model_cfg.NUM_OUTPUT_FEATURES
 
+    def _block_schedule(self):
+        """Per block: (block, next block's norm1, the Blocks from here on, the CompressBlock that ends the level) as plain
+        Python lists built once -- slicing an nn.ModuleList per block and frame builds new ModuleLists (~0.2 ms of host time
+        per frame, the frame's front is launch bound)."""
+        sched = getattr(self, "_sched", None)
+        if sched is None or sched[0] != len(self.backbone):
+            blocks = list(self.backbone)
+            rows = []
+            for i, blk in enumerate(blocks):
+                nxt_norm = blocks[i + 1].norm1 if i + 1 < len(blocks) else None
+                group = [b for b in blocks[i:] if isinstance(b, MixedScaleSparseTransformerBlock)
+                         and not isinstance(b, MixedScaleSparseTransformerCompressBlock)]
+                nxt_cmp = next((b for b in blocks[i:] if isinstance(b, MixedScaleSparseTransformerCompressBlock)), None)
+                rows.append((blk, nxt_norm, group, nxt_cmp))
+            sched = self._sched = (len(blocks), rows)
+        return sched[1]
+
     def set_impl(self, impl):
         assert impl in ("fused", "ops")
         for blk in self.backbone:
@@ -400,14 +421,13 @@ class MixedScaleSparseTransformer(nn.Module):
                 sp = fused.setup_input_level(self.backbone, kw)
             if sp is None:
                 sp = SparseTensor(map_table=None, **kw)
-            for i, blk in enumerate(self.backbone):
+            for i, (blk, nxt_norm, group, nxt_cmp) in enumerate(self._block_schedule()):
                 # lets a fused FFN epilogue also emit the next block's norm1 (mssvt_amd/fused.py)
-                sp._next_norm1 = self.backbone[i + 1].norm1 if i + 1 < len(self.backbone) else None
+                sp._next_norm1 = nxt_norm
                 # the Blocks from here on (fused.prepare_group orders / tabulates all that share a plan at once)
-                sp._plan_group = [b for b in self.backbone[i:] if isinstance(b, MixedScaleSparseTransformerBlock)]
+                sp._plan_group = group
                 # the CompressBlock that ends this resolution level: its window partition rides along with the Blocks'
-                sp._next_compress = next((b for b in self.backbone[i:]
-                                          if isinstance(b, MixedScaleSparseTransformerCompressBlock)), None)
+                sp._next_compress = nxt_cmp
                 sp = blk(sp, block_idx=i)
             if getattr(sp, "_level", None) is not None and arena is not None:
                 from . import fused  # a level that no fused CompressBlock closed: read its overflow words now
