@@ -478,6 +478,28 @@ long long mssvt_nms_workspace_bytes(int num_boxes);
 int mssvt_nms_bev(int num_boxes, const float *boxes_sorted, float thresh, void *workspace, int *keep,
                   int *num_keep_dev, void *stream);
 
+/* Weight / bias gradient of an nn.Linear over compact rows (training path; what autograd's library GEMM computes for
+ * the reference's to_qs / to_kvs / projs / linear1 / linear2, ref mssvt_utils.py:80-83, mssvt_backbone.py:25-27):
+ *   dW (Cout,Cin) = dY^T X,  db (Cout) = column sums of dY (db may be NULL);  X (M,Cin), dY (M,Cout) f32 row-major.
+ * Deterministic split over the M rows on the fp32 matrix cores: per-slice partial slabs in `workspace`
+ * (mssvt_linear_wgrad_workspace_floats(M,Cin,Cout) floats), added in slice order.  Cin, Cout multiples of 4,
+ * ceil(Cout/16) * (ceil(Cin/16) + 1) <= 160 (256 x 128, 128 x 256 ...); MSSVT_E_TOOLARGE otherwise.           */
+long long mssvt_linear_wgrad_workspace_floats(int M, int Cin, int Cout);
+int mssvt_linear_wgrad(int M, int Cin, int Cout, const float *X, const float *dY, float *dW, float *db,
+                       float *workspace, void *stream);
+
+/* Window attention on compact rows, forward and backward (training path; the softmax(QK^T)V of ref
+ * mssvt_utils.py:131-149 for one head group, without the padded (windows, slots) layout and the -100 mask):
+ * window w owns query rows [q_off[w], +q_cnt[w]) of q (R,cg) (already scaled) and key rows [k_off[w], +k_cnt[w]) of
+ * kv (Kn,2cg) = [K|V]; ranges of different windows are disjoint.  fwd: O (R,cg), lse (R,heads) = log-sum-exp of the
+ * scores.  bwd: dq (R,cg), dkv (Kn,2cg) from dO; every row is written by exactly one wave in a fixed order (no
+ * atomics, bit-identical run to run).  cg = heads * hd <= 128, hd in {4,8,16,32,64}; windows without keys give O = 0. */
+int mssvt_pair_attention_fwd(int nw, int cg, int heads, int hd, const int *q_off, const int *q_cnt, const int *k_off,
+                             const int *k_cnt, const float *q, const float *kv, float *O, float *lse, void *stream);
+int mssvt_pair_attention_bwd(int nw, int cg, int heads, int hd, const int *q_off, const int *q_cnt, const int *k_off,
+                             const int *k_cnt, const float *q, const float *kv, const float *O, const float *lse,
+                             const float *dO, float *dq, float *dkv, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

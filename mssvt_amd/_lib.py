@@ -30,6 +30,7 @@ def lib():
         _lib.mssvt_hip_status_string.restype = ctypes.c_char_p
         _lib.mssvt_hash_workspace_ints.restype = ctypes.c_longlong
         _lib.mssvt_nms_workspace_bytes.restype = ctypes.c_longlong
+        _lib.mssvt_linear_wgrad_workspace_floats.restype = ctypes.c_longlong
     return _lib
 
 

@@ -155,36 +155,107 @@ def repeat_rows(x, lengths, total):
     return _RepeatRows.apply(x, lengths, total)
 
 
-class _SegAttention(torch.autograd.Function):
-    """Softmax of the scores S (P, H) over the contiguous segments `lengths` (the keys of one query), then
-    O[r] = sum_p prob[p] V[p] -> (R, H, hd).  Backward written out with segmented reductions only (fixed order)."""
+class _PairAttention(torch.autograd.Function):
+    """softmax(q k^T) v of every window's queries against that window's keys (csrc/pair_attn.hip): one launch forward,
+    one backward, nothing of size (pairs, ...) in memory."""
 
     @staticmethod
-    def forward(ctx, S, V, lengths):
-        P = S.shape[0]
-        rep = lambda t: torch.repeat_interleave(t, lengths, dim=0, output_size=P)  # noqa: E731
-        m = torch.segment_reduce(S, "max", lengths=lengths, unsafe=True)
-        e = torch.exp(S - rep(m))
-        prob = e / rep(torch.segment_reduce(e, "sum", lengths=lengths, unsafe=True))
-        ctx.save_for_backward(prob, V)
-        ctx.lengths = lengths
-        return torch.segment_reduce(prob.unsqueeze(-1) * V, "sum", lengths=lengths, unsafe=True)
+    def forward(ctx, q, kv, wins, heads, hd):
+        q, kv = q.contiguous(), kv.contiguous()
+        R, cg = q.shape
+        O = torch.empty_like(q)
+        lse = torch.empty((R, heads), dtype=torch.float32, device=q.device)
+        nw = wins["q_off"].numel()
+        if R > 0:
+            _lib.call("mssvt_pair_attention_fwd", _i(nw), _i(cg), _i(heads), _i(hd), _lib.ptr(wins["q_off"]),
+                      _lib.ptr(wins["q_cnt"]), _lib.ptr(wins["k_off"]), _lib.ptr(wins["k_cnt"]), _lib.ptr(q), _lib.ptr(kv),
+                      _lib.ptr(O), _lib.ptr(lse), _lib.stream())
+        ctx.save_for_backward(q, kv, O, lse)
+        ctx.wins, ctx.shape = wins, (nw, cg, heads, hd)
+        return O
 
     @staticmethod
     def backward(ctx, dO):
-        prob, V = ctx.saved_tensors
-        lengths = ctx.lengths
-        P = prob.shape[0]
-        rep = lambda t: torch.repeat_interleave(t, lengths, dim=0, output_size=P)  # noqa: E731
-        dOp = rep(dO.contiguous())  # (P, H, hd)
-        dV = prob.unsqueeze(-1) * dOp
-        dp = (dOp * V).sum(-1)  # (P, H)
-        dS = prob * (dp - rep(torch.segment_reduce(prob * dp, "sum", lengths=lengths, unsafe=True)))
-        return dS, dV, None
+        q, kv, O, lse = ctx.saved_tensors
+        nw, cg, heads, hd = ctx.shape
+        wins = ctx.wins
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        if kv.shape[0] > 0 and nw > 0:
+            _lib.call("mssvt_pair_attention_bwd", _i(nw), _i(cg), _i(heads), _i(hd), _lib.ptr(wins["q_off"]),
+                      _lib.ptr(wins["q_cnt"]), _lib.ptr(wins["k_off"]), _lib.ptr(wins["k_cnt"]), _lib.ptr(q), _lib.ptr(kv),
+                      _lib.ptr(O), _lib.ptr(lse), _lib.ptr(dO.contiguous()), _lib.ptr(dq) if q.shape[0] else None,
+                      _lib.ptr(dkv), _lib.stream())
+        else:
+            dq.zero_()
+        return dq, dkv, None, None, None
 
 
-def _seg_softmax_weighted_sum(S, V, lengths):
-    return _SegAttention.apply(S.contiguous(), V.contiguous(), lengths)
+def pair_attention(q, kv, wins, heads, hd):
+    """q (R, cg) scaled queries, kv (Kn, 2 cg) = [K | V]; `wins` = int32 q_off / q_cnt / k_off / k_cnt per window
+    (every key row belongs to exactly one window).  Returns O (R, cg)."""
+    return _PairAttention.apply(q, kv, wins, heads, hd)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# nn.Linear with a deterministic split-K weight gradient (csrc/linear_wgrad.hip)
+# ---------------------------------------------------------------------------------------------------------
+
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(dev, M, cin, cout):
+    need = int(_lib.lib().mssvt_linear_wgrad_workspace_floats(_i(M), _i(cin), _i(cout)))
+    ws = _wgrad_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _wgrad_ws[dev] = torch.empty((need,), dtype=torch.float32, device=dev)
+    return ws
+
+
+def wgrad_supported(cin, cout):
+    return cin % 4 == 0 and cout % 4 == 0 and ((cout + 15) // 16) * ((cin + 15) // 16 + 1) <= 160
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b over compact rows.  dx is a library GEMM (tall output: fine); dW = dY^T X and db reduce over the
+    ROWS into a <= 256 x 128 result, which library GEMMs do at 7 % of the matrix pipe: one split-K MFMA launch here."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            x = x.contiguous()
+            M, cin, cout = x.shape[0], x.shape[1], w.shape[0]
+            dw = torch.zeros_like(w)
+            db = torch.zeros((cout,), dtype=w.dtype, device=w.device) if ctx.has_bias else None
+            if M > 0:
+                _lib.call("mssvt_linear_wgrad", _i(M), _i(cin), _i(cout), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw),
+                          _lib.ptr(db), _lib.ptr(_wgrad_workspace(x.device, M, cin, cout)), _lib.stream())
+        return dx, dw, db
+
+
+def linear(mod, x, scale_rows=None):
+    """``mod(x)`` for an nn.Linear (or a weight / bias pair) with the deterministic weight gradient."""
+    w, b = (mod.weight, mod.bias) if hasattr(mod, "weight") else mod
+    if w.dim() == 3:
+        w = w.squeeze(-1)  # Conv1d(k = 1)
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and wgrad_supported(w.shape[1], w.shape[0])
+            and torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad))):
+        return F.linear(x, w, b)
+    return _Linear.apply(x, w, b)
+
+
+def ffn(block, x):
+    """block._ffn with the deterministic weight gradients (ref mssvt_backbone.py:341-343)."""
+    return linear(block.linear2, block.dropout1(block.activation(linear(block.linear1, block.norm2(x)))))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -230,15 +301,10 @@ def _block_index_sets(block, sp, p):
         nk = valid.sum(1)  # keys per window
         koff = torch.cumsum(nk, 0) - nk
         k_rows = rows[valid]
-        # (query, key) pairs: every valid query of a window against every valid key of that window
-        plen = nk[s["q_win"]]  # pairs per query
-        P = int(plen.sum().item())
-        pair_q = torch.repeat_interleave(torch.arange(R, device=dev), plen, output_size=P)
-        pstart = torch.cumsum(plen, 0) - plen
-        pair_k = koff[s["q_win"]][pair_q] + (torch.arange(P, device=dev) - pstart[pair_q])
-        s["keys"].append(dict(k_rows=k_rows, k_rel=km[..., :3][valid].contiguous(), k_win=k_win, plen=plen,
-                              k_csr=Csr.gather(k_rows, N), pair_q=pair_q,
-                              pair_csr=Csr.gather(pair_k, k_rows.numel())))
+        wins = dict(q_off=od["q_off"][:nw].contiguous(), q_cnt=od["nq_valid"][:nw].contiguous(),
+                    k_off=koff.int().contiguous(), k_cnt=nk.int().contiguous())
+        s["keys"].append(dict(k_rows=k_rows, k_rel=km[..., :3][valid].contiguous(), k_win=k_win,
+                              k_csr=Csr.gather(k_rows, N), wins=wins))
     # interpolation / scatter table: 3 compact attention rows + weights per voxel (row R = the zero row)
     interp = key[1]
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
@@ -263,11 +329,14 @@ def _block_index_sets(block, sp, p):
 
 
 def _pos6(conv, rel, centre, c0=None, c1=None):
-    """relu(Conv1d(6 -> C, 1)([rel ; centre])) on compact rows (ref pos_proj, mssvt_backbone.py:43-47)."""
+    """relu(Conv1d(6 -> C, 1)([rel ; centre])) on compact rows (ref pos_proj, mssvt_backbone.py:43-47).  The six input
+    columns are padded to eight so that the weight gradient (rows x 6 -> C x 6: the library's slowest shape, 370 us per
+    call) goes through the split-K kernel as well."""
     w, b = conv.weight.squeeze(-1), conv.bias
     if c0 is not None:
         w, b = w[c0:c1], b[c0:c1]
-    return F.relu(F.linear(torch.cat([rel, centre], dim=1), w, b))
+    x = torch.cat([rel, centre, rel.new_zeros((rel.shape[0], 2))], dim=1)
+    return F.relu(linear((F.pad(w, (0, 2)), b), x))
 
 
 def block_forward(block, sp):
@@ -290,13 +359,10 @@ def block_forward(block, sp):
             ks = s["keys"][g]
             tok_k = gather_sum(xhat[:, c0:c1].contiguous(), ks["k_csr"]) + _pos6(
                 block.pos_proj[0], ks["k_rel"], s["centre"][ks["k_win"]], c0, c1)
-            q = ma.to_qs[g](tok_q[:, c0:c1]) * ma.scale  # (R, cg)
-            kv = ma.to_kvs[g](tok_k)  # (Kg, 2 cg) = [K | V]
-            kvp = gather_sum(kv, ks["pair_csr"])  # (P, 2 cg): the keys of every (query, key) pair
-            qp = repeat_rows(q, ks["plen"], kvp.shape[0])
-            S = (qp.view(-1, heads, hd) * kvp[:, :cg].reshape(-1, heads, hd)).sum(-1)  # (P, heads)
-            o = _seg_softmax_weighted_sum(S, kvp[:, cg:].reshape(-1, heads, hd), ks["plen"])  # (R, heads, hd)
-            outs.append(ma.projs[g](o.reshape(R, cg)))
+            q = linear(ma.to_qs[g], tok_q[:, c0:c1].contiguous()) * ma.scale  # (R, cg)
+            kv = linear(ma.to_kvs[g], tok_k)  # (Kg, 2 cg) = [K | V]
+            o = pair_attention(q, kv, ks["wins"], heads, hd)  # (R, cg)
+            outs.append(linear(ma.projs[g], o.reshape(R, cg)))
             c0 = c1
         attn = torch.cat(outs + [x_in.new_zeros((R, C - c0))] if c0 < C else outs, dim=1)
     else:
@@ -305,9 +371,9 @@ def block_forward(block, sp):
     upd = gather_sum(attn_ext, s["interp_csr"])  # (N, C): interpolated / scattered update of every owned voxel
     feats = torch.where(s["owned"].unsqueeze(1), upd, x_in)  # untouched voxels keep x_in (ref :317-338)
     new = block.drop_path(feats) + x_in
-    new = new + block.drop_path(block.dropout1(block._ffn(new)))
+    new = new + block.drop_path(block.dropout1(ffn(block, new)))
     if hasattr(block, "out_linear"):
-        new = block.out_linear(new)
+        new = linear(block.out_linear, new)
     sp.features = new
     sp.gather_dict = None
     sp._xhat = None
@@ -335,7 +401,9 @@ def _compress_index_sets(block, sp, p):
     cnt = valid.sum(1)
     vox_xyz = _metric(sp.indices, sp.point_cloud_range, sp.voxel_size)
     centre = _metric(p.win_ind[:nw], sp.point_cloud_range, p.win_size_m)
-    return dict(pair_win=pair_win, cnt=cnt, vox_csr=Csr.gather(pair_vox, N), centre=centre,
+    wins = dict(q_off=torch.arange(nw, dtype=torch.int32, device=dev), q_cnt=torch.ones(nw, dtype=torch.int32, device=dev),
+                k_off=(torch.cumsum(cnt, 0) - cnt).int().contiguous(), k_cnt=cnt.int().contiguous())
+    return dict(pair_win=pair_win, cnt=cnt, vox_csr=Csr.gather(pair_vox, N), centre=centre, wins=wins,
                 rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(), full=(cnt >= ns))
 
 
@@ -358,19 +426,16 @@ def compress_forward(block, sp):
     # query = channel-wise max over the zero padded list (ref :370): the zeros take part unless the list is full
     q_tok = torch.segment_reduce(xk, "max", lengths=s["cnt"], unsafe=True)
     q_tok = torch.where(s["full"].unsqueeze(1), q_tok, torch.clamp(q_tok, min=0.0))
-    pos = F.relu(F.linear(torch.cat([s["rel"], s["centre"][s["pair_win"]]], dim=1),
-                          block.pos_proj[0].weight.squeeze(-1), block.pos_proj[0].bias))
-    pos = F.relu(F.linear(pos, block.pos_proj[2].weight.squeeze(-1), block.pos_proj[2].bias))
+    pos = _pos6(block.pos_proj[0], s["rel"], s["centre"][s["pair_win"]])
+    pos = F.relu(linear(block.pos_proj[2], pos))
     tok_k = xk + pos
-    q = ma.to_qs[0](q_tok) * ma.scale  # (nw, C)
-    kv = ma.to_kvs[0](tok_k)  # (P, 2C)
-    qp = repeat_rows(q, s["cnt"], kv.shape[0])
-    S = (qp.view(-1, heads, hd) * kv[:, :C].reshape(-1, heads, hd)).sum(-1)
-    o = _seg_softmax_weighted_sum(S, kv[:, C:].reshape(-1, heads, hd), s["cnt"])
-    new = ma.projs[0](o.reshape(-1, C))
-    new = new + block.dropout1(block._ffn(new))  # no residual to the block input (ref :383-385)
+    q = linear(ma.to_qs[0], q_tok) * ma.scale  # (nw, C)
+    kv = linear(ma.to_kvs[0], tok_k)  # (P, 2C)
+    o = pair_attention(q, kv, s["wins"], heads, hd)  # (nw, C)
+    new = linear(ma.projs[0], o.reshape(-1, C))
+    new = new + block.dropout1(ffn(block, new))  # no residual to the block input (ref :383-385)
     if hasattr(block, "out_linear"):
-        new = block.out_linear(new)
+        new = linear(block.out_linear, new)
     sp.features = new
     sp._xhat = None
     return fused._compress_finish(sp, p, new)

@@ -106,3 +106,77 @@ def test_segment_sum_rows_matches_index_add():
     got2 = train_path.segment_sum_rows(src, c2.t_off, c2.t_idx, c2.t_w, N + 3)
     want2 = torch.zeros(N + 3, C, device=DEV, dtype=torch.float64).index_add_(0, idx, src.double() * w.double()[:, None])
     assert float((got2.double() - want2).abs().max()) < 1e-4 and float(got2[N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,cin,cout,bias", [(74270, 128, 256, True), (74270, 256, 128, True), (33001, 64, 64, True),
+                                             (185003, 64, 128, False), (1, 32, 16, True), (63, 8, 12, True),
+                                             (1000, 36, 20, True), (0, 16, 16, True)])
+def test_linear_weight_gradient_kernel(M, cin, cout, bias):
+    """mssvt_linear_wgrad (split-K fp32 MFMA + ordered slab sum) against float64 dY^T X; twice: bit-identical."""
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(M + cin)
+    x = torch.randn(M, cin, generator=g).to(DEV)
+    w = torch.randn(cout, cin, generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn(cout, generator=g).to(DEV).requires_grad_(True) if bias else None
+    dy = torch.randn(M, cout, generator=g).to(DEV)
+    grads = []
+    for _ in range(2):
+        w.grad = None
+        if b is not None:
+            b.grad = None
+        xin = x.clone().requires_grad_(True)
+        y = train_path.linear((w, b), xin)
+        assert y.grad_fn is not None and "Linear" in type(y.grad_fn).__name__
+        y.backward(dy)
+        grads.append((w.grad.clone(), None if b is None else b.grad.clone(), xin.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0])
+    want = dy.double().t() @ x.double()
+    scale = max(1.0, float(want.abs().max()))
+    assert float((grads[0][0].double() - want).abs().max()) <= 2e-6 * scale * max(1.0, M ** 0.5 / 16)
+    if b is not None:
+        assert torch.equal(grads[0][1], grads[1][1])
+        wb = dy.double().sum(0)
+        assert float((grads[0][1].double() - wb).abs().max()) <= 2e-6 * max(1.0, float(wb.abs().max())) * max(1.0, M ** 0.5 / 16)
+    torch.testing.assert_close(grads[0][2], dy @ w.detach(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cg,hd,max_q,max_k", [(64, 16, 20, 32), (128, 16, 1, 32), (32, 8, 45, 64), (16, 4, 3, 5),
+                                               (64, 32, 9, 12), (64, 64, 5, 7)])
+def test_pair_attention_kernels_vs_float64_autograd(cg, hd, max_q, max_k):
+    """mssvt_pair_attention_fwd / _bwd against a float64 torch restatement per window (windows with no query, with no
+    key, with more queries than one register pass holds); backward twice: bit-identical."""
+    from mssvt_amd import train_path
+    heads = cg // hd
+    g = torch.Generator().manual_seed(cg * 100 + hd)
+    nw = 300
+    q_cnt = torch.randint(0, max_q + 1, (nw,), generator=g)
+    k_cnt = torch.randint(0, max_k + 1, (nw,), generator=g)
+    q_cnt[:3], k_cnt[:3] = torch.tensor([0, max_q, max_q]), torch.tensor([max_k, 0, max_k])
+    q_off, k_off = torch.cumsum(q_cnt, 0) - q_cnt, torch.cumsum(k_cnt, 0) - k_cnt
+    R, Kn = int(q_cnt.sum()), int(k_cnt.sum())
+    q0, kv0, dO = torch.randn(R, cg, generator=g), torch.randn(Kn, 2 * cg, generator=g), torch.randn(R, cg, generator=g)
+    wins = {k: v.int().to(DEV) for k, v in dict(q_off=q_off, q_cnt=q_cnt, k_off=k_off, k_cnt=k_cnt).items()}
+    res = []
+    for _ in range(2):
+        q, kv = q0.to(DEV).requires_grad_(True), kv0.to(DEV).requires_grad_(True)
+        O = train_path.pair_attention(q, kv, wins, heads, hd)
+        O.backward(dO.to(DEV))
+        res.append((O.detach().clone(), q.grad.clone(), kv.grad.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    qd, kvd = q0.double().requires_grad_(True), kv0.double().requires_grad_(True)
+    outs = []
+    for w in range(nw):
+        qi = qd[q_off[w]:q_off[w] + q_cnt[w]].view(-1, heads, hd)
+        kw = kvd[k_off[w]:k_off[w] + k_cnt[w]]
+        if k_cnt[w] == 0:
+            outs.append(qi.reshape(-1, cg) * 0)
+            continue
+        k, v = kw[:, :cg].view(-1, heads, hd), kw[:, cg:].view(-1, heads, hd)
+        p = torch.softmax(torch.einsum("ihd,jhd->hij", qi, k), dim=-1)
+        outs.append(torch.einsum("hij,jhd->ihd", p, v).reshape(-1, cg))
+    want = torch.cat(outs)
+    want.backward(dO.double())
+    for got, ref, what in ((res[0][0], want.detach(), "O"), (res[0][1], qd.grad, "dq"), (res[0][2], kvd.grad, "dkv")):
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (what, err)
