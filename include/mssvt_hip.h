@@ -500,6 +500,16 @@ int mssvt_pair_attention_bwd(int nw, int cg, int heads, int hd, const int *q_off
                              const int *k_cnt, const float *q, const float *kv, const float *O, const float *lse,
                              const float *dO, float *dq, float *dkv, void *stream);
 
+/* Inverted index of a (weighted) row gather dst[d] = sum_{e in [off[d],off[d+1])} w[e] src[idx[e]] (off NULL: one entry
+ * per row), built on the device: grad_src[s] = sum_{p in [t_off[s],t_off[s+1])} t_w[p] grad_dst[t_idx[p]] with the
+ * entries of a source row in ascending e -- the fixed summation order that replaces the reference's atomicAdd backward
+ * (ref group_features_gpu.cu:15-47, sampling_gpu.cu:53-90).  Entries of drop_src (or out of [0,n_src)) are left out.
+ * *max_count = the longest list if one is longer than long_list, else 0.  t_off (n_src+1), t_idx / t_w (nnz; t_w NULL
+ * iff w NULL); workspace of mssvt_csr_transpose_workspace_bytes(nnz, n_src) bytes.                                    */
+long long mssvt_csr_transpose_workspace_bytes(int nnz, int n_src);
+int mssvt_csr_transpose(int nnz, int n_dst, int n_src, const int *off, const int *idx, const float *w, int drop_src,
+                        int long_list, int *t_off, int *t_idx, float *t_w, int *max_count, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

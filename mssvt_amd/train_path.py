@@ -47,32 +47,59 @@ def _ranges_sum(src, start, end, idx, w, n_dst):
 class Segments(object):
     """Entry ranges of a segmented sum ``dst[d] = sum_{e in [off[d], off[d+1])} w[e] src[idx[e]]`` (ascending e).
     Destinations with more than CHUNK entries are cut into fixed chunks (summed by separate lane groups, then added in
-    chunk order): the order is fixed either way, and no lane group serialises a whole launch."""
+    chunk order): the order is fixed either way, and no lane group serialises a whole launch.
 
-    def __init__(self, off, idx, w):
+    `longest`: None = look at the offsets now (one host sync); an int = the caller's bound (no sync); a 1-element device
+    tensor = the word mssvt_csr_transpose left (0 when no list is longer than CHUNK), read later by `resolve_all` for all
+    the index sets of a plan at once, or on first use."""
+
+    def __init__(self, off, idx, w, longest=None):
         self.idx, self.w, self.n_dst = idx, w, off.numel() - 1
+        self.off = off
+        self.start, self.end = off[:-1], off[1:]
+        self.heavy = None
+        self.pending = None
+        if longest is None:
+            counts = off[1:] - off[:-1]
+            self._cut(int(counts.max().item()) if self.n_dst else 0)
+        elif torch.is_tensor(longest):
+            self.pending = longest
+        else:
+            self._cut(int(longest))
+
+    def _cut(self, longest):
+        self.pending = None
+        if longest <= CHUNK:
+            return
+        off = self.off
         counts = off[1:] - off[:-1]
         heavy = counts > CHUNK
-        self.start = off[:-1].contiguous()
-        self.heavy = None
-        if self.n_dst and bool(heavy.any()):  # (one host sync per index set; the sets are cached per plan)
-            self.end = torch.where(heavy, self.start, off[1:]).contiguous()  # heavy rows: empty here, filled below
-            hd = torch.nonzero(heavy, as_tuple=True)[0]
-            hs, hc = self.start[hd].long(), counts[hd].long()
-            nch = (hc + CHUNK - 1) // CHUNK
-            M2 = int(nch.sum().item())
-            which = torch.repeat_interleave(torch.arange(hd.numel(), device=idx.device), nch, output_size=M2)
-            first = torch.cumsum(nch, 0) - nch
-            j = torch.arange(M2, device=idx.device) - first[which]
-            c_start = (hs[which] + j * CHUNK)
-            c_end = torch.minimum(c_start + CHUNK, hs[which] + hc[which])
-            self.heavy = dict(rows=hd, c_start=c_start.int().contiguous(), c_end=c_end.int().contiguous(),
-                              p_start=first.int().contiguous(), p_end=(first + nch).int().contiguous(),
-                              p_idx=torch.arange(M2, dtype=torch.int32, device=idx.device), n_chunks=M2)
-        else:
-            self.end = off[1:].contiguous()
+        dev = off.device
+        self.end = torch.where(heavy, self.start, off[1:]).contiguous()  # heavy rows: empty here, filled below
+        hd = torch.nonzero(heavy, as_tuple=True)[0]
+        hs, hc = self.start[hd].long(), counts[hd].long()
+        nch = (hc + CHUNK - 1) // CHUNK
+        M2 = int(nch.sum().item())
+        which = torch.repeat_interleave(torch.arange(hd.numel(), device=dev), nch, output_size=M2)
+        first = torch.cumsum(nch, 0) - nch
+        j = torch.arange(M2, device=dev) - first[which]
+        c_start = (hs[which] + j * CHUNK)
+        c_end = torch.minimum(c_start + CHUNK, hs[which] + hc[which])
+        self.heavy = dict(rows=hd, c_start=c_start.int().contiguous(), c_end=c_end.int().contiguous(),
+                          p_start=first.int().contiguous(), p_end=(first + nch).int().contiguous(),
+                          p_idx=torch.arange(M2, dtype=torch.int32, device=dev), n_chunks=M2)
+
+    @staticmethod
+    def resolve_all(segs):
+        """Read the longest-list words of all pending `segs` in ONE host sync and cut the long lists."""
+        segs = [g for g in segs if g.pending is not None]
+        if segs:
+            for g, longest in zip(segs, torch.cat([g.pending for g in segs]).tolist()):
+                g._cut(longest)
 
     def sum(self, src):
+        if self.pending is not None:
+            self._cut(int(self.pending.item()))
         dst = _ranges_sum(src, self.start, self.end, self.idx, self.w, self.n_dst)
         h = self.heavy
         if h is not None:
@@ -83,42 +110,53 @@ class Segments(object):
 
 def segment_sum_rows(src, off, idx, w, n_dst):
     """dst[d] = sum_{e in [off[d], off[d+1])} w[e] * src[idx[e]] in ascending e (HIP, deterministic)."""
-    return _ranges_sum(src, off[:-1].contiguous(), off[1:].contiguous(), idx, w, n_dst)
+    return _ranges_sum(src, off[:-1], off[1:], idx, w, n_dst)
+
+
+_csr_ws = {}
+
+
+def _csr_workspace(dev, nnz, n_src):
+    need = int(_lib.lib().mssvt_csr_transpose_workspace_bytes(_i(nnz), _i(n_src)))
+    ws = _csr_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _csr_ws[dev] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    return ws
 
 
 class Csr(object):
     """A (weighted) gather ``dst[d] = sum_e w[e] src[idx[e]]`` with its transpose (the inverted index that turns the
-    gradient scatter-add into a segmented sum).  Built once per index set and reused by every block sharing the plan.
-    `drop_src`: a source row whose gradient is not needed (the constant zero row): its list is left empty."""
+    gradient scatter-add into a segmented sum; mssvt_csr_transpose, csrc/csr_transpose.hip: no host sync).  Built once
+    per index set and reused by every block sharing the plan.  `drop_src`: a source row whose gradient is not needed (the
+    constant zero row): its list is left empty.  `off` None: a plain row gather.  `fwd_longest`: the caller's bound on
+    the entries per destination (<= CHUNK for everything this file builds)."""
 
-    def __init__(self, off, idx, w, n_src, drop_src=None):
-        self.off, self.idx, self.w, self.n_src = off, idx, w, int(n_src)
-        self.n_dst = off.numel() - 1
+    def __init__(self, off, idx, w, n_src, drop_src=None, fwd_longest=None):
+        dev = idx.device
+        idx = idx.int().contiguous()
         nnz = idx.numel()
-        counts = (off[1:] - off[:-1]).long()
-        dst_of = torch.repeat_interleave(torch.arange(self.n_dst, device=idx.device), counts, output_size=nnz)
-        key = idx.long()
-        keep = None
-        if drop_src is not None:
-            keep = torch.nonzero(key != drop_src, as_tuple=True)[0]
-            key, dst_of = key[keep], dst_of[keep]
-        order = torch.sort(key, stable=True).indices  # contributions of a source row in ascending entry order
-        t_idx = dst_of[order].int().contiguous()
-        wk = None if w is None else (w if keep is None else w[keep])
-        t_w = None if wk is None else wk[order].contiguous()
-        per_src = torch.bincount(key, minlength=self.n_src)
-        t_off = torch.zeros(self.n_src + 1, dtype=torch.int32, device=idx.device)
-        t_off[1:] = torch.cumsum(per_src, 0)
-        self.fwd = Segments(off, idx, w)
-        self.bwd = Segments(t_off, t_idx, t_w)
+        self.n_src = int(n_src)
+        self.n_dst = nnz if off is None else off.numel() - 1
+        t_off = torch.empty(self.n_src + 1, dtype=torch.int32, device=dev)
+        t_idx = torch.empty(nnz, dtype=torch.int32, device=dev)
+        t_w = None if w is None else torch.empty(nnz, dtype=torch.float32, device=dev)
+        longest = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.call("mssvt_csr_transpose", _i(nnz), _i(self.n_dst), _i(self.n_src), _lib.ptr(off), _lib.ptr(idx) if nnz else None,
+                  _lib.ptr(w) if nnz else None, _i(-1 if drop_src is None else int(drop_src)), _i(CHUNK), _lib.ptr(t_off),
+                  _lib.ptr(t_idx) if nnz else None, _lib.ptr(t_w) if (nnz and w is not None) else None, _lib.ptr(longest),
+                  _lib.ptr(_csr_workspace(dev, nnz, self.n_src)) if nnz else None, _lib.stream())
+        if off is None:
+            off = torch.arange(nnz + 1, dtype=torch.int32, device=dev)
+            fwd_longest = 1
+        self.off, self.idx, self.w = off, idx, w
+        self.fwd = Segments(off, idx, w, longest=fwd_longest)
+        self.bwd = Segments(t_off, t_idx, t_w, longest=longest)
         self.t_off, self.t_idx, self.t_w = t_off, t_idx, t_w
 
     @staticmethod
     def gather(idx, n_src):
         """Plain row gather dst[i] = src[idx[i]]."""
-        idx = idx.int().contiguous()
-        off = torch.arange(idx.numel() + 1, dtype=torch.int32, device=idx.device)
-        return Csr(off, idx, None, n_src)
+        return Csr(None, idx, None, n_src)
 
 
 class _SegmentSum(torch.autograd.Function):
@@ -322,8 +360,10 @@ def _block_index_sets(block, sp, p):
     idx3 = torch.where(owned.unsqueeze(1), idx3, torch.full_like(idx3, R))
     w3 = torch.where(owned.unsqueeze(1), tab_w[:N, :3], torch.zeros_like(tab_w[:N, :3]))
     off3 = torch.arange(0, 3 * N + 1, 3, dtype=torch.int32, device=dev)
-    s["interp_csr"] = Csr(off3, idx3.reshape(-1).contiguous(), w3.reshape(-1).contiguous(), R + 1, drop_src=R)
+    s["interp_csr"] = Csr(off3, idx3.reshape(-1).contiguous(), w3.reshape(-1).contiguous(), R + 1, drop_src=R,
+                          fwd_longest=3)
     s["owned"] = owned
+    Segments.resolve_all([s["q_csr"].bwd, s["interp_csr"].bwd] + [k["k_csr"].bwd for k in s["keys"]])  # one host sync
     cache[key] = s
     return s
 
@@ -403,7 +443,9 @@ def _compress_index_sets(block, sp, p):
     centre = _metric(p.win_ind[:nw], sp.point_cloud_range, p.win_size_m)
     wins = dict(q_off=torch.arange(nw, dtype=torch.int32, device=dev), q_cnt=torch.ones(nw, dtype=torch.int32, device=dev),
                 k_off=(torch.cumsum(cnt, 0) - cnt).int().contiguous(), k_cnt=cnt.int().contiguous())
-    return dict(pair_win=pair_win, cnt=cnt, vox_csr=Csr.gather(pair_vox, N), centre=centre, wins=wins,
+    vox_csr = Csr.gather(pair_vox, N)
+    Segments.resolve_all([vox_csr.bwd])
+    return dict(pair_win=pair_win, cnt=cnt, vox_csr=vox_csr, centre=centre, wins=wins,
                 rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(), full=(cnt >= ns))
 
 

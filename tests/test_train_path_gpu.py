@@ -180,3 +180,47 @@ def test_pair_attention_kernels_vs_float64_autograd(cg, hd, max_q, max_k):
     for got, ref, what in ((res[0][0], want.detach(), "O"), (res[0][1], qd.grad, "dq"), (res[0][2], kvd.grad, "dkv")):
         err = float((got.cpu().double() - ref).abs().max())
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (what, err)
+
+
+@pytest.mark.parametrize("nnz,n_src,ragged,heavy", [(5000, 700, False, False), (20000, 300, True, True), (1, 1, False, False),
+                                                    (0, 5, False, False), (70000, 100000, True, False)])
+def test_csr_transpose_matches_a_stable_sort(nnz, n_src, ragged, heavy):
+    """mssvt_csr_transpose against torch's stable sort: per source row the destinations in ascending entry order, the
+    dropped source left out, the longest-list word, and the chunked sum of a long list against float64."""
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(nnz + n_src)
+    idx = torch.randint(0, n_src, (nnz,), generator=g)
+    if heavy:
+        idx[::3] = 7  # a list of ~6.7k entries (voxel 0 of the reference's empty-pick quirk looks like this)
+    drop = 2 if n_src > 2 else None
+    if ragged:
+        cnt = torch.randint(0, 4, (nnz,), generator=g)
+        keep = int((torch.cumsum(cnt, 0) <= nnz).sum())
+        cnt = cnt[:keep]
+        cnt[-1] += nnz - int(cnt.sum())
+        off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(cnt, 0)]).int()
+        dst_of = torch.repeat_interleave(torch.arange(cnt.numel()), cnt)
+    else:
+        off, dst_of = None, torch.arange(nnz)
+    w = torch.rand(nnz, generator=g)
+    csr = train_path.Csr(None if off is None else off.to(DEV), idx.int().to(DEV), w.to(DEV), n_src, drop_src=drop,
+                         fwd_longest=None if off is None else 4)
+    keep = torch.ones(nnz, dtype=torch.bool) if drop is None else idx != drop
+    order = torch.sort(idx[keep], stable=True).indices
+    want_idx, want_w = dst_of[keep][order], w[keep][order]
+    per = torch.bincount(idx[keep], minlength=n_src)
+    want_off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(per, 0)])
+    n_keep = int(keep.sum())
+    assert torch.equal(csr.t_off.cpu().long(), want_off)
+    assert torch.equal(csr.t_idx.cpu()[:n_keep].long(), want_idx)
+    assert torch.equal(csr.t_w.cpu()[:n_keep], want_w)
+    longest = int(per.max()) if nnz else 0
+    assert int(csr.bwd.pending.item()) == (longest if longest > train_path.CHUNK else 0)
+    if nnz:
+        n_dst = dst_of.max().item() + 1 if nnz else 0
+        grad = torch.randn(int(csr.n_dst), 16, generator=g)
+        got = csr.bwd.sum(grad.to(DEV))
+        assert (csr.bwd.heavy is not None) == (longest > train_path.CHUNK)
+        ref = torch.zeros(n_src, 16, dtype=torch.float64).index_add_(0, idx[keep], (grad.double()[dst_of] * w.double()[:, None])[keep])
+        assert float((got.cpu().double() - ref).abs().max()) < 1e-3
+        assert torch.equal(got, csr.bwd.sum(grad.to(DEV)))
