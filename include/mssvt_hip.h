@@ -372,6 +372,12 @@ int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, c
  * row count is read on the device and n_rows is only the capacity.  phases: 3 = the whole
  * tail; with hidden != NULL 1 = only the first launch (LayerNorm + GEMM1 + ReLU -> hidden,
  * x parked in y), 2 = only the second (GEMM2 + residual + next norm) -- for measurement.
+ * phases 4 (hidden ignored, num_rows_dev allowed): ONE launch with register-stationary weights
+ * and every fp32 operand split exactly into two fp16 halves (3 x v_mfma_f32_16x16x32_f16 per
+ * product sum, fp32 accumulation: the fp32 kernels' error against float64 at 3/16 of the matrix
+ * cycles; no hidden round trip).  The CALLER guarantees the fp16 range: sqrt(C) max|norm_w| +
+ * max|norm_b| and max_h(|W1_h|_1 * that + |b1_h|) below 3e4 (mssvt_amd/fused.py checks the
+ * parameters once per version and keeps phases 3 otherwise).
  * Instantiated for (C,FF) in {(128,256),(64,128),(32,64)}; MSSVT_E_TOOLARGE otherwise.   */
 int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *x_in, const int *owner,
                     const float *norm_w, const float *norm_b, float eps, const float *W1,

@@ -729,6 +729,270 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
     }
 }
 
+// =====================================================================================================
+// Single-launch FFN tail, weights stationary in registers, fp32 operands split into two fp16 halves
+// =====================================================================================================
+// The fp32 matrix instruction above runs at 1/16 of the 16-bit rate, and at 62 us per FFN (both launches) it bounds
+// the frame.  Here every fp32 operand v is split exactly into  hi = fp16(v)  and  lo = fp16((v - hi) * 2^11)  (22+
+// mantissa bits together; the lo half is scaled so that it stays out of the fp16 subnormals) and a product sum is three
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation:
+//        sum a b  =  sum a_hi b_hi  +  2^-11 (sum a_hi b_lo + sum a_lo b_hi)            (a_lo b_lo ~ 2^-22: dropped)
+// 3/16 of the fp32 instruction's cycles for the same result to ~2^-21 relative per operand (measured against float64:
+// the same max error as the fp32 kernels).  The caller checks the fp16 RANGE of the operands from
+// the parameters (|LayerNorm output| <= sqrt(C) max|w| + max|b|, |hidden| <= max_h(|W1_h|_1 xmax + |b1_h|) < 3e4) and
+// keeps the fp32 kernels otherwise.
+//
+// With the matrix work that cheap the layout changes: one workgroup of FF/32 waves per CU; wave w keeps the W1 rows
+// and W2 columns of hidden units [32 w, 32 w + 32) in REGISTERS as MFMA A-fragments (2 x 64 VGPRs at C = 128) for
+// the whole launch -- no weight traffic through LDS, none per tile.  A tile of 16 rows is
+//   A. loaded row-wise by the whole workgroup (a lane = 4 channels of a row: coalesced 512-byte rows, the residual
+//      input built on the fly, LayerNorm by a DPP reduction over the row's lanes), split and written to LDS as the
+//      B-fragments of GEMM1 (8 KB);
+//   B. multiplied by every wave with ITS W1 slice: u^T[32 hidden][16 rows]; the accumulator layout of the 16x16 MFMA
+//      is again the B-operand layout of the next one (k slot (g, j) <-> hidden 16 (j / 4) + 4 g + j % 4), so u is split
+//      in place and multiplied by the wave's W2 slice: a partial y over 32 of the FF hidden units;
+//   C. the FF/32 partial tiles go through LDS and are added in wave order (fixed: deterministic) by the lane that
+//      still holds x for that row piece: y = x + sum + b2, the next block's LayerNorm, coalesced stores.
+// The (N, FF) hidden activations never exist in memory and x is read once: 76 MB of HBM traffic per FFN instead of
+// 270 MB.  Two workgroup barriers per tile; the next tile's row gathers are issued before the MFMA phases.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+#define MFMA_H(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16((av), (bv), acc, 0, 0, 0)
+#define FFW_SCALE 2048.0f
+#define FFW_INV (1.0f / 2048.0f)
+
+// v -> (hi, lo) halves of 4 floats
+__device__ __forceinline__ void ffw_split4(const float v0, const float v1, const float v2, const float v3, h16x4 &hi, h16x4 &lo) {
+    const fp16x2 a = __builtin_amdgcn_cvt_pkrtz(v0, v1), b = __builtin_amdgcn_cvt_pkrtz(v2, v3);
+    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz((v0 - (float)a[0]) * FFW_SCALE, (v1 - (float)a[1]) * FFW_SCALE);
+    const fp16x2 d = __builtin_amdgcn_cvt_pkrtz((v2 - (float)b[0]) * FFW_SCALE, (v3 - (float)b[1]) * FFW_SCALE);
+    hi = h16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
+    lo = h16x4{(_Float16)c[0], (_Float16)c[1], (_Float16)d[0], (_Float16)d[1]};
+}
+__device__ __forceinline__ h16x8 ffw_cat(const h16x4 a, const h16x4 b) {
+    return h16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <int L>
+__device__ __forceinline__ float ffw_row_sum(float v) {  // all-reduce over L consecutive lanes (L = 8, 16, 32)
+    v += DPP_MOV(v, 0xB1);
+    v += DPP_MOV(v, 0x4E);
+    v += DPP_MOV(v, 0x141);
+    if (L >= 16) v += DPP_MOV(v, 0x140);
+    if (L >= 32) v += lane_xor16(v);
+    return v;
+}
+
+template <int C, int FF>
+__global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a) {
+    constexpr int NW = FF / 32, NP = C / 32, NTC = C / 16, LPR = C / 4, RPW = MSSVT_WAVE / LPR, PS = C + 4;
+    static_assert(FF == 2 * C && NW * RPW == 16 && (LPR == 8 || LPR == 16 || LPR == 32), "16 rows per workgroup tile");
+    extern __shared__ float4 lds4[];
+    h16x8 *bfrag = reinterpret_cast<h16x8 *>(lds4);                                       // [NP][hi | lo][64 lanes]
+    float *part = reinterpret_cast<float *>(lds4) + NP * 2 * 64 * 4;                      // [NW][16 rows][PS]
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / MSSVT_WAVE);
+    const int r = wv * RPW + lane / LPR, q = lane % LPR;  // row-wise view: row of the tile, channels [4 q, 4 q + 4)
+    const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+    const int tiles = (n + 15) >> 4;
+    if (n <= 0 || (int)blockIdx.x >= tiles) return;
+    const bool tabbed = a.tab_row != nullptr;
+
+    // ---- the first tile's rows are requested before the weights (both pure latency) -------------------------
+    int tile = blockIdx.x;
+    int4 tr = make_int4(0, 0, 0, 0);
+    float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
+    int own = 0;
+#define FFW_TAB(tile_, tr_, tw_, own_)                                                                      \
+    {                                                                                                       \
+        const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
+        if (tabbed) { tr_ = a.tab_row[row_]; tw_ = a.tab_w[row_]; }                                         \
+        else if (a.owner) own_ = a.owner[row_];                                                             \
+    }
+    float4 rx, r1, r2, r3;
+    float w1, w2, w3, wx;
+#define FFW_ISSUE(tile_, tr_, tw_, own_)                                                                    \
+    {                                                                                                       \
+        const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
+        if (tabbed) {                                                                                       \
+            const bool un_ = tr_.x < 0; /* unowned voxel: 2 x_in; re-reads its own finite row with weight 0 */ \
+            const float *px_ = a.x_in + (size_t)row_ * C + 4 * q;                                           \
+            rx = *reinterpret_cast<const float4 *>(px_);                                                    \
+            r1 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.x * C + 4 * q);        \
+            r2 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.y * C + 4 * q);        \
+            r3 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.z * C + 4 * q);        \
+            w1 = un_ ? 0.f : tw_.x; w2 = un_ ? 0.f : tw_.y; w3 = un_ ? 0.f : tw_.z; wx = un_ ? 2.0f : 1.0f; \
+        } else {                                                                                            \
+            const bool dbl_ = a.owner != nullptr && own_ < 0;                                               \
+            rx = *reinterpret_cast<const float4 *>((dbl_ ? a.x_in : a.x_new) + (size_t)row_ * C + 4 * q);   \
+            wx = dbl_ ? 2.0f : 1.0f;                                                                        \
+        }                                                                                                   \
+    }
+    FFW_TAB(tile, tr, tw, own)
+    FFW_ISSUE(tile, tr, tw, own)
+    int4 trn = tr;
+    float4 twn = tw;
+    int ownn = own;
+    if (tile + (int)gridDim.x < tiles) FFW_TAB(tile + (int)gridDim.x, trn, twn, ownn)
+
+    // ---- this wave's weight slices -> A fragments (lane (la, g): row la of the tile, k slots 8 g .. 8 g + 7) ---
+    h16x8 W1h[2][NP], W1l[2][NP], W2h[NTC], W2l[NTC];
+    float bias1[2][4];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const int h = 32 * wv + 16 * T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias1[T][i] = a.b1[h + 4 * g + i];
+#pragma unroll
+        for (int P = 0; P < NP; ++P) {  // k slot (g, j) <-> channel 32 P + 8 g + j
+            const float *src = a.W1 + (size_t)(h + la) * C + 32 * P + 8 * g;
+            const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+            h16x4 h0, l0, h1, l1;
+            ffw_split4(v0.x, v0.y, v0.z, v0.w, h0, l0);
+            ffw_split4(v1.x, v1.y, v1.z, v1.w, h1, l1);
+            W1h[T][P] = ffw_cat(h0, h1);
+            W1l[T][P] = ffw_cat(l0, l1);
+        }
+    }
+#pragma unroll
+    for (int tc = 0; tc < NTC; ++tc) {  // k slot (g, j) <-> hidden 32 wv + 16 (j / 4) + 4 g + j % 4
+        const float *src = a.W2 + (size_t)(16 * tc + la) * FF + 32 * wv + 4 * g;
+        const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 16);
+        h16x4 h0, l0, h1, l1;
+        ffw_split4(v0.x, v0.y, v0.z, v0.w, h0, l0);
+        ffw_split4(v1.x, v1.y, v1.z, v1.w, h1, l1);
+        W2h[tc] = ffw_cat(h0, h1);
+        W2l[tc] = ffw_cat(l0, l1);
+    }
+    // row-wise constants of this lane's 4 channels
+    const float4 lnw = *reinterpret_cast<const float4 *>(a.ln_w + 4 * q), lnb = *reinterpret_cast<const float4 *>(a.ln_b + 4 * q);
+    const float4 bias2 = *reinterpret_cast<const float4 *>(a.b2 + 4 * q);
+    float4 ln2w = make_float4(0.f, 0.f, 0.f, 0.f), ln2b = ln2w;
+    if (a.y_norm) {
+        ln2w = *reinterpret_cast<const float4 *>(a.ln2_w + 4 * q);
+        ln2b = *reinterpret_cast<const float4 *>(a.ln2_b + 4 * q);
+    }
+
+    for (;;) {
+        const int tile_next = tile + gridDim.x;
+        const bool has_next = tile_next < tiles;
+        const bool live = tile * 16 + r < n;
+        const size_t row = (size_t)min(tile * 16 + r, n - 1);
+        // ---- A. x of this lane's row piece; the next tile's gathers leave now ----------------------------------
+        float4 x;
+        if (tabbed) {
+            x.x = ((r1.x * w1 + r2.x * w2) + r3.x * w3) + rx.x * wx;
+            x.y = ((r1.y * w1 + r2.y * w2) + r3.y * w3) + rx.y * wx;
+            x.z = ((r1.z * w1 + r2.z * w2) + r3.z * w3) + rx.z * wx;
+            x.w = ((r1.w * w1 + r2.w * w2) + r3.w * w3) + rx.w * wx;
+        } else {
+            x = make_float4(rx.x * wx, rx.y * wx, rx.z * wx, rx.w * wx);
+        }
+        if (has_next) {
+            FFW_ISSUE(tile_next, trn, twn, ownn)
+            if (tile_next + (int)gridDim.x < tiles) FFW_TAB(tile_next + (int)gridDim.x, trn, twn, ownn)
+        }
+        {   // LayerNorm (norm2) over the row's LPR lanes, split, B fragments of GEMM1
+            const float mean = ffw_row_sum<LPR>((x.x + x.y) + (x.z + x.w)) * (1.0f / C);
+            const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+            const float var = ffw_row_sum<LPR>(__builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0))));
+            const float rstd = rsqrtf(var * (1.0f / C) + a.eps);
+            h16x4 hi, lo;
+            ffw_split4(d0 * rstd * lnw.x + lnb.x, d1 * rstd * lnw.y + lnb.y, d2 * rstd * lnw.z + lnb.z, d3 * rstd * lnw.w + lnb.w,
+                       hi, lo);
+            // channel 4 q = 32 P + 8 gq + j0: fragment P, lane 16 gq + r, halves j0 .. j0 + 3
+            const int P = q >> 3, gq = (q >> 1) & 3, j0 = (q & 1) * 4;
+            h16x4 *dst = reinterpret_cast<h16x4 *>(bfrag + (P * 2) * 64 + 16 * gq + r) + (j0 >> 2);
+            dst[0] = hi;
+            dst[64 * 2] = lo;  // the lo fragment follows the hi fragment: 64 lanes x 2 h16x4
+        }
+        __syncthreads();
+        // ---- B. u^T = relu(W1 xn + b1) for this wave's 32 hidden units, then its share of W2 u --------------------
+        f32x4 um[2], ul[2];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            um[T] = f32x4{bias1[T][0], bias1[T][1], bias1[T][2], bias1[T][3]};
+            ul[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int P = 0; P < NP; ++P) {
+            const h16x8 bh = bfrag[(P * 2) * 64 + lane], bl = bfrag[(P * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                MFMA_H(um[T], W1h[T][P], bh);
+                MFMA_H(ul[T], W1h[T][P], bl);
+                MFMA_H(ul[T], W1l[T][P], bh);
+            }
+        }
+        h16x8 uh, ulo;
+        {
+            h16x4 h0, l0, h1, l1;
+            ffw_split4(fmaxf(um[0][0] + ul[0][0] * FFW_INV, 0.f), fmaxf(um[0][1] + ul[0][1] * FFW_INV, 0.f),
+                       fmaxf(um[0][2] + ul[0][2] * FFW_INV, 0.f), fmaxf(um[0][3] + ul[0][3] * FFW_INV, 0.f), h0, l0);
+            ffw_split4(fmaxf(um[1][0] + ul[1][0] * FFW_INV, 0.f), fmaxf(um[1][1] + ul[1][1] * FFW_INV, 0.f),
+                       fmaxf(um[1][2] + ul[1][2] * FFW_INV, 0.f), fmaxf(um[1][3] + ul[1][3] * FFW_INV, 0.f), h1, l1);
+            uh = ffw_cat(h0, h1);
+            ulo = ffw_cat(l0, l1);
+        }
+        float *pw = part + (size_t)wv * 16 * PS + la * PS + 4 * g;  // lane (row la, g): channels 16 tc + 4 g .. + 3
+#pragma unroll
+        for (int tc = 0; tc < NTC; ++tc) {
+            f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f}, l = m;
+            MFMA_H(m, W2h[tc], uh);
+            MFMA_H(l, W2h[tc], ulo);
+            MFMA_H(l, W2l[tc], uh);
+            *reinterpret_cast<float4 *>(pw + 16 * tc) =
+                make_float4(m[0] + l[0] * FFW_INV, m[1] + l[1] * FFW_INV, m[2] + l[2] * FFW_INV, m[3] + l[3] * FFW_INV);
+        }
+        __syncthreads();
+        // ---- C. y = x + b2 + sum over the waves' partial tiles, in wave order ---------------------------------------
+        float4 y = bias2;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float4 pv = *reinterpret_cast<const float4 *>(part + (size_t)w * 16 * PS + r * PS + 4 * q);
+            y.x += pv.x; y.y += pv.y; y.z += pv.z; y.w += pv.w;
+        }
+        y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
+        if (live) *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = y;
+        if (a.y_norm) {
+            const float mean = ffw_row_sum<LPR>((y.x + y.y) + (y.z + y.w)) * (1.0f / C);
+            const float d0 = y.x - mean, d1 = y.y - mean, d2 = y.z - mean, d3 = y.w - mean;
+            const float var = ffw_row_sum<LPR>(__builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0))));
+            const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
+            if (live)
+                *reinterpret_cast<float4 *>(a.y_norm + row * C + 4 * q) =
+                    make_float4(d0 * rstd * ln2w.x + ln2b.x, d1 * rstd * ln2w.y + ln2b.y, d2 * rstd * ln2w.z + ln2b.z,
+                                d3 * rstd * ln2w.w + ln2b.w);
+        }
+        if (!has_next) break;
+        tile = tile_next;
+    }
+#undef FFW_TAB
+#undef FFW_ISSUE
+}
+
+template <int C, int FF>
+static int launch_ffn_ws(const FfnArgs &a, hipStream_t stream) {
+    constexpr int NW = FF / 32;
+    const size_t lds = (size_t)(C / 32) * 2 * 64 * 16 + (size_t)NW * 16 * (C + 4) * 4;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ffn_ws<C, FF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int tiles = (a.n_rows + 15) / 16;
+    int grid = cus * (NW >= 8 ? 1 : 8 / NW);  // 8 waves per CU
+    if (grid > tiles) grid = tiles;
+    if (grid < 1) return MSSVT_OK;
+    k_ffn_ws<C, FF><<<grid, NW * MSSVT_WAVE, lds, stream>>>(a);
+    return mssvt_launch_status();
+}
+
 template <int C, int FF>
 static int launch_ffn_split(const FfnArgs &a, float *hidden, int phases, hipStream_t stream) {
     const size_t lds_up = ((size_t)FF * (C + 4) + FF + 2 * C) * 4, lds_down = ((size_t)C * (FF + 4) + 3 * C) * 4;
@@ -758,6 +1022,12 @@ static int launch_ffn_split(const FfnArgs &a, float *hidden, int phases, hipStre
 }
 
 static int dispatch_ffn(int C, int FF, const FfnArgs &a, float *hidden, int phases, hipStream_t st) {
+    if (phases == 4) {  // single launch, split fp16 operands (the caller has checked their range)
+        if (C == 128 && FF == 256) return launch_ffn_ws<128, 256>(a, st);
+        if (C == 64 && FF == 128) return launch_ffn_ws<64, 128>(a, st);
+        if (C == 32 && FF == 64) return launch_ffn_ws<32, 64>(a, st);
+        return MSSVT_E_TOOLARGE;
+    }
     if (hidden) {
         if (C == 128 && FF == 256) return launch_ffn_split<128, 256>(a, hidden, phases, st);
         if (C == 64 && FF == 128) return launch_ffn_split<64, 128>(a, hidden, phases, st);

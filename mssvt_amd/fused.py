@@ -389,6 +389,12 @@ FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
 FFN_SPLIT = os.environ.get("MSSVT_FFN_SPLIT", "1") != "0"
 CMP_FUSED = os.environ.get("MSSVT_CMP_FUSED", "1") != "0"
 FFN_TIMER = None  # bench.py sets this to a list to time k_ffn_up live (see _ffn_tail)
+# arithmetic of the FFN's matrix products: "f16x3" = every fp32 operand split exactly into two fp16 halves, three
+# 16-bit MFMAs per product sum, fp32 accumulation (k_ffn_ws: same error against float64 as the fp32 instruction, 3/16 of
+# its cycles, one launch); "f32" = v_mfma_f32_16x16x4_f32 (k_ffn_up + k_ffn_down).  A module attribute `ffn_arith`
+# overrides it; operands outside the fp16 range (checked from the parameters) always take "f32".
+FFN_ARITH = os.environ.get("MSSVT_FFN_ARITH", "f16x3")
+FFN_F16_LIMIT = 3.0e4
 OCC_COLUMNS = os.environ.get("MSSVT_OCC_COLUMNS", "1") != "0"
 
 
@@ -401,6 +407,23 @@ def _ffn_refs(block):
             b1=block.linear1.bias, W2=block.linear2.weight, b2=block.linear2.bias, lnw=block.norm2.weight,
             lnb=block.norm2.bias, eps=float(block.norm2.eps), has_out=hasattr(block, 'out_linear'))
     return r
+
+
+@torch.no_grad()
+def _ffn_f16_range_ok(fr):
+    """True when the operands of the split-fp16 FFN stay inside the fp16 range whatever the input rows are: a
+    LayerNorm output is bounded by sqrt(C) max|w| + max|b|, a hidden activation by max_h(|W1_h|_1 xmax + |b1_h|).
+    Evaluated once per parameter version (one small host sync)."""
+    ts = (fr["W1"], fr["b1"], fr["W2"], fr["b2"], fr["lnw"], fr["lnb"])
+    ver = tuple(t._version for t in ts)
+    if fr.get("f16_ver") != ver:
+        W1, b1, W2, b2, lnw, lnb = [t.detach().float() for t in ts]
+        xmax = (fr["C"] ** 0.5) * lnw.abs().max() + lnb.abs().max()
+        hmax = (W1.abs().sum(1) * xmax + b1.abs()).max()
+        worst = torch.stack([xmax, hmax, W1.abs().max(), W2.abs().max()]).max()
+        fr["f16_ok"] = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
+        fr["f16_ver"] = ver
+    return fr["f16_ok"]
 
 
 def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=None, apply_out=True, phases=3):
@@ -423,8 +446,10 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=No
         y_norm = None
         if nxt is not None and not has_out and nxt.normalized_shape[0] == C:
             y_norm = torch.empty_like(x_new)
-        # two launches with LDS-resident weights; the hidden activations go through this scratch
-        split = FFN_SPLIT or n_rows_dev is not None  # a device-side row count needs the two-launch form
+        if phases == 3 and getattr(block, "ffn_arith", FFN_ARITH) == "f16x3" and _ffn_f16_range_ok(fr):
+            phases = 4  # one launch, split fp16 operands, no hidden scratch
+        # fp32 MFMA: two launches with LDS-resident weights; the hidden activations go through this scratch
+        split = phases != 4 and (FFN_SPLIT or n_rows_dev is not None)  # a device-side row count needs the two-launch form
         hidden = torch.empty((n, FF), dtype=torch.float32, device=x_new.device) if split else None
         tail = (_P(fr["lnw"]), _P(fr["lnb"]), _f(fr["eps"]), _P(fr["W1"]), _P(fr["b1"]), _P(fr["W2"]), _P(fr["b2"]), _P(y),
                 _P(nxt.weight if y_norm is not None else None),
