@@ -372,7 +372,8 @@ int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, c
  * row count is read on the device and n_rows is only the capacity.  phases: 3 = the whole
  * tail; with hidden != NULL 1 = only the first launch (LayerNorm + GEMM1 + ReLU -> hidden,
  * x parked in y), 2 = only the second (GEMM2 + residual + next norm) -- for measurement.
- * phases 4 (hidden ignored, num_rows_dev allowed): ONE launch with register-stationary weights
+ * phases 4 (num_rows_dev allowed; hidden = NULL, or the fragments written by
+ * mssvt_ffn_pack_weights for these W1 / W2: saves the in-kernel split): ONE launch with register-stationary weights
  * and every fp32 operand split exactly into two fp16 halves (3 x v_mfma_f32_16x16x32_f16 per
  * product sum, fp32 accumulation: the fp32 kernels' error against float64 at 3/16 of the matrix
  * cycles; no hidden round trip).  The CALLER guarantees the fp16 range: sqrt(C) max|norm_w| +
@@ -384,6 +385,11 @@ int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *
                     const float *b1, const float *W2, const float *b2, float *y,
                     const float *next_norm_w, const float *next_norm_b, float next_eps, float *y_norm,
                     float *hidden, const int *num_rows_dev, int phases, void *stream);
+
+/* W1 / W2 of mssvt_ffn_fused split into fp16 (hi, lo) MFMA fragments, once per parameter version: `packed` of
+ * mssvt_ffn_packed_bytes(C, FF) bytes (0: shape not instantiated), passed as `hidden` with phases 4.          */
+long long mssvt_ffn_packed_bytes(int C, int FF);
+int mssvt_ffn_pack_weights(int C, int FF, const float *W1, const float *W2, void *packed, void *stream);
 
 /* Table form of mssvt_block_interp_scatter: for every voxel owned by a list slot, tab_row (N,4)
  * int32 = the three rows of `attn` (row = w*nq + slot; empty slots / zero weights -> zero_row) and

@@ -742,19 +742,24 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
 // the parameters (|LayerNorm output| <= sqrt(C) max|w| + max|b|, |hidden| <= max_h(|W1_h|_1 xmax + |b1_h|) < 3e4) and
 // keeps the fp32 kernels otherwise.
 //
-// With the matrix work that cheap the layout changes: one workgroup of FF/32 waves per CU; wave w keeps the W1 rows
-// and W2 columns of hidden units [32 w, 32 w + 32) in REGISTERS as MFMA A-fragments (2 x 64 VGPRs at C = 128) for
-// the whole launch -- no weight traffic through LDS, none per tile.  A tile of 16 rows is
+// With the matrix work that cheap the layout changes: one workgroup of FF/32 = C/16 waves per CU; wave w keeps, as
+// MFMA A-fragments in REGISTERS for the whole launch (2 x 64 VGPRs at C = 128), the W1 rows of hidden units
+// [32 w, 32 w + 32) and the W2 rows of output channels [16 w, 16 w + 16) -- no weight traffic through LDS, none per
+// tile.  A tile of 16 rows is
 //   A. loaded row-wise by the whole workgroup (a lane = 4 channels of a row: coalesced 512-byte rows, the residual
 //      input built on the fly, LayerNorm by a DPP reduction over the row's lanes), split and written to LDS as the
-//      B-fragments of GEMM1 (8 KB);
-//   B. multiplied by every wave with ITS W1 slice: u^T[32 hidden][16 rows]; the accumulator layout of the 16x16 MFMA
-//      is again the B-operand layout of the next one (k slot (g, j) <-> hidden 16 (j / 4) + 4 g + j % 4), so u is split
-//      in place and multiplied by the wave's W2 slice: a partial y over 32 of the FF hidden units;
-//   C. the FF/32 partial tiles go through LDS and are added in wave order (fixed: deterministic) by the lane that
-//      still holds x for that row piece: y = x + sum + b2, the next block's LayerNorm, coalesced stores.
-// The (N, FF) hidden activations never exist in memory and x is read once: 76 MB of HBM traffic per FFN instead of
-// 270 MB.  Two workgroup barriers per tile; the next tile's row gathers are issued before the MFMA phases.
+//      B-fragments of GEMM1 (8 KB);                                                                     [barrier]
+//   B. multiplied by every wave with ITS W1 slice: u^T[32 hidden][16 rows].  The accumulator layout of the 16x16 MFMA
+//      is the B-operand layout of the next one (k slot (g, j) <-> hidden 16 (j / 4) + 4 g + j % 4), so u is split in
+//      place and published as this wave's k-slice of GEMM2's B-fragments (2 KB per wave);               [barrier]
+//   C. every wave multiplies ALL k-slices by its W2 rows: 16 output channels x 16 rows, complete sums in a fixed
+//      order (deterministic), + b2, into a 16 x C tile in LDS;                                          [barrier]
+//   D. the lane that still holds x for a row piece adds it, applies the next block's LayerNorm and stores whole rows.
+// The (N, FF) hidden activations never exist in memory and x is read once: 131 MB of HBM traffic per FFN at 74k rows
+// instead of 270 MB.  The phases of consecutive tiles are software-pipelined (see the loop) so that each barrier
+// interval has one MFMA phase and one row-wise phase: two barriers per tile.  (First version: split-K over
+// the hidden units in GEMM2 with the FF/32 partial tiles summed through LDS -- 128 more VALU instructions per wave
+// and tile for the partial epilogues than the third barrier costs; the phases are VALU-issue bound, not MFMA bound.)
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
@@ -773,6 +778,14 @@ __device__ __forceinline__ void ffw_split4(const float v0, const float v1, const
 __device__ __forceinline__ h16x8 ffw_cat(const h16x4 a, const h16x4 b) {
     return h16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
+__device__ __forceinline__ void ffw_split8(const float *p0, const float *p1, h16x8 &hi, h16x8 &lo) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(p0), v1 = *reinterpret_cast<const float4 *>(p1);
+    h16x4 h0, l0, h1, l1;
+    ffw_split4(v0.x, v0.y, v0.z, v0.w, h0, l0);
+    ffw_split4(v1.x, v1.y, v1.z, v1.w, h1, l1);
+    hi = ffw_cat(h0, h1);
+    lo = ffw_cat(l0, l1);
+}
 
 template <int L>
 __device__ __forceinline__ float ffw_row_sum(float v) {  // all-reduce over L consecutive lanes (L = 8, 16, 32)
@@ -784,22 +797,81 @@ __device__ __forceinline__ float ffw_row_sum(float v) {  // all-reduce over L co
     return v;
 }
 
+// A-fragments of wave wv, lane (la, g): W1 rows 32 wv + 16 T + la, k slot (g, j) <-> channel 32 P + 8 g + j;
+// W2 rows 16 wv + la, k slice ks: k slot (g, j) <-> hidden 32 ks + 16 (j / 4) + 4 g + j % 4 (the accumulator layout of GEMM1)
 template <int C, int FF>
-__global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a) {
-    constexpr int NW = FF / 32, NP = C / 32, NTC = C / 16, LPR = C / 4, RPW = MSSVT_WAVE / LPR, PS = C + 4;
-    static_assert(FF == 2 * C && NW * RPW == 16 && (LPR == 8 || LPR == 16 || LPR == 32), "16 rows per workgroup tile");
+__device__ __forceinline__ void ffw_weight_frags(const float *W1, const float *W2, int wv, int la, int g,
+                                                 h16x8 (&W1h)[2][C / 32], h16x8 (&W1l)[2][C / 32], h16x8 (&W2h)[FF / 32],
+                                                 h16x8 (&W2l)[FF / 32]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int P = 0; P < C / 32; ++P) {
+            const float *src = W1 + (size_t)(32 * wv + 16 * T + la) * C + 32 * P + 8 * g;
+            ffw_split8(src, src + 4, W1h[T][P], W1l[T][P]);
+        }
+#pragma unroll
+    for (int ks = 0; ks < FF / 32; ++ks) {
+        const float *src = W2 + (size_t)(16 * wv + la) * FF + 32 * ks + 4 * g;
+        ffw_split8(src, src + 16, W2h[ks], W2l[ks]);
+    }
+}
+
+// the fragments of all waves, split once per parameter version: [wave][fragment][lane] x 16 bytes
+template <int C, int FF>
+__global__ void __launch_bounds__(MSSVT_WAVE) k_ffn_pack(const float *W1, const float *W2, h16x8 *packed) {
+    constexpr int NP = C / 32, NW = FF / 32, NF = 4 * NP + 2 * NW;
+    const int wv = blockIdx.x, lane = lane_id();
+    h16x8 W1h[2][NP], W1l[2][NP], W2h[NW], W2l[NW];
+    ffw_weight_frags<C, FF>(W1, W2, wv, lane & 15, lane >> 4, W1h, W1l, W2h, W2l);
+    h16x8 *dst = packed + (size_t)wv * NF * 64 + lane;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int P = 0; P < NP; ++P) {
+            dst[((T * NP + P) * 2) * 64] = W1h[T][P];
+            dst[((T * NP + P) * 2 + 1) * 64] = W1l[T][P];
+        }
+#pragma unroll
+    for (int ks = 0; ks < NW; ++ks) {
+        dst[(4 * NP + 2 * ks) * 64] = W2h[ks];
+        dst[(4 * NP + 2 * ks + 1) * 64] = W2l[ks];
+    }
+}
+
+#ifdef MSSVT_STAMPS
+__device__ unsigned long long g_ws_stamps[4 * 8 * 16];  // [block < 4][wave][phase]
+extern "C" int mssvt_debug_read_ffn_ws_stamps(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws_stamps), sizeof(g_ws_stamps));
+}
+#define WSTAMP(k_) { const unsigned long long t_ = __builtin_readcyclecounter(); ws_acc[k_] += t_ - ws_t; ws_t = t_; }
+#else
+#define WSTAMP(k_)
+#endif
+
+template <int C, int FF, bool TABBED, bool NORM2>
+__global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a, const h16x8 *packed) {
+#ifdef MSSVT_STAMPS
+    unsigned long long ws_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ws_t = __builtin_readcyclecounter();
+    int ws_tiles = 0;
+#endif
+    constexpr int NW = FF / 32, NP = C / 32, LPR = C / 4, RPW = MSSVT_WAVE / LPR, PS = C + 4;
+    static_assert(FF == 2 * C && NW * RPW == 16 && NW * 16 == C && (LPR == 8 || LPR == 16 || LPR == 32),
+                  "16 rows per workgroup tile, one 16-channel output tile per wave");
     extern __shared__ float4 lds4[];
-    h16x8 *bfrag = reinterpret_cast<h16x8 *>(lds4);                                       // [NP][hi | lo][64 lanes]
-    float *part = reinterpret_cast<float *>(lds4) + NP * 2 * 64 * 4;                      // [NW][16 rows][PS]
+    h16x8 *bfrag = reinterpret_cast<h16x8 *>(lds4);  // [NP][hi | lo][64 slots]   B operands of GEMM1
+    h16x8 *ufrag = bfrag + NP * 2 * 64;              // [NW][hi | lo][64 lanes]   B operands of GEMM2, one k-slice per wave
+    float *ytile = reinterpret_cast<float *>(ufrag + NW * 2 * 64);  // [16 rows][PS]
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / MSSVT_WAVE);
     const int r = wv * RPW + lane / LPR, q = lane % LPR;  // row-wise view: row of the tile, channels [4 q, 4 q + 4)
     const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
     const int tiles = (n + 15) >> 4;
     if (n <= 0 || (int)blockIdx.x >= tiles) return;
-    const bool tabbed = a.tab_row != nullptr;
 
-    // ---- the first tile's rows are requested before the weights (both pure latency) -------------------------
+    // Rows past the end are CLAMPED to row n - 1 everywhere (table, gathers, stores): such lanes compute exactly what the
+    // lanes of row n - 1 compute and store the same values to the same place -- no predication, hence no branches
+    // inside the barrier intervals (the scheduler interleaves MFMA and VALU only within one basic block).
     int tile = blockIdx.x;
     int4 tr = make_int4(0, 0, 0, 0);
     float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -807,15 +879,15 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a)
 #define FFW_TAB(tile_, tr_, tw_, own_)                                                                      \
     {                                                                                                       \
         const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
-        if (tabbed) { tr_ = a.tab_row[row_]; tw_ = a.tab_w[row_]; }                                         \
+        if (TABBED) { tr_ = a.tab_row[row_]; tw_ = a.tab_w[row_]; }                                         \
         else if (a.owner) own_ = a.owner[row_];                                                             \
     }
     float4 rx, r1, r2, r3;
-    float w1, w2, w3, wx;
+    float w1 = 0.f, w2 = 0.f, w3 = 0.f, wx = 1.f;
 #define FFW_ISSUE(tile_, tr_, tw_, own_)                                                                    \
     {                                                                                                       \
         const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
-        if (tabbed) {                                                                                       \
+        if (TABBED) {                                                                                       \
             const bool un_ = tr_.x < 0; /* unowned voxel: 2 x_in; re-reads its own finite row with weight 0 */ \
             const float *px_ = a.x_in + (size_t)row_ * C + 4 * q;                                           \
             rx = *reinterpret_cast<const float4 *>(px_);                                                    \
@@ -829,158 +901,198 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a)
             wx = dbl_ ? 2.0f : 1.0f;                                                                        \
         }                                                                                                   \
     }
+#define FFW_COMBINE(x_)                                                                                     \
+    if (TABBED) {                                                                                           \
+        x_.x = ((r1.x * w1 + r2.x * w2) + r3.x * w3) + rx.x * wx;                                           \
+        x_.y = ((r1.y * w1 + r2.y * w2) + r3.y * w3) + rx.y * wx;                                           \
+        x_.z = ((r1.z * w1 + r2.z * w2) + r3.z * w3) + rx.z * wx;                                           \
+        x_.w = ((r1.w * w1 + r2.w * w2) + r3.w * w3) + rx.w * wx;                                           \
+    } else {                                                                                                \
+        x_ = make_float4(rx.x * wx, rx.y * wx, rx.z * wx, rx.w * wx);                                       \
+    }
+    // LayerNorm (norm2) over the row's LPR lanes, split, B fragments of GEMM1.  channel 4 q = 32 P + 8 gq + j0: fragment
+    // P, lane (la = r, g = gq), halves j0 .. j0 + 3.  Slot of lane (la, g) inside a fragment: 16 g + ((la + 4 g + P) & 15)
+    // -- the 16 (P, gq) writers of a row hit 16 different 16-byte bank groups (plain 16 g + la: all of them the same
+    // one), the readers of a 16-lane phase still 16 different
+#define FFW_NORM_TO_BFRAG(x_)                                                                               \
+    {                                                                                                       \
+        const float mean_ = ffw_row_sum<LPR>((x_.x + x_.y) + (x_.z + x_.w)) * (1.0f / C);                   \
+        const float d0_ = x_.x - mean_, d1_ = x_.y - mean_, d2_ = x_.z - mean_, d3_ = x_.w - mean_;         \
+        const float var_ = ffw_row_sum<LPR>(                                                                \
+            __builtin_fmaf(d3_, d3_, __builtin_fmaf(d2_, d2_, __builtin_fmaf(d1_, d1_, d0_ * d0_))));       \
+        const float rstd_ = rsqrtf(var_ * (1.0f / C) + a.eps);                                              \
+        h16x4 hi_, lo_;                                                                                     \
+        ffw_split4(d0_ * rstd_ * lnw.x + lnb.x, d1_ * rstd_ * lnw.y + lnb.y, d2_ * rstd_ * lnw.z + lnb.z,   \
+                   d3_ * rstd_ * lnw.w + lnb.w, hi_, lo_);                                                  \
+        const int P_ = q >> 3, gq_ = (q >> 1) & 3, j0_ = (q & 1) * 4;                                       \
+        h16x4 *dst_ = reinterpret_cast<h16x4 *>(bfrag + (P_ * 2) * 64 + 16 * gq_ + ((r + 4 * gq_ + P_) & 15)) + (j0_ >> 2); \
+        dst_[0] = hi_;                                                                                      \
+        dst_[64 * 2] = lo_; /* the lo fragment follows the hi fragment: 64 slots x 2 h16x4 */               \
+    }
+    // u^T = relu(W1 xn + b1) for this wave's 32 hidden units -> its k-slice of GEMM2's B operand
+#define FFW_GEMM1()                                                                                         \
+    {                                                                                                       \
+        f32x4 um_[2], ul_[2], uk_[2]; /* hi hi | hi lo | lo hi: six independent accumulation chains */      \
+        h16x8 bh_[NP], bl_[NP];                                                                             \
+        _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                                   \
+            const int slot_ = 16 * g + ((la + 4 * g + P) & 15);                                             \
+            bh_[P] = bfrag[(P * 2) * 64 + slot_];                                                           \
+            bl_[P] = bfrag[(P * 2 + 1) * 64 + slot_];                                                       \
+        }                                                                                                   \
+        _Pragma("unroll") for (int T = 0; T < 2; ++T) {                                                    \
+            um_[T] = f32x4{bias1[T][0], bias1[T][1], bias1[T][2], bias1[T][3]};                             \
+            ul_[T] = f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
+            uk_[T] = f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
+        }                                                                                                   \
+        _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                                   \
+            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(um_[T], W1h[T][P], bh_[P]);               \
+            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(ul_[T], W1h[T][P], bl_[P]);               \
+            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(uk_[T], W1l[T][P], bh_[P]);               \
+        }                                                                                                   \
+        h16x4 h0_, l0_, h1_, l1_;                                                                           \
+        ffw_split4(FFW_U(0, 0), FFW_U(0, 1), FFW_U(0, 2), FFW_U(0, 3), h0_, l0_);                           \
+        ffw_split4(FFW_U(1, 0), FFW_U(1, 1), FFW_U(1, 2), FFW_U(1, 3), h1_, l1_);                           \
+        ufrag[(wv * 2) * 64 + lane] = ffw_cat(h0_, h1_);                                                    \
+        ufrag[(wv * 2 + 1) * 64 + lane] = ffw_cat(l0_, l1_);                                                \
+    }
+#define FFW_U(T_, i_) fmaxf(__builtin_fmaf(ul_[T_][i_] + uk_[T_][i_], FFW_INV, um_[T_][i_]), 0.f)
+
+    // ---- the first tile's rows are requested before the weights (both pure latency) -------------------------
     FFW_TAB(tile, tr, tw, own)
     FFW_ISSUE(tile, tr, tw, own)
     int4 trn = tr;
     float4 twn = tw;
     int ownn = own;
-    if (tile + (int)gridDim.x < tiles) FFW_TAB(tile + (int)gridDim.x, trn, twn, ownn)
+    FFW_TAB(min(tile + (int)gridDim.x, tiles - 1), trn, twn, ownn)
 
-    // ---- this wave's weight slices -> A fragments (lane (la, g): row la of the tile, k slots 8 g .. 8 g + 7) ---
-    h16x8 W1h[2][NP], W1l[2][NP], W2h[NTC], W2l[NTC];
+    // ---- this wave's weight slices as A fragments: pre-split by k_ffn_pack, or split here ---------------------
+    h16x8 W1h[2][NP], W1l[2][NP], W2h[NW], W2l[NW];
+    if (packed) {
+        const h16x8 *src = packed + (size_t)wv * (4 * NP + 2 * NW) * 64 + lane;
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                W1h[T][P] = src[((T * NP + P) * 2) * 64];
+                W1l[T][P] = src[((T * NP + P) * 2 + 1) * 64];
+            }
+#pragma unroll
+        for (int ks = 0; ks < NW; ++ks) {
+            W2h[ks] = src[(4 * NP + 2 * ks) * 64];
+            W2l[ks] = src[(4 * NP + 2 * ks + 1) * 64];
+        }
+    } else {
+        ffw_weight_frags<C, FF>(a.W1, a.W2, wv, la, g, W1h, W1l, W2h, W2l);
+    }
     float bias1[2][4];
 #pragma unroll
-    for (int T = 0; T < 2; ++T) {
-        const int h = 32 * wv + 16 * T;
+    for (int T = 0; T < 2; ++T)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias1[T][i] = a.b1[h + 4 * g + i];
-#pragma unroll
-        for (int P = 0; P < NP; ++P) {  // k slot (g, j) <-> channel 32 P + 8 g + j
-            const float *src = a.W1 + (size_t)(h + la) * C + 32 * P + 8 * g;
-            const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
-            h16x4 h0, l0, h1, l1;
-            ffw_split4(v0.x, v0.y, v0.z, v0.w, h0, l0);
-            ffw_split4(v1.x, v1.y, v1.z, v1.w, h1, l1);
-            W1h[T][P] = ffw_cat(h0, h1);
-            W1l[T][P] = ffw_cat(l0, l1);
-        }
-    }
-#pragma unroll
-    for (int tc = 0; tc < NTC; ++tc) {  // k slot (g, j) <-> hidden 32 wv + 16 (j / 4) + 4 g + j % 4
-        const float *src = a.W2 + (size_t)(16 * tc + la) * FF + 32 * wv + 4 * g;
-        const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 16);
-        h16x4 h0, l0, h1, l1;
-        ffw_split4(v0.x, v0.y, v0.z, v0.w, h0, l0);
-        ffw_split4(v1.x, v1.y, v1.z, v1.w, h1, l1);
-        W2h[tc] = ffw_cat(h0, h1);
-        W2l[tc] = ffw_cat(l0, l1);
-    }
+        for (int i = 0; i < 4; ++i) bias1[T][i] = a.b1[32 * wv + 16 * T + 4 * g + i];
+    const float4 bias2 = *reinterpret_cast<const float4 *>(a.b2 + 16 * wv + 4 * g);  // MFMA view: channels 16 wv + 4 g + i
     // row-wise constants of this lane's 4 channels
     const float4 lnw = *reinterpret_cast<const float4 *>(a.ln_w + 4 * q), lnb = *reinterpret_cast<const float4 *>(a.ln_b + 4 * q);
-    const float4 bias2 = *reinterpret_cast<const float4 *>(a.b2 + 4 * q);
     float4 ln2w = make_float4(0.f, 0.f, 0.f, 0.f), ln2b = ln2w;
-    if (a.y_norm) {
+    if (NORM2) {
         ln2w = *reinterpret_cast<const float4 *>(a.ln2_w + 4 * q);
         ln2b = *reinterpret_cast<const float4 *>(a.ln2_b + 4 * q);
     }
 
+    // Software pipeline over the tiles, two barrier intervals per tile, each holding one MFMA phase and one row-wise
+    // (VALU / memory) phase of a DIFFERENT tile so that the matrix pipe and the vector ALU overlap:
+    //   I2(t) = { GEMM2(t) -> y tile  |  A(t+1): x, LayerNorm, split -> B fragments; row gathers of t+2 leave }  [barrier]
+    //   I1(t) = { D(t): y tile + x -> y, next LayerNorm, stores  |  GEMM1(t+1) -> this wave's k-slice of u }     [barrier]
+    // bfrag(t+1) is written while the others may still be in GEMM2(t) (everybody is past GEMM1(t)); ufrag(t+1) and the
+    // reads of ytile(t) share an interval (everybody is past GEMM2(t)).  Past the last tile the pipeline repeats the
+    // last tile (A and GEMM1 once more, results unused) instead of branching.
+    float4 xc;
+    FFW_COMBINE(xc)
+    {
+        const int t1 = min(tile + (int)gridDim.x, tiles - 1);
+        FFW_ISSUE(t1, trn, twn, ownn)
+        FFW_TAB(min(t1 + (int)gridDim.x, tiles - 1), trn, twn, ownn)
+    }
+    FFW_NORM_TO_BFRAG(xc)
+    __syncthreads();
+    FFW_GEMM1()
+    WSTAMP(0)
+    __syncthreads();
     for (;;) {
         const int tile_next = tile + gridDim.x;
         const bool has_next = tile_next < tiles;
-        const bool live = tile * 16 + r < n;
-        const size_t row = (size_t)min(tile * 16 + r, n - 1);
-        // ---- A. x of this lane's row piece; the next tile's gathers leave now ----------------------------------
-        float4 x;
-        if (tabbed) {
-            x.x = ((r1.x * w1 + r2.x * w2) + r3.x * w3) + rx.x * wx;
-            x.y = ((r1.y * w1 + r2.y * w2) + r3.y * w3) + rx.y * wx;
-            x.z = ((r1.z * w1 + r2.z * w2) + r3.z * w3) + rx.z * wx;
-            x.w = ((r1.w * w1 + r2.w * w2) + r3.w * w3) + rx.w * wx;
-        } else {
-            x = make_float4(rx.x * wx, rx.y * wx, rx.z * wx, rx.w * wx);
-        }
-        if (has_next) {
-            FFW_ISSUE(tile_next, trn, twn, ownn)
-            if (tile_next + (int)gridDim.x < tiles) FFW_TAB(tile_next + (int)gridDim.x, trn, twn, ownn)
-        }
-        {   // LayerNorm (norm2) over the row's LPR lanes, split, B fragments of GEMM1
-            const float mean = ffw_row_sum<LPR>((x.x + x.y) + (x.z + x.w)) * (1.0f / C);
-            const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
-            const float var = ffw_row_sum<LPR>(__builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0))));
-            const float rstd = rsqrtf(var * (1.0f / C) + a.eps);
-            h16x4 hi, lo;
-            ffw_split4(d0 * rstd * lnw.x + lnb.x, d1 * rstd * lnw.y + lnb.y, d2 * rstd * lnw.z + lnb.z, d3 * rstd * lnw.w + lnb.w,
-                       hi, lo);
-            // channel 4 q = 32 P + 8 gq + j0: fragment P, lane 16 gq + r, halves j0 .. j0 + 3
-            const int P = q >> 3, gq = (q >> 1) & 3, j0 = (q & 1) * 4;
-            h16x4 *dst = reinterpret_cast<h16x4 *>(bfrag + (P * 2) * 64 + 16 * gq + r) + (j0 >> 2);
-            dst[0] = hi;
-            dst[64 * 2] = lo;  // the lo fragment follows the hi fragment: 64 lanes x 2 h16x4
-        }
-        __syncthreads();
-        // ---- B. u^T = relu(W1 xn + b1) for this wave's 32 hidden units, then its share of W2 u --------------------
-        f32x4 um[2], ul[2];
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            um[T] = f32x4{bias1[T][0], bias1[T][1], bias1[T][2], bias1[T][3]};
-            ul[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int P = 0; P < NP; ++P) {
-            const h16x8 bh = bfrag[(P * 2) * 64 + lane], bl = bfrag[(P * 2 + 1) * 64 + lane];
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                MFMA_H(um[T], W1h[T][P], bh);
-                MFMA_H(ul[T], W1h[T][P], bl);
-                MFMA_H(ul[T], W1l[T][P], bh);
-            }
-        }
-        h16x8 uh, ulo;
+        const int t1 = has_next ? tile_next : tile;  // the tile whose A / GEMM1 run in this iteration
+        WSTAMP(1)
+        // ---- I2: GEMM2(t): this wave's 16 output channels over all k-slices | A(t1) ------------------------------
+        float4 xn;
         {
-            h16x4 h0, l0, h1, l1;
-            ffw_split4(fmaxf(um[0][0] + ul[0][0] * FFW_INV, 0.f), fmaxf(um[0][1] + ul[0][1] * FFW_INV, 0.f),
-                       fmaxf(um[0][2] + ul[0][2] * FFW_INV, 0.f), fmaxf(um[0][3] + ul[0][3] * FFW_INV, 0.f), h0, l0);
-            ffw_split4(fmaxf(um[1][0] + ul[1][0] * FFW_INV, 0.f), fmaxf(um[1][1] + ul[1][1] * FFW_INV, 0.f),
-                       fmaxf(um[1][2] + ul[1][2] * FFW_INV, 0.f), fmaxf(um[1][3] + ul[1][3] * FFW_INV, 0.f), h1, l1);
-            uh = ffw_cat(h0, h1);
-            ulo = ffw_cat(l0, l1);
-        }
-        float *pw = part + (size_t)wv * 16 * PS + la * PS + 4 * g;  // lane (row la, g): channels 16 tc + 4 g .. + 3
+            f32x4 m = f32x4{bias2.x, bias2.y, bias2.z, bias2.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
 #pragma unroll
-        for (int tc = 0; tc < NTC; ++tc) {
-            f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f}, l = m;
-            MFMA_H(m, W2h[tc], uh);
-            MFMA_H(l, W2h[tc], ulo);
-            MFMA_H(l, W2l[tc], uh);
-            *reinterpret_cast<float4 *>(pw + 16 * tc) =
-                make_float4(m[0] + l[0] * FFW_INV, m[1] + l[1] * FFW_INV, m[2] + l[2] * FFW_INV, m[3] + l[3] * FFW_INV);
+            for (int ks = 0; ks < NW; ++ks) {
+                const h16x8 uh = ufrag[(ks * 2) * 64 + lane], ulo = ufrag[(ks * 2 + 1) * 64 + lane];
+                MFMA_H(m, W2h[ks], uh);
+                MFMA_H(l, W2h[ks], ulo);
+                MFMA_H(k, W2l[ks], uh);
+            }
+            FFW_COMBINE(xn)
+            {
+                const int t2 = min(t1 + (int)gridDim.x, tiles - 1);
+                FFW_ISSUE(t2, trn, twn, ownn)
+                FFW_TAB(min(t2 + (int)gridDim.x, tiles - 1), trn, twn, ownn)
+            }
+            FFW_NORM_TO_BFRAG(xn)
+            *reinterpret_cast<float4 *>(ytile + la * PS + 16 * wv + 4 * g) =
+                make_float4(__builtin_fmaf(l[0] + k[0], FFW_INV, m[0]), __builtin_fmaf(l[1] + k[1], FFW_INV, m[1]),
+                            __builtin_fmaf(l[2] + k[2], FFW_INV, m[2]), __builtin_fmaf(l[3] + k[3], FFW_INV, m[3]));
         }
+        WSTAMP(2)
         __syncthreads();
-        // ---- C. y = x + b2 + sum over the waves' partial tiles, in wave order ---------------------------------------
-        float4 y = bias2;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float4 pv = *reinterpret_cast<const float4 *>(part + (size_t)w * 16 * PS + r * PS + 4 * q);
-            y.x += pv.x; y.y += pv.y; y.z += pv.z; y.w += pv.w;
-        }
-        y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
-        if (live) *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = y;
-        if (a.y_norm) {
-            const float mean = ffw_row_sum<LPR>((y.x + y.y) + (y.z + y.w)) * (1.0f / C);
-            const float d0 = y.x - mean, d1 = y.y - mean, d2 = y.z - mean, d3 = y.w - mean;
-            const float var = ffw_row_sum<LPR>(__builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0))));
-            const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
-            if (live)
+        WSTAMP(3)
+        // ---- I1: D(t): y = x + (W2 u + b2), the next block's LayerNorm, whole rows out | GEMM1(t1) ------------------
+        {
+            const size_t row = (size_t)min(tile * 16 + r, n - 1);
+            float4 y = *reinterpret_cast<const float4 *>(ytile + r * PS + 4 * q);
+            y.x += xc.x; y.y += xc.y; y.z += xc.z; y.w += xc.w;
+            *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = y;
+            if (NORM2) {
+                const float mean = ffw_row_sum<LPR>((y.x + y.y) + (y.z + y.w)) * (1.0f / C);
+                const float d0 = y.x - mean, d1 = y.y - mean, d2 = y.z - mean, d3 = y.w - mean;
+                const float var = ffw_row_sum<LPR>(__builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0))));
+                const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
                 *reinterpret_cast<float4 *>(a.y_norm + row * C + 4 * q) =
                     make_float4(d0 * rstd * ln2w.x + ln2b.x, d1 * rstd * ln2w.y + ln2b.y, d2 * rstd * ln2w.z + ln2b.z,
                                 d3 * rstd * ln2w.w + ln2b.w);
+            }
+            FFW_GEMM1()
         }
+        WSTAMP(4)
+        __syncthreads();
+        WSTAMP(5)
+#ifdef MSSVT_STAMPS
+        ++ws_tiles;
+#endif
+        xc = xn;
         if (!has_next) break;
         tile = tile_next;
     }
+    WSTAMP(6)
+#undef FFW_COMBINE
+#undef FFW_NORM_TO_BFRAG
+#undef FFW_GEMM1
+#undef FFW_U
+#ifdef MSSVT_STAMPS
+    if (lane == 0 && blockIdx.x < 4) {
+        for (int k = 0; k < 7; ++k) g_ws_stamps[(blockIdx.x * 8 + (wv & 7)) * 16 + k] = ws_acc[k];
+        g_ws_stamps[(blockIdx.x * 8 + (wv & 7)) * 16 + 9] = ws_tiles;
+    }
+#endif
 #undef FFW_TAB
 #undef FFW_ISSUE
 }
 
 template <int C, int FF>
-static int launch_ffn_ws(const FfnArgs &a, hipStream_t stream) {
+static int launch_ffn_ws(const FfnArgs &a, const void *packed, hipStream_t stream) {
     constexpr int NW = FF / 32;
-    const size_t lds = (size_t)(C / 32) * 2 * 64 * 16 + (size_t)NW * 16 * (C + 4) * 4;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ffn_ws<C, FF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
+    const size_t lds = (size_t)(C / 32 + NW) * 2 * 64 * 16 + (size_t)16 * (C + 4) * 4;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -989,8 +1101,36 @@ static int launch_ffn_ws(const FfnArgs &a, hipStream_t stream) {
     int grid = cus * (NW >= 8 ? 1 : 8 / NW);  // 8 waves per CU
     if (grid > tiles) grid = tiles;
     if (grid < 1) return MSSVT_OK;
-    k_ffn_ws<C, FF><<<grid, NW * MSSVT_WAVE, lds, stream>>>(a);
+    const h16x8 *pk = reinterpret_cast<const h16x8 *>(packed);
+    const dim3 block(NW * MSSVT_WAVE);
+    if (a.tab_row) {
+        if (a.y_norm) k_ffn_ws<C, FF, true, true><<<grid, block, lds, stream>>>(a, pk);
+        else k_ffn_ws<C, FF, true, false><<<grid, block, lds, stream>>>(a, pk);
+    } else {
+        if (a.y_norm) k_ffn_ws<C, FF, false, true><<<grid, block, lds, stream>>>(a, pk);
+        else k_ffn_ws<C, FF, false, false><<<grid, block, lds, stream>>>(a, pk);
+    }
     return mssvt_launch_status();
+}
+
+template <int C, int FF>
+static int launch_ffn_pack(const float *W1, const float *W2, void *packed, hipStream_t stream) {
+    k_ffn_pack<C, FF><<<FF / 32, MSSVT_WAVE, 0, stream>>>(W1, W2, reinterpret_cast<h16x8 *>(packed));
+    return mssvt_launch_status();
+}
+
+extern "C" long long mssvt_ffn_packed_bytes(int C, int FF) {
+    if (!((C == 128 && FF == 256) || (C == 64 && FF == 128) || (C == 32 && FF == 64))) return 0;
+    return (long long)(FF / 32) * (4 * (C / 32) + 2 * (FF / 32)) * 64 * 16;
+}
+
+extern "C" int mssvt_ffn_pack_weights(int C, int FF, const float *W1, const float *W2, void *packed, void *stream) {
+    if (!W1 || !W2 || !packed) return MSSVT_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 128 && FF == 256) return launch_ffn_pack<128, 256>(W1, W2, packed, st);
+    if (C == 64 && FF == 128) return launch_ffn_pack<64, 128>(W1, W2, packed, st);
+    if (C == 32 && FF == 64) return launch_ffn_pack<32, 64>(W1, W2, packed, st);
+    return MSSVT_E_TOOLARGE;
 }
 
 template <int C, int FF>
@@ -1022,10 +1162,11 @@ static int launch_ffn_split(const FfnArgs &a, float *hidden, int phases, hipStre
 }
 
 static int dispatch_ffn(int C, int FF, const FfnArgs &a, float *hidden, int phases, hipStream_t st) {
-    if (phases == 4) {  // single launch, split fp16 operands (the caller has checked their range)
-        if (C == 128 && FF == 256) return launch_ffn_ws<128, 256>(a, st);
-        if (C == 64 && FF == 128) return launch_ffn_ws<64, 128>(a, st);
-        if (C == 32 && FF == 64) return launch_ffn_ws<32, 64>(a, st);
+    if (phases == 4) {  // single launch, split fp16 operands (the caller has checked their range); hidden = the
+                        // fragments of mssvt_ffn_pack_weights, or NULL: split in the kernel's prologue
+        if (C == 128 && FF == 256) return launch_ffn_ws<128, 256>(a, hidden, st);
+        if (C == 64 && FF == 128) return launch_ffn_ws<64, 128>(a, hidden, st);
+        if (C == 32 && FF == 64) return launch_ffn_ws<32, 64>(a, hidden, st);
         return MSSVT_E_TOOLARGE;
     }
     if (hidden) {

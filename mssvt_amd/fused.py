@@ -410,20 +410,27 @@ def _ffn_refs(block):
 
 
 @torch.no_grad()
-def _ffn_f16_range_ok(fr):
-    """True when the operands of the split-fp16 FFN stay inside the fp16 range whatever the input rows are: a
-    LayerNorm output is bounded by sqrt(C) max|w| + max|b|, a hidden activation by max_h(|W1_h|_1 xmax + |b1_h|).
-    Evaluated once per parameter version (one small host sync)."""
+def _ffn_f16_weights(fr):
+    """The split-fp16 fragments of W1 / W2 (mssvt_ffn_pack_weights) when the operands of the split-fp16 FFN stay inside
+    the fp16 range whatever the input rows are, else None: a LayerNorm output is bounded by sqrt(C) max|w| + max|b|, a
+    hidden activation by max_h(|W1_h|_1 xmax + |b1_h|).  Evaluated once per parameter version (one small host sync)."""
     ts = (fr["W1"], fr["b1"], fr["W2"], fr["b2"], fr["lnw"], fr["lnb"])
-    ver = tuple(t._version for t in ts)
+    ver = tuple(t._version for t in ts) + (fr["W1"].data_ptr(), fr["W2"].data_ptr())
     if fr.get("f16_ver") != ver:
         W1, b1, W2, b2, lnw, lnb = [t.detach().float() for t in ts]
         xmax = (fr["C"] ** 0.5) * lnw.abs().max() + lnb.abs().max()
         hmax = (W1.abs().sum(1) * xmax + b1.abs()).max()
         worst = torch.stack([xmax, hmax, W1.abs().max(), W2.abs().max()]).max()
-        fr["f16_ok"] = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
+        ok = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
+        packed = None
+        if ok:
+            nbytes = int(_lib.lib().mssvt_ffn_packed_bytes(_i(fr["C"]), _i(fr["FF"])))
+            packed = torch.empty((nbytes,), dtype=torch.uint8, device=fr["W1"].device)
+            _lib.call("mssvt_ffn_pack_weights", _i(fr["C"]), _i(fr["FF"]), _lib.ptr(fr["W1"].detach().contiguous()),
+                      _lib.ptr(fr["W2"].detach().contiguous()), _lib.ptr(packed), _lib.stream())
+        fr["f16_packed"] = packed
         fr["f16_ver"] = ver
-    return fr["f16_ok"]
+    return fr["f16_packed"]
 
 
 def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=None, apply_out=True, phases=3):
@@ -446,11 +453,14 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=No
         y_norm = None
         if nxt is not None and not has_out and nxt.normalized_shape[0] == C:
             y_norm = torch.empty_like(x_new)
-        if phases == 3 and getattr(block, "ffn_arith", FFN_ARITH) == "f16x3" and _ffn_f16_range_ok(fr):
-            phases = 4  # one launch, split fp16 operands, no hidden scratch
+        packed = None
+        if phases == 3 and getattr(block, "ffn_arith", FFN_ARITH) == "f16x3":
+            packed = _ffn_f16_weights(fr)
+            if packed is not None:
+                phases = 4  # one launch, split fp16 operands, no hidden scratch
         # fp32 MFMA: two launches with LDS-resident weights; the hidden activations go through this scratch
         split = phases != 4 and (FFN_SPLIT or n_rows_dev is not None)  # a device-side row count needs the two-launch form
-        hidden = torch.empty((n, FF), dtype=torch.float32, device=x_new.device) if split else None
+        hidden = torch.empty((n, FF), dtype=torch.float32, device=x_new.device) if split else packed
         tail = (_P(fr["lnw"]), _P(fr["lnb"]), _f(fr["eps"]), _P(fr["W1"]), _P(fr["b1"]), _P(fr["W2"]), _P(fr["b2"]), _P(y),
                 _P(nxt.weight if y_norm is not None else None),
                 _P(nxt.bias if y_norm is not None else None),
