@@ -344,6 +344,10 @@ int mssvt_compress_attention_group(int C, int c0, int Cg, int head_dim, float sc
  * k_ind / win_vstart / win_cnt / pair_win: from mssvt_window_plan_one with disjoint_lists = 1,
  * with_pad = 0.  Wpos1 (C,6), Wpos2 (C,C), Wq (C,C), Wkv (2C,C), Wo (C,C) + biases: the module's
  * parameters.  Scratch: qp (win_capacity,C), ktok (N,C), score (N,C/head_dim), vp (N,C).
+ * split_f16 != 0: the C x C products with every fp32 operand split exactly into two fp16 halves
+ * (3 x v_mfma_f32_16x16x32_f16, fp32 accumulation: the fp32 instruction's error at 3/16 of its
+ * cycles); the CALLER guarantees the fp16 range of xhat, the positional hidden layer, the key
+ * tokens and the V rows (mssvt_amd/fused.py bounds them from the parameters), else pass 0.
  * Instantiated for C in {32,64,128}, head_dim in {8,16,32} (C/head_dim <= 8).               */
 int mssvt_compress_fused(
     int C, int head_dim, float scale, int max_num_win1, int num_voxels, const int *num_wins_dev, int win_capacity,
@@ -351,7 +355,7 @@ int mssvt_compress_fused(
     const int *pair_win, const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3,
     const float *xhat, const float *Wpos1, const float *bpos1, const float *Wpos2, const float *bpos2,
     const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
-    float *qp, float *ktok, float *score, float *vp, float *out, void *stream);
+    float *qp, float *ktok, float *score, float *vp, float *out, int split_f16, void *stream);
 
 /* Rows per sample of a (N,4) [b,z,y,x] int32 index tensor -> counts (B) int32, on the device
  * (ref: the host loops with .item() of mssvt_utils.py:35-37 / mssvt_backbone.py:124-130).   */

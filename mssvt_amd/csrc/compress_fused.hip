@@ -94,6 +94,108 @@ __device__ __forceinline__ void cf_gemm(f32x4 (&acc)[NT], const float *W_l, cons
     }
 }
 
+// ---- the same products with every fp32 operand split exactly into two fp16 halves (see ffn.hip, k_ffn_ws): hi =
+// fp16(v), lo = fp16((v - hi) 2^11); sum a b = sum a_hi b_hi + 2^-11 (sum a_hi b_lo + sum a_lo b_hi), three
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation: the fp32 instruction's error against float64 at 3/16 of its cycles.
+// LDS row of a weight matrix: C halves hi | C halves lo (+ 16 bytes: the same (C + 4)-float stride, conflict free);
+// inside a 32-channel group channel 16 h + 4 g + j sits at half 8 g + 4 h + j, so that lane (row, g) reads its 8 k
+// slots as one ds_read_b128 and the B operand is just the split of x[2 P] | x[2 P + 1] (lane (row, g): channels
+// 32 P + 4 g + j and 32 P + 16 + 4 g + j).  The caller guarantees the fp16 range of the operands (fused.py).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+#define CF_SCALE 2048.0f
+#define CF_INV (1.0f / 2048.0f)
+
+__device__ __forceinline__ void cf_split4(const float v0, const float v1, const float v2, const float v3, h16x4 &hi, h16x4 &lo) {
+    const fp16x2 a = __builtin_amdgcn_cvt_pkrtz(v0, v1), b = __builtin_amdgcn_cvt_pkrtz(v2, v3);
+    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz((v0 - (float)a[0]) * CF_SCALE, (v1 - (float)a[1]) * CF_SCALE);
+    const fp16x2 d = __builtin_amdgcn_cvt_pkrtz((v2 - (float)b[0]) * CF_SCALE, (v3 - (float)b[1]) * CF_SCALE);
+    hi = h16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
+    lo = h16x4{(_Float16)c[0], (_Float16)c[1], (_Float16)d[0], (_Float16)d[1]};
+}
+
+template <int COLS, int LS>
+__device__ __forceinline__ void cf_stage_h(float *dst, const float *src, int rows) {
+    constexpr int UN = 8;
+    const int total = rows * COLS;
+    for (int e0 = threadIdx.x * 4; e0 < total; e0 += blockDim.x * 4 * UN) {
+        float4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * blockDim.x * 4;
+            v[u] = e < total ? *reinterpret_cast<const float4 *>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * blockDim.x * 4;
+            if (e < total) {
+                const int c = e % COLS, c32 = c & 31;  // c32 = 16 h + 4 g (a float4 never straddles a group of 4)
+                const int half = (c - c32) + 8 * ((c32 >> 2) & 3) + 4 * (c32 >> 4);
+                h16x4 hi, lo;
+                cf_split4(v[u].x, v[u].y, v[u].z, v[u].w, hi, lo);
+                _Float16 *row = reinterpret_cast<_Float16 *>(dst + (size_t)(e / COLS) * LS);
+                *reinterpret_cast<h16x4 *>(row + half) = hi;
+                *reinterpret_cast<h16x4 *>(row + COLS + half) = lo;
+            }
+        }
+    }
+}
+
+template <int NT, int LS>
+__device__ __forceinline__ void cf_gemm_h(f32x4 (&acc)[NT], const float *W_l, const f32x4 (&x)[NT], int la, int g) {
+    static_assert(NT % 2 == 0, "32-channel k steps");
+    constexpr int NP = NT / 2, UG = NT > 4 ? 4 : NT;
+    h16x8 xh[NP], xl[NP];
+#pragma unroll
+    for (int P = 0; P < NP; ++P) {
+        h16x4 h0, l0, h1, l1;
+        cf_split4(x[2 * P][0], x[2 * P][1], x[2 * P][2], x[2 * P][3], h0, l0);
+        cf_split4(x[2 * P + 1][0], x[2 * P + 1][1], x[2 * P + 1][2], x[2 * P + 1][3], h1, l1);
+        xh[P] = h16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        xl[P] = h16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NT; u0 += UG) {
+        const _Float16 *wbase = reinterpret_cast<const _Float16 *>(W_l + (size_t)(16 * u0 + la) * LS) + 8 * g;
+        f32x4 lo[UG];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) lo[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int P = 0; P < NP; ++P) {
+            h16x8 wh[UG], wl[UG];
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const _Float16 *wr = wbase + (size_t)u * 16 * LS * 2 + 32 * P;
+                wh[u] = *reinterpret_cast<const h16x8 *>(wr);
+                wl[u] = *reinterpret_cast<const h16x8 *>(wr + 16 * NT);
+            }
+#pragma unroll
+            for (int u = 0; u < UG; ++u) acc[u0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], xh[P], acc[u0 + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) lo[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], xl[P], lo[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) lo[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], xh[P], lo[u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[u0 + u][i] = __builtin_fmaf(lo[u][i], CF_INV, acc[u0 + u][i]);
+    }
+}
+
+template <bool H, int COLS, int LS>
+__device__ __forceinline__ void cf_stage_x(float *dst, const float *src, int rows) {
+    if (H) cf_stage_h<COLS, LS>(dst, src, rows);
+    else cf_stage<COLS, LS>(dst, src, rows);
+}
+template <bool H, int NT, int LS>
+__device__ __forceinline__ void cf_gemm_x(f32x4 (&acc)[NT], const float *W_l, const f32x4 (&x)[NT], int la, int g) {
+    if (H) cf_gemm_h<NT, LS>(acc, W_l, x, la, g);
+    else cf_gemm<NT, LS>(acc, W_l, x, la, g);
+}
+
 // The K4 lists of a tile's 16 windows -> LDS (one coalesced round trip instead of one dependent
 // load per list step); lst[r * ns + s] = global feature row of slot s of window r (or of slot 0 when
 // s >= cnt: a valid row whose contribution is masked by the caller)
@@ -111,13 +213,13 @@ __device__ __forceinline__ void cf_stage_lists(int *lst, const CmpArgs &a, int t
 }
 
 // ---- A: queries ---------------------------------------------------------------------------------
-template <int C>
+template <int C, bool H>
 __device__ __forceinline__ void cmp_query_body(const CmpArgs &a, int block_id, int num_blocks) {
     constexpr int NT = C / 16, LS = C + 4;
     extern __shared__ float4 lds4[];
     float *Wq_l = reinterpret_cast<float *>(lds4), *bq_l = Wq_l + C * LS;
     int *lst = reinterpret_cast<int *>(bq_l + C) + (threadIdx.x / MSSVT_WAVE) * 16 * a.ns;
-    cf_stage<C, LS>(Wq_l, a.Wq, C);
+    cf_stage_x<H, C, LS>(Wq_l, a.Wq, C);
     for (int e = threadIdx.x; e < C; e += blockDim.x) bq_l[e] = a.bq[e];
     __syncthreads();
     const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
@@ -162,7 +264,7 @@ __device__ __forceinline__ void cmp_query_body(const CmpArgs &a, int block_id, i
             const float4 b = *reinterpret_cast<const float4 *>(bq_l + 16 * u + 4 * g);
             acc[u] = f32x4{b.x, b.y, b.z, b.w};
         }
-        cf_gemm<NT, LS>(acc, Wq_l, m, la, g);
+        cf_gemm_x<H, NT, LS>(acc, Wq_l, m, la, g);
         if (live) {
             float *dst = a.qp + (size_t)w * C + 4 * g;
 #pragma unroll
@@ -174,12 +276,12 @@ __device__ __forceinline__ void cmp_query_body(const CmpArgs &a, int block_id, i
 }
 
 // ---- B: key tokens --------------------------------------------------------------------------------
-template <int C>
+template <int C, bool H>
 __device__ __forceinline__ void cmp_keys_body(const CmpArgs &a, int block_id, int num_blocks) {
     constexpr int NT = C / 16, LS = C + 4;
     extern __shared__ float4 lds4[];
     float *W2_l = reinterpret_cast<float *>(lds4), *b2_l = W2_l + C * LS;
-    cf_stage<C, LS>(W2_l, a.Wp2, C);
+    cf_stage_x<H, C, LS>(W2_l, a.Wp2, C);
     for (int e = threadIdx.x; e < C; e += blockDim.x) b2_l[e] = a.bp2[e];
     const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
     // layer 1 as a K = 8 product: inputs d = 4 s + g of step s = (rel.x, rel.y, rel.z, c.x | c.y, c.z, 1, 0);
@@ -225,7 +327,7 @@ __device__ __forceinline__ void cmp_keys_body(const CmpArgs &a, int block_id, in
             const float4 b = *reinterpret_cast<const float4 *>(b2_l + 16 * u + 4 * g);
             acc[u] = f32x4{b.x, b.y, b.z, b.w};
         }
-        cf_gemm<NT, LS>(acc, W2_l, h, la, g);
+        cf_gemm_x<H, NT, LS>(acc, W2_l, h, la, g);
         if (live) {
             float *dst = a.ktok + (size_t)v * C + 4 * g;
             const bool in_list = pw >= 0;  // a voxel in no list (truncated window): finite dummy row
@@ -241,7 +343,7 @@ __device__ __forceinline__ void cmp_keys_body(const CmpArgs &a, int block_id, in
 
 // A and B in ONE launch: they are independent (windows -> qp, voxels -> ktok), and the query side is a
 // latency-bound walk over the window lists that hides under the key side's matrix work.
-template <int C>
+template <int C, bool H>
 __global__ void __launch_bounds__(CFQ_NW *MSSVT_WAVE) k_cmp_query_keys(CmpArgs a, int query_blocks) {
     // roles alternate so that both kinds are resident from the start (dispatch is in block order)
     const int key_blocks = gridDim.x - query_blocks, both = 2 * min(query_blocks, key_blocks);
@@ -249,19 +351,19 @@ __global__ void __launch_bounds__(CFQ_NW *MSSVT_WAVE) k_cmp_query_keys(CmpArgs a
     const bool query = b < both ? (b & 1) == 0 : query_blocks > key_blocks;
     const int id = b < both ? b >> 1 : b - both / 2;
     if (query)
-        cmp_query_body<C>(a, id, query_blocks);
+        cmp_query_body<C, H>(a, id, query_blocks);
     else
-        cmp_keys_body<C>(a, id, key_blocks);
+        cmp_keys_body<C, H>(a, id, key_blocks);
 }
 
 // ---- C: K scores + V rows ---------------------------------------------------------------------------
-template <int C, int HD>
+template <int C, int HD, bool H>
 __global__ void __launch_bounds__(CFK_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
     constexpr int NT = C / 16, LS = C + 4, NH = C / HD;
     static_assert(HD == 8 || HD == 16 || HD == 32, "head dims instantiated: 8, 16, 32");
     extern __shared__ float4 lds4[];
     float *W_l = reinterpret_cast<float *>(lds4), *b_l = W_l + 2 * C * LS;  // [Wk ; Wv] rows, [bk ; bv]
-    cf_stage<C, LS>(W_l, a.Wkv, 2 * C);
+    cf_stage_x<H, C, LS>(W_l, a.Wkv, 2 * C);
     for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) b_l[e] = a.bkv[e];
     __syncthreads();
     const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
@@ -289,7 +391,7 @@ __global__ void __launch_bounds__(CFK_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
             const float4 b = *reinterpret_cast<const float4 *>(b_l + 16 * u + 4 * g);
             acc[u] = f32x4{b.x, b.y, b.z, b.w};
         }
-        cf_gemm<NT, LS>(acc, W_l, x, la, g);
+        cf_gemm_x<H, NT, LS>(acc, W_l, x, la, g);
         float part[NT];
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
@@ -327,7 +429,7 @@ __global__ void __launch_bounds__(CFK_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
             const float4 b = *reinterpret_cast<const float4 *>(b_l + C + 16 * u + 4 * g);
             acc[u] = f32x4{b.x, b.y, b.z, b.w};
         }
-        cf_gemm<NT, LS>(acc, W_l + (size_t)C * LS, x, la, g);
+        cf_gemm_x<H, NT, LS>(acc, W_l + (size_t)C * LS, x, la, g);
         if (live) {
             float *dst = a.vp + (size_t)v * C + 4 * g;
 #pragma unroll
@@ -338,13 +440,13 @@ __global__ void __launch_bounds__(CFK_NW *MSSVT_WAVE) k_cmp_kv(CmpArgs a) {
 }
 
 // ---- D: softmax, weighted V sum, output projection --------------------------------------------------
-template <int C, int HD>
+template <int C, int HD, bool H>
 __global__ void __launch_bounds__(CFO_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
     constexpr int NT = C / 16, LS = C + 4, NH = C / HD;
     extern __shared__ float4 lds4[];
     float *Wo_l = reinterpret_cast<float *>(lds4), *bo_l = Wo_l + C * LS;
     int *lst = reinterpret_cast<int *>(bo_l + C) + (threadIdx.x / MSSVT_WAVE) * 16 * a.ns;
-    cf_stage<C, LS>(Wo_l, a.Wo, C);
+    cf_stage_x<H, C, LS>(Wo_l, a.Wo, C);
     for (int e = threadIdx.x; e < C; e += blockDim.x) bo_l[e] = a.bo[e];
     __syncthreads();
     const int lane = lane_id(), la = lane & 15, g = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
@@ -409,7 +511,7 @@ __global__ void __launch_bounds__(CFO_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
             const float4 b = *reinterpret_cast<const float4 *>(bo_l + 16 * u + 4 * g);
             acc[u] = f32x4{b.x, b.y, b.z, b.w};
         }
-        cf_gemm<NT, LS>(acc, Wo_l, o, la, g);
+        cf_gemm_x<H, NT, LS>(acc, Wo_l, o, la, g);
         if (live) {
             float *dst = a.out + (size_t)w * C + 4 * g;
 #pragma unroll
@@ -429,7 +531,7 @@ static int cf_prepare(K kernel, size_t lds_bytes) {
     return MSSVT_OK;
 }
 
-template <int C, int HD>
+template <int C, int HD, bool H>
 static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t stream) {
     constexpr int LS = C + 4;
     const size_t lds1 = ((size_t)C * LS + C) * 4, lds2 = ((size_t)2 * C * LS + 2 * C) * 4;
@@ -437,8 +539,8 @@ static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t strea
     const size_t lds_q = lds1 + (size_t)CFQ_NW * 16 * a.ns * 4, lds_o = lds1 + (size_t)CFO_NW * 16 * a.ns * 4;
     if (lds_q > 160 * 1024 || lds_o > 160 * 1024) return MSSVT_E_TOOLARGE;
     int rc;
-    if ((rc = cf_prepare(k_cmp_query_keys<C>, lds_q)) ||
-        (rc = cf_prepare(k_cmp_kv<C, HD>, lds2)) || (rc = cf_prepare(k_cmp_out<C, HD>, lds_o)))
+    if ((rc = cf_prepare(k_cmp_query_keys<C, H>, lds_q)) ||
+        (rc = cf_prepare(k_cmp_kv<C, HD, H>, lds2)) || (rc = cf_prepare(k_cmp_out<C, HD, H>, lds_o)))
         return rc;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
@@ -452,9 +554,9 @@ static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t strea
     const int slots = cus * per_q;
     int g_w = min(max(slots / 3, 1), max(wt, 1)), g_v = min(max(slots - g_w, 1), max(vt, 1));
     const int g_v2 = min(cus, max(vt, 1)), g_o = min(cus * per_o, max(wt, 1));
-    k_cmp_query_keys<C><<<g_w + g_v, CFQ_NW * MSSVT_WAVE, lds_q, stream>>>(a, g_w);
-    k_cmp_kv<C, HD><<<g_v2, CFK_NW * MSSVT_WAVE, lds2, stream>>>(a);
-    k_cmp_out<C, HD><<<g_o, CFO_NW * MSSVT_WAVE, lds_o, stream>>>(a);
+    k_cmp_query_keys<C, H><<<g_w + g_v, CFQ_NW * MSSVT_WAVE, lds_q, stream>>>(a, g_w);
+    k_cmp_kv<C, HD, H><<<g_v2, CFK_NW * MSSVT_WAVE, lds2, stream>>>(a);
+    k_cmp_out<C, HD, H><<<g_o, CFO_NW * MSSVT_WAVE, lds_o, stream>>>(a);
     return mssvt_launch_status();
 }
 
@@ -464,7 +566,7 @@ extern "C" int mssvt_compress_fused(
     const int *pair_win, const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3,
     const float *xhat, const float *Wpos1, const float *bpos1, const float *Wpos2, const float *bpos2,
     const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
-    float *qp, float *ktok, float *score, float *vp, float *out, void *stream) {
+    float *qp, float *ktok, float *score, float *vp, float *out, int split_f16, void *stream) {
     if (!num_wins_dev || !win_ind || !indices || !k_ind || !win_vstart || !win_cnt || !pair_win ||
         !host_voxel_size3 || !host_range_min3 || !host_win_size3 || !xhat || !Wpos1 || !bpos1 || !Wpos2 || !bpos2 ||
         !Wq || !bq || !Wkv || !bkv || !Wo || !bo || !qp || !ktok || !score || !vp || !out || C <= 0 ||
@@ -483,8 +585,9 @@ extern "C" int mssvt_compress_fused(
     a.Wq = Wq; a.bq = bq; a.Wkv = Wkv; a.bkv = bkv; a.Wo = Wo; a.bo = bo;
     a.qp = qp; a.ktok = ktok; a.score = score; a.vp = vp; a.out = out;
     hipStream_t st = (hipStream_t)stream;
-#define CF_CASE(c, hd) \
-    if (C == c && head_dim == hd) return launch_compress<c, hd>(a, win_capacity, st);
+#define CF_CASE(c, hd)                                                                                    \
+    if (C == c && head_dim == hd)                                                                         \
+        return split_f16 ? launch_compress<c, hd, true>(a, win_capacity, st) : launch_compress<c, hd, false>(a, win_capacity, st);
     CF_CASE(128, 16)
     CF_CASE(128, 32)
     CF_CASE(64, 8)
