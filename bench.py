@@ -18,7 +18,7 @@ scaling); the time is the max over ranks between barriers.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   "timing":       median / p10 / p90 of >= 50 steps timed one by one with HIP events (SURVEY 8d);
-  "roofline":     the dominant kernel (k_ffn_up, fp32 MFMA bound) measured live with HIP events, and
+  "roofline":     the dominant kernel (k_ffn_ws: the FFN tail in one launch, HBM bound) measured live with HIP events, and
                   "frame": the whole frame's algorithmic bytes / FLOP against both roofs;
   "cpu_baseline": the CPU oracle (a port of the reference's CUDA semantics; the reference has no CPU
                   path) timed on this box's host: the whole forward on all cores and on one thread.
@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--cfg", default=None, help="backbone yaml (default: mssvt_amd/cfgs/mssvt.yaml = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--ffn-arith", choices=["f16x3", "f32"], default=None,
+                    help="matrix products of the FFN / CompressBlock: split-fp16 operands (default) or the fp32 MFMA")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
     return ap.parse_args(argv)
 
@@ -187,6 +189,16 @@ def cpu_baseline(net, cfg, vc_np, feats_np, batch, gpu_out=None):
     return res
 
 
+def ffn_arith_name(net):
+    """How the FFN / CompressBlock matrix products are computed (mssvt_amd/fused.py FFN_ARITH)."""
+    from mssvt_amd import fused
+    if net.backbone[0].impl != "fused":
+        return "library GEMM (fp32)"
+    if getattr(net.backbone[0], "ffn_arith", fused.FFN_ARITH) == "f16x3":
+        return "fp32 operands split exactly into two fp16 halves, 3 x v_mfma_f32_16x16x32_f16, fp32 accumulate (error ~ fp32 MFMA)"
+    return "v_mfma_f32_16x16x4_f32"
+
+
 def workload_name(args, cfg_given):
     if cfg_given:
         return "%s: %d-point scene x batch %d per GPU" % (os.path.basename(args.cfg), args.points, args.batch)
@@ -225,6 +237,9 @@ def main():
     if args.impl:
         net.set_impl(args.impl)
     net.set_attn_dtype(args.attn_dtype)
+    if args.ffn_arith:
+        from mssvt_amd import fused as _fused
+        _fused.FFN_ARITH = args.ffn_arith
     vc_np, feats_np, vc, feats = make_inputs(args.points, args.batch, rank, dev)
 
     if args.train:
@@ -280,7 +295,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.attn_dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": workload_name(args, bool(args.cfg)),
-                       "impl": impl, "attn_dtype": args.attn_dtype, "voxels_per_gpu": int(vc.shape[0]),
+                       "impl": impl, "attn_dtype": args.attn_dtype, "ffn_arith": ffn_arith_name(net),
+                       "voxels_per_gpu": int(vc.shape[0]),
                        "output_voxels": int(sp_out.features.shape[0]),
                        "parallelism": "scenes sharded over %d GPU(s), %s" % (
                            world, "DDP gradient all-reduce (%s)" % backend if args.train else "no data-path collective"),

@@ -475,15 +475,21 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=No
                 _lib.call("mssvt_ffn_fused", _i(n), _i(C), _i(FF), _P(x_new), _P(x_in),
                           _P(owner), *tail_)
 
-        if FFN_TIMER is not None and split and phases == 3:
-            # bench.py's live roofline: HIP events around k_ffn_up inside the timed steps (two C calls
-            # instead of one: the same two launches, the same stream)
+        if FFN_TIMER is not None and phases == 4:
+            # bench.py's live roofline: HIP events around k_ffn_ws inside a repeat of the timed steps
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch(tail)
+            e1.record()
+            FFN_TIMER.append(("ws", e0, e1, n if n_rows_dev is None else n_rows_dev, C, FF, y_norm is not None))
+        elif FFN_TIMER is not None and split and phases == 3:
+            # fp32 arithmetic: k_ffn_up alone (two C calls instead of one: the same two launches, the same stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             launch(tail[:-2] + (_i(1), tail[-1]))
             e1.record()
             launch(tail[:-2] + (_i(2), tail[-1]))
-            FFN_TIMER.append((e0, e1, n if n_rows_dev is None else n_rows_dev, C, FF))
+            FFN_TIMER.append(("up", e0, e1, n if n_rows_dev is None else n_rows_dev, C, FF, y_norm is not None))
         else:
             launch(tail)
         sp._xhat = (y_norm, nxt, y) if y_norm is not None else None
@@ -911,23 +917,29 @@ def _compress_finish(sp, p, features):
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix-core peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
 
 
+MFMA_F16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense 16-bit matrix-core peak (256 CUs x 4096 FLOP/clk x 2.4 GHz)
+
+
 def ffn_timer_summary(samples):
-    """(launches, total FLOP, total seconds) of the k_ffn_up launches recorded through FFN_TIMER."""
-    flop, sec = 0.0, 0.0
-    for e0, e1, rows, C, FF in samples:
+    """{"ws" | "up": (launches, total voxel rows, rows with a second LayerNorm output, total seconds, C, FF)} of the FFN
+    launches recorded through FFN_TIMER."""
+    out = {}
+    for kind, e0, e1, rows, C, FF, norm2 in samples:
         rows = int(rows.item()) if torch.is_tensor(rows) else int(rows)
-        flop += 2.0 * C * FF * rows
-        sec += e0.elapsed_time(e1) * 1e-3
-    return len(samples), flop, sec
+        cnt, tot, tot2, sec, _, _ = out.get(kind, (0, 0, 0, 0.0, C, FF))
+        out[kind] = (cnt + 1, tot + rows, tot2 + (rows if norm2 else 0), sec + e0.elapsed_time(e1) * 1e-3, C, FF)
+    return out
 
 
 def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
-    """Roofline of the dominant kernel of the frame on the bench inputs: k_ffn_up<128,256> (LayerNorm +
-    GEMM1 + ReLU of the FFN tail, 5 launches per frame, the largest share of GPU time), timed alone
-    with HIP events through the `phases` argument of the C entry point.  It is bound by the fp32 matrix
-    cores: algorithmic FLOP per launch = 2 * C * FF per voxel row.  The other
-    two heavy kernels are reported beside it: k_ffn_down (same bound) and the attention call of a
-    Block (3 launches; gather-latency bound, its HBM roofline is given for reference)."""
+    """Roofline of the dominant kernel of the frame on the bench inputs.
+
+    Split-fp16 arithmetic (default): k_ffn_ws<128,256>, the whole FFN tail in one launch (5 per frame, the largest share
+    of GPU time).  HBM bound: algorithmic bytes per voxel row = 4 C read (x_in) + 4 C written (y) + 4 C written (the next
+    block's LayerNorm of y, when the launch emits it -- it replaces that block's own read + write pass); the 3 attention
+    rows interpolated into the input are NOT counted (17 MB per launch, L2 / Infinity-Cache resident), so the figure is
+    conservative.  fp32 arithmetic (ffn_arith = "f32"): k_ffn_up, fp32 MFMA bound, 2 C FF FLOP per row.
+    The attention call of a Block (3 launches; gather-latency bound) is reported beside it."""
     import json
     from .mssvt_utils import SparseTensor
     blk = net.backbone[0]
@@ -961,17 +973,21 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
         abuf = _attn_buffer(p, nq, C, x_in.device)
         abuf.zero_()
         sp._next_norm1 = net.backbone[1].norm1
-        ms_up = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf), phases=1), 20)
-        ms_down = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf), phases=2), 20)
+        split16 = getattr(blk, "ffn_arith", FFN_ARITH) == "f16x3" and _ffn_f16_weights(_ffn_refs(blk)) is not None
+        if split16:
+            ms_ws = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf)), 20)
+            ms_up = ms_down = None
+        else:
+            ms_ws = None
+            ms_up = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf), phases=1), 20)
+            ms_down = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf), phases=2), 20)
     N, FF = x_in.shape[0], blk.linear1.out_features
     flop = 2.0 * C * FF * N
-    tf_up = flop / (ms_up * 1e-3) / 1e12
-    tf_down = flop / (ms_down * 1e-3) / 1e12
     # window metadata + valid key rows (Cg wide) + query rows in and attention rows out (C wide); the Q~ / Xbar
     # hand-off between the three launches is NOT algorithmic (it is this implementation's own traffic)
     alg = nw * (16 + 16 * (nq + 2 * K)) + n_keys * 4 * cg + 2 * n_q * 4 * C
     gbs = alg / (ms_attn * 1e-3) / 1e9
-    # HBM bytes per launch of k_ffn_up from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    # HBM bytes per launch of the FFN kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for
     # 16-B-per-lane reads on gfx950); bench.py cannot collect counters itself
     traffic, attn_pmc = None, None
@@ -979,7 +995,7 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
     if os.path.exists(pmc):
         with open(pmc) as f:
             counters = json.load(f)
-        traffic = counters.get("k_ffn_up<128,256>", {}).get("hbm_bytes_per_launch")
+        traffic = counters.get("k_ffn_ws<128,256>" if split16 else "k_ffn_up<128,256>", {}).get("hbm_bytes_per_launch")
         # the window-attention kernels' measured HBM bytes and MFMA-pipe busy fraction (same PMC passes)
         attn_pmc = {k: {"hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"),
                         "mfma_busy_frac": v.get("mfma_busy_frac_of_gpu_active")}
@@ -993,38 +1009,68 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
         ceilings = {"mfma_f32_tflops": max(mc.get("mfma_f32_tflops", {}).values(), default=None),
                     "hbm_copy_gbs": max((v for k, v in mc.get("hbm_gbs", {}).items() if k.startswith("copy")), default=None),
                     "hbm_read_gbs": max((v for k, v in mc.get("hbm_gbs", {}).items() if k.startswith("read")), default=None)}
-    if traffic is not None and live is not None and live[0] > 0:
-        # the PMC passes ran full-size launches (N rows); the live average mixes in the smaller CompressBlock tail
-        traffic = int(traffic * (live[1] / live[0] / (2.0 * C * FF)) / N)
-    head = {"achieved": tf_up, "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_up * 1e3,
-            "units_per_launch": {"voxel_rows": N, "flop_per_row": 2 * C * FF},
-            "timing": "HIP events around 20 isolated launches on the bench frame"}
-    if live is not None and live[0] > 0:
-        # measured over a repeat of the K timed steps: every k_ffn_up launch (4 Block tails of N rows + the
-        # CompressBlock tail of nw rows per frame) between two HIP events on its stream
-        cnt, lflop, lsec = live
-        head = {"achieved": lflop / lsec / 1e12, "algorithmic_flop_per_launch": lflop / cnt,
-                "avg_launch_us": lsec / cnt * 1e6,
-                "units_per_launch": {"voxel_rows_mean": lflop / cnt / (2 * C * FF), "flop_per_row": 2 * C * FF,
-                                     "launches_timed": cnt},
-                "timing": "HIP events around every k_ffn_up launch of a repeat of the timed steps",
-                "isolated_launch_us_full_frame_rows": ms_up * 1e3}
-    return {"bound": "mfma", "kernel": "k_ffn_up<128,256> (norm2 + GEMM1 + ReLU of the FFN tail, fp32 MFMA; input built "
-                                       "from x_in + 3 attention rows)",
-            "achieved": head["achieved"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": head["achieved"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "measured_ceilings": ceilings,
-            "algorithmic_flop_per_launch": head["algorithmic_flop_per_launch"], "avg_launch_us": head["avg_launch_us"],
-            "units_per_launch": head["units_per_launch"], "timing": head["timing"],
-            **({"isolated_launch_us_full_frame_rows": head["isolated_launch_us_full_frame_rows"]}
-               if "isolated_launch_us_full_frame_rows" in head else {}),
-            "other_kernels": [
-                {"bound": "mfma", "kernel": "k_ffn_down<128,256> (GEMM2 + residual + next norm1)", "achieved": tf_down,
-                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_down / MFMA_F32_PEAK_TFLOPS,
-                 "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_down * 1e3},
+    other = []
+    if split16:
+        # bytes per row: x_in + y + the next block's LayerNorm output (every full-size launch of the frame emits it)
+        row_bytes = 12.0 * C
+        alg_b = row_bytes * N
+        head = {"achieved": alg_b / (ms_ws * 1e-3) / 1e9, "alg": alg_b, "avg_launch_us": ms_ws * 1e3,
+                "units_per_launch": {"voxel_rows": N, "bytes_per_row": row_bytes, "matrix_flop_per_row": 4 * C * FF},
+                "timing": "HIP events around 20 isolated launches on the bench frame"}
+        s_ = (live or {}).get("ws")
+        if s_ and s_[0] > 0:
+            cnt, rows, rows2, sec, _, _ = s_
+            lb = 8.0 * C * rows + 4.0 * C * rows2
+            head = {"achieved": lb / sec / 1e9, "alg": lb / cnt, "avg_launch_us": sec / cnt * 1e6,
+                    "units_per_launch": {"voxel_rows_mean": rows / cnt,
+                                         "bytes_per_row": "8 C, + 4 C when the next LayerNorm is emitted",
+                                         "matrix_flop_per_row": 4 * C * FF, "launches_timed": cnt},
+                    "timing": "HIP events around every k_ffn_ws launch of a repeat of the timed steps",
+                    "isolated_launch_us_full_frame_rows": ms_ws * 1e3}
+            if traffic is not None:
+                traffic = int(traffic * (rows / cnt) / N)  # the PMC passes ran full-size launches (N rows)
+        res = {"bound": "hbm",
+               "kernel": "k_ffn_ws<128,256> (FFN tail in one launch: input from x_in + 3 attention rows, norm2, linear1 + ReLU + "
+                         "linear2 with split-fp16 operands, residual, next norm1)",
+               "achieved": head["achieved"], "peak": peak_gbs, "unit": "GB/s", "frac": head["achieved"] / peak_gbs,
+               "traffic": traffic, "measured_ceilings": ceilings, "algorithmic_bytes_per_launch": head["alg"],
+               "avg_launch_us": head["avg_launch_us"], "units_per_launch": head["units_per_launch"], "timing": head["timing"],
+               "matrix": {"flop_per_launch_f32_equivalent": 2.0 * flop,
+                          "mfma_issued": "3 x v_mfma_f32_16x16x32_f16 per 16x16x32 product, fp32 accumulate",
+                          "tflops_f32_equivalent_isolated": 2.0 * flop / (ms_ws * 1e-3) / 1e12,
+                          "frac_of_f16_peak_incl_3x": 3 * 2.0 * flop / (ms_ws * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}}
+        if "isolated_launch_us_full_frame_rows" in head:
+            res["isolated_launch_us_full_frame_rows"] = head["isolated_launch_us_full_frame_rows"]
+    else:
+        tf_up = flop / (ms_up * 1e-3) / 1e12
+        tf_down = flop / (ms_down * 1e-3) / 1e12
+        head = {"achieved": tf_up, "alg": flop, "avg_launch_us": ms_up * 1e3,
+                "units_per_launch": {"voxel_rows": N, "flop_per_row": 2 * C * FF},
+                "timing": "HIP events around 20 isolated launches on the bench frame"}
+        s_ = (live or {}).get("up")
+        if s_ and s_[0] > 0:
+            cnt, rows, _, sec, _, _ = s_
+            head = {"achieved": 2.0 * C * FF * rows / sec / 1e12, "alg": 2.0 * C * FF * rows / cnt, "avg_launch_us": sec / cnt * 1e6,
+                    "units_per_launch": {"voxel_rows_mean": rows / cnt, "flop_per_row": 2 * C * FF, "launches_timed": cnt},
+                    "timing": "HIP events around every k_ffn_up launch of a repeat of the timed steps"}
+            if traffic is not None:
+                traffic = int(traffic * (rows / cnt) / N)
+        res = {"bound": "mfma",
+               "kernel": "k_ffn_up<128,256> (norm2 + GEMM1 + ReLU of the FFN tail, fp32 MFMA; input built from x_in + 3 attention rows)",
+               "achieved": head["achieved"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": head["achieved"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "measured_ceilings": ceilings,
+               "algorithmic_flop_per_launch": head["alg"], "avg_launch_us": head["avg_launch_us"],
+               "units_per_launch": head["units_per_launch"], "timing": head["timing"]}
+        other.append({"bound": "mfma", "kernel": "k_ffn_down<128,256> (GEMM2 + residual + next norm1)", "achieved": tf_down,
+                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_down / MFMA_F32_PEAK_TFLOPS,
+                      "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_down * 1e3})
+    other.append(
                 {"bound": "hbm", "kernel": "mssvt_block_attention, both head groups (k_attn_q + k_attn_kv + k_attn_o, grid.y = group)",
                  "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs,
                  "algorithmic_bytes_per_launch": alg, "avg_launch_us": ms_attn * 1e3,
                  "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q},
                  "pmc": attn_pmc,
                  "note": "algorithmic bytes exclude the Q~ / Xbar hand-off between the launches; pmc = HBM bytes "
-                         "(2 FETCH + WRITE) and MFMA-pipe busy fraction per launch from profiles/pmc_traffic.json"}]}
+                         "(2 FETCH + WRITE) and MFMA-pipe busy fraction per launch from profiles/pmc_traffic.json"})
+    res["other_kernels"] = other
+    return res
