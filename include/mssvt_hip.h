@@ -284,6 +284,20 @@ int mssvt_block_attention_bf16(
     const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
     const float *const *host_bo, const float *Wpos, const float *bpos, float *attn, void *stream);
 
+/* The same single launch with fp32-accurate products: every MFMA operand split exactly into two fp16 halves
+ * (hi + 2^-11 lo; 3 x v_mfma_f32_16x16x32_f16 per product sum, fp32 accumulation: the fp32 matrix instruction's error
+ * against float64 at 3/16 of its cycles), keys projected in the kernel, no hand-off through HBM.  Arguments of
+ * mssvt_block_attention minus qbuf.  The CALLER guarantees the fp16 range of tokens, Q' (scaled), K', V'
+ * (mssvt_amd/fused.py bounds them from the parameters) and runs mssvt_block_attention otherwise.
+ * MSSVT_E_TOOLARGE: shape not instantiated (use the fp32 entry point).                                    */
+int mssvt_block_attention_f16x3(
+    int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
+    int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
+    const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
+    const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
+    const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *attn, void *stream);
+
 /* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
  * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):
  * x_new[v] = interp(v) + x_in[v] for every voxel v owned by a list slot; rows of other

@@ -223,6 +223,7 @@ def two_scale_plan(block, sp):
     p.qmeta_odd, p.qmeta_even, p.qmeta_win1 = f4(n_o), f4(n_e), f4(n1)
     p.kmeta = [f4(K), f4(K)]
     p.wcentre = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+    p.coord_bound = max(abs(float(v)) for v in sp.point_cloud_range)  # |metric coordinate| of any voxel / window centre
     p.nq_valid = torch.empty((3, cap), dtype=torch.int32, device=dev)
     p.orders = {}
     owners = mssvt_ops.full_neg1((3, cap), dev)
@@ -370,6 +371,37 @@ def _attn_refs(block, groups):
     return r
 
 
+# arithmetic of the fp32 attention: "f16x3" = ONE launch, keys projected in the kernel, every MFMA operand split exactly
+# into two fp16 halves (csrc/block_attn_f16x3.hip: the fp32 instruction's error, no hand-off through HBM); "f32" = the
+# three fp32-MFMA launches of csrc/block_attn.hip.  Operands outside the fp16 range always take "f32".
+ATTN_ARITH = os.environ.get("MSSVT_ATTN_ARITH", "f32")
+
+
+@torch.no_grad()
+def _attn_f16_ok(block, r, p):
+    """True when tokens and projections of the window attention stay inside the fp16 range whatever the input is:
+    |xhat| <= sqrt(C) max|w| + max|b|, the positional term <= |Wp_c|_1 max|coordinate| + |bp_c| (relative offsets and
+    window centres are metres inside the point cloud range), Q' / K' / V' by |W_row|_1 times the token bound (+ bias),
+    O <= the V' bound.  Once per parameter version (one small host sync)."""
+    ts = [block.norm1.weight, block.norm1.bias, r["Wp"], r["bp"]] + list(r["Wq"]) + list(r["bq"]) + list(r["Wkv"]) + \
+        list(r["bkv"]) + list(r["Wo"])
+    ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + (float(p.coord_bound),)
+    if r.get("f16_ver") != ver:
+        g1, b1, Wp, bp = [t.detach().float() for t in ts[:4]]
+        C = g1.numel()
+        xmax = (C ** 0.5) * g1.abs().max() + b1.abs().max()
+        tmax = xmax + (Wp.reshape(C, -1).abs().sum(1) * p.coord_bound + bp.abs()).max()
+        worst = [tmax]
+        for Wq, bq, Wkv, bkv, Wo in zip(r["Wq"], r["bq"], r["Wkv"], r["bkv"], r["Wo"]):
+            worst.append((Wq.detach().abs().sum(1) * tmax + bq.detach().abs()).max() * abs(r["scale"]) * 1.4426950408889634)
+            worst.append((Wkv.detach().abs().sum(1) * tmax + bkv.detach().abs()).max())
+            worst += [Wq.detach().abs().max(), Wkv.detach().abs().max(), Wo.detach().abs().max()]
+        worst = torch.stack([w.float() for w in worst]).max()
+        r["f16_ok"] = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
+        r["f16_ver"] = ver
+    return r["f16_ok"]
+
+
 def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
     """mssvt_block_attention (or its bf16-operand form) for the given head groups (default: all)."""
     r = _attn_refs(block, groups)
@@ -381,6 +413,8 @@ def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
             pa(r["bq"]), pa(r["Wkv"]), pa(r["bkv"]), pa(r["Wo"]), pa(r["bo"]), _P(r["Wp"]), _P(r["bp"]))
     if getattr(block, "attn_dtype", "f32") == "bf16" and r["bf16_ok"]:
         _lib.call("mssvt_block_attention_bf16", *head, _P(attn), _lib.stream())
+    elif r["bf16_ok"] and getattr(block, "attn_arith", ATTN_ARITH) == "f16x3" and _attn_f16_ok(block, r, p):
+        _lib.call("mssvt_block_attention_f16x3", *head, _P(attn), _lib.stream())
     else:
         _lib.call("mssvt_block_attention", *head, _P(qbuf), _P(attn), _lib.stream())
 
