@@ -371,6 +371,12 @@ int mssvt_compress_fused(
     const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
     float *qp, float *ktok, float *score, float *vp, float *out, int split_f16, void *stream);
 
+/* Backward of mssvt_layer_norm (training path; autograd's LayerNorm backward in the reference): dx (N,C), dweight (C),
+ * dbias (C) from x, dy; mean / rstd are recomputed.  The column sums are per-workgroup partial rows in `workspace`
+ * (512 * 2 * C floats) added in workgroup order: deterministic.  C in {16,32,64,128,256}.                      */
+int mssvt_layer_norm_backward(const float *x, const float *dy, int num_rows, int C, const float *weight, float eps,
+                              float *dx, float *dweight, float *dbias, float *workspace, void *stream);
+
 /* Rows per sample of a (N,4) [b,z,y,x] int32 index tensor -> counts (B) int32, on the device
  * (ref: the host loops with .item() of mssvt_utils.py:35-37 / mssvt_backbone.py:124-130).   */
 int mssvt_batch_counts(const int *indices, int num_rows, int batch_size, int *counts, void *stream);

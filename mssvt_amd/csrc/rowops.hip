@@ -100,3 +100,100 @@ extern "C" int mssvt_layer_norm(const float *x, int num_rows, int C, const float
 #undef LN_CASE
     return MSSVT_E_TOOLARGE;  // C not in {16, 32, 64, 128, 256}: the caller uses the framework's LayerNorm
 }
+
+// ---- LayerNorm backward (training path): dx per row, d(weight) / d(bias) as deterministic column sums -----------------
+// Same row layout as k_layer_norm (LPR lanes x 4 channels per row).  A workgroup walks a contiguous chunk of rows and
+// keeps its column sums in registers; lanes / waves holding the same channels are then added in a fixed order through
+// LDS and the workgroup's partial row goes to `part` ([workgroup][2][C]); k_layer_norm_bwd_reduce adds the partial rows in
+// workgroup order.  No atomics: bit-identical from run to run (torch's kernel is, too; this one reads x and dy once and
+// recomputes mean / rstd instead of keeping them: 12 C bytes per row against 20 C).
+#define LNB_WG 512  // workgroups (partial rows)
+template <int LPR>
+__global__ void __launch_bounds__(256) k_layer_norm_bwd(const float *x, const float *dy, int n, const float *w, float eps,
+                                                        int rows_per_wg, float *dx, float *part) {
+    constexpr int C = LPR * 4, RPW = MSSVT_WAVE / LPR, RPI = 4 * RPW;  // rows per workgroup instruction
+    __shared__ float red[4 * RPW][2 * C];
+    const int lane = lane_id(), wv = threadIdx.x / MSSVT_WAVE;
+    const int rl = wv * RPW + lane / LPR, col = (lane % LPR) * 4;
+    const float4 g4 = *reinterpret_cast<const float4 *>(w + col);
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(n, r0 + rows_per_wg);
+    for (int rb = r0; rb < r1; rb += RPI) {
+        const int row = rb + rl;
+        const bool live = row < r1;
+        const size_t off = (size_t)(live ? row : r0) * C + col;
+        const float4 v = *reinterpret_cast<const float4 *>(x + off);
+        float4 d = *reinterpret_cast<const float4 *>(dy + off);
+        if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int o = LPR / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        const float m = s * (1.0f / C);
+        const float cx = v.x - m, cy = v.y - m, cz = v.z - m, cw = v.w - m;
+        float q = (cx * cx + cy * cy) + (cz * cz + cw * cw);
+#pragma unroll
+        for (int o = LPR / 2; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+        const float rs = rsqrtf(q * (1.0f / C) + eps);
+        const float hx = cx * rs, hy = cy * rs, hz = cz * rs, hw = cw * rs;  // normalised row
+        const float gx = d.x * g4.x, gy = d.y * g4.y, gz = d.z * g4.z, gw = d.w * g4.w;
+        float a = (gx + gy) + (gz + gw), b = (gx * hx + gy * hy) + (gz * hz + gw * hw);
+#pragma unroll
+        for (int o = LPR / 2; o >= 1; o >>= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+        }
+        a *= (1.0f / C);
+        b *= (1.0f / C);
+        if (live)
+            *reinterpret_cast<float4 *>(dx + off) =
+                make_float4(rs * (gx - a - hx * b), rs * (gy - a - hy * b), rs * (gz - a - hz * b), rs * (gw - a - hw * b));
+        sg.x += d.x * hx; sg.y += d.y * hy; sg.z += d.z * hz; sg.w += d.w * hw;
+        sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+    }
+    *reinterpret_cast<float4 *>(&red[rl][col]) = sg;
+    *reinterpret_cast<float4 *>(&red[rl][C + col]) = sb;
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4 * RPW; ++k) t += red[k][c];
+        part[(size_t)blockIdx.x * 2 * C + c] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_layer_norm_bwd_reduce(const float *part, int nwg, int C2, float *dw, float *db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C2) return;
+    float t = 0.f;
+    for (int k = 0; k < nwg; ++k) t += part[(size_t)k * C2 + c];
+    if (c < C2 / 2) dw[c] = t;
+    else db[c - C2 / 2] = t;
+}
+
+extern "C" int mssvt_layer_norm_backward(const float *x, const float *dy, int num_rows, int C, const float *weight, float eps,
+                                         float *dx, float *dweight, float *dbias, float *workspace, void *stream_) {
+    if (!x || !dy || !weight || !dx || !dweight || !dbias || !workspace || num_rows < 0 || C <= 0) return MSSVT_E_BADARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (num_rows == 0) {
+        hipError_t e = hipMemsetAsync(dweight, 0, (size_t)C * 4, stream);
+        if (e == hipSuccess) e = hipMemsetAsync(dbias, 0, (size_t)C * 4, stream);
+        return (int)e;
+    }
+#define LNB_CASE(lpr)                                                                                        \
+    if (C == 4 * lpr) {                                                                                      \
+        const int rpi = 4 * (MSSVT_WAVE / lpr);                                                              \
+        int rows = (num_rows + LNB_WG - 1) / LNB_WG;                                                         \
+        rows = (rows + rpi - 1) / rpi * rpi;                                                                 \
+        const int nwg = (num_rows + rows - 1) / rows;                                                        \
+        k_layer_norm_bwd<lpr><<<nwg, 256, 0, stream>>>(x, dy, num_rows, weight, eps, rows, dx, workspace);   \
+        k_layer_norm_bwd_reduce<<<divup(2 * C, 256), 256, 0, stream>>>(workspace, nwg, 2 * C, dweight, dbias); \
+        return mssvt_launch_status();                                                                        \
+    }
+    LNB_CASE(4)
+    LNB_CASE(8)
+    LNB_CASE(16)
+    LNB_CASE(32)
+    LNB_CASE(64)
+#undef LNB_CASE
+    return MSSVT_E_TOOLARGE;
+}

@@ -272,8 +272,9 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x = x.contiguous()
             M, cin, cout = x.shape[0], x.shape[1], w.shape[0]
-            dw = torch.zeros_like(w)
-            db = torch.zeros((cout,), dtype=w.dtype, device=w.device) if ctx.has_bias else None
+            alloc = torch.empty if M > 0 else torch.zeros
+            dw = alloc(w.shape, dtype=w.dtype, device=w.device)
+            db = alloc((cout,), dtype=w.dtype, device=w.device) if ctx.has_bias else None
             if M > 0:
                 _lib.call("mssvt_linear_wgrad", _i(M), _i(cin), _i(cout), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw),
                           _lib.ptr(db), _lib.ptr(_wgrad_workspace(x.device, M, cin, cout)), _lib.stream())
@@ -291,9 +292,46 @@ def linear(mod, x, scale_rows=None):
     return _Linear.apply(x, w, b)
 
 
+class _LayerNorm(torch.autograd.Function):
+    """nn.LayerNorm over the channels of compact rows: forward k_layer_norm, backward k_layer_norm_bwd (csrc/rowops.hip;
+    x and dy read once, column sums in a fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.call("mssvt_layer_norm", _lib.ptr(x), _i(x.shape[0]), _i(x.shape[1]), _lib.ptr(w), _lib.ptr(b),
+                  ctypes.c_float(eps), _lib.ptr(y), _lib.stream())
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, C = x.shape
+        dy = dy.contiguous()
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        ws = _wgrad_ws.get(("ln", x.device))
+        if ws is None:
+            ws = _wgrad_ws[("ln", x.device)] = torch.empty((512 * 2 * 256,), dtype=torch.float32, device=x.device)
+        _lib.call("mssvt_layer_norm_backward", _lib.ptr(x), _lib.ptr(dy), _i(N), _i(C), _lib.ptr(w), ctypes.c_float(ctx.eps),
+                  _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream())
+        return dx, dw, db, None
+
+
+def layer_norm(norm, x):
+    """``norm(x)`` for an nn.LayerNorm over the last dimension of (N, C) rows."""
+    C = x.shape[1]
+    if (C not in fused.LN_WIDTHS or x.dtype != torch.float32 or not x.is_cuda or x.shape[0] == 0 or not torch.is_grad_enabled()
+            or norm.weight is None or norm.bias is None):
+        return norm(x)
+    return _LayerNorm.apply(x, norm.weight, norm.bias, float(norm.eps))
+
+
 def ffn(block, x):
     """block._ffn with the deterministic weight gradients (ref mssvt_backbone.py:341-343)."""
-    return linear(block.linear2, block.dropout1(block.activation(linear(block.linear1, block.norm2(x)))))
+    return linear(block.linear2, block.dropout1(block.activation(linear(block.linear1, layer_norm(block.norm2, x)))))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -385,7 +423,7 @@ def block_forward(block, sp):
         return block.forward_ops(sp)
     x_in = sp.features
     N, C = x_in.shape
-    xhat = block.norm1(x_in)
+    xhat = layer_norm(block.norm1, x_in)
     p = fused.two_scale_plan(block, sp)
     s = _block_index_sets(block, sp, p)
     R, ma = s["R"], block.ms_attn
@@ -458,7 +496,7 @@ def compress_forward(block, sp):
     """Differentiable forward of a MixedScaleSparseTransformerCompressBlock (ref mssvt_backbone.py:351-398)."""
     if not compress_supported(block, sp) or sp.features.shape[0] == 0:
         return block.forward_ops(sp)
-    x = block.norm1(sp.features)
+    x = layer_norm(block.norm1, sp.features)
     C = x.shape[1]
     p = fused.one_scale_plan(block, sp)  # K2 + K4 on the device, one host sync (the output shape)
     s = _compress_index_sets(block, sp, p)

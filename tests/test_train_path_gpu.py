@@ -224,3 +224,33 @@ def test_csr_transpose_matches_a_stable_sort(nnz, n_src, ragged, heavy):
         ref = torch.zeros(n_src, 16, dtype=torch.float64).index_add_(0, idx[keep], (grad.double()[dst_of] * w.double()[:, None])[keep])
         assert float((got.cpu().double() - ref).abs().max()) < 1e-3
         assert torch.equal(got, csr.bwd.sum(grad.to(DEV)))
+
+
+@pytest.mark.parametrize("N,C", [(74270, 128), (1000, 64), (7, 16), (33, 256), (5000, 32)])
+def test_layer_norm_backward_kernel(N, C):
+    """mssvt_layer_norm_backward against float64 autograd; twice: bit-identical."""
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(N + C)
+    x0 = (torch.randn(N, C, generator=g) * 2 + 0.3)
+    dy = torch.randn(N, C, generator=g)
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(C, generator=g))
+    res = []
+    for _ in range(2):
+        norm.weight.grad = norm.bias.grad = None
+        x = x0.to(DEV).requires_grad_(True)
+        y = train_path.layer_norm(norm, x)
+        assert "LayerNorm" in type(y.grad_fn).__name__ and "Native" not in type(y.grad_fn).__name__
+        y.backward(dy.to(DEV))
+        res.append((y.detach().clone(), x.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    xd = x0.double().requires_grad_(True)
+    wd, bd = norm.weight.detach().cpu().double().requires_grad_(True), norm.bias.detach().cpu().double().requires_grad_(True)
+    yd = torch.nn.functional.layer_norm(xd, (C,), wd, bd, norm.eps)
+    yd.backward(dy.double())
+    for got, ref, what in zip(res[0], (yd.detach(), xd.grad, wd.grad, bd.grad), ("y", "dx", "dw", "db")):
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err <= 3e-6 * max(1.0, float(ref.abs().max())) * max(1.0, N ** 0.5 / 16), (what, err)
