@@ -101,6 +101,53 @@ def test_fused_ffn_kernel_matches_torch(C, FF, n, split):
     np.testing.assert_allclose(yn.cpu().numpy(), want_n.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("C,FF,n", [(128, 256, 74270), (128, 256, 5000), (64, 128, 1000), (32, 64, 129), (128, 256, 7), (64, 128, 16)])
+def test_ffn_single_launch_split_fp16_matches_float64(C, FF, n, packed):
+    """k_ffn_ws (phases = 4: register-stationary weights, every fp32 operand split exactly into two fp16 halves, 3 MFMAs
+    per product sum) against a float64 restatement: the error of the fp32-instruction kernels (phases = 3), far inside
+    the fp32 parity tolerance; with the weight fragments pre-split (mssvt_ffn_pack_weights) and split in the kernel."""
+    import ctypes
+    from mssvt_amd import _lib
+    torch.manual_seed(C + n)
+    x_new = torch.randn(n, C, device=DEV) * 2
+    x_in = torch.randn(n, C, device=DEV)
+    owner = torch.randint(-1, 3, (n,), device=DEV, dtype=torch.int32)
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    ln2 = torch.nn.LayerNorm(C).to(DEV)
+    l1, l2 = torch.nn.Linear(C, FF).to(DEV), torch.nn.Linear(FF, C).to(DEV)
+    with torch.no_grad():
+        for m in (ln, ln2):
+            m.weight.add_(0.2 * torch.randn_like(m.weight))
+            m.bias.add_(0.2 * torch.randn_like(m.bias))
+        d = lambda t: t.detach().double()  # noqa: E731
+        x = torch.where((owner >= 0).unsqueeze(1), d(x_new), 2.0 * d(x_in))
+        h = torch.nn.functional.layer_norm(x, (C,), d(ln.weight), d(ln.bias), ln.eps)
+        want = x + torch.relu(h @ d(l1.weight).t() + d(l1.bias)) @ d(l2.weight).t() + d(l2.bias)
+        want_n = torch.nn.functional.layer_norm(want, (C,), d(ln2.weight), d(ln2.bias), ln2.eps)
+    i, f = ctypes.c_int, ctypes.c_float
+    res = {}
+    for phases in (3, 4):
+        y, yn = torch.empty_like(x_new), torch.empty_like(x_new)
+        if phases == 3:
+            ws = torch.empty((n, FF), device=DEV)
+        elif packed:
+            ws = torch.empty((int(_lib.lib().mssvt_ffn_packed_bytes(i(C), i(FF))),), dtype=torch.uint8, device=DEV)
+            assert ws.numel() == 2 * 2 * C * FF * 2  # hi + lo halves of both matrices
+            _lib.call("mssvt_ffn_pack_weights", i(C), i(FF), _lib.ptr(l1.weight), _lib.ptr(l2.weight), _lib.ptr(ws), _lib.stream())
+        else:
+            ws = None
+        _lib.call("mssvt_ffn_fused", i(n), i(C), i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
+                  _lib.ptr(ln.weight), _lib.ptr(ln.bias), f(ln.eps), _lib.ptr(l1.weight), _lib.ptr(l1.bias),
+                  _lib.ptr(l2.weight), _lib.ptr(l2.bias), _lib.ptr(y), _lib.ptr(ln2.weight), _lib.ptr(ln2.bias),
+                  f(ln2.eps), _lib.ptr(yn), _lib.ptr(ws), None, i(phases), _lib.stream())
+        res[phases] = (float((y.double() - want).abs().max()), float((yn.double() - want_n).abs().max()))
+    scale = max(1.0, float(want.abs().max()))
+    print("max err vs float64: fp32 MFMA %.2e / %.2e, split fp16 %.2e / %.2e (scale %.1f)" % (res[3] + res[4] + (scale,)))
+    assert res[4][0] <= 4e-6 * scale and res[4][1] <= 2e-5
+    assert res[4][0] <= 4 * res[3][0] + 1e-6  # the same order as the fp32 instruction
+
+
 @pytest.mark.parametrize("pts,B", [(20000, 1), (160000, 2), (300000, 1), (50, 3)])
 def test_voxelizer_bit_exact(pts, B):
     """Bitmap + rank voxelizer == sorted-unique formulation of DynamicVFE (voxel indices bit-exact)."""
@@ -235,3 +282,29 @@ def test_voxelizer_drops_non_finite_and_foreign_points():
     assert (pv[bad] == -1).all()
     np.testing.assert_array_equal(vc.cpu().numpy(), want_vc)
     np.testing.assert_array_equal(pv[good][kept], want_inv)
+
+
+def test_split_fp16_range_guard_keeps_the_fp32_kernels_for_large_parameters():
+    """Operands that could leave the fp16 range (bounded from the parameters) must not take the split-fp16 kernels: the
+    FFN tail then runs the fp32-instruction pair and still matches torch."""
+    from mssvt_amd import config, fused
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval()
+    blk = net.backbone[0]
+    fr = fused._ffn_refs(blk)
+    assert fused._ffn_f16_weights(fr) is not None
+    with torch.no_grad():
+        blk.linear1.weight.mul_(300.0)  # hidden bound = |W1_h|_1 * sqrt(C) ... now far beyond 6e4
+    assert fused._ffn_f16_weights(fused._ffn_refs(blk)) is None
+    x = torch.randn(3000, 128, device=DEV)
+
+    class SP(object):
+        _next_norm1 = None
+    with torch.no_grad():
+        y = fused._ffn_tail(blk, SP(), x)
+        want = x + blk.linear2(torch.relu(blk.linear1(blk.norm2(x))))
+    assert float((y - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    # and back: a new parameter version is checked again
+    with torch.no_grad():
+        blk.linear1.weight.mul_(1.0 / 300.0)
+    assert fused._ffn_f16_weights(fused._ffn_refs(blk)) is not None
