@@ -554,6 +554,76 @@ def layer_norm(x, norm):
     return y
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Index work of a frame on a second HIP stream (MixedScaleSparseTransformer.async_index)
+# ---------------------------------------------------------------------------------------------------------
+# Everything a resolution level needs before its first feature kernel -- sample counts, voxel hash table, occupancy
+# columns, window partitions, the two-scale plan (K3 + 2 x FPS + masks + metadata), work orders, interpolation tables, the
+# CompressBlock's plan -- depends on the voxel INDICES only: integer / VALU / latency bound work, ~25 % of a frame's GPU
+# time, while the feature kernels are HBM / matrix bound.  With `async_index` the forward issues it on a side stream and
+# the feature kernels on the caller's stream behind one event; the next frame's index work then runs UNDER this frame's
+# feature kernels (the host is one frame ahead anyway: the forward's only host wait is an early device-to-host copy of
+# the window count).  Buffers allocated on the side stream and read by the feature kernels are handed to the caching
+# allocator with `record_stream`, so that a buffer freed by the host is not reused by the next frame's index work
+# while this frame's feature kernels still read it.
+_side_streams = {}
+
+
+def side_stream(dev):
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(idx)
+    if s is None:
+        s = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
+@torch.no_grad()
+def prefetch_level(schedule, sp):
+    """All index work of the input level, on the CURRENT stream: the plans of its Blocks (with their work orders and
+    interpolation tables) and the plan of the CompressBlock that ends it.  The feature phase finds them cached."""
+    from .mssvt_backbone import MixedScaleSparseTransformerCompressBlock as Compress
+    done = set()
+    for blk, _nxt_norm, group, nxt_cmp in schedule:
+        if getattr(blk, "impl", None) != "fused":
+            break
+        if isinstance(blk, Compress):
+            C = sp.features.shape[1]
+            if compress_supported(blk, sp) and CMP_FUSED and blk.linear1.in_features == C and _compress_fused_ok(blk, sp, C):
+                sp._cmp_plan = (blk, one_scale_plan(blk, sp, sync=False))
+            break
+        if not supported(blk, sp) or blk.linear1.in_features != sp.features.shape[1] or hasattr(blk, "out_linear"):
+            break
+        k = blk.plan_key()
+        if k in done:
+            continue
+        done.add(k)
+        sp._plan_group, sp._next_compress = group, nxt_cmp
+        p = two_scale_plan(blk, sp)
+        if group and not getattr(p, "group_done", False):
+            p.group_done = True
+            prepare_group([b for b in group if b.plan_key() == k and supported(b, sp)], sp, p)
+
+
+def record_streams(roots, stream):
+    """`record_stream(stream)` on every device tensor reachable from `roots` (plans, level state, arena)."""
+    seen, stack = set(), list(roots)
+    while stack:
+        o = stack.pop()
+        if o is None or id(o) in seen:
+            continue
+        seen.add(id(o))
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                o.record_stream(stream)
+        elif isinstance(o, dict):
+            stack.extend(o.values())
+        elif isinstance(o, (list, tuple)):
+            stack.extend(o)
+        elif isinstance(o, _Plan) or type(o).__name__ in ("SparseTensor", "FillArena"):
+            stack.extend(o.__dict__.values())
+
+
 def block_forward(block, sp):
     """Fused forward of a MixedScaleSparseTransformerBlock (eval / no-grad)."""
     if not supported(block, sp):
@@ -841,7 +911,8 @@ def _compress_forward_fused(block, sp, xhat, x_in):
     (the output shape)."""
     C = x_in.shape[1]
     dev = x_in.device
-    p = one_scale_plan(block, sp, sync=False)
+    pre = sp.__dict__.pop("_cmp_plan", None)  # built ahead on the index stream (prefetch_level)
+    p = pre[1] if pre is not None and pre[0] is block else one_scale_plan(block, sp, sync=False)
     if not p.disjoint or p.with_pad:
         return None, p
     N, cap_w, ns = p.N, max(p.N, 1), block.max_num_win1

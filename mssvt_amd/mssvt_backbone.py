@@ -20,6 +20,9 @@ Two execution paths compute the same function:
   ``mssvt_ops`` / ``pointnet2_utils`` (HIP kernels) and torch dense math -- the
   structure of the reference's forward, kept as the mid-level parity surface.
 """
+import contextlib
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -344,6 +347,11 @@ class MixedScaleSparseTransformer(nn.Module):
         self.voxel_size = [float(v) for v in voxel_size]
         self.point_cloud_range = [float(v) for v in point_cloud_range]
         self.hash_size = model_cfg.get('HASH_SIZE', None)
+        # index work of a frame on a side stream (see forward); async_inputs_resident: the caller guarantees that
+        # voxel_coords is complete when forward is called (not pending on the current stream), which lets the next
+        # frame's index work start under this frame's feature kernels
+        self.async_index = os.environ.get('MSSVT_ASYNC_INDEX', '0') == '1'
+        self.async_inputs_resident = False
         params = model_cfg.PARAMS if hasattr(model_cfg, 'PARAMS') else model_cfg['PARAMS']
         get = lambda p, k, d=None: (p.get(k, d) if hasattr(p, 'get') else getattr(p, k, d))  # noqa: E731
         # stochastic-depth schedule: len(PARAMS)-1 rates, so the last PARAM must be a CompressBlock
@@ -406,21 +414,41 @@ class MixedScaleSparseTransformer(nn.Module):
 
     def forward(self, batch_dict):
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+        fused_path = feats.is_cuda and any(getattr(b, 'impl', None) == 'fused' for b in self.backbone)
+        # index work of the frame on a side stream (mssvt_amd/fused.py, "Index work of a frame on a second HIP stream")
+        side = main = None
+        if fused_path and self.async_index and not torch.is_grad_enabled():
+            from . import fused
+            main, side = torch.cuda.current_stream(feats.device), fused.side_stream(feats.device)
+            ready = batch_dict.get('voxel_coords_ready')  # optional event: the indices are complete behind it
+            if ready is not None:
+                side.wait_event(ready)
+            elif not self.async_inputs_resident:
+                side.wait_stream(main)  # whoever produced the indices did so on the caller's stream
         # one -1 fill for all hash tables / owner arrays of the forward (sized from the previous forward)
         arena = None
-        if feats.is_cuda and any(getattr(b, 'impl', None) == 'fused' for b in self.backbone):
-            arena = mssvt_ops.FillArena(getattr(self, '_fill_demand', 0), feats.device)
-        mssvt_ops.FillArena.current = arena
         try:
-            kw = dict(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
-                      voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
-                      batch_size=batch_dict['batch_size'], hash_size=self.hash_size, gather_dict=None)
-            sp = None
-            if arena is not None and not torch.is_grad_enabled():
-                from . import fused  # one call sets up the whole input level for the fused blocks
-                sp = fused.setup_input_level(self.backbone, kw)
-            if sp is None:
-                sp = SparseTensor(map_table=None, **kw)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if fused_path:
+                    arena = mssvt_ops.FillArena(getattr(self, '_fill_demand', 0), feats.device)
+                mssvt_ops.FillArena.current = arena
+                kw = dict(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
+                          voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
+                          batch_size=batch_dict['batch_size'], hash_size=self.hash_size, gather_dict=None)
+                sp = None
+                if arena is not None and not torch.is_grad_enabled():
+                    from . import fused  # one call sets up the whole input level for the fused blocks
+                    sp = fused.setup_input_level(self.backbone, kw)
+                if sp is None:
+                    sp = SparseTensor(map_table=None, **kw)
+                if side is not None:
+                    if getattr(sp, "_level", None) is not None:
+                        fused.prefetch_level(self._block_schedule(), sp)
+                    done = torch.cuda.Event()
+                    done.record(side)
+            if side is not None:
+                main.wait_event(done)
+                fused.record_streams([sp, arena], main)
             for i, (blk, nxt_norm, group, nxt_cmp) in enumerate(self._block_schedule()):
                 # lets a fused FFN epilogue also emit the next block's norm1 (mssvt_amd/fused.py)
                 sp._next_norm1 = nxt_norm

@@ -610,3 +610,35 @@ def test_backward_matches_the_reference_run(golden_dir, name, cls):
     close(x.grad, d["grad_input"], "input")
     for k, p in blk.named_parameters():
         close(p.grad if p.grad is not None else torch.zeros_like(p), d["grad." + k], k)
+
+
+def test_index_work_on_a_side_stream_gives_identical_frames():
+    """async_index: the index work of a frame on a second HIP stream, the next frame's under this frame's feature kernels
+    (buffers handed over with record_stream).  A run of different frames back to back, no synchronisation in between,
+    must equal the single-stream forward bit for bit."""
+    from mssvt_amd import config
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval()
+    frames = []
+    for i, n in enumerate((30000, 52000, 8000, 41000, 30000, 61000)):
+        pts = synthetic.make_batch_points(n, 1 + i % 2, 100 + i)
+        vc, _, _ = synthetic.voxelize_numpy(pts)
+        frames.append((torch.from_numpy(vc).to(DEV), torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(i)).to(DEV),
+                       1 + i % 2))
+    torch.cuda.synchronize()
+
+    def run(async_index):
+        net.async_index, net.async_inputs_resident = async_index, async_index
+        outs = []
+        with torch.no_grad():
+            for rep in range(3):
+                for vc, feats, B in frames:
+                    sp = net(dict(voxel_features=feats, voxel_coords=vc, batch_size=B))["encoded_spconv_tensor"]
+                    outs.append((sp.features, sp.indices))
+        torch.cuda.synchronize()
+        return outs
+
+    want, got = run(False), run(True)
+    net.async_index = False
+    for (fa, ia), (fb, ib) in zip(want, got):
+        assert torch.equal(ia, ib) and torch.equal(fa, fb)
