@@ -359,7 +359,7 @@ def _block_index_sets(block, sp, p):
     N = sp.indices.shape[0]
     q_ind, nq, owner_q = fused._query(block, p)
     od = fused._work_order(block, p, nq, N)
-    nw, R = int(p.num_wins.item()), int(od["n_rows"].item())  # host values: one sync per (plan, pattern)
+    nw, R = torch.cat([p.num_wins.reshape(1), od["n_rows"].reshape(1)]).tolist()  # host values: one sync
     s = {"nw": nw, "R": R, "nq": nq}
     meta = od["row_meta"][:R]
     s["q_rows"] = meta[:, 3].contiguous().view(torch.int32)
@@ -371,16 +371,18 @@ def _block_index_sets(block, sp, p):
     s["keys"] = []
     for g in range(2):
         km = p.kmeta[g][:nw]
+        K = km.shape[1]
         rows = km[..., 3].contiguous().view(torch.int32)
         valid = rows >= 0
-        k_win = torch.nonzero(valid, as_tuple=True)[0]
+        flat = torch.nonzero(valid.reshape(-1), as_tuple=True)[0]  # the one sync of this scale: every size follows from it
+        k_win = flat // K
         nk = valid.sum(1)  # keys per window
         koff = torch.cumsum(nk, 0) - nk
-        k_rows = rows[valid]
+        k_rows = rows.reshape(-1)[flat]
+        k_rel = km[..., :3].reshape(-1, 3)[flat].contiguous()
         wins = dict(q_off=od["q_off"][:nw].contiguous(), q_cnt=od["nq_valid"][:nw].contiguous(),
                     k_off=koff.int().contiguous(), k_cnt=nk.int().contiguous())
-        s["keys"].append(dict(k_rows=k_rows, k_rel=km[..., :3][valid].contiguous(), k_win=k_win,
-                              k_csr=Csr.gather(k_rows, N), wins=wins))
+        s["keys"].append(dict(k_rows=k_rows, k_rel=k_rel, k_win=k_win, k_csr=Csr.gather(k_rows, N), wins=wins))
     # interpolation / scatter table: 3 compact attention rows + weights per voxel (row R = the zero row)
     interp = key[1]
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
@@ -474,8 +476,9 @@ def _compress_index_sets(block, sp, p):
     N, nw, ns = sp.indices.shape[0], p.nw, block.max_num_win1
     k = p.k_ind[:nw]
     valid = k >= 0
-    pair_win = torch.nonzero(valid, as_tuple=True)[0]
-    pair_vox = (k[valid].long() + p.win_vstart[:nw].long()[pair_win]).int().contiguous()
+    flat = torch.nonzero(valid.reshape(-1), as_tuple=True)[0]  # one sync: the pair count
+    pair_win = flat // ns
+    pair_vox = (k.reshape(-1)[flat].long() + p.win_vstart[:nw].long()[pair_win]).int().contiguous()
     cnt = valid.sum(1)
     vox_xyz = _metric(sp.indices, sp.point_cloud_range, sp.voxel_size)
     centre = _metric(p.win_ind[:nw], sp.point_cloud_range, p.win_size_m)
