@@ -8,7 +8,7 @@
 //                        emitted by the previous block's fused FFN epilogue, csrc/ffn.hip).
 #include "common.hip.h"
 
-#define BC_ROWS 16   // rows per thread
+#define BC_ROWS 4    // rows per thread (16: 19 workgroups for a 74k-voxel scene, 10.9 us of serial row loads; 4: 73 workgroups)
 #define BC_LDS 1024  // samples counted in LDS per workgroup
 __global__ void __launch_bounds__(256) k_batch_counts(const int *indices, int n, int batch_size, int *counts) {
     // one global atomic per (workgroup, sample present in it): single-address atomics cost ~11 ns each
