@@ -7,6 +7,7 @@ from mssvt_amd import config
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = config.build_backbone_from_cfg().to(dev).eval()
+net.async_inputs_resident = net.async_index  # MSSVT_ASYNC_INDEX=1: the next frame's index work under this frame's features
 ins = [bench.make_inputs(p, 1, s, dev)[2:] for p, s in ((160000, 0), (120000, 1), (200000, 2), (60000, 3))]
 ref = None
 with torch.no_grad():
