@@ -43,3 +43,22 @@ def test_bench_configs2_flags():
     res = _bench("--batch", "2", "--attn-dtype", "bf16")
     assert res["dtype"] == "bf16" and res["config"]["attn_dtype"] == "bf16" and res["n_gpus"] == 1
     assert res["timing"]["p10_ms"] <= res["timing"]["median_ms"] <= res["timing"]["p90_ms"]
+
+
+def test_bench_ffn_arith_flag_and_roofline_object():
+    """--ffn-arith selects the FFN / CompressBlock arithmetic and the JSON says which one ran; the default line carries the
+    roofline of the dominant kernel (k_ffn_ws, HBM bound) with the whole-frame object."""
+    res = _bench("--ffn-arith", "f32")
+    assert "v_mfma_f32_16x16x4_f32" in res["config"]["ffn_arith"]
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--points", "20000",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, env=e, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "split exactly into two fp16 halves" in res["config"]["ffn_arith"]
+    rf = res["roofline"]
+    assert rf["bound"] == "hbm" and "k_ffn_ws" in rf["kernel"] and 0 < rf["frac"] < 1 and rf["unit"] == "GB/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["frame"]["frac"] > 0
+    assert any("mssvt_block_attention" in o["kernel"] for o in rf["other_kernels"])
