@@ -1,4 +1,11 @@
-// ffn.hip -- fused per-voxel feed-forward tail of an MsSVT block on the fp32 matrix cores.
+// ffn.hip -- fused per-voxel feed-forward tail of an MsSVT block on the matrix cores.
+//
+// Three generations live here, newest last (each section explains why it replaced the one before):
+//   k_ffn          one launch, weights streamed through LDS in chunks, fp32 MFMA            (kept for A/B)
+//   k_ffn_up/down  two launches, whole weight matrix resident in LDS, fp32 MFMA             (ffn_arith = "f32", and
+//                                                                      parameters outside the fp16 range)
+//   k_ffn_ws       one launch, weights stationary in registers, fp32 operands split into two fp16 halves
+//                  (3 x v_mfma_f32_16x16x32_f16 per product sum: fp32-instruction accuracy)   (the default)
 //
 // Replaces, per block, the reference's (ref: mssvt_backbone.py:298-343 / :383-387)
 //     3-NN interpolation + scatter + shortcut      K9, K10, index_put, add
