@@ -547,12 +547,14 @@ static int launch_compress(const CmpArgs &a, int win_capacity, hipStream_t strea
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
     const int vt = (a.num_voxels + 15) / 16, wt = (win_capacity + 15) / 16;
-    // every workgroup resident at once (blocks per CU by LDS), the roles of the first launch split ~1 : 2 (a key tile
-    // carries a C x C product on top of its positional layer, a query tile mostly waits for its list walk)
+    // every workgroup resident at once (blocks per CU by LDS); the roles of the first launch share them
     const int per_q = (int)((160 * 1024) / lds_q) < 1 ? 1 : (int)((160 * 1024) / lds_q);
     const int per_o = (int)((160 * 1024) / lds_o) < 1 ? 1 : (int)((160 * 1024) / lds_o);
     const int slots = cus * per_q;
-    int g_w = min(max(slots / 3, 1), max(wt, 1)), g_v = min(max(slots - g_w, 1), max(vt, 1));
+    // fp32 products: ~1 : 2 (a key tile carries a C x C product on top of its positional layer, a query tile mostly waits
+    // for its list walk); with the split-fp16 products the key side is cheap and the latency-bound query side sets the
+    // launch time: 1 : 1 measured best (33 % -> 42 / 319 us at one / eight scenes, 50 % -> 36 / 230, 67 % -> 44 / 309)
+    int g_w = min(max(H ? slots / 2 : slots / 3, 1), max(wt, 1)), g_v = min(max(slots - g_w, 1), max(vt, 1));
     const int g_v2 = min(cus, max(vt, 1)), g_o = min(cus * per_o, max(wt, 1));
     k_cmp_query_keys<C, H><<<g_w + g_v, CFQ_NW * MSSVT_WAVE, lds_q, stream>>>(a, g_w);
     k_cmp_kv<C, HD, H><<<g_v2, CFK_NW * MSSVT_WAVE, lds2, stream>>>(a);
