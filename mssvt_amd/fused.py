@@ -453,7 +453,10 @@ def _ffn_f16_weights(fr):
     if fr.get("f16_ver") != ver:
         W1, b1, W2, b2, lnw, lnb = [t.detach().float() for t in ts]
         xmax = (fr["C"] ** 0.5) * lnw.abs().max() + lnb.abs().max()
-        hmax = (W1.abs().sum(1) * xmax + b1.abs()).max()
+        # |W1_h . x| <= |W1_h|_1 max|x|  and  <= |W1_h|_2 |x|_2 with |x|_2 <= sqrt(C) max|w| + |b|_2 (a normalised row has
+        # length sqrt(C)): the smaller of the two
+        x2 = (fr["C"] ** 0.5) * lnw.abs().max() + lnb.norm()
+        hmax = (torch.minimum(W1.abs().sum(1) * xmax, W1.norm(dim=1) * x2) + b1.abs()).max()
         worst = torch.stack([xmax, hmax, W1.abs().max(), W2.abs().max()]).max()
         ok = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
         packed = None
