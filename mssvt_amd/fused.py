@@ -898,11 +898,16 @@ def _compress_f16_ok(block, sp):
         g1, b1, Wp1, bp1, Wp2, bp2, Wq, Wkv, bkv, Wo = [t.detach().float() for t in ts]
         C = g1.numel()
         coord = max(abs(float(v)) for v in sp.point_cloud_range)
+        # element-wise and Euclidean bounds side by side; a product row is bounded by the smaller of |W_o|_1 max|x| and
+        # |W_o|_2 |x|_2
         xmax = (C ** 0.5) * g1.abs().max() + b1.abs().max()
-        hmax = (Wp1.reshape(C, -1).abs().sum(1) * coord + bp1.abs()).max()
-        kmax = xmax + (Wp2.reshape(C, -1).abs().sum(1) * hmax + bp2.abs()).max()
-        vmax = (Wkv.abs().sum(1) * kmax + bkv.abs()).max()
-        worst = torch.stack([xmax, hmax, kmax, vmax, Wq.abs().max(), Wkv.abs().max(), Wo.abs().max(), Wp2.abs().max()]).max()
+        x2 = (C ** 0.5) * g1.abs().max() + b1.norm()
+        hvec = Wp1.reshape(C, -1).abs().sum(1) * coord + bp1.abs()  # positional hidden layer, per channel
+        W2 = Wp2.reshape(C, -1)
+        pvec = torch.minimum(W2.abs().sum(1) * hvec.max(), W2.norm(dim=1) * hvec.norm()) + bp2.abs()
+        kmax, k2 = xmax + pvec.max(), x2 + pvec.norm()  # key tokens = xhat + positional term
+        vmax = (torch.minimum(Wkv.abs().sum(1) * kmax, Wkv.norm(dim=1) * k2) + bkv.abs()).max()
+        worst = torch.stack([xmax, hvec.max(), kmax, vmax, Wq.abs().max(), Wkv.abs().max(), Wo.abs().max(), Wp2.abs().max()]).max()
         cache["ok"] = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
         cache["ver"] = ver
     return cache["ok"]
