@@ -192,6 +192,27 @@ int mssvt_level_setup(int num_voxels, int batch_size, int x_max, int y_max, int 
                       int *const *host_tables, int *const *host_scratch_tables, int *const *host_vcount,
                       int *workspaces, long long workspace_stride_ints, void *stream);
 
+/* The same level set-up for a voxel list that is SORTED by (b,x,y,z) -- the order DynamicVFE emits
+ * (vfe/dynamic_vfe.py:83-93,114-118: torch.unique over the voxel keys) -- from one occupancy bitmap, without the
+ * voxel hash table (K1, ms_sparse_attention_gpu.cu:66-97), without the insert-min / rank passes of K2 (:117-168)
+ * and without counting atomics (mssvt_utils.py:35-37), three launches behind one fill (z_max <= 64):
+ *   v_bs_cnt (B), sample_start (B+1) rows of every sample; occ_columns (B*X*Y words, bit z);
+ *   column_vbase (B*X*Y): voxels of the sample in earlier columns (index of cell (x,y,z) in its sample =
+ *   column_vbase + popcount(word below z)); per partition k < num_sets (<= 4): win_ind[k] (num_voxels,4) window rows
+ *   [b,wz,wy,wx] in first-occurrence order, tables[k] (B,H,2) pre-filled with -1 or NULL (no table wanted),
+ *   vcount[k] (B) windows per sample, ws[k]: 4 header ints ([0] status bits, [1] number of windows).
+ * level_status[0] gets ST_UNSORTED (8) when the list is not strictly ascending in (b,x,y,z) or holds an out-of-grid
+ * voxel; every partition then reports 0 windows and the caller must use mssvt_level_setup (any order).
+ * zero_region / zero_bytes: one caller allocation cleared by this call that contains sample_start, occ_columns,
+ * level_status and the ws headers.  scratch: mssvt_level_sorted_scratch_ints(B, X, Y) ints.                     */
+long long mssvt_level_sorted_scratch_ints(int batch_size, int x_max, int y_max);
+int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_max, int z_max, int hash_size,
+                             const int *v_indices, void *zero_region, long long zero_bytes, int *v_bs_cnt,
+                             int *sample_start, unsigned long long *occ_columns, int *column_vbase, int *level_status,
+                             int num_sets, const int *host_win_grid3, const int *host_win_size3,
+                             const int *host_max_num_wins, int *const *host_win_ind, int *const *host_tables,
+                             int *const *host_vcount, int *const *host_ws, int *scratch, void *stream);
+
 /* Fused window plan of a two-scale Block: K3 + 2 x K7 + 2 x K8 + the key-mask logic
  * of ref mssvt_backbone.py:247-258 in one launch, one wavefront per window, hit lists
  * kept in LDS.  num_wins_dev: DEVICE scalar (e.g. workspace+1 of
@@ -204,7 +225,10 @@ int mssvt_level_setup(int num_voxels, int batch_size, int x_max, int y_max, int 
  * Optional resolved metadata (kmeta1 == NULL: skipped): qmeta_* (cap,max_num_*,4), kmeta1/2
  * (cap,K,4) f32 = (voxel centre - window centre in metres, bits of the global feature row or
  * -1 for empty / masked slots); wcentre (cap,4) = window centre; nq_valid (3,cap) = valid odd /
- * even / win1 entries per window.  indices (N,4) voxel coords.                               */
+ * even / win1 entries per window.  indices (N,4) voxel coords.
+ * column_vbase / level_status_dev (optional, with occ_columns; from mssvt_level_setup_sorted): for a voxel list sorted
+ * by (b,x,y,z) the index of an occupied cell is column_vbase + popcount(column word below z) and the hash is not
+ * probed at all (xyz_to_vidx may then be NULL); when level_status_dev[0] has ST_UNSORTED (8) set the hash is used. */
 int mssvt_window_plan_two(
     int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
     int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
@@ -216,7 +240,8 @@ int mssvt_window_plan_two(
     const int *indices, const float *host_voxel_size3, const float *host_range_min3,
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
     float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
-    const int *host_footprint4, const int *packed_offsets, void *stream);
+    const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
+    void *stream);
 
 /* Occupancy columns of a voxel set (z_max <= 64): columns (B*x_max*y_max) 64-bit words, bit z of
  * word (b*x_max + x)*y_max + y set when cell (b,x,y,z) holds a voxel.  Optional input of
@@ -318,13 +343,18 @@ int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_interpolation, 
  * window sizes): pair row = the voxel's feature row, pad row of window w = num_voxels + w,
  * pair_win must be pre-filled with -1, pair_base = -1.  Otherwise rows are reserved through
  * counters[0] (= rows handed out; cleared by this call) and pair_base[w] is the window's
- * first row.  With disjoint lists counters[0] is not touched.                            */
+ * first row.  With disjoint lists counters[0] is not touched.
+ * occ_columns / column_vbase / level_status_dev (optional, all or none; mssvt_level_setup_sorted): sorted voxel
+ * list -> occupancy bit = hit, column base + popcount below z = voxel index, the hash is not probed
+ * (xyz_to_vidx may be NULL) unless level_status_dev[0] has ST_UNSORTED (8) set.                    */
 int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws,
                           int max_num_win1, int hash_size, int num_win1, const int *vox_query_win1,
                           const int *win_indices, const int *num_wins_dev, int win_capacity,
                           const int *xyz_to_vidx, const int *v_bs_cnt, int with_pad,
                           int disjoint_lists, int num_voxels, int *k_ind, int *win_vstart, int *win_cnt,
-                          int *pair_base, int *pair_win, int *pair_vox, int *counters, void *stream);
+                          int *pair_base, int *pair_win, int *pair_vox, int *counters,
+                          const unsigned long long *occ_columns, const int *column_vbase,
+                          const int *level_status_dev, void *stream);
 /* out (R,C) = relu(W1 [voxel centre - window centre ; window centre] + b1) per pair row
  * (first layer of pos_proj, ref :49-54, :372-373).                                     */
 int mssvt_compress_pos1(int C, const int *num_rows_dev, int row_capacity, const int *pair_win,

@@ -33,6 +33,7 @@ def lib():
         _lib.mssvt_linear_wgrad_workspace_floats.restype = ctypes.c_longlong
         _lib.mssvt_csr_transpose_workspace_bytes.restype = ctypes.c_longlong
         _lib.mssvt_ffn_packed_bytes.restype = ctypes.c_longlong
+        _lib.mssvt_level_sorted_scratch_ints.restype = ctypes.c_longlong
     return _lib
 
 

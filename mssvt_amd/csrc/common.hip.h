@@ -17,6 +17,7 @@
 #define ST_DUP 1
 #define ST_TABLE_OVERFLOW 2
 #define ST_WIN_OVERFLOW 4
+#define ST_UNSORTED 8  // mssvt_level_setup_sorted: the voxel list is not strictly (b,x,y,z)-ascending / in-grid
 
 static inline int mssvt_launch_status() {
     hipError_t e = hipGetLastError();

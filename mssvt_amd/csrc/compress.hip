@@ -36,10 +36,13 @@ __global__ void __launch_bounds__(CP_WPB *MSSVT_WAVE)
                       int hash_size, int n_win1, const int *q_win1, const int *win_indices,
                       const int *num_wins, const slot_t *table, const int *v_bs_cnt, int with_pad,
                       int disjoint, int num_voxels, int *k_ind, int *win_vstart, int *win_cnt,
-                      int *pair_base, int *pair_win, int *pair_vox, int *counters) {
+                      int *pair_base, int *pair_win, int *pair_vox, int *counters,
+                      const unsigned long long *occ, const int *col_vbase, const int *level_status) {
     const int w = blockIdx.x * CP_WPB + threadIdx.x / MSSVT_WAVE;
     if (w >= *num_wins) return;
     const int lane = lane_id();
+    // sorted voxel list (mssvt_level_setup_sorted): occupancy bit = hit, column base + popcount below = index
+    const bool ranked = occ != nullptr && col_vbase != nullptr && !(level_status[0] & ST_UNSORTED);
     const int4 wi = reinterpret_cast<const int4 *>(win_indices)[w];
     const slot_t *tab = table + (size_t)wi.x * hash_size;
     int vstart = 0;
@@ -69,8 +72,15 @@ __global__ void __launch_bounds__(CP_WPB *MSSVT_WAVE)
             int sv = MSSVT_EMPTY;
             if (q < n_win1) {
                 const int sx = cx + q_win1[q * 3 + 0], sy = cy + q_win1[q * 3 + 1], sz = cz + q_win1[q * 3 + 2];
-                if (!(sx >= x_max || sx < 0 || sy >= y_max || sy < 0 || sz >= z_max || sz < 0))
-                    sv = table_find(sx * y_max * z_max + sy * z_max + sz, hash_size, tab);
+                if (!(sx >= x_max || sx < 0 || sy >= y_max || sy < 0 || sz >= z_max || sz < 0)) {
+                    if (ranked) {
+                        const size_t col = ((size_t)wi.x * x_max + sx) * y_max + sy;
+                        const unsigned long long word = occ[col];
+                        if ((word >> sz) & 1ull) sv = col_vbase[col] + __popcll(word & ((1ull << sz) - 1ull));
+                    } else if (table) {
+                        sv = table_find(sx * y_max * z_max + sy * z_max + sz, hash_size, tab);
+                    }
+                }
             }
             const bool hit = sv != MSSVT_EMPTY;
             const unsigned long long m = __ballot(hit);
@@ -228,8 +238,10 @@ extern "C" int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, 
                                      const int *v_bs_cnt, int with_pad, int disjoint_lists,
                                      int num_voxels, int *k_ind, int *win_vstart, int *win_cnt,
                                      int *pair_base, int *pair_win, int *pair_vox, int *counters,
-                                     void *stream) {
-    if (!vox_query_win1 || !win_indices || !num_wins_dev || !xyz_to_vidx || !v_bs_cnt || !k_ind ||
+                                     const unsigned long long *occ_columns, const int *column_vbase,
+                                     const int *level_status_dev, void *stream) {
+    const bool ranked = occ_columns && column_vbase && level_status_dev && z_max <= 64;
+    if (!vox_query_win1 || !win_indices || !num_wins_dev || (!xyz_to_vidx && !ranked) || !v_bs_cnt || !k_ind ||
         !win_vstart || !win_cnt || !pair_base || !pair_win || !pair_vox || !counters || hash_size <= 0 ||
         max_num_win1 <= 0)
         return MSSVT_E_BADARG;
@@ -241,7 +253,8 @@ extern "C" int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, 
     k_window_plan_one<<<divup(win_capacity, CP_WPB), CP_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(
         x_max, y_max, z_max, x_ws, y_ws, z_ws, max_num_win1, hash_size, num_win1, vox_query_win1,
         win_indices, num_wins_dev, reinterpret_cast<const slot_t *>(xyz_to_vidx), v_bs_cnt, with_pad,
-        disjoint_lists, num_voxels, k_ind, win_vstart, win_cnt, pair_base, pair_win, pair_vox, counters);
+        disjoint_lists, num_voxels, k_ind, win_vstart, win_cnt, pair_base, pair_win, pair_vox, counters,
+        ranked ? occ_columns : nullptr, ranked ? column_vbase : nullptr, ranked ? level_status_dev : nullptr);
     return mssvt_launch_status();
 }
 

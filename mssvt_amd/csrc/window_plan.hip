@@ -21,11 +21,9 @@
 // is sized for the capacity and surplus waves exit.
 #include <stdlib.h>
 #include "common.hip.h"
-
 #define PLAN_MAX_WPB 4
 
 struct PlanArgs {
-    int fps_nmax, fps_bs;  // LDS sampler scratch (0: every list fits a register sampler)
     int x_max, y_max, z_max, x_ws, y_ws, z_ws;
     int max_odd, max_even, max_win1, max_win2;
     int hash_size, batch_size;
@@ -49,11 +47,16 @@ struct PlanArgs {
     const int *indices;
     float vsx, vsy, vsz, minx, miny, minz, wsx, wsy, wsz;
     int lds_words_per_wave;
+    int hit_cap;  // entries of the per-wave hit sequence (>= number of table offsets, even)
     // optional occupancy columns (mssvt_occupancy_columns): one 64-bit word per (b, x, y), bit z set
     // when the cell holds a voxel; fx0/fy0/fnx/fny = bounding box of the tables' (x, y) offsets
     const unsigned long long *occ;
     int fx0, fy0, fnx, fny;
     const int *q_packed;  // with occ: the four tables concatenated, one pack_off() word per offset
+    // optional, with occ: voxels of the sample in the columns before (b, x, y) of a voxel list that is sorted by
+    // (b, x, y, z) -- the index of an occupied cell is then col_vbase + popcount(column word below z) and the hash
+    // is not probed at all; level_status = the device word in which mssvt_level_setup_sorted reports ST_UNSORTED
+    const int *col_vbase, *level_status;
 };
 
 __device__ __forceinline__ float plan_centre(int idx, float cell, float lo) {
@@ -66,235 +69,153 @@ __device__ __forceinline__ int pack_off(int ox, int oy, int oz) {
     return (ox + 64) | ((oy + 64) << 8) | ((oz + 64) << 16);
 }
 
-// Farthest point sampling over an LDS list of packed integer offsets (padding = offset 0),
-// replaying a reference block of `bs` threads (ref sampling_gpu.cu:100-216).  Writes the m
-// picked slot numbers to fps_out[0..m).
-__device__ __forceinline__ void fps_on_list(const int *packed, int n, int m, int bs, float *temp,
-                                            float *bv, int *bidx, int *fps_out, int lane) {
-    for (int k = lane; k < n; k += MSSVT_WAVE) temp[k] = 1e10f;
-    if (lane == 0) fps_out[0] = 0;
-    wave_lds_sync();
-    int old = 0;
-    const int top = bs < MSSVT_WAVE ? bs : MSSVT_WAVE;
-    for (int j = 1; j < m; ++j) {
-        const int po = packed[old];
-        const float x1 = (float)((po & 255) - 64), y1 = (float)(((po >> 8) & 255) - 64),
-                    z1 = (float)(((po >> 16) & 255) - 64);
-        float best = -1.0f;
-        int besti = 0;
-        for (int vt = lane; vt < bs; vt += MSSVT_WAVE) {
-            best = -1.0f;
-            besti = 0;
-            for (int k = vt; k < n; k += bs) {
-                const int p = packed[k];
-                const float dx = (float)((p & 255) - 64) - x1, dy = (float)(((p >> 8) & 255) - 64) - y1,
-                            dz = (float)(((p >> 16) & 255) - 64) - z1;
-                const float d2 = fminf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), temp[k]);
-                temp[k] = d2;
-                besti = d2 > best ? k : besti;
-                best = d2 > best ? d2 : best;
-            }
-            if (bs > MSSVT_WAVE) {
-                bv[vt] = best;
-                bidx[vt] = besti;
-            }
-        }
-        for (int s = bs >> 1; s >= MSSVT_WAVE; s >>= 1) {
-            wave_lds_sync();
-            for (int t = lane; t < s; t += MSSVT_WAVE) {
-                const float v1 = bv[t], v2 = bv[t + s];
-                const int i1 = bidx[t], i2 = bidx[t + s];
-                bv[t] = fmaxf(v1, v2);
-                bidx[t] = v2 > v1 ? i2 : i1;
-            }
-        }
-        if (bs > MSSVT_WAVE) {
-            wave_lds_sync();
-            best = bv[lane];
-            besti = bidx[lane];
-        }
-        for (int s = top >> 1; s >= 1; s >>= 1) {
-            const float v2 = __shfl_down(best, s);
-            const int i2 = __shfl_down(besti, s);
-            besti = v2 > best ? i2 : besti;
-            best = fmaxf(best, v2);
-        }
-        old = __builtin_amdgcn_readfirstlane(besti);
-        if (lane == 0) fps_out[j] = old;
-        wave_lds_sync();
+// ---- farthest point sampling on the hit sequence ---------------------------------------------------------
+// (ref pointnet2/pointnet2_batch/src/sampling_gpu.cu:93-216 replayed; see fps_nn.hip for the operator form)
+//
+// Offsets are integers in [-60, 60]: every squared distance is an integer < 2^16, exact in fp32, so the sampler
+// runs on integers with the same outcome: |a - b|^2 = |a|^2 - 2 a.b + |b|^2 is ONE v_dot4_i32_i8 (a and -2 b packed
+// as signed bytes) plus one add.  One 32-bit key
+//     (distance << 12) | ((1023 - bit-reversed thread id) << 2) | (first slot of the thread ? 2 : 0) | 1
+// orders candidates exactly like the reference's block: larger distance first; among equal distances the
+// shared-memory tree keeps the lower thread at every stride bs/2 ... 1, i.e. the smallest BIT-REVERSED thread id;
+// inside a thread the later slot wins only on a STRICTLY larger distance (bit 1).  0 = no candidate.  One wave
+// max per round; the winner's thread id and slot are decoded from the key itself (scalar), no ballot / readlane.
+#define FPS_BIG 0xFFFFFu  // "1e10": replaced by a real distance in the first round
+__device__ __forceinline__ unsigned int wave_max_u32_uniform(unsigned int v) {
+    unsigned int t;
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = t > v ? t : v;   // quad_perm [1,0,3,2]
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = t > v ? t : v;   // quad_perm [2,3,0,1]
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = t > v ? t : v;  // row_half_mirror
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = t > v ? t : v;  // row_mirror
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;  // row_bcast:15
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;  // row_bcast:31
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+// signed-byte packs of an offset (x, y, z) and of -2 (x, y, z) (|offset| <= 60)
+__device__ __forceinline__ int fps_pack_s8(int x, int y, int z) { return (x & 255) | ((y & 255) << 8) | ((z & 255) << 16); }
+__device__ __forceinline__ void fps_unpack(int pk, int &x, int &y, int &z) {
+    x = (pk & 255) - 64; y = ((pk >> 8) & 255) - 64; z = ((pk >> 16) & 255) - 64;
+}
+// thread of the reference block with the smallest bit-reversed id in [lo, bs): the one with the most trailing zeros
+__device__ __forceinline__ int fps_min_rev_thread(int lo, int L) {
+    for (int t = L - 1; t >= 0; --t) {
+        const int c = (lo + (1 << t) - 1) & ~((1 << t) - 1);
+        if (c < (1 << L)) return c;
     }
+    return lo;
+}
+__device__ __forceinline__ int fps_decode_pick(unsigned int mkey, int L, int bs) {
+    const unsigned int rev = 1023u - ((mkey >> 2) & 1023u);
+    const int vt = L ? (int)(__brev(rev) >> (32 - L)) : 0;
+    return vt + ((mkey & 2u) ? 0 : bs);
 }
 
-// Fast path of the same sampler for the case that matters: the list holds nv <= 64 valid entries
-// (front-packed, as K3 produces them) followed by padding, and nv <= bs.  All padding slots carry
-// the same offset (0,0,0), hence the same running min-distance `tpad`, so nothing needs to be
-// scanned per slot.  The reference block is reproduced analytically:
+// Fast path, the case that matters: the list holds nv <= 64 valid entries (front-packed, as K3 produces
+// them) followed by padding, and nv <= bs.  All padding slots carry the same offset (0,0,0), hence the same running
+// min-distance `tpad`, so nothing needs to be scanned per slot.  The reference block is reproduced analytically:
 //   * reference thread vt visits slots vt, vt+bs (n <= 2*bs - 1): for vt < nv that is one valid slot
 //     then (if it exists) one padding slot, taken only if tpad is STRICTLY larger; for vt >= nv it
 //     is padding only -> (tpad, vt);
-//   * the shared-memory tree keeps the lower slot on ties at every level (strides bs/2 ... 1), i.e.
-//     among threads with the maximal value the one with the smallest BIT-REVERSED id wins.
-// One lane per valid entry, min-distances in registers, two wave reductions per round, no LDS.
-__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned int o = (unsigned int)__shfl_xor((int)v, off);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-// Offsets are integers in [-64, 63]: every squared distance is an integer < 2^16, exact in fp32, so the
-// sampler can run on integers with the same outcome.  One 32-bit key = (distance << 11) | ((1023 -
-// bit-reversed thread id) << 1) | 1 orders candidates exactly like the reference's tree (larger
-// distance first, then the smaller bit-reversed id; 0 = no candidate): ONE wave max per round replaces a
-// float max plus a tie-break min.
-#define FPS_BIG 0xFFFFFu  // "1e10": replaced by a real distance in the first round
-__device__ __forceinline__ unsigned int fps_key(unsigned int dist, unsigned int rev) {
-    return (dist << 11) | ((1023u - rev) << 1) | 1u;
-}
-__device__ __forceinline__ unsigned int wave_max_u32_uniform(unsigned int v) {
-    unsigned int o;
-    o = DPP_MOV_U(v, 0xB1); v = o > v ? o : v;
-    o = DPP_MOV_U(v, 0x4E); v = o > v ? o : v;
-    o = DPP_MOV_U(v, 0x141); v = o > v ? o : v;
-    o = DPP_MOV_U(v, 0x140); v = o > v ? o : v;
-    const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 16),
-                       r2 = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
-    const unsigned int a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
-    return a > b ? a : b;
-}
-
-__device__ __forceinline__ void fps_on_list_fast(const int *packed, int n, int nv, int m, int bs,
-                                                 int *fps_out, int lane) {
-    int L = 0;
-    while ((1 << L) < bs) ++L;
+//   * among the pure-padding threads [nv, bs) the tree favours the smallest bit-reversed id (fps_min_rev_thread).
+// One lane per valid entry (pk = its packed offset, PACK0 on the other lanes), min-distances in registers.
+__device__ __forceinline__ void fps_on_list_fast(int pk, int n, int nv, int m, int bs, int *fps_out, int lane) {
+    const int L = 31 - __clz(bs);
     const bool mine = lane < nv;
-    const int pk = packed[mine ? lane : 0];
-    const int xk = (pk & 255) - 64, yk = ((pk >> 8) & 255) - 64, zk = ((pk >> 16) & 255) - 64;
-    unsigned int tk = FPS_BIG, tpad = FPS_BIG;
-    const unsigned int myrev = mine ? (__brev((unsigned int)lane) >> (32 - L)) : 0u;
-    const bool has_second = mine && lane + bs < n;  // this thread's second slot (padding)
-    // pure-padding threads vt in [nv, bs): the tree favours the smallest bit-reversed id
-    const bool padgroup = nv < bs;
-    unsigned int vp_rev = 0u;
-    int vp = 0;
-    if (padgroup) {
-        unsigned int best = 0xFFFFFFFFu;
-        for (int vt = nv + lane; vt < bs; vt += MSSVT_WAVE) {
-            const unsigned int r = __brev((unsigned int)vt) >> (32 - L);
-            best = r < best ? r : best;
-        }
-        vp_rev = wave_min_u32_uniform(best);
-        vp = (int)(__brev(vp_rev) >> (32 - L));  // bit reversal is an involution on L bits
-    }
+    int xk, yk, zk;
+    fps_unpack(pk, xk, yk, zk);
+    const int a4 = fps_pack_s8(xk, yk, zk), m2 = fps_pack_s8(-2 * xk, -2 * yk, -2 * zk);
+    const int na = xk * xk + yk * yk + zk * zk;
+    const unsigned int myrev = __brev((unsigned int)lane) >> (32 - L);
+    const unsigned int tb = mine ? (((1023u - myrev) << 2) | 3u) : 0u;  // first slot of thread `lane`
+    const bool has_second = mine && lane + bs < n;                      // this thread's second slot (padding)
+    const unsigned int tb2 = has_second ? (tb & ~2u) : 0u;
+    const bool padgroup = nv < bs;  // pure-padding threads vt in [nv, bs)
+    const int vp = padgroup ? fps_min_rev_thread(nv, L) : 0;
+    const unsigned int vp_tb = ((1023u - (__brev((unsigned int)vp) >> (32 - L))) << 2) | 3u;
+    unsigned int tk = mine ? FPS_BIG : 0u, tpad = FPS_BIG;
     int old = 0;
     if (lane == 0) fps_out[0] = 0;
     for (int j = 1; j < m; ++j) {
-        int x1 = 0, y1 = 0, z1 = 0;  // a padding slot sits at offset (0,0,0)
-        if (old < nv) {  // `old` is wave-uniform: v_readlane, no LDS round trip
-            const int ol = __builtin_amdgcn_readfirstlane(old);
-            x1 = __builtin_amdgcn_readlane(xk, ol);
-            y1 = __builtin_amdgcn_readlane(yk, ol);
-            z1 = __builtin_amdgcn_readlane(zk, ol);
-        }
-        {
-            const int dx = xk - x1, dy = yk - y1, dz = zk - z1;
-            const unsigned int d = (unsigned int)(__mul24(dz, dz) + __mul24(dy, dy) + __mul24(dx, dx));
-            tk = d < tk ? d : tk;
-            const unsigned int pd = (unsigned int)(x1 * x1 + y1 * y1 + z1 * z1);  // wave-uniform: scalar ALU
-            tpad = pd < tpad ? pd : tpad;
-        }
-        unsigned int best = tk;
-        int besti = lane;
-        if (has_second && tpad > best) {
-            best = tpad;
-            besti = lane + bs;
-        }
-        const unsigned int key = mine ? fps_key(best, myrev) : 0u;
+        // offset of the last pick: a valid entry's, or (0,0,0) of a padding slot (`old` is wave-uniform)
+        const bool ov = old < nv;
+        const int ol = ov ? old : 0;
+        int s_m2 = __builtin_amdgcn_readlane(m2, ol), s_nb = __builtin_amdgcn_readlane(na, ol);
+        s_m2 = ov ? s_m2 : 0;
+        s_nb = ov ? s_nb : 0;
+        const unsigned int d = (unsigned int)(__builtin_amdgcn_sdot4(a4, s_m2, na, false) + s_nb);
+        tk = d < tk ? d : tk;
+        tpad = (unsigned int)s_nb < tpad ? (unsigned int)s_nb : tpad;
+        const unsigned int k1 = (tk << 12) | tb;
+        const unsigned int k2 = has_second ? ((tpad << 12) | tb2) : 0u;
+        const unsigned int key = k1 > k2 ? k1 : k2;
         const unsigned int mkey = wave_max_u32_uniform(key);
-        const unsigned int M = mkey >> 11;  // 0 when there is no valid entry at all (nv == 0)
         int pick;
-        if (padgroup && (nv == 0 || fps_key(tpad, vp_rev) > mkey)) {
+        if (padgroup && (((tpad << 12) | vp_tb) > mkey))
             pick = vp;
-        } else {
-            const unsigned long long wm = __ballot(key == mkey);  // bit-reversed ids are unique: one lane
-            pick = __builtin_amdgcn_readlane(besti, __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1));
-        }
+        else
+            pick = fps_decode_pick(mkey, L, bs);
         old = pick;
         if (lane == 0) fps_out[j] = old;
-        if (M == 0u && (!padgroup || tpad == 0u) && !(nv < n && tpad > 0u)) {
+        if ((mkey >> 12) == 0u && (!padgroup || tpad == 0u) && !(nv < n && tpad > 0u)) {
             // every remaining min-distance is 0: all further rounds tie completely and return slot 0
             for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
-            if (old == 0) break;
+            break;
         }
     }
 }
 
-// Register form of the same sampler for lists of any fill (bs <= 512, i.e. n < 1024): the reference
-// block's thread vt = lane + 64 k owns slots vt and vt + bs (n < 2 bs), both kept in registers with their
-// running min-distances -- padding slots are ordinary slots at offset (0,0,0).  Per round: update
-// 2 TPL distances, reduce the lane's TPL threads and then the wave with the tree's tie rule (among the
-// maximal values the smallest BIT-REVERSED thread id wins; inside a thread the lower slot), fetch the
-// picked slot's offset from the LDS list.  No LDS tree, no per-slot LDS traffic: ~0.5 k cycles per
-// round against ~4 k for fps_on_list (10 % of the windows of a 160k-point scene hold > 64 entries and
+// Register form of the same sampler for lists of any fill (bs <= 64 TPL, n < 2 bs): the reference
+// block's thread vt = lane + 64 k owns slots vt and vt + bs, both kept in registers with their
+// running min-distances -- padding slots (>= nv) are ordinary slots at offset (0,0,0).  Per round: update
+// 2 TPL distances, reduce the lane's TPL threads and then the wave, fetch the picked slot's offset from the LDS
+// list.  No LDS tree, no per-slot LDS traffic (10 % of the windows of a 160k-point scene hold > 64 entries and
 // used to set the run time of the whole plan kernel).
 template <int TPL>
-__device__ __forceinline__ void fps_on_list_regs(const int *packed, int n, int m, int bs, int *fps_out, int lane) {
-    int L = 0;
-    while ((1 << L) < bs) ++L;
-    int xa[TPL], ya[TPL], za[TPL], xb[TPL], yb[TPL], zb[TPL];
-    unsigned int da[TPL], db[TPL], rev[TPL];
-    bool ea[TPL], eb[TPL];
+__device__ __forceinline__ void fps_on_list_regs(const int *packed, int nv, int n, int m, int bs, int *fps_out, int lane) {
+    const int L = 31 - __clz(bs);
+    int a4[TPL], b4[TPL], na[TPL], nb[TPL];
+    unsigned int da[TPL], db[TPL], tba[TPL], tbb[TPL];
 #pragma unroll
     for (int k = 0; k < TPL; ++k) {
         const int vt = lane + MSSVT_WAVE * k;
-        ea[k] = vt < bs && vt < n;
-        eb[k] = vt < bs && vt + bs < n;
-        const int pa = packed[ea[k] ? vt : 0], pb = packed[eb[k] ? vt + bs : 0];
-        xa[k] = (pa & 255) - 64; ya[k] = ((pa >> 8) & 255) - 64; za[k] = ((pa >> 16) & 255) - 64;
-        xb[k] = (pb & 255) - 64; yb[k] = ((pb >> 8) & 255) - 64; zb[k] = ((pb >> 16) & 255) - 64;
-        da[k] = db[k] = FPS_BIG;
-        rev[k] = L ? __brev((unsigned int)vt) >> (32 - L) : 0u;
+        const bool ea = vt < bs && vt < n, eb = vt < bs && vt + bs < n;
+        const int pa = (ea && vt < nv) ? packed[vt] : PACK0, pb = (eb && vt + bs < nv) ? packed[vt + bs] : PACK0;
+        int x, y, z;
+        fps_unpack(pa, x, y, z);
+        a4[k] = fps_pack_s8(x, y, z); na[k] = x * x + y * y + z * z;
+        fps_unpack(pb, x, y, z);
+        b4[k] = fps_pack_s8(x, y, z); nb[k] = x * x + y * y + z * z;
+        const unsigned int rev = L ? __brev((unsigned int)vt) >> (32 - L) : 0u;
+        tba[k] = ea ? (((1023u - rev) << 2) | 3u) : 0u;
+        tbb[k] = eb ? (((1023u - rev) << 2) | 1u) : 0u;
+        da[k] = ea ? FPS_BIG : 0u;
+        db[k] = eb ? FPS_BIG : 0u;
     }
     int old = 0;
     if (lane == 0) fps_out[0] = 0;
     for (int j = 1; j < m; ++j) {
-        const int po = packed[old];
-        const int x1 = (po & 255) - 64, y1 = ((po >> 8) & 255) - 64, z1 = ((po >> 16) & 255) - 64;
-        unsigned int bestkey = 0u;  // integer keys: see fps_key
-        int besti = 0;
+        const int po = __builtin_amdgcn_readfirstlane(old < nv ? packed[old] : PACK0);
+        int x1, y1, z1;
+        fps_unpack(po, x1, y1, z1);
+        const int s_m2 = fps_pack_s8(-2 * x1, -2 * y1, -2 * z1), s_nb = x1 * x1 + y1 * y1 + z1 * z1;
+        unsigned int bestkey = 0u;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
-            if (!ea[k]) continue;
-            const int vt = lane + MSSVT_WAVE * k;
-            int dx = xa[k] - x1, dy = ya[k] - y1, dz = za[k] - z1;
-            unsigned int d = (unsigned int)(__mul24(dz, dz) + __mul24(dy, dy) + __mul24(dx, dx));
+            unsigned int d = (unsigned int)(__builtin_amdgcn_sdot4(a4[k], s_m2, na[k], false) + s_nb);
             da[k] = d < da[k] ? d : da[k];
-            unsigned int tb = da[k];
-            int ti = vt;
-            if (eb[k]) {
-                dx = xb[k] - x1; dy = yb[k] - y1; dz = zb[k] - z1;
-                d = (unsigned int)(__mul24(dz, dz) + __mul24(dy, dy) + __mul24(dx, dx));
-                db[k] = d < db[k] ? d : db[k];
-                if (db[k] > tb) {  // the later slot only on a STRICTLY larger distance
-                    tb = db[k];
-                    ti = vt + bs;
-                }
-            }
-            const unsigned int key = fps_key(tb, rev[k]);
-            if (key > bestkey) {
-                bestkey = key;
-                besti = ti;
-            }
+            d = (unsigned int)(__builtin_amdgcn_sdot4(b4[k], s_m2, nb[k], false) + s_nb);
+            db[k] = d < db[k] ? d : db[k];
+            const unsigned int ka = (da[k] << 12) | tba[k], kb = tbb[k] ? ((db[k] << 12) | tbb[k]) : 0u;
+            const unsigned int kk = ka > kb ? ka : kb;
+            bestkey = kk > bestkey ? kk : bestkey;
         }
         const unsigned int mkey = wave_max_u32_uniform(bestkey);
-        const unsigned long long wm = __ballot(bestkey == mkey);  // unique: thread ids differ
-        old = __builtin_amdgcn_readlane(besti, __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1));
+        old = fps_decode_pick(mkey, L, bs);
         if (lane == 0) fps_out[j] = old;
-        if ((mkey >> 11) == 0u) {
+        if ((mkey >> 12) == 0u) {
             // every min-distance is 0 from here on: all further rounds tie completely -> thread 0, slot 0
             for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
-            if (old == 0) break;
+            break;
         }
     }
 }
@@ -313,59 +234,69 @@ extern "C" int mssvt_debug_read_plan_stamps(unsigned long long *host) {
 #define PSTAMP()
 #endif
 
+// lanes below k as a 64-bit mask (wave-uniform k: scalar ALU)
+__device__ __forceinline__ unsigned long long lanes_below(int k) {
+    return k <= 0 ? 0ull : k >= 64 ? ~0ull : (1ull << k) - 1ull;
+}
+
+// One list of a window (K3's vox_ind_* row, ref ms_sparse_attention_gpu.cu:238-262): entries [first, first + nv) of
+// the hit sequence, -1 padded to maxn; its resolved metadata; the owner array of its voxels.
+__device__ __forceinline__ void plan_emit_list(const PlanArgs &a, int w, int lane, int maxn, int nv, int first, const int *hpk,
+                                               const int *hsv, int *ind, float4 *qmeta, int *owner, int vstart, int cx, int cy,
+                                               int cz, float wcx, float wcy, float wcz) {
+    const float4 none = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
+    for (int k = lane; k < maxn; k += MSSVT_WAVE) {
+        const bool valid = k < nv;
+        const int e = valid ? first + k : 0;
+        const int sv = valid ? hsv[e] : MSSVT_EMPTY;
+        ind[(size_t)w * maxn + k] = sv;
+        if (a.kmeta1) {
+            float4 m = none;
+            if (valid) {
+                int ox, oy, oz;
+                fps_unpack(hpk[e], ox, oy, oz);
+                m = make_float4(plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
+                                plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
+            }
+            qmeta[(size_t)w * maxn + k] = m;
+        }
+        if (valid) atomicMax(owner + vstart + sv, w * maxn + k);
+    }
+}
+
 // FPS_TPL = largest "reference threads per lane" the register sampler is instantiated for in this
-// kernel (8: lists below 1024 entries; 16: below 2048, e.g. 11 x 11 x 11 windows -- a separate
-// instantiation so that the common one keeps its register footprint)
-// MODE 0: one launch does everything.  MODE 1 ("light") + MODE 2 ("heavy"): the register samplers for lists with more
-// than 64 entries set the register footprint of the whole kernel (127 VGPRs = 4 waves / SIMD) although ~10 % of the
-// windows need them, and the kernel is a chain of dependent round trips that lives on occupancy.  The light launch
-// holds only the samplers of the common case (<= 64 valid entries) and leaves a window that needs more after its
-// list phase, flagged through a NEGATIVE win_vstart entry (-1 - vstart); the heavy launch runs the full code for
-// the flagged windows only (they redo their list phase: 10 % of the windows) and restores the entry.
-template <int FPS_TPL, int MODE>
-__global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, MODE == 1 ? 2 : 1) k_window_plan(PlanArgs a) {
+// kernel (4: lists below 512 entries, e.g. 7 x 7 x 7 windows; 8: below 1024; 16: below 2048, e.g. 11 x 11 x 11 --
+// separate instantiations so that the common one keeps its register footprint)
+//
+// One wavefront per window.  K3 (ref :193-350) as ONE ordered hit sequence: the four query tables are scanned in
+// their concatenated order (odd | even | win1_other | win2_other, 64 offsets per step); a hit appends to the
+// sequence; the reference's four lists are prefixes / ranges of it (odd = the first min(#odd hits, max_odd) entries,
+// even = min(#even hits, max_even) entries from #odd hits on, win1 = the first min(#hits of the first three tables,
+// max_win1), win2 = the first min(#hits, max_win2)), so every hit is stored and resolved once.
+//   hit test      with occupancy columns: one 64-bit word per (x, y) column of the neighbourhood (bit z), loaded
+//                 once; without (z > 64): a hash probe per offset (the reference's way)
+//   voxel index   sorted voxel list: column base + popcount(column word below z) -- no hash at all;
+//                 any other order: one hash probe per hit, all in flight together
+template <int FPS_TPL>
+__global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanArgs a) {
     extern __shared__ int lds[];
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
     const int w = blockIdx.x * (blockDim.x / MSSVT_WAVE) + wv;
     if (w >= *a.num_wins) return;  // wave-uniform
-    if (MODE == 2 && a.win_vstart[w] >= 0) return;  // the light launch finished this window
     int si = 0;
     (void)si;
     PSTAMP()
 #ifdef MSSVT_STAMPS
     if (lane == 0 && w < 32768) g_plan_span[2 * w] = __builtin_readcyclecounter();
 #endif
+    const int K = a.key_num_sample;
     int *base = lds + (size_t)wv * a.lds_words_per_wave;
-    int *l1_ind = base;
-    int *l1_c = l1_ind + a.max_win1;
-    int *l2_ind = l1_c + a.max_win1;
-    int *l2_c = l2_ind + a.max_win2;
-    // scratch of the LDS sampler: only lists beyond the register samplers' reach get it (fps_nmax = fps_bs = 0
-    // otherwise -- half of a wave's LDS at the 7 x 7 x 7 windows, i.e. 32 instead of 22 windows per CU in flight)
-    const int nmax = a.fps_nmax;
-    float *temp = reinterpret_cast<float *>(l2_c + a.max_win2);
-    int *fps_out = reinterpret_cast<int *>(temp + nmax);
-    float *bv = reinterpret_cast<float *>(fps_out + a.key_num_sample);
-    const int bsmax = a.fps_bs;
-    int *bidx = reinterpret_cast<int *>(bv + bsmax);
-
-    for (int k = lane; k < a.max_win1; k += MSSVT_WAVE) {
-        l1_ind[k] = -1;
-        l1_c[k] = PACK0;
-    }
-    for (int k = lane; k < a.max_win2; k += MSSVT_WAVE) {
-        l2_ind[k] = -1;
-        l2_c[k] = PACK0;
-    }
-    for (int k = lane; k < a.max_odd; k += MSSVT_WAVE) a.ind_odd[(size_t)w * a.max_odd + k] = -1;
-    for (int k = lane; k < a.max_even; k += MSSVT_WAVE) a.ind_even[(size_t)w * a.max_even + k] = -1;
-    const float4 none = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
-    if (a.kmeta1) {
-        for (int k = lane; k < a.max_odd; k += MSSVT_WAVE) a.qmeta_odd[(size_t)w * a.max_odd + k] = none;
-        for (int k = lane; k < a.max_even; k += MSSVT_WAVE) a.qmeta_even[(size_t)w * a.max_even + k] = none;
-    }
-    wave_lds_sync();
-    PSTAMP()
+    int *hpk = base;              // hit sequence: packed offsets in table order
+    int *hsv = hpk + a.hit_cap;   // ... and the voxel index (inside the sample) of each hit
+    int *fps_out = hsv + a.hit_cap;
+    unsigned long long *colw = reinterpret_cast<unsigned long long *>(fps_out + ((K + 1) & ~1));  // 8-byte aligned
+    const int ncols = a.fnx * a.fny;
+    int *cbase = reinterpret_cast<int *>(colw + ncols);
 
     const int4 wi = reinterpret_cast<const int4 *>(a.win_indices)[w];  // [b,wz,wy,wx]
     const slot_t *tab = a.table + (size_t)wi.x * a.hash_size;
@@ -378,19 +309,11 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, MODE == 1 ? 2 : 1) k
                 wcz = plan_centre(wi.y, a.wsz, a.minz);
     if (a.kmeta1 && lane == 0) a.wcentre[w] = make_float4(wcx, wcy, wcz, 0.f);
     const int e0 = a.n_odd, e1 = e0 + a.n_even, e2 = e1 + a.n_win1, total = e2 + a.n_win2;
-    int cnt_odd = 0, cnt_even = 0, cnt_w1 = 0, cnt_w2 = 0;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (a.occ) {
-        // ---- K3 with occupancy columns: the hit test needs no hash probe (one 64-bit word per (x, y)
-        // column of the neighbourhood, loaded once), positions come from ballots alone, and the hash is
-        // probed only for the hits -- all of them in one round instead of one dependent round per 64 offsets
-        unsigned long long *colw = reinterpret_cast<unsigned long long *>(
-            (reinterpret_cast<size_t>(bidx + bsmax) + 7) & ~(size_t)7);  // 8-byte aligned (the wave's region is)
-        int *lo_c = reinterpret_cast<int *>(colw + a.fnx * a.fny);
-        int *le_c = lo_c + a.max_odd;
-        const int ncols = a.fnx * a.fny;
+    const bool use_occ = a.occ != nullptr;
+    const bool ranked = use_occ && a.col_vbase != nullptr && !(a.level_status[0] & ST_UNSORTED);
+    int pre[PLAN_PRE];
+    if (use_occ) {
         // the first PLAN_PRE x 64 offsets travel together with the column words
-        int pre[PLAN_PRE];
 #pragma unroll
         for (int ci = 0; ci < PLAN_PRE; ++ci) {
             const int q = ci * MSSVT_WAVE + lane;
@@ -398,19 +321,26 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, MODE == 1 ? 2 : 1) k
         }
         for (int c = lane; c < ncols; c += MSSVT_WAVE) {
             const int sx = cx + a.fx0 + c / a.fny, sy = cy + a.fy0 + c % a.fny;
-            colw[c] = (sx >= 0 && sx < a.x_max && sy >= 0 && sy < a.y_max)
-                          ? a.occ[((size_t)wi.x * a.x_max + sx) * a.y_max + sy] : 0ull;
+            const bool in = sx >= 0 && sx < a.x_max && sy >= 0 && sy < a.y_max;
+            const size_t col = ((size_t)wi.x * a.x_max + (in ? sx : 0)) * a.y_max + (in ? sy : 0);
+            const unsigned long long word = a.occ[col];
+            colw[c] = in ? word : 0ull;
+            if (ranked) cbase[c] = a.col_vbase[col];
         }
         wave_lds_sync();
-        for (int bq = 0; bq < total; bq += MSSVT_WAVE) {
-            if (cnt_w2 >= a.max_win2 && cnt_w1 >= a.max_win1 && (cnt_even >= a.max_even || bq >= e1) &&
-                (cnt_odd >= a.max_odd || bq >= e0))
-                break;
-            const int q = bq + lane;
-            const int seg = (q >= e0) + (q >= e1) + (q >= e2);
-            bool hit = false;
+    }
+    PSTAMP()
+    // ---- K3: the hit sequence ---------------------------------------------------------------------------
+    int cnt_odd = 0, cnt_le1 = 0, cnt_le2 = 0, cnt_all = 0;  // hits of the first 1 / 2 / 3 / 4 tables
+    for (int bq = 0; bq < total; bq += MSSVT_WAVE) {
+        if (cnt_all >= a.max_win2 && cnt_le2 >= a.max_win1 && (cnt_le1 - cnt_odd >= a.max_even || bq >= e1) &&
+            (cnt_odd >= a.max_odd || bq >= e0))
+            break;
+        const int q = bq + lane;
+        bool hit = false;
+        int pk = PACK0, sv = MSSVT_EMPTY;
+        if (use_occ) {
             const int ci = bq / MSSVT_WAVE;
-            int pk = PACK0;
             if (ci < PLAN_PRE) {
 #pragma unroll
                 for (int u = 0; u < PLAN_PRE; ++u) pk = ci == u ? pre[u] : pk;  // ci is wave-uniform: scalar selects
@@ -418,222 +348,104 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, MODE == 1 ? 2 : 1) k
                 pk = a.q_packed[q];
             }
             if (q < total) {
-                const int ox = (pk & 255) - 64, oy = ((pk >> 8) & 255) - 64, oz = ((pk >> 16) & 255) - 64;
+                int ox, oy, oz;
+                fps_unpack(pk, ox, oy, oz);
                 const int sz = cz + oz, dx = ox - a.fx0, dy = oy - a.fy0;
                 // columns outside the grid are zero words; sz outside [0, z_max) has no bit set
                 if (sz >= 0 && sz < a.z_max && dx >= 0 && dx < a.fnx && dy >= 0 && dy < a.fny)
                     hit = (colw[dx * a.fny + dy] >> sz) & 1ull;
             }
-            const unsigned long long m_all = __ballot(hit);
-            if (m_all == 0) continue;
-            const unsigned long long m_odd = __ballot(hit && seg == 0);
-            const unsigned long long m_even = __ballot(hit && seg == 1);
-            const unsigned long long m_w1 = __ballot(hit && seg <= 2);
-            if (hit) {
-                if (seg == 0) {
-                    const int p = cnt_odd + __popcll(m_odd & below);
-                    if (p < a.max_odd) lo_c[p] = pk;
-                }
-                if (seg == 1) {
-                    const int p = cnt_even + __popcll(m_even & below);
-                    if (p < a.max_even) le_c[p] = pk;
-                }
-                if (seg <= 2) {
-                    const int p = cnt_w1 + __popcll(m_w1 & below);
-                    if (p < a.max_win1) l1_c[p] = pk;
-                }
-                const int p2 = cnt_w2 + __popcll(m_all & below);
-                if (p2 < a.max_win2) l2_c[p2] = pk;
-            }
-            cnt_odd += __popcll(m_odd);
-            cnt_even += __popcll(m_even);
-            cnt_w1 += __popcll(m_w1);
-            cnt_w2 += __popcll(m_all);
-        }
-        wave_lds_sync();
-        // the hits of all four lists, concatenated: one hash probe each, all in flight together
-        const int n0 = min(cnt_odd, a.max_odd), n1 = n0 + min(cnt_even, a.max_even),
-                  n2 = n1 + min(cnt_w1, a.max_win1), n3 = n2 + min(cnt_w2, a.max_win2);
-        for (int e = lane; e < n3; e += MSSVT_WAVE) {
-            const int lst = (e >= n0) + (e >= n1) + (e >= n2);
-            const int p = e - (lst == 0 ? 0 : lst == 1 ? n0 : lst == 2 ? n1 : n2);
-            const int pk = lst == 0 ? lo_c[p] : lst == 1 ? le_c[p] : lst == 2 ? l1_c[p] : l2_c[p];
-            const int ox = (pk & 255) - 64, oy = ((pk >> 8) & 255) - 64, oz = ((pk >> 16) & 255) - 64;
-            const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
-            int sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
-            // an occupied cell the table does not know: only after a voxel-table overflow (status bit set, the
-            // caller raises at the end of the frame).  Until then every index downstream must stay in range and
-            // the counts must match the entries: the entry is redirected to the sample's first voxel.
-            if (sv == MSSVT_EMPTY) sv = 0;
-            if (lst == 0) {
-                a.ind_odd[(size_t)w * a.max_odd + p] = sv;
-                if (sv != MSSVT_EMPTY) {
-                    if (a.kmeta1)
-                        a.qmeta_odd[(size_t)w * a.max_odd + p] = make_float4(
-                            plan_centre(sx, a.vsx, a.minx) - wcx, plan_centre(sy, a.vsy, a.miny) - wcy,
-                            plan_centre(sz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
-                    atomicMax(a.owner_odd + vstart + sv, w * a.max_odd + p);
-                }
-            } else if (lst == 1) {
-                a.ind_even[(size_t)w * a.max_even + p] = sv;
-                if (sv != MSSVT_EMPTY) {
-                    if (a.kmeta1)
-                        a.qmeta_even[(size_t)w * a.max_even + p] = make_float4(
-                            plan_centre(sx, a.vsx, a.minx) - wcx, plan_centre(sy, a.vsy, a.miny) - wcy,
-                            plan_centre(sz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
-                    atomicMax(a.owner_even + vstart + sv, w * a.max_even + p);
-                }
-            } else if (lst == 2) {
-                l1_ind[p] = sv;
-                if (sv != MSSVT_EMPTY) atomicMax(a.owner_win1 + vstart + sv, w * a.max_win1 + p);
-            } else {
-                l2_ind[p] = sv;
-            }
-        }
-    } else {
-        // ---- K3: probe all offsets, 64 per step, ordered append ----------------------
-        for (int bq = 0; bq < total; bq += MSSVT_WAVE) {
-            if (cnt_w2 >= a.max_win2 && cnt_w1 >= a.max_win1 && (cnt_even >= a.max_even || bq >= e1) &&
-                (cnt_odd >= a.max_odd || bq >= e0))
-                break;
-            const int q = bq + lane;
+        } else if (q < total) {
             const int seg = (q >= e0) + (q >= e1) + (q >= e2);
-            int sv = MSSVT_EMPTY, ox = 0, oy = 0, oz = 0;
-            if (q < total) {
-                const int *src = seg == 0 ? a.q_odd + q * 3
-                               : seg == 1 ? a.q_even + (q - e0) * 3
-                               : seg == 2 ? a.q_win1 + (q - e1) * 3
-                                          : a.q_win2 + (q - e2) * 3;
-                ox = src[0];
-                oy = src[1];
-                oz = src[2];
-                const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
-                if (!(sx >= a.x_max || sx < 0 || sy >= a.y_max || sy < 0 || sz >= a.z_max || sz < 0))
-                    sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
-            }
-            const bool hit = sv != MSSVT_EMPTY;
-            const unsigned long long m_all = __ballot(hit);
-            if (m_all == 0) continue;
-            const unsigned long long m_odd = __ballot(hit && seg == 0);
-            const unsigned long long m_even = __ballot(hit && seg == 1);
-            const unsigned long long m_w1 = __ballot(hit && seg <= 2);
-            if (hit) {
-                const int pk = pack_off(ox, oy, oz);
-                if (seg == 0) {
-                    const int p = cnt_odd + __popcll(m_odd & below);
-                    if (p < a.max_odd) {
-                        a.ind_odd[(size_t)w * a.max_odd + p] = sv;
-                        if (a.kmeta1)
-                            a.qmeta_odd[(size_t)w * a.max_odd + p] = make_float4(
-                                plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
-                                plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
-                        atomicMax(a.owner_odd + vstart + sv, w * a.max_odd + p);
-                    }
-                }
-                if (seg == 1) {
-                    const int p = cnt_even + __popcll(m_even & below);
-                    if (p < a.max_even) {
-                        a.ind_even[(size_t)w * a.max_even + p] = sv;
-                        if (a.kmeta1)
-                            a.qmeta_even[(size_t)w * a.max_even + p] = make_float4(
-                                plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
-                                plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
-                        atomicMax(a.owner_even + vstart + sv, w * a.max_even + p);
-                    }
-                }
-                if (seg <= 2) {
-                    const int p = cnt_w1 + __popcll(m_w1 & below);
-                    if (p < a.max_win1) {
-                        l1_ind[p] = sv;
-                        l1_c[p] = pk;
-                        atomicMax(a.owner_win1 + vstart + sv, w * a.max_win1 + p);
-                    }
-                }
-                const int p2 = cnt_w2 + __popcll(m_all & below);
-                if (p2 < a.max_win2) {
-                    l2_ind[p2] = sv;
-                    l2_c[p2] = pk;
-                }
-            }
-            cnt_odd += __popcll(m_odd);
-            cnt_even += __popcll(m_even);
-            cnt_w1 += __popcll(m_w1);
-            cnt_w2 += __popcll(m_all);
+            const int *src = seg == 0 ? a.q_odd + q * 3
+                           : seg == 1 ? a.q_even + (q - e0) * 3
+                           : seg == 2 ? a.q_win1 + (q - e1) * 3
+                                      : a.q_win2 + (q - e2) * 3;
+            const int ox = src[0], oy = src[1], oz = src[2];
+            pk = pack_off(ox, oy, oz);
+            const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
+            if (!(sx >= a.x_max || sx < 0 || sy >= a.y_max || sy < 0 || sz >= a.z_max || sz < 0))
+                sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
+            hit = sv != MSSVT_EMPTY;
         }
+        const unsigned long long m_all = __ballot(hit);
+        if (m_all == 0) continue;
+        if (hit) {
+            const int p = cnt_all + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m_all >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)m_all, 0u));
+            hpk[p] = pk;
+            if (!use_occ) hsv[p] = sv;
+        }
+        cnt_odd += __popcll(m_all & lanes_below(e0 - bq));
+        cnt_le1 += __popcll(m_all & lanes_below(e1 - bq));
+        cnt_le2 += __popcll(m_all & lanes_below(e2 - bq));
+        cnt_all += __popcll(m_all);
     }
     wave_lds_sync();
-    PSTAMP()
-    if (MODE == 1) {
-        // does either scale need a register sampler beyond <1> (reference block > 64 threads and > 64 valid entries,
-        // or more valid entries than block threads)?  -> the heavy launch takes this window
-        bool heavy = false;
-        for (int scale = 0; scale < 2; ++scale) {
-            const int n = scale ? a.max_win2 : a.max_win1, bs = scale ? a.bs2 : a.bs1;
-            const int nv = min(scale ? cnt_w2 : cnt_w1, n);
-            const bool fast = nv <= MSSVT_WAVE && nv <= bs && bs >= 2;
-            heavy = heavy || (!fast && bs > 64);
-        }
-        if (heavy) {
-            if (lane == 0) a.win_vstart[w] = -1 - vstart;
-            return;
-        }
-    }
-    if (MODE == 2 && lane == 0) a.win_vstart[w] = vstart;
-    if (a.kmeta1 && lane == 0) {
-        a.nq_valid[w] = min(cnt_odd, a.max_odd);
-        a.nq_valid[a.win_capacity + w] = min(cnt_even, a.max_even);
-        a.nq_valid[2 * a.win_capacity + w] = min(cnt_w1, a.max_win1);
-    }
-    for (int k = lane; k < a.max_win1; k += MSSVT_WAVE) {
-        const int sv = l1_ind[k];
-        a.ind_win1[(size_t)w * a.max_win1 + k] = sv;
-        if (a.kmeta1) {
-            float4 m = none;
-            if (sv >= 0) {
-                const int pk = l1_c[k];
-                m = make_float4(plan_centre(cx + (pk & 255) - 64, a.vsx, a.minx) - wcx,
-                                plan_centre(cy + ((pk >> 8) & 255) - 64, a.vsy, a.miny) - wcy,
-                                plan_centre(cz + ((pk >> 16) & 255) - 64, a.vsz, a.minz) - wcz,
-                                __builtin_bit_cast(float, vstart + sv));
+    const int nO = min(cnt_odd, a.max_odd), nE = min(cnt_le1 - cnt_odd, a.max_even), n1 = min(cnt_le2, a.max_win1),
+              n2 = min(cnt_all, a.max_win2);
+    if (use_occ) {
+        // voxel index of every hit some list holds
+        const int hmax = max(max(n1, n2), max(nO, cnt_odd + nE));
+        for (int e = lane; e < hmax; e += MSSVT_WAVE) {
+            int ox, oy, oz;
+            fps_unpack(hpk[e], ox, oy, oz);
+            const int sz = cz + oz;
+            int sv;
+            if (ranked) {
+                const int c = (ox - a.fx0) * a.fny + (oy - a.fy0);
+                sv = cbase[c] + __popcll(colw[c] & ((1ull << sz) - 1ull));
+            } else {
+                sv = a.table ? table_find((cx + ox) * a.y_max * a.z_max + (cy + oy) * a.z_max + sz, a.hash_size, tab) : MSSVT_EMPTY;
+                // an occupied cell the table does not know: only after a voxel-table overflow (status bit set, the
+                // caller raises at the end of the frame).  Until then every index downstream must stay in range and
+                // the counts must match the entries: the entry is redirected to the sample's first voxel.
+                if (sv == MSSVT_EMPTY) sv = 0;
             }
-            a.qmeta_win1[(size_t)w * a.max_win1 + k] = m;
+            hsv[e] = sv;
         }
+        wave_lds_sync();
     }
-
+    PSTAMP()
+    plan_emit_list(a, w, lane, a.max_odd, nO, 0, hpk, hsv, a.ind_odd, a.qmeta_odd, a.owner_odd, vstart, cx, cy, cz, wcx, wcy, wcz);
+    plan_emit_list(a, w, lane, a.max_even, nE, cnt_odd, hpk, hsv, a.ind_even, a.qmeta_even, a.owner_even, vstart, cx, cy, cz, wcx,
+                   wcy, wcz);
+    plan_emit_list(a, w, lane, a.max_win1, n1, 0, hpk, hsv, a.ind_win1, a.qmeta_win1, a.owner_win1, vstart, cx, cy, cz, wcx, wcy,
+                   wcz);
+    if (a.kmeta1 && lane == 0) {
+        a.nq_valid[w] = nO;
+        a.nq_valid[a.win_capacity + w] = nE;
+        a.nq_valid[2 * a.win_capacity + w] = n1;
+    }
     PSTAMP()
     // ---- K7 + K8 + masks for both scales (ref mssvt_backbone.py:247-258) -----------
-    const int K = a.key_num_sample;
+    const float4 none = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
     for (int scale = 0; scale < 2; ++scale) {
-        const int *lind = scale ? l2_ind : l1_ind;
-        const int *lc = scale ? l2_c : l1_c;
         const int n = scale ? a.max_win2 : a.max_win1;
         const int bs = scale ? a.bs2 : a.bs1;
-        const int nv = min(scale ? cnt_w2 : cnt_w1, n);
+        const int nv = scale ? n2 : n1;
         if (nv <= MSSVT_WAVE && nv <= bs && bs >= 2)
-            fps_on_list_fast(lc, n, nv, K, bs, fps_out, lane);
+            fps_on_list_fast(lane < nv ? hpk[lane] : PACK0, n, nv, K, bs, fps_out, lane);
         else if (bs <= 64)
-            fps_on_list_regs<1>(lc, n, K, bs, fps_out, lane);
-        else if (MODE == 1) {
-            // unreachable: such a window left for the heavy launch above
-        } else if (bs == 128)
-            fps_on_list_regs<2>(lc, n, K, bs, fps_out, lane);
+            fps_on_list_regs<1>(hpk, nv, n, K, bs, fps_out, lane);
+        else if (bs == 128)
+            fps_on_list_regs<2>(hpk, nv, n, K, bs, fps_out, lane);
         else if (bs == 256)
-            fps_on_list_regs<4>(lc, n, K, bs, fps_out, lane);
-        else if (bs == 512)
-            fps_on_list_regs<8>(lc, n, K, bs, fps_out, lane);
+            fps_on_list_regs<4>(hpk, nv, n, K, bs, fps_out, lane);
+        else if (FPS_TPL >= 8 && bs == 512)
+            fps_on_list_regs<FPS_TPL >= 8 ? 8 : 1>(hpk, nv, n, K, bs, fps_out, lane);
         else if (FPS_TPL >= 16 && bs == 1024)
-            fps_on_list_regs<FPS_TPL >= 16 ? 16 : 1>(lc, n, K, bs, fps_out, lane);
-        else if (a.fps_bs)
-            fps_on_list(lc, n, K, bs, temp, bv, bidx, fps_out, lane);
+            fps_on_list_regs<FPS_TPL >= 16 ? 16 : 1>(hpk, nv, n, K, bs, fps_out, lane);
         wave_lds_sync();
         PSTAMP()
         int *kout = (scale ? a.k_ind2 : a.k_ind1) + (size_t)w * K;
         unsigned char *mout = (scale ? a.k_mask2 : a.k_mask1) + (size_t)w * K;
         for (int j = lane; j < K; j += MSSVT_WAVE) {
             const int f = fps_out[j];
+            const bool entry = f < nv;  // a list entry (else an empty slot: index -1, offset (0,0,0))
             // ref :253-256: the index is round-tripped through fp32 and "(x + 0.1).int()"
             // truncates toward zero -> a picked EMPTY slot (-1) becomes voxel 0 of the sample
-            const int kid = (int)((float)lind[f] + 0.1f);
+            const int kid = (int)((float)(entry ? hsv[f] : MSSVT_EMPTY) + 0.1f);
             kout[j] = kid;
             const bool masked = (j > 0 && f == 0) || kid < 0;
             mout[j] = (unsigned char)(masked ? 1 : 0);
@@ -641,11 +453,12 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, MODE == 1 ? 2 : 1) k
                 float4 m = none;
                 if (!masked) {
                     float px, py, pz;
-                    if (lind[f] >= 0) {  // a list entry: its voxel is the window centre cell + offset
-                        const int pk = lc[f];
-                        px = plan_centre(cx + (pk & 255) - 64, a.vsx, a.minx);
-                        py = plan_centre(cy + ((pk >> 8) & 255) - 64, a.vsy, a.miny);
-                        pz = plan_centre(cz + ((pk >> 16) & 255) - 64, a.vsz, a.minz);
+                    if (entry) {  // a list entry: its voxel is the window centre cell + offset
+                        int ox, oy, oz;
+                        fps_unpack(hpk[f], ox, oy, oz);
+                        px = plan_centre(cx + ox, a.vsx, a.minx);
+                        py = plan_centre(cy + oy, a.vsy, a.miny);
+                        pz = plan_centre(cz + oz, a.vsz, a.minz);
                     } else {  // the reference quirk: an empty slot became voxel 0 of the sample
                         const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + kid];
                         px = plan_centre(vi.w, a.vsx, a.minx);
@@ -684,14 +497,15 @@ extern "C" int mssvt_window_plan_two(
     const int *indices, const float *host_voxel_size3, const float *host_range_min3,
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
     float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
-    const int *host_footprint4, const int *packed_offsets, void *stream) {
-    if (!win_indices || !num_wins_dev || !xyz_to_vidx || !v_bs_cnt || !ind_odd || !ind_even ||
+    const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
+    void *stream) {
+    if (!win_indices || !num_wins_dev || !v_bs_cnt || !ind_odd || !ind_even ||
         !ind_win1 || !k_ind1 || !k_ind2 || !k_mask1 || !k_mask2 || !win_vstart || !owner_win1 ||
         !owner_odd || !owner_even || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
-        max_num_win2 <= 0 || max_num_odd <= 0 || max_num_even <= 0)
+        max_num_win2 <= 0 || max_num_odd <= 0 || max_num_even <= 0 || (column_vbase && !level_status_dev))
         return MSSVT_E_BADARG;
     if (win_capacity <= 0) return MSSVT_OK;
-    // offsets are packed into bytes (|offset| <= 63) -- far beyond any window in use
+    // offsets are packed into bytes (|offset| <= 60) -- far beyond any window in use
     if (x_ws > 60 || y_ws > 60 || z_ws > 60 || key_num_sample > 1024) return MSSVT_E_TOOLARGE;
     // the register samplers examine slots [0, 2 bs) with bs = min(2^floor(log2 n), 1024) (the reference's block
     // size): lists of 2048 slots or more (e.g. 13 x 13 x 13 windows) are not covered -> the caller's operator path
@@ -732,14 +546,12 @@ extern "C" int mssvt_window_plan_two(
     } else {
         a.vsx = a.vsy = a.vsz = a.minx = a.miny = a.minz = a.wsx = a.wsy = a.wsz = 0.f;
     }
-    const int nmax = max_num_win1 > max_num_win2 ? max_num_win1 : max_num_win2;
     const int bsmax = a.bs1 > a.bs2 ? a.bs1 : a.bs2;
-    // the register samplers cover reference block sizes up to 512 (1024 in the <16> instantiation)
-    const bool lds_fps = bsmax > 1024;
-    a.fps_nmax = lds_fps ? nmax : 0;
-    a.fps_bs = lds_fps ? bsmax : 0;
-    a.lds_words_per_wave = 2 * max_num_win1 + 2 * max_num_win2 + a.fps_nmax + key_num_sample + 2 * a.fps_bs;
+    const int total = num_odd + num_even + num_win1 + num_win2;
+    a.hit_cap = (total + 1) & ~1;
+    a.lds_words_per_wave = 2 * a.hit_cap + ((key_num_sample + 1) & ~1);
     a.occ = nullptr;
+    a.col_vbase = a.level_status = nullptr;
     a.fx0 = a.fy0 = a.fnx = a.fny = 0;
     a.q_packed = packed_offsets;
     if (occ_columns && host_footprint4 && packed_offsets && z_max <= 64 && host_footprint4[2] > 0 &&
@@ -747,10 +559,15 @@ extern "C" int mssvt_window_plan_two(
         a.occ = occ_columns;
         a.fx0 = host_footprint4[0]; a.fy0 = host_footprint4[1];
         a.fnx = host_footprint4[2]; a.fny = host_footprint4[3];
-        // + the column words (8-byte aligned) and the odd / even offset lists
-        a.lds_words_per_wave += 1 + 2 * a.fnx * a.fny + max_num_odd + max_num_even;
+        a.col_vbase = column_vbase;
+        a.level_status = level_status_dev;
+        // + the column words (8 bytes each) and the column bases
+        a.lds_words_per_wave += 3 * a.fnx * a.fny;
         a.lds_words_per_wave += a.lds_words_per_wave & 1;  // keep every wave's region 8-byte aligned
+    } else if (!xyz_to_vidx || !vox_query_odd || !vox_query_even || !vox_query_win1 || !vox_query_win2) {
+        return MSSVT_E_BADARG;
     }
+    if (!a.col_vbase && !xyz_to_vidx) return MSSVT_E_BADARG;  // the hash is the only source of voxel indices then
     // waves (windows) per workgroup: the count that puts the most waves on a CU (160 KiB of LDS,
     // workgroups <= 64 KiB), ties -> larger workgroups (fewer of them to dispatch)
     int wpb = 1, best_waves = 0;
@@ -766,34 +583,23 @@ extern "C" int mssvt_window_plan_two(
     if (getenv("MSSVT_PLAN_WPB")) wpb = atoi(getenv("MSSVT_PLAN_WPB"));
     const size_t lds_bytes = (size_t)a.lds_words_per_wave * 4 * wpb;
     if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
-    const bool big = bsmax > 512;  // lists of 1024 .. 2047 slots: the instantiation with the 16-slot register sampler
-    // light + heavy launch pair: MEASURED SLOWER than the single launch (160k points: 68 + 54 us against 93 us; batch 8:
-    // 561 + 244 against 772 us) -- at 8 waves / SIMD the light launch turns VALU-issue bound (the single launch already
-    // issues vector instructions 61 % of the time at 4 waves / SIMD) and the heavy windows form a tail-bound launch of
-    // their own.  Kept behind MSSVT_PLAN_SPLIT=1 (the -m gpu suite passes either way).
-    const bool split = bsmax > 64 && !a.fps_bs && getenv("MSSVT_PLAN_SPLIT") && atoi(getenv("MSSVT_PLAN_SPLIT")) == 1;
-    const void *kernels[4] = {reinterpret_cast<const void *>(k_window_plan<8, 0>), reinterpret_cast<const void *>(k_window_plan<16, 0>),
-                              reinterpret_cast<const void *>(k_window_plan<8, 1>), nullptr};
-    kernels[3] = big ? reinterpret_cast<const void *>(k_window_plan<16, 2>) : reinterpret_cast<const void *>(k_window_plan<8, 2>);
+    // lists of 512 .. 1023 / 1024 .. 2047 slots: the instantiations with the 8- / 16-slot register samplers
+    const int tpl = bsmax > 512 ? 16 : bsmax > 256 ? 8 : 4;
+    const void *kernel = tpl == 16  ? reinterpret_cast<const void *>(k_window_plan<16>)
+                         : tpl == 8 ? reinterpret_cast<const void *>(k_window_plan<8>)
+                                    : reinterpret_cast<const void *>(k_window_plan<4>);
     if (lds_bytes > 64 * 1024) {
-        for (int i = 0; i < 4; ++i) {
-            hipError_t e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return (int)e;
-        }
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
     }
     const dim3 grid(divup(win_capacity, wpb)), block(wpb * MSSVT_WAVE);
     hipStream_t st = (hipStream_t)stream;
-    if (split) {
-        k_window_plan<8, 1><<<grid, block, lds_bytes, st>>>(a);
-        if (big)
-            k_window_plan<16, 2><<<grid, block, lds_bytes, st>>>(a);
-        else
-            k_window_plan<8, 2><<<grid, block, lds_bytes, st>>>(a);
-    } else if (big) {
-        k_window_plan<16, 0><<<grid, block, lds_bytes, st>>>(a);
-    } else {
-        k_window_plan<8, 0><<<grid, block, lds_bytes, st>>>(a);
-    }
+    if (tpl == 16)
+        k_window_plan<16><<<grid, block, lds_bytes, st>>>(a);
+    else if (tpl == 8)
+        k_window_plan<8><<<grid, block, lds_bytes, st>>>(a);
+    else
+        k_window_plan<4><<<grid, block, lds_bytes, st>>>(a);
     return mssvt_launch_status();
 }
 

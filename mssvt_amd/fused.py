@@ -70,16 +70,92 @@ def supported(block, sp):
 
 
 @torch.no_grad()
-def level_state(sp):
-    """Per voxel-set (resolution level) device state shared by all plans on it."""
+def level_state(sp, blocks=()):
+    """Per voxel-set (resolution level) device state shared by all plans on it.  A level the backbone did not set up
+    (a Block called on its own SparseTensor) tries the sorted set-up first and reads its verdict with one host sync;
+    the backbone's input level is set up speculatively without one (setup_input_level)."""
     st = getattr(sp, "_level", None)
     if st is None or st["indices"] is not sp.indices:
+        if SORTED_LEVELS and not getattr(sp, "_no_sorted_level", False):
+            st = _sorted_level(list(blocks), sp.indices, sp.batch_size, sp.hash_size, sp.spatial_shape)
+            if st is not None and int(st["level_status"].item()) & mssvt_ops.ST_UNSORTED:
+                st = None
+            if st is not None:
+                sp.v_bs_cnt, sp._cnt_of = st["v_bs_cnt"], sp.indices
+                sp._level = st
+                return st
         cnt = getattr(sp, "v_bs_cnt", None)
         if cnt is None or getattr(sp, "_cnt_of", None) is not sp.indices:
             cnt = batch_counts(sp.indices, sp.batch_size)
         st = {"indices": sp.indices, "v_bs_cnt": cnt, "plans": {}}
         sp._level = st
     return st
+
+
+# Levels whose voxel list is sorted by (b, x, y, z) -- what DynamicVFE / the device voxelizer emit -- are set up from
+# one occupancy bitmap (csrc/level_sorted.hip): no voxel hash table, no insert-min / rank passes, no counting atomics.
+# The device verifies the order; a list in any other order takes the order-agnostic kernels (mssvt_level_setup).
+SORTED_LEVELS = os.environ.get("MSSVT_SORTED_LEVELS", "1") != "0"
+
+
+class UnsortedVoxels(Exception):
+    """Internal: a speculatively sorted level turned out not to be (the frame is redone on the order-agnostic path)."""
+
+
+def _level_partitions(blocks):
+    """The distinct window partitions of the Blocks up to and including the first CompressBlock (at most 4)."""
+    from .mssvt_backbone import MixedScaleSparseTransformerCompressBlock as Compress
+    todo, keys = [], set()
+    for b in blocks:
+        k = _partition_key(b)
+        if k not in keys and len(todo) < 4:
+            keys.add(k)
+            todo.append(b)
+        if isinstance(b, Compress):
+            break
+    return todo
+
+
+@torch.no_grad()
+def _sorted_level(blocks, indices, B, H, spatial_shape):
+    """Level state from `mssvt_level_setup_sorted` (counts, occupancy columns, column bases, window partitions of
+    `blocks`), or None when not applicable.  The caller checks st["level_status"] for ST_UNSORTED."""
+    from .mssvt_backbone import MixedScaleSparseTransformerCompressBlock as Compress
+    n = indices.shape[0]
+    X, Y, Z = (int(v) for v in spatial_shape)
+    if not (OCC_COLUMNS and indices.is_cuda and n > 0 and indices.dtype == torch.int32 and indices.is_contiguous()
+            and Z <= 64):
+        return None
+    dev = indices.device
+    B, H = int(B), int(H)
+    todo = _level_partitions(blocks)
+    k = len(todo)
+    al = lambda v: (int(v) + 63) // 64 * 64  # noqa: E731  (256-byte aligned pieces)
+    sizes = [64, 64 * max(k, 1), al(B + 1), 2 * B * X * Y]
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    zero = torch.empty(sum(sizes), dtype=torch.int32, device=dev)  # cleared by the call itself
+    status = zero[0:1]
+    hdrs = [zero[offs[1] + 64 * i: offs[1] + 64 * (i + 1)] for i in range(k)]
+    start = zero[offs[2]:offs[2] + B + 1]
+    occ = zero[offs[3]:offs[3] + 2 * B * X * Y].view(torch.int64)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    vbase = torch.empty(B * X * Y, dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(_lib.lib().mssvt_level_sorted_scratch_ints(_i(B), _i(X), _i(Y))), dtype=torch.int32, device=dev)
+    # only a CompressBlock's window table is ever read (it becomes the map_table of the block's output)
+    tables = [mssvt_ops.full_neg1((B, H, 2), dev) if isinstance(b, Compress) else None for b in todo]
+    wins = [torch.empty((n, 4), dtype=torch.int32, device=dev) for _ in range(k)]
+    vcounts = torch.empty((max(k, 1), B), dtype=torch.int32, device=dev)
+    shapes = [[[X, Y, Z][i] // b.win1_size[i] for i in range(3)] for b in todo]
+    ints = lambda rows: (ctypes.c_int * max(3 * k, 1))(*[int(v) for r in rows for v in r])  # noqa: E731
+    ptrs = lambda ts: (ctypes.c_void_p * max(k, 1))(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
+    _lib.call("mssvt_level_setup_sorted", _i(n), _i(B), _i(X), _i(Y), _i(Z), _i(H), _P(indices), _P(zero),
+              ctypes.c_longlong(zero.numel() * 4), _P(cnt), _P(start), _P(occ), _P(vbase), _P(status), _i(k),
+              ints(shapes), ints([b.win1_size for b in todo]),
+              (ctypes.c_int * max(k, 1))(*[int(b.max_num_wins) for b in todo]), ptrs(wins), ptrs(tables),
+              ptrs([vcounts[i] for i in range(k)]), ptrs(hdrs), _P(scratch), _lib.stream())
+    return {"indices": indices, "v_bs_cnt": cnt, "plans": {}, "occ": occ, "vbase": vbase, "level_status": status,
+            "sorted": True, "status_words": [status], "_zero": zero,
+            "partitions": {_partition_key(b): (wins[i], tables[i], vcounts[i], hdrs[i]) for i, b in enumerate(todo)}}
 
 
 PARTITION_GROUPS = True  # a Block's window partition and the next CompressBlock's share their launches
@@ -89,13 +165,14 @@ def _partition_key(block):
     return (tuple(int(v) for v in block.win1_size), int(block.max_num_wins))
 
 
-def window_partition(block, sp, st):
+def window_partition(block, sp, st, need_table=False):
     """(win_ind, window table, windows per sample, workspace) of `block`'s windows on this level, cached per
     (window size, max_num_wins).  The partition of the CompressBlock that ends the level only depends on the
-    same voxel indices, so it is computed in the same launches (`mssvt_window_partition_multi`)."""
+    same voxel indices, so it is computed in the same launches (`mssvt_window_partition_multi`).  On a sorted level
+    the partitions of Blocks come without a window table (None: nobody reads it); need_table builds it."""
     parts = st.setdefault("partitions", {})
     key = _partition_key(block)
-    if key not in parts:
+    if key not in parts or (need_table and parts[key][1] is None):
         todo = [block]
         nxt = getattr(sp, "_next_compress", None)
         if (PARTITION_GROUPS and nxt is not None and nxt is not block and _partition_key(nxt) not in parts
@@ -113,7 +190,7 @@ LEVEL_SETUP = True  # counts + voxel table + occupancy columns + window partitio
 
 
 @torch.no_grad()
-def setup_input_level(blocks, sp_kwargs):
+def setup_input_level(blocks, sp_kwargs, assume_sorted=True):
     """SparseTensor of the backbone input with everything its first resolution level needs (`mssvt_level_setup`:
     per-sample counts, voxel hash table, occupancy columns, the window partitions of the Blocks up to and
     including the first CompressBlock) produced behind ONE fill instead of five.  None when not applicable."""
@@ -126,14 +203,16 @@ def setup_input_level(blocks, sp_kwargs):
     dev = indices.device
     B, H = int(sp_kwargs["batch_size"]), int(sp_kwargs["hash_size"])
     X, Y, Z = (int(v) for v in sp_kwargs["spatial_shape"])
-    todo, keys = [], set()
-    for b in blocks:
-        k = _partition_key(b)
-        if k not in keys and len(todo) < 4:
-            keys.add(k)
-            todo.append(b)
-        if isinstance(b, Compress):
-            break
+    if assume_sorted and SORTED_LEVELS:
+        # speculative: no host sync here, the verdict (ST_UNSORTED) is read with the frame's other status words
+        st = _sorted_level(blocks, indices, B, H, sp_kwargs["spatial_shape"])
+        if st is not None:
+            sp = SparseTensor(lazy_map_table=True, **sp_kwargs)
+            sp.v_bs_cnt, sp._cnt_of, sp.map_status = st["v_bs_cnt"], sp.indices, None
+            st["speculative"] = True
+            sp._level = st
+            return sp
+    todo = _level_partitions(blocks)
     k = len(todo)
     use_occ = OCC_COLUMNS and Z <= 64
     al = lambda v: (int(v) + 63) // 64 * 64  # noqa: E731  (256-byte aligned pieces)
@@ -180,6 +259,14 @@ def occupancy_columns(sp, st):
     return st["occ"]
 
 
+def _voxel_table(sp, st, occ):
+    """The voxel hash table for a plan kernel -- or None on a sorted level (column bases instead): the table of such a
+    level is only built when somebody asks for `sp.map_table`."""
+    if st.get("sorted") and occ is not None and st.get("vbase") is not None:
+        return sp._map_table  # whatever exists; never forces the build
+    return sp.map_table
+
+
 def _table_footprint(block, t):
     """(min x offset, min y offset, x extent, y extent) over the four query tables (host, cached)."""
     fp = getattr(block, "_footprint_cache", None)
@@ -195,7 +282,7 @@ def _table_footprint(block, t):
 
 @torch.no_grad()
 def two_scale_plan(block, sp):
-    st = level_state(sp)
+    st = level_state(sp, [block] + ([sp._next_compress] if getattr(sp, "_next_compress", None) is not None else []))
     key = block.plan_key()
     if key in st["plans"]:
         return st["plans"][key]
@@ -230,18 +317,22 @@ def two_scale_plan(block, sp):
     p.owner_win1, p.owner_odd, p.owner_even = owners[0], owners[1], owners[2]
     t = block._tables_on(dev)
     fp4, packed = _table_footprint(block, t)
+    occ = occupancy_columns(sp, st)
+    if occ is not None and fp4[2] * fp4[3] > 1024:
+        occ = None  # footprint beyond the plan kernel's column tile: it probes the hash instead
     _lib.call("mssvt_window_plan_two", *[_i(int(v)) for v in sp.spatial_shape],
               *[_i(int(v)) for v in block.win1_size], _i(n_o), _i(n_e), _i(n1), _i(n2), _i(H), _i(B),
               _i(t['odd'].shape[0]), _i(t['even'].shape[0]), _i(t['win1'].shape[0]), _i(t['win2'].shape[0]),
               _P(t['odd']), _P(t['even']), _P(t['win1']), _P(t['win2']), _i(K),
-              _P(p.win_ind), _P(p.num_wins), _i(cap), _P(sp.map_table),
+              _P(p.win_ind), _P(p.num_wins), _i(cap), _P(_voxel_table(sp, st, occ)),
               _P(st["v_bs_cnt"]), _P(p.ind_odd), _P(p.ind_even), _P(p.ind_win1),
               _P(p.k_ind[0]), _P(p.k_ind[1]), _P(p.k_mask[0]), _P(p.k_mask[1]),
               _P(p.win_vstart), _P(p.owner_win1), _P(p.owner_odd), _P(p.owner_even),
               _P(sp.indices), _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m),
               _P(p.qmeta_odd), _P(p.qmeta_even), _P(p.qmeta_win1), _P(p.kmeta[0]),
-              _P(p.kmeta[1]), _P(p.wcentre), _P(p.nq_valid), _P(occupancy_columns(sp, st)),
-              fp4, _P(packed), _lib.stream())
+              _P(p.kmeta[1]), _P(p.wcentre), _P(p.nq_valid), _P(occ),
+              fp4, _P(packed), _P(st.get("vbase") if occ is not None else None),
+              _P(st.get("level_status") if occ is not None else None), _lib.stream())
     st["plans"][key] = p
     return p
 
@@ -771,13 +862,15 @@ def compress_supported(block, sp):
 def one_scale_plan(block, sp, sync=True):
     """K2 + K4 + pair-row allocation for a CompressBlock; sync=True: one host sync here (the ragged
     kernels size their buffers with the window count), sync=False: the caller reads p.ws later."""
-    st = level_state(sp)
+    st = level_state(sp, [block])
     dev = sp.indices.device
     N, B, H = sp.indices.shape[0], sp.batch_size, sp.hash_size
     p = _Plan()
     p.new_spatial_shape = [sp.spatial_shape[i] // block.win1_size[i] for i in range(3)]
     p.win_size_m = [sp.voxel_size[i] * block.win1_size[i] for i in range(3)]
     p.win_ind, p.win_table, p.k_bs_cnt, ws = window_partition(block, sp, st)
+    if p.win_table is None:  # a sorted level built this partition for a Block: no table yet
+        p.win_ind, p.win_table, p.k_bs_cnt, ws = window_partition(block, sp, st, need_table=True)
     p.num_wins = ws[1:2]
     cap = max(N, 1)
     ns = block.max_num_win1
@@ -804,13 +897,15 @@ def one_scale_plan(block, sp, sync=True):
                                                        dtype=torch.int32, device=dev)
     p.num_rows = ws[2:3]
     t = block._tables_on(dev)
+    occ = st.get("occ") if st.get("sorted") else None
     _lib.call("mssvt_window_plan_one", *[_i(int(v)) for v in sp.spatial_shape],
               *[_i(int(v)) for v in block.win1_size], _i(ns), _i(H), _i(t['win1'].shape[0]), _P(t['win1']),
-              _P(p.win_ind), _P(p.num_wins), _i(cap), _P(sp.map_table),
+              _P(p.win_ind), _P(p.num_wins), _i(cap), _P(_voxel_table(sp, st, occ)),
               _P(st["v_bs_cnt"]), _i(p.with_pad), _i(p.disjoint), _i(N), _P(p.k_ind),
               _P(p.win_vstart),
               _P(p.win_cnt), _P(p.pair_base), _P(p.pair_win), _P(p.pair_vox),
-              _P(p.num_rows), _lib.stream())
+              _P(p.num_rows), _P(occ), _P(st.get("vbase") if occ is not None else None),
+              _P(st.get("level_status") if occ is not None else None), _lib.stream())
     p.ws, p.N = ws, N
     if not sync:
         # the window count is final here, ~250 us of GPU work before the block ends: copy it to pinned
@@ -832,6 +927,7 @@ def one_scale_plan(block, sp, sync=True):
         words.append(sp.map_status)
     host = (torch.cat(words) if len(words) > 1 else ws[:3]).tolist()
     status, p.nw, p.R = host[:3]
+    _raise_if_unsorted(st, host[3:])
     for extra in host[3:]:
         status |= extra & (mssvt_ops.ST_TABLE_OVERFLOW | mssvt_ops.ST_WINDOW_OVERFLOW)
     if p.disjoint:
@@ -851,7 +947,9 @@ def check_level_status(sp, max_num_wins=None):
     if not words or (st is not None and st.get("status_checked")):
         return
     status = 0
-    for w in torch.cat(words).tolist():
+    host = torch.cat(words).tolist()
+    _raise_if_unsorted(st, host)
+    for w in host:
         status |= w & (mssvt_ops.ST_TABLE_OVERFLOW | mssvt_ops.ST_WINDOW_OVERFLOW)
     if st is not None:
         st["status_checked"] = True
@@ -859,6 +957,13 @@ def check_level_status(sp, max_num_wins=None):
         raise _lib.MssvtHipError("a sample has more windows than max_num_wins")
     if status & mssvt_ops.ST_TABLE_OVERFLOW:
         raise _lib.MssvtHipError("hash table overflow (hash_size=%d)" % sp.hash_size)
+
+
+def _raise_if_unsorted(st, words):
+    """A level that was set up speculatively as sorted (no host sync) and is not: every partition reported 0 windows,
+    the frame's output is empty -- the caller (MixedScaleSparseTransformer.forward) redoes it on the order-agnostic path."""
+    if st is not None and st.get("speculative") and any(w & mssvt_ops.ST_UNSORTED for w in words):
+        raise UnsortedVoxels()
 
 
 def _check_plan_status(block, status, H):
@@ -942,6 +1047,7 @@ def _compress_forward_fused(block, sp, xhat, x_in):
     p.host_ev.synchronize()  # the forward's single host wait: the output shape (copied out long ago)
     host = p.host_ws.tolist()
     status, nw = host[0], host[1]
+    _raise_if_unsorted(getattr(sp, "_level", None), host[3:])
     for extra in host[3:]:  # voxel hash table / Block plans: overflow must not pass silently
         status |= extra & (mssvt_ops.ST_TABLE_OVERFLOW | mssvt_ops.ST_WINDOW_OVERFLOW)
     _check_plan_status(block, status, sp.hash_size)
@@ -1024,6 +1130,9 @@ def _compress_finish(sp, p, features):
     sp.gather_dict = None
     sp._level = None
     sp._ops_plans = None
+    # the output rows are in window order (first occurrence), which is (b,x,y,z)-sorted for pillar windows only:
+    # later levels take the order-agnostic set-up instead of a sorted attempt + host sync per level
+    sp._no_sorted_level = True
     return sp
 
 

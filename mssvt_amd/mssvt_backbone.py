@@ -413,6 +413,25 @@ class MixedScaleSparseTransformer(nn.Module):
         return self
 
     def forward(self, batch_dict):
+        """ref mssvt_backbone.py:450-472.  The input level is set up speculatively as (b,x,y,z)-sorted -- the order
+        DynamicVFE emits -- without a host sync (csrc/level_sorted.hip); the device verifies it, and a frame whose voxel
+        list is in another order is redone on the order-agnostic kernels (`assume_sorted` then stays off for the next
+        `_unsorted_backoff` frames)."""
+        from . import fused
+        skip = getattr(self, "_unsorted_skip", 0)
+        if skip > 0:
+            self._unsorted_skip = skip - 1
+            return self._forward(batch_dict, False)
+        try:
+            return self._forward(batch_dict, self.assume_sorted)
+        except fused.UnsortedVoxels:
+            self._unsorted_skip = self._unsorted_backoff
+            return self._forward(batch_dict, False)
+
+    assume_sorted = True
+    _unsorted_backoff = 64
+
+    def _forward(self, batch_dict, assume_sorted):
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         fused_path = feats.is_cuda and any(getattr(b, 'impl', None) == 'fused' for b in self.backbone)
         # index work of the frame on a side stream (mssvt_amd/fused.py, "Index work of a frame on a second HIP stream")
@@ -438,7 +457,7 @@ class MixedScaleSparseTransformer(nn.Module):
                 sp = None
                 if arena is not None and not torch.is_grad_enabled():
                     from . import fused  # one call sets up the whole input level for the fused blocks
-                    sp = fused.setup_input_level(self.backbone, kw)
+                    sp = fused.setup_input_level(self.backbone, kw, assume_sorted)
                 if sp is None:
                     sp = SparseTensor(map_table=None, **kw)
                 if side is not None:

@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 
-ST_DUPLICATE_KEY, ST_TABLE_OVERFLOW, ST_WINDOW_OVERFLOW = 1, 2, 4
+ST_DUPLICATE_KEY, ST_TABLE_OVERFLOW, ST_WINDOW_OVERFLOW, ST_UNSORTED = 1, 2, 4, 8
 
 # The reference asserts ``features.shape[0] == features_batch_cnt.sum()`` (mssvt_ops.py:157-160),
 # which costs two host syncs per call; here those checks are opt-in.

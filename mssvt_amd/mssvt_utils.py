@@ -49,7 +49,7 @@ class SparseTensor(object):
     ref: mssvt_utils.py:21-62."""
 
     def __init__(self, features, indices, spatial_shape, voxel_size, point_cloud_range, batch_size,
-                 hash_size, map_table=None, gather_dict=None):
+                 hash_size, map_table=None, gather_dict=None, lazy_map_table=False):
         self.features = features
         self.indices = indices
         self.spatial_shape = spatial_shape
@@ -59,12 +59,30 @@ class SparseTensor(object):
         self.hash_size = hash_size
         self.gather_dict = gather_dict
         self.v_bs_cnt = None
-        self.map_table = self.build_map_table() if map_table is None else map_table
+        self._map_table = map_table
+        if map_table is None and not lazy_map_table:
+            self._map_table = self.build_map_table()
         self._cnt_of = self.indices if self.v_bs_cnt is not None else None
+
+    @property
+    def map_table(self):
+        """Per-sample hash table key -> voxel index (ref build_map_table, mssvt_utils.py:31-48).  With
+        ``lazy_map_table`` it is built on first use: the fused path of a (b,x,y,z)-sorted voxel list resolves cells
+        through occupancy columns (csrc/level_sorted.hip) and never reads it."""
+        if self._map_table is None:
+            self._map_table = self.build_map_table()
+        return self._map_table
+
+    @map_table.setter
+    def map_table(self, value):
+        self._map_table = value
 
     @torch.no_grad()
     def build_map_table(self):
-        cnt = self.v_bs_cnt = batch_counts(self.indices, self.batch_size)  # kept: the plans need it too
+        cnt = self.v_bs_cnt
+        if cnt is None or getattr(self, "_cnt_of", None) is not self.indices:
+            cnt = self.v_bs_cnt = batch_counts(self.indices, self.batch_size)  # kept: the plans need it too
+            self._cnt_of = self.indices
         table = mssvt_ops.build_hash_table(self.batch_size, self.hash_size, self.spatial_shape, self.indices, cnt)
         self.map_status = getattr(mssvt_ops.build_hash_table, "last_status", None)  # device status word of this table
         return table

@@ -23,12 +23,14 @@ def _block(ws, m1, m2, K, pattern=1, C=32, heads=(2, 2)):
                                               ([[3, 3, 5], [7, 7, 7]], 6, 20, 8, 3, 30000),
                                               ([[2, 2, 2], [4, 4, 4]], 8, 64, 16, 1, 20000),
                                               ([[5, 5, 7], [11, 11, 11]], 175, 1331, 32, 1, 60000)])
-@pytest.mark.parametrize("occ", [True, False])
+@pytest.mark.parametrize("occ", ["ranked", "columns", "probes"])
 def test_window_plan_matches_oracle(ws, m1, m2, K, B, pts, occ, monkeypatch):
-    """occ: K3 hit test through the occupancy columns (default) / through hash probes (z > 64 fallback)."""
+    """occ: voxel indices from the column bases of a sorted level (default) / K3 hit test through the occupancy
+    columns, one hash probe per hit (any voxel order) / through hash probes alone (z > 64 fallback)."""
     from mssvt_amd import fused
     from mssvt_amd.mssvt_utils import SparseTensor
-    monkeypatch.setattr(fused, "OCC_COLUMNS", occ)
+    monkeypatch.setattr(fused, "OCC_COLUMNS", occ != "probes")
+    monkeypatch.setattr(fused, "SORTED_LEVELS", occ == "ranked")
     H = 200003
     p_np = synthetic.make_batch_points(pts, B, 11)
     vc, _, _ = synthetic.voxelize_numpy(p_np)
@@ -37,6 +39,7 @@ def test_window_plan_matches_oracle(ws, m1, m2, K, B, pts, occ, monkeypatch):
                       spatial_shape=synthetic.GRID_SIZE, voxel_size=synthetic.VOXEL_SIZE,
                       point_cloud_range=synthetic.POINT_CLOUD_RANGE, batch_size=B, hash_size=H)
     p = fused.two_scale_plan(blk, sp)
+    assert bool(sp._level.get("sorted")) == (occ == "ranked")
     nw = int(p.num_wins.item())
     # oracle
     tabs = {k: v.cpu().numpy() for k, v in blk.vox_query_table.items()}
@@ -246,7 +249,7 @@ def test_level_setup_equals_the_single_entry_points(pts, B):
               voxel_size=net.voxel_size, point_cloud_range=net.point_cloud_range, batch_size=B,
               hash_size=net.hash_size, gather_dict=None)
     with torch.no_grad():
-        got = fused.setup_input_level(net.backbone, kw)
+        got = fused.setup_input_level(net.backbone, kw, assume_sorted=False)  # the order-agnostic set-up
         want = SparseTensor(map_table=None, **kw)
     assert got is not None
     assert torch.equal(got.v_bs_cnt, want.v_bs_cnt) and torch.equal(got.map_table, want.map_table)
@@ -264,6 +267,77 @@ def test_level_setup_equals_the_single_entry_points(pts, B):
         st, nw = ws[:2].tolist()
         assert [st, nw] == ws_w[:2].tolist() and st == 0 and nw > 0
         assert torch.equal(win[:nw], win_w[:nw]) and torch.equal(table, table_w) and torch.equal(vcount, vcount_w)
+
+
+@pytest.mark.parametrize("pts,B,empty", [(20000, 3, None), (160000, 1, None), (30000, 4, 1), (30000, 3, 0), (30000, 3, 2)])
+def test_sorted_level_setup_equals_the_order_agnostic_one(pts, B, empty):
+    """mssvt_level_setup_sorted (occupancy bitmap -> counts, column bases, window partitions in first-occurrence order,
+    window tables; csrc/level_sorted.hip) against the hash / atomics path on (b,x,y,z)-sorted lists, bit for bit --
+    also with an empty sample in front / in the middle / at the end."""
+    from mssvt_amd import config, fused, mssvt_ops
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(dev).eval()
+    vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(pts, B, 35))
+    if empty is not None:
+        vc = vc[vc[:, 0] != empty]
+    idx = torch.from_numpy(vc).to(dev)
+    X, Y, Z = net.grid_size
+    with torch.no_grad():
+        st = fused._sorted_level(list(net.backbone), idx, B, net.hash_size, net.grid_size)
+    assert st is not None and int(st["level_status"].item()) == 0
+    cnt = np.bincount(vc[:, 0], minlength=B)
+    np.testing.assert_array_equal(st["v_bs_cnt"].cpu().numpy(), cnt)
+    occ = np.zeros((B, X, Y), np.uint64)
+    np.bitwise_or.at(occ, (vc[:, 0], vc[:, 3], vc[:, 2]), np.uint64(1) << vc[:, 1].astype(np.uint64))
+    np.testing.assert_array_equal(st["occ"].cpu().numpy().view(np.uint64).reshape(B, X, Y), occ)
+    # column base + popcount below z = the voxel's index inside its sample
+    start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    vbase = st["vbase"].cpu().numpy().reshape(B, X, Y)
+    below = np.array([bin(int(w) & ((1 << int(z)) - 1)).count("1") for w, z in
+                      zip(occ[vc[:, 0], vc[:, 3], vc[:, 2]], vc[:, 1])])
+    np.testing.assert_array_equal(vbase[vc[:, 0], vc[:, 3], vc[:, 2]] + below, np.arange(vc.shape[0]) - start[vc[:, 0]])
+    assert len(st["partitions"]) == 2
+    for blk in net.backbone:
+        win, table, vcount, ws = st["partitions"][fused._partition_key(blk)]
+        shape = [net.grid_size[i] // blk.win1_size[i] for i in range(3)]
+        win_w, table_w, vcount_w, ws_w = mssvt_ops.window_partition_device(blk.win1_size, blk.max_num_wins, B,
+                                                                           net.hash_size, shape, idx)
+        stw, nw = ws[:2].tolist()
+        assert [stw, nw] == ws_w[:2].tolist() and stw == 0 and nw > 0
+        assert torch.equal(win[:nw], win_w[:nw]) and torch.equal(vcount, vcount_w)
+        if table is not None:  # only the CompressBlock's window table is kept
+            assert torch.equal(table, table_w)
+    assert any(t[1] is not None for t in st["partitions"].values())
+
+
+@pytest.mark.parametrize("how", ["shuffled", "duplicate", "out_of_grid", "swapped_pair"])
+def test_sorted_level_setup_rejects_any_other_order(how):
+    """ST_UNSORTED for lists that are not strictly (b,x,y,z)-ascending and in-grid; every partition then reports 0 windows
+    (downstream kernels of a speculative frame run on nothing)."""
+    from mssvt_amd import config, fused, mssvt_ops
+    dev = torch.device("cuda", 0)
+    net = config.build_backbone_from_cfg().to(dev).eval()
+    vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(20000, 2, 37))
+    rng = np.random.default_rng(0)
+    if how == "shuffled":
+        for b in range(2):
+            sel = np.nonzero(vc[:, 0] == b)[0]
+            vc[sel] = vc[rng.permutation(sel)]
+    elif how == "duplicate":
+        vc = np.concatenate([vc[:100], vc[99:]])
+    elif how == "out_of_grid":
+        vc = vc.copy()
+        vc[500, 3] = net.grid_size[0] + 3
+    else:
+        vc = vc.copy()
+        vc[[700, 701]] = vc[[701, 700]]
+    idx = torch.from_numpy(np.ascontiguousarray(vc)).to(dev)
+    with torch.no_grad():
+        st = fused._sorted_level(list(net.backbone), idx, 2, net.hash_size, net.grid_size)
+    assert int(st["level_status"].item()) & mssvt_ops.ST_UNSORTED
+    for win, table, vcount, ws in st["partitions"].values():
+        assert ws[1].item() == 0
 
 
 def test_voxelizer_drops_non_finite_and_foreign_points():

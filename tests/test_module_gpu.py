@@ -167,6 +167,41 @@ def test_backbone_matches_oracle_on_waymo_shaped_scene(impl):
     assert_feat_close(sp.features.cpu().numpy(), want.features)
 
 
+def test_unsorted_voxel_order_falls_back_and_matches_the_oracle():
+    """The backbone sets its input level up speculatively as (b,x,y,z)-sorted (csrc/level_sorted.hip).  A frame whose
+    voxels come in another order (e.g. from a spconv voxel generator instead of DynamicVFE) is detected on the device
+    and redone on the order-agnostic kernels: same function, the oracle's canonical orders for THAT voxel order;
+    a sorted frame afterwards takes the order-agnostic path too while the back-off lasts, and both give the oracle's
+    result."""
+    from mssvt_amd import fused
+    from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
+    C, B, H = 32, 2, 100003
+    pts = synthetic.make_batch_points(8000, B, 300)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    rng = np.random.default_rng(1)
+    shuf = vc.copy()
+    for b in range(B):
+        sel = np.nonzero(vc[:, 0] == b)[0]
+        shuf[sel] = vc[rng.permutation(sel)]
+    params = _mid_params(C)
+    torch.manual_seed(0)
+    net = MixedScaleSparseTransformer(_cfg(params, H, C), C, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
+                                      synthetic.POINT_CLOUD_RANGE).eval()
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    assert net.assume_sorted and fused.SORTED_LEVELS
+    for coords in (vc, shuf, vc):
+        feats = torch.randn(coords.shape[0], C, generator=torch.Generator().manual_seed(0)).numpy()
+        want = block_ref.backbone_forward(sd, params, feats, coords, B, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
+                                          synthetic.POINT_CLOUD_RANGE, H)
+        with torch.no_grad():
+            sp = net(dict(voxel_features=torch.from_numpy(feats).to(DEV), voxel_coords=torch.from_numpy(coords).to(DEV),
+                          batch_size=B))["encoded_spconv_tensor"]
+        np.testing.assert_array_equal(sp.indices.cpu().numpy(), want.indices)
+        assert_feat_close(sp.features.cpu().numpy(), want.features)
+    assert net._unsorted_skip == net._unsorted_backoff - 1  # the third frame ran inside the back-off
+
+
 @pytest.mark.parametrize("B", [1, 4])
 def test_full_size_frame_fused_matches_operator_path(B):
     """BASELINE configs[1] (B = 1) and the per-GPU shape of configs[3] (4 scenes per GPU) at full size (160k
