@@ -222,13 +222,15 @@ int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_ma
  * slot picked by FPS becomes voxel 0, as in the reference); k_mask1/k_mask2 (cap,K)
  * bytes, 1 = masked; win_vstart (cap) first feature row of the window's sample;
  * owner_* (N) pre-filled -1: highest flat list slot (w*max_num + s) holding the voxel.
- * Optional resolved metadata (kmeta1 == NULL: skipped): qmeta_* (cap,max_num_*,4), kmeta1/2
+ * Optional resolved metadata (kmeta1 == NULL: skipped; each qmeta_* may be NULL on its own): qmeta_* (cap,max_num_*,4), kmeta1/2
  * (cap,K,4) f32 = (voxel centre - window centre in metres, bits of the global feature row or
  * -1 for empty / masked slots); wcentre (cap,4) = window centre; nq_valid (3,cap) = valid odd /
  * even / win1 entries per window.  indices (N,4) voxel coords.
  * column_vbase / level_status_dev (optional, with occ_columns; from mssvt_level_setup_sorted): for a voxel list sorted
  * by (b,x,y,z) the index of an occupied cell is column_vbase + popcount(column word below z) and the hash is not
- * probed at all (xyz_to_vidx may then be NULL); when level_status_dev[0] has ST_UNSORTED (8) set the hash is used. */
+ * probed at all (xyz_to_vidx may then be NULL); when level_status_dev[0] has ST_UNSORTED (8) set the hash is used.
+ * win_counts_dev (optional, B ints: windows per sample, as the window partition reports them): the windows are
+ * then processed centre-out inside every sample (heaviest first on lidar scenes); the outputs do not depend on it. */
 int mssvt_window_plan_two(
     int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
     int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
@@ -241,13 +243,14 @@ int mssvt_window_plan_two(
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
     float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
     const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
-    void *stream);
+    const int *win_counts_dev, void *stream);
 
 /* Occupancy columns of a voxel set (z_max <= 64): columns (B*x_max*y_max) 64-bit words, bit z of
  * word (b*x_max + x)*y_max + y set when cell (b,x,y,z) holds a voxel.  Optional input of
  * mssvt_window_plan_two (together with host_footprint4 = {min x offset, min y offset, x extent,
  * y extent} of the four query tables and packed_offsets = the tables concatenated odd | even |
- * win1 | win2, one word (x+64) | (y+64)<<8 | (z+64)<<16 per offset, on the device): the K3 hit test then reads one word per (x,y) column of the
+ * win1 | win2, one word (x+64) | (y+64)<<7 | (z+64)<<14 | column<<21 per offset, column = (x - min x) * y extent +
+ * (y - min y), on the device; |offset| <= 60, x extent * y extent <= 1024): the K3 hit test then reads one word per (x,y) column of the
  * neighbourhood instead of probing the hash for each of its cells (ref K3 probes all of them,
  * ms_sparse_attention_gpu.cu:193-330); the hash is only probed for the hits.               */
 int mssvt_occupancy_columns(const int *indices, int num_voxels, int batch_size, int x_max, int y_max,

@@ -22,6 +22,9 @@
 #include <stdlib.h>
 #include "common.hip.h"
 #define PLAN_MAX_WPB 4
+#ifndef PLAN_WAVES_PER_SIMD
+#define PLAN_WAVES_PER_SIMD 5  // register budget of the common instantiation (96 VGPRs; 8, 6 and 4 waves measured the same)
+#endif
 
 struct PlanArgs {
     int x_max, y_max, z_max, x_ws, y_ws, z_ws;
@@ -47,26 +50,30 @@ struct PlanArgs {
     const int *indices;
     float vsx, vsy, vsz, minx, miny, minz, wsx, wsy, wsz;
     int lds_words_per_wave;
-    int hit_cap;  // entries of the per-wave hit sequence (>= number of table offsets, even)
+    int hit_cap;   // entries of the per-wave hit sequence (>= number of table offsets, even)
+    int meta_cap;  // hits whose resolved metadata is kept in LDS (covers the odd / even / win1 lists)
     // optional occupancy columns (mssvt_occupancy_columns): one 64-bit word per (b, x, y), bit z set
     // when the cell holds a voxel; fx0/fy0/fnx/fny = bounding box of the tables' (x, y) offsets
     const unsigned long long *occ;
-    int fx0, fy0, fnx, fny;
+    int fx0, fy0, fnx, fny, fny_magic;  // (c * fny_magic) >> 20 == c / fny for every column c of the footprint
     const int *q_packed;  // with occ: the four tables concatenated, one pack_off() word per offset
     // optional, with occ: voxels of the sample in the columns before (b, x, y) of a voxel list that is sorted by
     // (b, x, y, z) -- the index of an occupied cell is then col_vbase + popcount(column word below z) and the hash
     // is not probed at all; level_status = the device word in which mssvt_level_setup_sorted reports ST_UNSORTED
     const int *col_vbase, *level_status;
+    const int *win_counts;  // (unused: a centre-out work order was measured and bought nothing)
 };
 
 __device__ __forceinline__ float plan_centre(int idx, float cell, float lo) {
     return __fadd_rn(__fmul_rn(__fadd_rn((float)idx, 0.5f), cell), lo);
 }
 
-#define PACK0 (64 | (64 << 8) | (64 << 16))
-#define PLAN_PRE 8  // 64-offset steps of K3 whose packed offsets are preloaded into registers
+// one word per table offset: (x + 64) | (y + 64) << 7 | (z + 64) << 14 | column << 21, column = (x - fx0) * fny + (y - fy0)
+// = the offset's (x, y) column inside the tables' footprint (0 without occupancy columns)
+#define PACK0 (64 | (64 << 7) | (64 << 14))
+#define PLAN_PRE 6  // 64-offset steps of K3 whose packed offsets are preloaded into registers (7 x 7 x 7: 343 offsets)
 __device__ __forceinline__ int pack_off(int ox, int oy, int oz) {
-    return (ox + 64) | ((oy + 64) << 8) | ((oz + 64) << 16);
+    return (ox + 64) | ((oy + 64) << 7) | ((oz + 64) << 14);
 }
 
 // ---- farthest point sampling on the hit sequence ---------------------------------------------------------
@@ -81,20 +88,23 @@ __device__ __forceinline__ int pack_off(int ox, int oy, int oz) {
 // inside a thread the later slot wins only on a STRICTLY larger distance (bit 1).  0 = no candidate.  One wave
 // max per round; the winner's thread id and slot are decoded from the key itself (scalar), no ballot / readlane.
 #define FPS_BIG 0xFFFFFu  // "1e10": replaced by a real distance in the first round
+template <int ROWS = 4>  // candidates only in lanes [0, 16 ROWS)
 __device__ __forceinline__ unsigned int wave_max_u32_uniform(unsigned int v) {
     unsigned int t;
     t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = t > v ? t : v;   // quad_perm [1,0,3,2]
     t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = t > v ? t : v;   // quad_perm [2,3,0,1]
     t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = t > v ? t : v;  // row_half_mirror
     t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = t > v ? t : v;  // row_mirror
+    if (ROWS == 1) return (unsigned int)__builtin_amdgcn_readlane((int)v, 15);
     t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;  // row_bcast:15
+    if (ROWS == 2) return (unsigned int)__builtin_amdgcn_readlane((int)v, 31);
     t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;  // row_bcast:31
     return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 // signed-byte packs of an offset (x, y, z) and of -2 (x, y, z) (|offset| <= 60)
 __device__ __forceinline__ int fps_pack_s8(int x, int y, int z) { return (x & 255) | ((y & 255) << 8) | ((z & 255) << 16); }
 __device__ __forceinline__ void fps_unpack(int pk, int &x, int &y, int &z) {
-    x = (pk & 255) - 64; y = ((pk >> 8) & 255) - 64; z = ((pk >> 16) & 255) - 64;
+    x = (pk & 127) - 64; y = ((pk >> 7) & 127) - 64; z = ((pk >> 14) & 127) - 64;
 }
 // thread of the reference block with the smallest bit-reversed id in [lo, bs): the one with the most trailing zeros
 __device__ __forceinline__ int fps_min_rev_thread(int lo, int L) {
@@ -118,6 +128,7 @@ __device__ __forceinline__ int fps_decode_pick(unsigned int mkey, int L, int bs)
 //     is padding only -> (tpad, vt);
 //   * among the pure-padding threads [nv, bs) the tree favours the smallest bit-reversed id (fps_min_rev_thread).
 // One lane per valid entry (pk = its packed offset, PACK0 on the other lanes), min-distances in registers.
+template <bool REGPICKS, int ROWS>
 __device__ __forceinline__ void fps_on_list_fast(int pk, int n, int nv, int m, int bs, int *fps_out, int lane) {
     const int L = 31 - __clz(bs);
     const bool mine = lane < nv;
@@ -128,14 +139,17 @@ __device__ __forceinline__ void fps_on_list_fast(int pk, int n, int nv, int m, i
     const unsigned int myrev = __brev((unsigned int)lane) >> (32 - L);
     const unsigned int tb = mine ? (((1023u - myrev) << 2) | 3u) : 0u;  // first slot of thread `lane`
     const bool has_second = mine && lane + bs < n;                      // this thread's second slot (padding)
-    const unsigned int tb2 = has_second ? (tb & ~2u) : 0u;
+    const unsigned int tb2 = has_second ? (tb & ~2u) : 0u, hs_mask = has_second ? 0xFFFFFFFFu : 0u;
     const bool padgroup = nv < bs;  // pure-padding threads vt in [nv, bs)
     const int vp = padgroup ? fps_min_rev_thread(nv, L) : 0;
-    const unsigned int vp_tb = ((1023u - (__brev((unsigned int)vp) >> (32 - L))) << 2) | 3u;
-    unsigned int tk = mine ? FPS_BIG : 0u, tpad = FPS_BIG;
-    int old = 0;
-    if (lane == 0) fps_out[0] = 0;
-    for (int j = 1; j < m; ++j) {
+    const unsigned int vp_tb = padgroup ? (((1023u - (__brev((unsigned int)vp) >> (32 - L))) << 2) | 3u) : 0u;
+    const unsigned int pgmask = padgroup ? 0xFFFFFFFFu : 0u;
+    // no padding slot at all (nv == n): tpad is never looked at -> 0 keeps the exit test to one compare
+    unsigned int tk = mine ? FPS_BIG : 0u, tpad = nv < n ? FPS_BIG : 0u;
+    int old = 0, picks = 0;
+    if (!REGPICKS && lane == 0) fps_out[0] = 0;
+    int j = 1;
+    for (; j < m; ++j) {
         // offset of the last pick: a valid entry's, or (0,0,0) of a padding slot (`old` is wave-uniform)
         const bool ov = old < nv;
         const int ol = ov ? old : 0;
@@ -145,22 +159,24 @@ __device__ __forceinline__ void fps_on_list_fast(int pk, int n, int nv, int m, i
         const unsigned int d = (unsigned int)(__builtin_amdgcn_sdot4(a4, s_m2, na, false) + s_nb);
         tk = d < tk ? d : tk;
         tpad = (unsigned int)s_nb < tpad ? (unsigned int)s_nb : tpad;
+        const unsigned int tp12 = tpad << 12;
         const unsigned int k1 = (tk << 12) | tb;
-        const unsigned int k2 = has_second ? ((tpad << 12) | tb2) : 0u;
+        const unsigned int k2 = (tp12 & hs_mask) | tb2;
         const unsigned int key = k1 > k2 ? k1 : k2;
-        const unsigned int mkey = wave_max_u32_uniform(key);
-        int pick;
-        if (padgroup && (((tpad << 12) | vp_tb) > mkey))
-            pick = vp;
-        else
-            pick = fps_decode_pick(mkey, L, bs);
-        old = pick;
-        if (lane == 0) fps_out[j] = old;
-        if ((mkey >> 12) == 0u && (!padgroup || tpad == 0u) && !(nv < n && tpad > 0u)) {
-            // every remaining min-distance is 0: all further rounds tie completely and return slot 0
-            for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
-            break;
-        }
+        const unsigned int mkey = wave_max_u32_uniform<ROWS>(key);
+        const int dec = fps_decode_pick(mkey, L, bs);
+        old = ((tp12 | vp_tb) & pgmask) > mkey ? vp : dec;  // a pure-padding thread outranks every entry
+        if (REGPICKS)
+            picks = lane == j ? old : picks;
+        else if (lane == 0)
+            fps_out[j] = old;
+        // every remaining min-distance is 0: all further rounds tie completely and return slot 0
+        if ((mkey | tp12) < 4096u) break;
+    }
+    if (REGPICKS) {
+        if (lane < m) fps_out[lane] = lane <= j ? picks : 0;
+    } else {
+        for (int jj = j + 1 + lane; jj < m; jj += MSSVT_WAVE) fps_out[jj] = 0;
     }
 }
 
@@ -221,7 +237,7 @@ __device__ __forceinline__ void fps_on_list_regs(const int *packed, int nv, int 
 }
 
 #ifdef MSSVT_STAMPS  // developer instrumentation
-__device__ unsigned long long g_plan_stamps[64 * 16];
+__device__ unsigned long long g_plan_stamps[32768 * 16];
 __device__ unsigned long long g_plan_span[32768 * 2];
 extern "C" int mssvt_debug_read_plan_span(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_plan_span), sizeof(g_plan_span));
@@ -229,7 +245,11 @@ extern "C" int mssvt_debug_read_plan_span(unsigned long long *host) {
 extern "C" int mssvt_debug_read_plan_stamps(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_plan_stamps), sizeof(g_plan_stamps));
 }
-#define PSTAMP() if (lane == 0 && w < 64 && si < 16) g_plan_stamps[w * 16 + si++] = __builtin_readcyclecounter();
+#define PSTAMP()                                                                                   \
+    {                                                                                              \
+        if (lane == 0 && si < 16 && w < 32768) g_plan_stamps[w * 16 + si] = __builtin_readcyclecounter(); \
+        ++si;                                                                                      \
+    }
 #else
 #define PSTAMP()
 #endif
@@ -240,27 +260,23 @@ __device__ __forceinline__ unsigned long long lanes_below(int k) {
 }
 
 // One list of a window (K3's vox_ind_* row, ref ms_sparse_attention_gpu.cu:238-262): entries [first, first + nv) of
-// the hit sequence, -1 padded to maxn; its resolved metadata; the owner array of its voxels.
-__device__ __forceinline__ void plan_emit_list(const PlanArgs &a, int w, int lane, int maxn, int nv, int first, const int *hpk,
-                                               const int *hsv, int *ind, float4 *qmeta, int *owner, int vstart, int cx, int cy,
-                                               int cz, float wcx, float wcy, float wcz) {
-    const float4 none = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
+// the hit sequence, -1 padded to maxn; its resolved metadata (copied from the per-hit rows in LDS; optional); the owner
+// array of its voxels.
+__device__ __forceinline__ void plan_emit_list(int w, int lane, int maxn, int nv, int first, const int *hsv, const float4 *hmeta,
+                                               int *ind, float4 *qmeta, int *owner, int vstart) {
     for (int k = lane; k < maxn; k += MSSVT_WAVE) {
         const bool valid = k < nv;
         const int e = valid ? first + k : 0;
         const int sv = valid ? hsv[e] : MSSVT_EMPTY;
         ind[(size_t)w * maxn + k] = sv;
-        if (a.kmeta1) {
-            float4 m = none;
-            if (valid) {
-                int ox, oy, oz;
-                fps_unpack(hpk[e], ox, oy, oz);
-                m = make_float4(plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
-                                plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
-            }
-            qmeta[(size_t)w * maxn + k] = m;
+        if (qmeta) {
+            const float4 m = hmeta[e];  // (component-wise select: a float4 select goes through scratch)
+            qmeta[(size_t)w * maxn + k] = make_float4(valid ? m.x : 0.f, valid ? m.y : 0.f, valid ? m.z : 0.f,
+                                                       valid ? m.w : __builtin_bit_cast(float, -1));
         }
+#if !(defined(PLAN_ABLATE) && PLAN_ABLATE == 5)  // (timing-only build 5: no owner atomics)
         if (valid) atomicMax(owner + vstart + sv, w * maxn + k);
+#endif
     }
 }
 
@@ -277,11 +293,18 @@ __device__ __forceinline__ void plan_emit_list(const PlanArgs &a, int w, int lan
 //                 once; without (z > 64): a hash probe per offset (the reference's way)
 //   voxel index   sorted voxel list: column base + popcount(column word below z) -- no hash at all;
 //                 any other order: one hash probe per hit, all in flight together
-template <int FPS_TPL>
-__global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanArgs a) {
+//
+// RANKED = the voxel indices come from the column bases of a sorted level (mssvt_level_setup_sorted): that instantiation
+// holds no hash probe at all -- besides the probes themselves this matters for the STORES: a load in a probe loop
+// whose last result may stay unconsumed makes the compiler wait vmcnt(0) wherever its register is reused, i.e. for
+// every store issued since (vmcnt retires in order: 5 full write round trips per window, 40 of 65 us of this kernel).
+template <int FPS_TPL, bool RANKED>
+__global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_WAVES_PER_SIMD : 1) k_window_plan(PlanArgs a) {
     extern __shared__ int lds[];
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
     const int w = blockIdx.x * (blockDim.x / MSSVT_WAVE) + wv;
+    // (issued before the window count is known: the two loads travel together; the grid is sized for the capacity)
+    const int4 wi = reinterpret_cast<const int4 *>(a.win_indices)[min(w, a.win_capacity - 1)];  // [b,wz,wy,wx]
     if (w >= *a.num_wins) return;  // wave-uniform
     int si = 0;
     (void)si;
@@ -291,36 +314,45 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
 #endif
     const int K = a.key_num_sample;
     int *base = lds + (size_t)wv * a.lds_words_per_wave;
-    int *hpk = base;              // hit sequence: packed offsets in table order
-    int *hsv = hpk + a.hit_cap;   // ... and the voxel index (inside the sample) of each hit
+    float4 *hmeta = reinterpret_cast<float4 *>(base);  // resolved metadata of the first meta_cap hits (16-byte aligned)
+    int *hpk = base + 4 * a.meta_cap;                  // hit sequence: packed offsets in table order
+    int *hsv = hpk + a.hit_cap;                        // ... and the voxel index (inside the sample) of each hit
     int *fps_out = hsv + a.hit_cap;
     unsigned long long *colw = reinterpret_cast<unsigned long long *>(fps_out + ((K + 1) & ~1));  // 8-byte aligned
     const int ncols = a.fnx * a.fny;
     int *cbase = reinterpret_cast<int *>(colw + ncols);
 
-    const int4 wi = reinterpret_cast<const int4 *>(a.win_indices)[w];  // [b,wz,wy,wx]
     const slot_t *tab = a.table + (size_t)wi.x * a.hash_size;
     int vstart = 0;
     for (int k = 0; k < wi.x; ++k) vstart += a.v_bs_cnt[k];
-    if (lane == 0) a.win_vstart[w] = vstart;
+    // vmcnt retires in order: a wait for a LOAD also waits for every store issued before it (a full write round trip).
+    // So every load of a window is issued up here -- also voxel 0 of the sample, which an FPS-picked empty slot turns
+    // into (the (x + 0.1).int() quirk below) -- and no store is issued before the column words are back.
+    int4 v0 = make_int4(0, 0, 0, 0);
+    if (a.kmeta1) v0 = reinterpret_cast<const int4 *>(a.indices)[vstart];  // (a live window's sample holds >= 1 voxel)
     const int cx = wi.w * a.x_ws + a.x_ws / 2, cy = wi.z * a.y_ws + a.y_ws / 2,
               cz = wi.y * a.z_ws + a.z_ws / 2;
     const float wcx = plan_centre(wi.w, a.wsx, a.minx), wcy = plan_centre(wi.z, a.wsy, a.miny),
                 wcz = plan_centre(wi.y, a.wsz, a.minz);
-    if (a.kmeta1 && lane == 0) a.wcentre[w] = make_float4(wcx, wcy, wcz, 0.f);
     const int e0 = a.n_odd, e1 = e0 + a.n_even, e2 = e1 + a.n_win1, total = e2 + a.n_win2;
-    const bool use_occ = a.occ != nullptr;
-    const bool ranked = use_occ && a.col_vbase != nullptr && !(a.level_status[0] & ST_UNSORTED);
+    const bool use_occ = RANKED || a.occ != nullptr;
+    const bool ranked = RANKED;
+    // (a level that turned out unsorted reports 0 windows; should a caller pass window rows of its own: nothing to do)
+    if (RANKED && (a.level_status[0] & ST_UNSORTED)) return;
     int pre[PLAN_PRE];
     if (use_occ) {
         // the first PLAN_PRE x 64 offsets travel together with the column words
+        // (only the steps that will run: a load whose result is never consumed stays "pending" for the compiler, which
+        // then waits vmcnt(0) -- i.e. for every store issued since -- wherever its register is reused)
 #pragma unroll
         for (int ci = 0; ci < PLAN_PRE; ++ci) {
             const int q = ci * MSSVT_WAVE + lane;
-            pre[ci] = q < total ? a.q_packed[q] : PACK0;
+            pre[ci] = PACK0;
+            if (ci * MSSVT_WAVE < total) pre[ci] = a.q_packed[min(q, total - 1)];
         }
         for (int c = lane; c < ncols; c += MSSVT_WAVE) {
-            const int sx = cx + a.fx0 + c / a.fny, sy = cy + a.fy0 + c % a.fny;
+            const int ccx = (int)(((unsigned int)c * (unsigned int)a.fny_magic) >> 20);  // = c / fny (checked by the host)
+            const int sx = cx + a.fx0 + ccx, sy = cy + a.fy0 + (c - ccx * a.fny);
             const bool in = sx >= 0 && sx < a.x_max && sy >= 0 && sy < a.y_max;
             const size_t col = ((size_t)wi.x * a.x_max + (in ? sx : 0)) * a.y_max + (in ? sy : 0);
             const unsigned long long word = a.occ[col];
@@ -329,94 +361,135 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         }
         wave_lds_sync();
     }
+    // metadata of the sample's voxel 0 (see above; consumed here so that no load is pending once the stores start)
+    const float4 m0 = make_float4(plan_centre(v0.w, a.vsx, a.minx) - wcx, plan_centre(v0.z, a.vsy, a.miny) - wcy,
+                                  plan_centre(v0.y, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart));
     PSTAMP()
+#if defined(PLAN_ABLATE) && PLAN_ABLATE == 2  // timing-only build: stop after the column loads
+    if (colw[lane % max(ncols, 1)] == 0x1234567ull) a.win_vstart[w] = 1;
+    return;
+#endif
     // ---- K3: the hit sequence ---------------------------------------------------------------------------
-    int cnt_odd = 0, cnt_le1 = 0, cnt_le2 = 0, cnt_all = 0;  // hits of the first 1 / 2 / 3 / 4 tables
-    for (int bq = 0; bq < total; bq += MSSVT_WAVE) {
-        if (cnt_all >= a.max_win2 && cnt_le2 >= a.max_win1 && (cnt_le1 - cnt_odd >= a.max_even || bq >= e1) &&
-            (cnt_odd >= a.max_odd || bq >= e0))
-            break;
-        const int q = bq + lane;
-        bool hit = false;
-        int pk = PACK0, sv = MSSVT_EMPTY;
-        if (use_occ) {
-            const int ci = bq / MSSVT_WAVE;
-            if (ci < PLAN_PRE) {
-#pragma unroll
-                for (int u = 0; u < PLAN_PRE; ++u) pk = ci == u ? pre[u] : pk;  // ci is wave-uniform: scalar selects
-            } else if (q < total) {
-                pk = a.q_packed[q];
-            }
-            if (q < total) {
-                int ox, oy, oz;
-                fps_unpack(pk, ox, oy, oz);
-                const int sz = cz + oz, dx = ox - a.fx0, dy = oy - a.fy0;
-                // columns outside the grid are zero words; sz outside [0, z_max) has no bit set
-                if (sz >= 0 && sz < a.z_max && dx >= 0 && dx < a.fnx && dy >= 0 && dy < a.fny)
-                    hit = (colw[dx * a.fny + dy] >> sz) & 1ull;
-            }
-        } else if (q < total) {
-            const int seg = (q >= e0) + (q >= e1) + (q >= e2);
-            const int *src = seg == 0 ? a.q_odd + q * 3
-                           : seg == 1 ? a.q_even + (q - e0) * 3
-                           : seg == 2 ? a.q_win1 + (q - e1) * 3
-                                      : a.q_win2 + (q - e2) * 3;
-            const int ox = src[0], oy = src[1], oz = src[2];
-            pk = pack_off(ox, oy, oz);
-            const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
-            if (!(sx >= a.x_max || sx < 0 || sy >= a.y_max || sy < 0 || sz >= a.z_max || sz < 0))
-                sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
-            hit = sv != MSSVT_EMPTY;
-        }
+    // hits of the first 1 / 2 / 3 / 4 tables; a count is fixed in the step that holds its table's end (-1: not reached,
+    // every hit so far belongs to it)
+    int cnt_odd = -1, cnt_le1 = -1, cnt_le2 = -1, cnt_all = 0;
+    bool stop = false;
+    // one 64-offset step: `hit` / `pk` / `sv` of this lane's offset -> the sequence and the counts
+    auto append = [&](int bq, bool hit, int pk, int sv) __attribute__((always_inline)) {
         const unsigned long long m_all = __ballot(hit);
-        if (m_all == 0) continue;
+        // position of a hit in this lane = hits before it; the hits before lane (e - bq) are those of the tables below e
+        const int p = cnt_all + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m_all >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)m_all, 0u));
+        // (branch-free: the steps of the unrolled part stay one basic block and their LDS reads overlap)
+        const int r0 = __builtin_amdgcn_readlane(p, (e0 - bq) & 63), r1 = __builtin_amdgcn_readlane(p, (e1 - bq) & 63),
+                  r2 = __builtin_amdgcn_readlane(p, (e2 - bq) & 63);
+        cnt_odd = (unsigned int)(e0 - bq) < 64u ? r0 : cnt_odd;
+        cnt_le1 = (unsigned int)(e1 - bq) < 64u ? r1 : cnt_le1;
+        cnt_le2 = (unsigned int)(e2 - bq) < 64u ? r2 : cnt_le2;
         if (hit) {
-            const int p = cnt_all + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m_all >> 32),
-                                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)m_all, 0u));
             hpk[p] = pk;
             if (!use_occ) hsv[p] = sv;
         }
-        cnt_odd += __popcll(m_all & lanes_below(e0 - bq));
-        cnt_le1 += __popcll(m_all & lanes_below(e1 - bq));
-        cnt_le2 += __popcll(m_all & lanes_below(e2 - bq));
         cnt_all += __popcll(m_all);
+        // no list takes another entry (ref :238, :274, :310)?
+        const int nb = bq + MSSVT_WAVE;
+        stop = cnt_all >= a.max_win2 && (nb >= e2 || cnt_all >= a.max_win1) &&
+               (nb >= e1 || (nb >= e0 && cnt_all - cnt_odd >= a.max_even)) && (nb >= e0 || cnt_all >= a.max_odd);
+    };
+    if (use_occ) {
+        // the offset's column word sits at colw[pk >> 21]; columns outside the grid are zero words, z outside
+        // [0, z_max) has no bit set
+        auto occ_step = [&](int bq, int pk) __attribute__((always_inline)) {
+            const int sz = cz + ((pk >> 14) & 127) - 64;
+            bool hit = false;
+            if ((unsigned int)sz < (unsigned int)a.z_max) hit = (colw[(unsigned int)pk >> 21] >> sz) & 1ull;  // (PACK0 lanes: q >= total)
+            append(bq, hit && bq + lane < total, pk, MSSVT_EMPTY);
+        };
+        // (the preloaded steps run without the early stop: their LDS reads are independent and overlap; the lists are
+        // cut to their capacity below either way)
+#pragma unroll
+        for (int ci = 0; ci < PLAN_PRE; ++ci) occ_step(ci * MSSVT_WAVE, pre[ci]);  // (a step past the tables finds no hit)
+        for (int bq = PLAN_PRE * MSSVT_WAVE; bq < total && !stop; bq += MSSVT_WAVE)
+            occ_step(bq, bq + lane < total ? a.q_packed[bq + lane] : PACK0);
+    } else if (!RANKED) {
+        for (int bq = 0; bq < total && !stop; bq += MSSVT_WAVE) {
+            const int q = bq + lane;
+            int pk = PACK0, sv = MSSVT_EMPTY;
+            if (q < total) {
+                const int seg = (q >= e0) + (q >= e1) + (q >= e2);
+                const int *src = seg == 0 ? a.q_odd + q * 3
+                               : seg == 1 ? a.q_even + (q - e0) * 3
+                               : seg == 2 ? a.q_win1 + (q - e1) * 3
+                                          : a.q_win2 + (q - e2) * 3;
+                const int ox = src[0], oy = src[1], oz = src[2];
+                pk = pack_off(ox, oy, oz);
+                const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
+                if (!(sx >= a.x_max || sx < 0 || sy >= a.y_max || sy < 0 || sz >= a.z_max || sz < 0))
+                    sv = table_find(sx * a.y_max * a.z_max + sy * a.z_max + sz, a.hash_size, tab);
+            }
+            append(bq, sv != MSSVT_EMPTY, pk, sv);
+        }
     }
+    if (cnt_odd < 0) cnt_odd = cnt_all;
+    if (cnt_le1 < 0) cnt_le1 = cnt_all;
+    if (cnt_le2 < 0) cnt_le2 = cnt_all;
     wave_lds_sync();
     const int nO = min(cnt_odd, a.max_odd), nE = min(cnt_le1 - cnt_odd, a.max_even), n1 = min(cnt_le2, a.max_win1),
               n2 = min(cnt_all, a.max_win2);
-    if (use_occ) {
-        // voxel index of every hit some list holds
+    {
+        // voxel index of every hit some list holds (with columns), resolved metadata of those the odd / even / win1
+        // lists and the win1 keys hold
+        const int mneed = a.kmeta1 ? min(max(n1, max(nO, cnt_odd + nE)), a.meta_cap) : 0;
         const int hmax = max(max(n1, n2), max(nO, cnt_odd + nE));
         for (int e = lane; e < hmax; e += MSSVT_WAVE) {
+            const int pk = hpk[e];
             int ox, oy, oz;
-            fps_unpack(hpk[e], ox, oy, oz);
-            const int sz = cz + oz;
+            fps_unpack(pk, ox, oy, oz);
             int sv;
-            if (ranked) {
-                const int c = (ox - a.fx0) * a.fny + (oy - a.fy0);
-                sv = cbase[c] + __popcll(colw[c] & ((1ull << sz) - 1ull));
+            if (RANKED) {
+                const int c = (unsigned int)pk >> 21;
+                sv = cbase[c] + __popcll(colw[c] & ((1ull << (cz + oz)) - 1ull));
+                hsv[e] = sv;
+            } else if (!use_occ) {
+                sv = hsv[e];
             } else {
-                sv = a.table ? table_find((cx + ox) * a.y_max * a.z_max + (cy + oy) * a.z_max + sz, a.hash_size, tab) : MSSVT_EMPTY;
-                // an occupied cell the table does not know: only after a voxel-table overflow (status bit set, the
-                // caller raises at the end of the frame).  Until then every index downstream must stay in range and
-                // the counts must match the entries: the entry is redirected to the sample's first voxel.
-                if (sv == MSSVT_EMPTY) sv = 0;
+                const int sz = cz + oz;
+                {
+                    sv = a.table ? table_find((cx + ox) * a.y_max * a.z_max + (cy + oy) * a.z_max + sz, a.hash_size, tab) : MSSVT_EMPTY;
+                    // an occupied cell the table does not know: only after a voxel-table overflow (status bit set, the
+                    // caller raises at the end of the frame).  Until then every index downstream must stay in range and
+                    // the counts must match the entries: the entry is redirected to the sample's first voxel.
+                    if (sv == MSSVT_EMPTY) sv = 0;
+                }
+                hsv[e] = sv;
             }
-            hsv[e] = sv;
+            if (e < mneed)
+                hmeta[e] = make_float4(plan_centre(cx + ox, a.vsx, a.minx) - wcx, plan_centre(cy + oy, a.vsy, a.miny) - wcy,
+                                       plan_centre(cz + oz, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart + sv));
         }
         wave_lds_sync();
+        // every load is back before the first store goes out -- and the compiler knows it: a load it believes pending
+        // on some path (the probe loop, a table step beyond the preloaded ones) would otherwise cost a vmcnt(0) after stores
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     PSTAMP()
-    plan_emit_list(a, w, lane, a.max_odd, nO, 0, hpk, hsv, a.ind_odd, a.qmeta_odd, a.owner_odd, vstart, cx, cy, cz, wcx, wcy, wcz);
-    plan_emit_list(a, w, lane, a.max_even, nE, cnt_odd, hpk, hsv, a.ind_even, a.qmeta_even, a.owner_even, vstart, cx, cy, cz, wcx,
-                   wcy, wcz);
-    plan_emit_list(a, w, lane, a.max_win1, n1, 0, hpk, hsv, a.ind_win1, a.qmeta_win1, a.owner_win1, vstart, cx, cy, cz, wcx, wcy,
-                   wcz);
-    if (a.kmeta1 && lane == 0) {
-        a.nq_valid[w] = nO;
-        a.nq_valid[a.win_capacity + w] = nE;
-        a.nq_valid[2 * a.win_capacity + w] = n1;
+#if defined(PLAN_ABLATE) && PLAN_ABLATE == 3  // timing-only build: stop after K3 + indices
+    if (hsv[lane] == 0x12345678) a.win_vstart[w] = 1;
+    return;
+#endif
+    plan_emit_list(w, lane, a.max_odd, nO, 0, hsv, hmeta, a.ind_odd, a.kmeta1 ? a.qmeta_odd : nullptr, a.owner_odd, vstart);
+    plan_emit_list(w, lane, a.max_even, nE, cnt_odd, hsv, hmeta, a.ind_even, a.kmeta1 ? a.qmeta_even : nullptr, a.owner_even, vstart);
+    plan_emit_list(w, lane, a.max_win1, n1, 0, hsv, hmeta, a.ind_win1, a.kmeta1 ? a.qmeta_win1 : nullptr, a.owner_win1, vstart);
+    if (lane == 0) {
+        a.win_vstart[w] = vstart;
+        if (a.kmeta1) {
+            a.wcentre[w] = make_float4(wcx, wcy, wcz, 0.f);
+            a.nq_valid[w] = nO;
+            a.nq_valid[a.win_capacity + w] = nE;
+            a.nq_valid[2 * a.win_capacity + w] = n1;
+        }
     }
+
     PSTAMP()
     // ---- K7 + K8 + masks for both scales (ref mssvt_backbone.py:247-258) -----------
     const float4 none = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
@@ -424,9 +497,22 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
         const int n = scale ? a.max_win2 : a.max_win1;
         const int bs = scale ? a.bs2 : a.bs1;
         const int nv = scale ? n2 : n1;
-        if (nv <= MSSVT_WAVE && nv <= bs && bs >= 2)
-            fps_on_list_fast(lane < nv ? hpk[lane] : PACK0, n, nv, K, bs, fps_out, lane);
-        else if (bs <= 64)
+#if defined(PLAN_ABLATE) && PLAN_ABLATE == 1  // timing-only build: no sampling
+        if (lane < K) fps_out[lane] = 0;
+        if (false) {
+#else
+        if (nv <= MSSVT_WAVE && nv <= bs && bs >= 2) {
+#endif
+            const int pk0 = lane < nv ? hpk[lane] : PACK0;
+            if (K > MSSVT_WAVE)
+                fps_on_list_fast<false, 4>(pk0, n, nv, K, bs, fps_out, lane);
+            else if (nv <= 16)
+                fps_on_list_fast<true, 1>(pk0, n, nv, K, bs, fps_out, lane);
+            else if (nv <= 32)
+                fps_on_list_fast<true, 2>(pk0, n, nv, K, bs, fps_out, lane);
+            else
+                fps_on_list_fast<true, 4>(pk0, n, nv, K, bs, fps_out, lane);
+        } else if (bs <= 64)
             fps_on_list_regs<1>(hpk, nv, n, K, bs, fps_out, lane);
         else if (bs == 128)
             fps_on_list_regs<2>(hpk, nv, n, K, bs, fps_out, lane);
@@ -452,22 +538,25 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE) k_window_plan(PlanAr
             if (a.kmeta1) {
                 float4 m = none;
                 if (!masked) {
-                    float px, py, pz;
-                    if (entry) {  // a list entry: its voxel is the window centre cell + offset
-                        int ox, oy, oz;
-                        fps_unpack(hpk[f], ox, oy, oz);
-                        px = plan_centre(cx + ox, a.vsx, a.minx);
-                        py = plan_centre(cy + oy, a.vsy, a.miny);
-                        pz = plan_centre(cz + oz, a.vsz, a.minz);
-                    } else {  // the reference quirk: an empty slot became voxel 0 of the sample
-                        const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + kid];
-                        px = plan_centre(vi.w, a.vsx, a.minx);
-                        py = plan_centre(vi.z, a.vsy, a.miny);
-                        pz = plan_centre(vi.y, a.vsz, a.minz);
+                    if (entry && f < a.meta_cap && scale == 0) {
+                        m = hmeta[f];  // (the win1 keys are win1 list entries: resolved above)
+                    } else {
+                        if (entry) {  // a list entry: its voxel is the window centre cell + offset
+                            int ox, oy, oz;
+                            fps_unpack(hpk[f], ox, oy, oz);
+                            const float px = plan_centre(cx + ox, a.vsx, a.minx), py = plan_centre(cy + oy, a.vsy, a.miny),
+                                        pz = plan_centre(cz + oz, a.vsz, a.minz);
+                            m = make_float4(px - wcx, py - wcy, pz - wcz, __builtin_bit_cast(float, vstart + kid));
+                        } else {  // the reference quirk: an empty slot became voxel 0 of the sample (kid == 0)
+                            m = m0;
+                        }
                     }
-                    m = make_float4(px - wcx, py - wcy, pz - wcz, __builtin_bit_cast(float, vstart + kid));
                 }
+#if !(defined(PLAN_ABLATE) && PLAN_ABLATE == 6)  // (timing-only build 6: no key metadata stores)
                 (scale ? a.kmeta2 : a.kmeta1)[(size_t)w * K + j] = m;
+#else
+                if (m.x == 123.f) a.win_vstart[w] = 1;
+#endif
             }
         }
         wave_lds_sync();
@@ -498,7 +587,7 @@ extern "C" int mssvt_window_plan_two(
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
     float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
     const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
-    void *stream) {
+    const int *win_counts_dev, void *stream) {
     if (!win_indices || !num_wins_dev || !v_bs_cnt || !ind_odd || !ind_even ||
         !ind_win1 || !k_ind1 || !k_ind2 || !k_mask1 || !k_mask2 || !win_vstart || !owner_win1 ||
         !owner_odd || !owner_even || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
@@ -537,9 +626,8 @@ extern "C" int mssvt_window_plan_two(
     a.win_capacity = win_capacity;
     a.indices = indices;
     if (kmeta1) {
-        if (!qmeta_odd || !qmeta_even || !qmeta_win1 || !kmeta2 || !wcentre || !nq_valid || !indices || !host_voxel_size3 ||
-            !host_range_min3 || !host_win_size3)
-            return MSSVT_E_BADARG;
+        if (!kmeta2 || !wcentre || !nq_valid || !indices || !host_voxel_size3 || !host_range_min3 || !host_win_size3)
+            return MSSVT_E_BADARG;  // (qmeta_odd / _even / _win1: each optional)
         a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
         a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
         a.wsx = host_win_size3[0]; a.wsy = host_win_size3[1]; a.wsz = host_win_size3[2];
@@ -549,16 +637,25 @@ extern "C" int mssvt_window_plan_two(
     const int bsmax = a.bs1 > a.bs2 ? a.bs1 : a.bs2;
     const int total = num_odd + num_even + num_win1 + num_win2;
     a.hit_cap = (total + 1) & ~1;
-    a.lds_words_per_wave = 2 * a.hit_cap + ((key_num_sample + 1) & ~1);
+    a.meta_cap = 0;
+    if (kmeta1) {
+        a.meta_cap = max_num_win1 > num_odd + max_num_even ? max_num_win1 : num_odd + max_num_even;
+        if (a.meta_cap > a.hit_cap) a.meta_cap = a.hit_cap;
+    }
+    a.lds_words_per_wave = 4 * a.meta_cap + 2 * a.hit_cap + ((key_num_sample + 1) & ~1);
     a.occ = nullptr;
     a.col_vbase = a.level_status = nullptr;
-    a.fx0 = a.fy0 = a.fnx = a.fny = 0;
+    a.win_counts = win_counts_dev;
+    a.fx0 = a.fy0 = a.fnx = a.fny = a.fny_magic = 0;
     a.q_packed = packed_offsets;
     if (occ_columns && host_footprint4 && packed_offsets && z_max <= 64 && host_footprint4[2] > 0 &&
         host_footprint4[3] > 0 && host_footprint4[2] * host_footprint4[3] <= 1024) {
         a.occ = occ_columns;
         a.fx0 = host_footprint4[0]; a.fy0 = host_footprint4[1];
         a.fnx = host_footprint4[2]; a.fny = host_footprint4[3];
+        a.fny_magic = (1 << 20) / a.fny + 1;
+        for (int c = 0; c < a.fnx * a.fny; ++c)
+            if ((int)(((unsigned int)c * (unsigned int)a.fny_magic) >> 20) != c / a.fny) return MSSVT_E_TOOLARGE;  // (never: c < 1024)
         a.col_vbase = column_vbase;
         a.level_status = level_status_dev;
         // + the column words (8 bytes each) and the column bases
@@ -585,21 +682,17 @@ extern "C" int mssvt_window_plan_two(
     if (lds_bytes > 160 * 1024) return MSSVT_E_TOOLARGE;
     // lists of 512 .. 1023 / 1024 .. 2047 slots: the instantiations with the 8- / 16-slot register samplers
     const int tpl = bsmax > 512 ? 16 : bsmax > 256 ? 8 : 4;
-    const void *kernel = tpl == 16  ? reinterpret_cast<const void *>(k_window_plan<16>)
-                         : tpl == 8 ? reinterpret_cast<const void *>(k_window_plan<8>)
-                                    : reinterpret_cast<const void *>(k_window_plan<4>);
+    const bool ranked = a.col_vbase != nullptr;
+    typedef void (*plan_kernel_t)(PlanArgs);
+    const plan_kernel_t kernel = ranked ? (tpl == 16 ? k_window_plan<16, true> : tpl == 8 ? k_window_plan<8, true> : k_window_plan<4, true>)
+                                        : (tpl == 16 ? k_window_plan<16, false> : tpl == 8 ? k_window_plan<8, false> : k_window_plan<4, false>);
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
     const dim3 grid(divup(win_capacity, wpb)), block(wpb * MSSVT_WAVE);
     hipStream_t st = (hipStream_t)stream;
-    if (tpl == 16)
-        k_window_plan<16><<<grid, block, lds_bytes, st>>>(a);
-    else if (tpl == 8)
-        k_window_plan<8><<<grid, block, lds_bytes, st>>>(a);
-    else
-        k_window_plan<4><<<grid, block, lds_bytes, st>>>(a);
+    kernel<<<grid, block, lds_bytes, st>>>(a);
     return mssvt_launch_status();
 }
 

@@ -275,17 +275,25 @@ def _table_footprint(block, t):
         lo, hi = allt.min(0).values, allt.max(0).values
         arr = (ctypes.c_int * 4)(int(lo[0]), int(lo[1]), int(hi[0] - lo[0] + 1), int(hi[1] - lo[1] + 1))
         a64 = allt.to(torch.int64) + 64
-        packed = (a64[:, 0] | (a64[:, 1] << 8) | (a64[:, 2] << 16)).to(torch.int32).to(t['win2'].device)
-        fp = block._footprint_cache = (t['win2'], arr, packed)
+        # one word per offset: (x+64) | (y+64)<<7 | (z+64)<<14 | column<<21, column = the offset's (x, y) cell of the footprint
+        col = (allt[:, 0].to(torch.int64) - int(lo[0])) * int(hi[1] - lo[1] + 1) + (allt[:, 1].to(torch.int64) - int(lo[1]))
+        fits = int(arr[2]) * int(arr[3]) <= 1024 and int(a64.max()) < 128 and int(a64.min()) >= 0
+        packed = (a64[:, 0] | (a64[:, 1] << 7) | (a64[:, 2] << 14) | ((col if fits else col * 0) << 21)).to(torch.int32)
+        fp = block._footprint_cache = (t['win2'], arr, packed.to(t['win2'].device))
     return fp[1], fp[2]
 
 
 @torch.no_grad()
-def two_scale_plan(block, sp):
+def two_scale_plan(block, sp, all_lists=False):
     st = level_state(sp, [block] + ([sp._next_compress] if getattr(sp, "_next_compress", None) is not None else []))
     key = block.plan_key()
     if key in st["plans"]:
-        return st["plans"][key]
+        p = st["plans"][key]
+        if _qmeta(block, p) is not None:
+            return p
+        # a Block with a query pattern the plan was not built for (Blocks called one by one): once more, every list
+        del st["plans"][key]
+        return two_scale_plan(block, sp, all_lists=True)
     dev = sp.indices.device
     N = sp.indices.shape[0]
     B, H = sp.batch_size, sp.hash_size
@@ -307,7 +315,14 @@ def two_scale_plan(block, sp):
     p.win_vstart = torch.empty(cap, dtype=torch.int32, device=dev)
     p.qbuf = None
     f4 = lambda n: torch.empty((cap, n, 4), dtype=torch.float32, device=dev)  # noqa: E731
-    p.qmeta_odd, p.qmeta_even, p.qmeta_win1 = f4(n_o), f4(n_e), f4(n1)
+    # resolved metadata of the query lists: only for the query patterns of the Blocks that share this plan (each list
+    # costs 16 bytes per slot and window; k_query_rows is their one consumer)
+    pats = {block.cbs_pattern} | {b.cbs_pattern for b in (getattr(sp, "_plan_group", None) or ()) if b.plan_key() == key}
+    if all_lists:
+        pats = {0, 1, 2}
+    p.qmeta_odd = f4(n_o) if 1 in pats else None
+    p.qmeta_even = f4(n_e) if 0 in pats else None
+    p.qmeta_win1 = f4(n1) if 2 in pats else None
     p.kmeta = [f4(K), f4(K)]
     p.wcentre = torch.empty((cap, 4), dtype=torch.float32, device=dev)
     p.coord_bound = max(abs(float(v)) for v in sp.point_cloud_range)  # |metric coordinate| of any voxel / window centre
@@ -320,7 +335,8 @@ def two_scale_plan(block, sp):
     occ = occupancy_columns(sp, st)
     if occ is not None and fp4[2] * fp4[3] > 1024:
         occ = None  # footprint beyond the plan kernel's column tile: it probes the hash instead
-    _lib.call("mssvt_window_plan_two", *[_i(int(v)) for v in sp.spatial_shape],
+    p._plan_args = (  # raw pointers / sizes only (tools/time_plan.py launches the kernel alone with them)
+              *[_i(int(v)) for v in sp.spatial_shape],
               *[_i(int(v)) for v in block.win1_size], _i(n_o), _i(n_e), _i(n1), _i(n2), _i(H), _i(B),
               _i(t['odd'].shape[0]), _i(t['even'].shape[0]), _i(t['win1'].shape[0]), _i(t['win2'].shape[0]),
               _P(t['odd']), _P(t['even']), _P(t['win1']), _P(t['win2']), _i(K),
@@ -332,7 +348,8 @@ def two_scale_plan(block, sp):
               _P(p.qmeta_odd), _P(p.qmeta_even), _P(p.qmeta_win1), _P(p.kmeta[0]),
               _P(p.kmeta[1]), _P(p.wcentre), _P(p.nq_valid), _P(occ),
               fp4, _P(packed), _P(st.get("vbase") if occ is not None else None),
-              _P(st.get("level_status") if occ is not None else None), _lib.stream())
+              _P(st.get("level_status") if occ is not None else None), _P(p.k_bs_cnt))
+    _lib.call("mssvt_window_plan_two", *p._plan_args, _lib.stream())
     st["plans"][key] = p
     return p
 
