@@ -40,6 +40,7 @@
 //
 // Windows (B) are processed in the plan's work order (heaviest first), dealt round-robin to the
 // wavefronts of a persistent grid.
+#include <stdlib.h>
 #include "common.hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -373,9 +374,22 @@ __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_o(AttnPack p
 // masked slots score -inf (the reference adds -100: weight <= e^-100); key tiles without an unmasked
 // slot are skipped.  Software pipeline across windows: metadata two windows ahead, the feature rows
 // of the next window in flight under this window's MFMAs.
+#ifdef MSSVT_STAMPS
+// per wave: [0] entry, [1] first rows issued, [2] exit, [3] windows done, [4..9] cycles summed over its windows:
+// token build (waits for the row gathers), prefetch issue, tile -> LDS, scores + softmax (waits for Qt), PV + store, passes
+__device__ unsigned long long g_attn_kv_stamps[8192 * 12];
+extern "C" int mssvt_debug_read_attn_kv_stamps(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_kv_stamps), sizeof(g_attn_kv_stamps));
+}
+#define KVS_T() __builtin_readcyclecounter()
+#else
+#define KVS_T() 0ull
+#endif
 template <int CG, int HD, int HP, int KT>
 __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnPack pack) {
     const AttnArgs &a = pack.g[blockIdx.y];
+    unsigned long long ks_entry = KVS_T(), ks_first = 0, ks_sum[6] = {0, 0, 0, 0, 0, 0}, ks_n = 0, ks_t = 0;
+    (void)ks_entry; (void)ks_first; (void)ks_sum; (void)ks_n; (void)ks_t;
     constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, NH = CG / HD, QROW = HP * CG, QPP = 16 / HP;
     constexpr int LSK = CGP + 4;  // LDS row stride of the key tile
     extern __shared__ float4 lds4[];
@@ -455,7 +469,9 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
     KV_ISSUE_ROWS()
     KV_LOAD_META()
     w_p = a.perm[min(wi + 2 * wstep, w_last)];
+    ks_first = KVS_T();
     for (; wi < n_act; wi += wstep) {
+        ks_t = KVS_T();
         // ---- this window: stage R -> working registers ------------------------------------------------
         const float4 wc = wc_r;
         // a window whose rows would not fit the compact arrays is skipped (cannot happen with the caller's bound)
@@ -476,6 +492,10 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
                 for (int i = 0; i < 4; ++i) T1[t][u][i] = T1n[t][u][i] + fmaxf(p1[i], 0.0f);
             }
         }
+#ifdef MSSVT_STAMPS
+        asm volatile("" :: "v"(T1[0][0][0]));
+        { const unsigned long long t_ = KVS_T(); ks_sum[0] += t_ - ks_t; ks_t = t_; }
+#endif
         // first query pass: its Qt rows travel while the key tile is transposed
         const int hh = la % HP;
         const bool head_ok = hh < NH;
@@ -493,6 +513,9 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
         KV_ISSUE_ROWS()
         KV_LOAD_META()
         w_p = a.perm[min(wi + 3 * wstep, w_last)];
+#ifdef MSSVT_STAMPS
+        { const unsigned long long t_ = KVS_T(); ks_sum[1] += t_ - ks_t; ks_t = t_; }
+#endif
         // key tile -> LDS (the T2 operand is read back column-wise)
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
@@ -503,8 +526,12 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
                     make_float4(T1[t][S][0], T1[t][S][1], T1[t][S][2], T1[t][S][3]);
         }
         wave_lds_sync();
+#ifdef MSSVT_STAMPS
+        { const unsigned long long t_ = KVS_T(); ks_sum[2] += t_ - ks_t; ks_t = t_; }
+#endif
         // queries, QPP per pass: column la = query * HP + head
         for (int q0 = 0; q0 < nqv; q0 += QPP) {
+            ++ks_sum[5];
             const int q = q0 + la / HP;
             const bool q_ok = q < nqv && head_ok;
             if (q0 > 0) {
@@ -557,6 +584,10 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
             sum += lane_xor16(sum);
             sum += lane_xor32(sum);
             const float inv = __builtin_amdgcn_rcpf(sum);  // slot 0 of a list is never masked: sum >= 1
+#ifdef MSSVT_STAMPS
+            asm volatile("" :: "v"(inv));
+            { const unsigned long long t_ = KVS_T(); ks_sum[3] += t_ - ks_t; ks_t = t_; }
+#endif
             // Xbar^T[c][col] = sum_key T[key][c] P[key][col]; A operand = the LDS tile read column-wise
             f32x4 acc[NT];
 #pragma unroll
@@ -583,15 +614,30 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
                         store_handoff(qrow + c, acc[u]);
                 }
             }
+#ifdef MSSVT_STAMPS
+            { const unsigned long long t_ = KVS_T(); ks_sum[4] += t_ - ks_t; ks_t = t_; }
+#endif
         }
         wave_lds_sync();  // the next window rewrites the tile
+        ++ks_n;
     }
+#ifdef MSSVT_STAMPS
+    {
+        const int wid = (blockIdx.y * gridDim.x + blockIdx.x) * ATTN_ROW_WAVES + wv;
+        if (lane == 0 && wid < 8192) {
+            unsigned long long *o = g_attn_kv_stamps + (size_t)wid * 12;
+            o[0] = ks_entry; o[1] = ks_first; o[2] = KVS_T(); o[3] = ks_n;
+            for (int i = 0; i < 6; ++i) o[4 + i] = ks_sum[i];
+        }
+    }
+#endif
 #undef ATTN_Q_ROWS
 #undef ATTN_O_ROWS
 #undef KV_LOAD_META
 #undef KV_ISSUE_ROWS
 #undef KV_ROW4
 }
+
 
 template <int CG, int HD, int HP>
 static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hipStream_t stream) {
@@ -608,8 +654,15 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hip
     const size_t lds_q = ((size_t)2 * CGP * LS + CGP * 8 + CGP) * 4, lds_o = ((size_t)2 * CGP * LS + 2 * CGP) * 4;
     const int K = pack.g[0].K;
     k_attn_q<CG, HD, HP><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
-    // B: persistent over the work order, 8 workgroups of 4 waves per CU at most (VGPR bound)
-    const dim3 kv_grid(cus * 8 / ng > 0 ? cus * 8 / ng : 1, ng);
+    // B: persistent over the work order with exactly the waves that are resident (3 workgroups of 4 waves per CU at the
+    // 164 VGPRs of the K = 32 instantiation): every further workgroup would run in a later round and pay the prologue
+    // (positional weights, three dependent metadata round trips: ~9 k cycles, as much as one window) again for its few
+    // windows -- 8 per CU: 47.0 us mean per launch, 3 per CU: 42.9 us.  Measured and dropped (round 3): one wave per
+    // window without a work list (the ~37 k empty workgroups of a capacity-sized grid cost 5 k cycles each: 92 us), and
+    // the same pipeline squeezed under 128 VGPRs for 4 waves / SIMD (18 spilled registers, 63 us): per window the SIMD
+    // is busy ~3.2 k of the wave's 9.7 k cycles, more than half of it fp32 matrix instructions -- not a latency problem.
+    static const int kv_wgs = getenv("MSSVT_ATTN_KV_WGS") ? atoi(getenv("MSSVT_ATTN_KV_WGS")) : 3;
+    const dim3 kv_grid(cus * kv_wgs / ng > 0 ? cus * kv_wgs / ng : 1, ng);
     const size_t lds_tile = (size_t)ATTN_ROW_WAVES * 16 * LS * 4;  // per key tile of 16 slots, all waves
     if (K <= 16)
         k_attn_kv<CG, HD, HP, 1><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, lds_tile, stream>>>(pack);
