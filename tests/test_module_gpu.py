@@ -254,6 +254,46 @@ def test_full_size_frame_matches_the_oracle(impl):
     assert_feat_close(sp.features.cpu().numpy(), want.features)
 
 
+def _oracle_pin(cfg, points, B, seed0, feat_seed, min_rows):
+    """One full-size frame through the CPU oracle's whole forward and through the fused HIP path: output voxel
+    indices bit-exact, features within assert_feat_close."""
+    from mssvt_amd import config
+    from oracle import cref
+    pts = synthetic.make_batch_points(points, B, seed0=seed0)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(feat_seed))
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg(cfg).eval()
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    cref.set_num_threads(0)
+    want = block_ref.backbone_forward(sd, [dict(p) for p in cfg.MODEL.BACKBONE_3D.PARAMS], feats.numpy(), vc, B,
+                                      synthetic.GRID_SIZE, synthetic.VOXEL_SIZE, synthetic.POINT_CLOUD_RANGE, net.hash_size)
+    net = net.to(DEV).set_impl("fused")
+    with torch.no_grad():
+        sp = net(dict(voxel_features=feats.to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV), batch_size=B))[
+            "encoded_spconv_tensor"]
+    assert want.features.shape[0] > min_rows
+    np.testing.assert_array_equal(sp.indices.cpu().numpy(), want.indices)
+    assert_feat_close(sp.features.cpu().numpy(), want.features)
+
+
+def test_batch_of_four_full_size_matches_the_oracle():
+    """BASELINE configs[3] (the per-GPU shape of the 8-GPU run: 4 scenes x 160k points, mssvt.yaml) pinned to the
+    oracle at full size -- not only to the operator path (test_full_size_frame_fused_matches_operator_path[4])."""
+    from mssvt_amd import config
+    _oracle_pin(config.load_yaml(config.DEFAULT_CFG), 160000, 4, 50, 1004, 100000)
+
+
+def test_dense_scene_enlarged_windows_matches_the_oracle():
+    """BASELINE configs[4] pinned to the oracle at full size: 300k points, windows [5,5,7] / [11,11,11], every win1 voxel
+    a query (cfgs/mssvt_enlarged.yaml): lists of up to 1331 slots, the register samplers beyond 64 entries, K3 over 21
+    column steps -- so far pinned by one 2 306-voxel golden (block_enlarged_stride1.npz) and against the operator path."""
+    import os
+    from mssvt_amd import config
+    cfg = config.load_yaml(os.path.join(os.path.dirname(config.__file__), "cfgs", "mssvt_enlarged.yaml"))
+    _oracle_pin(cfg, 300000, 1, 3, 11, 40000)
+
+
 def test_scene_sharding_invariance_at_full_size():
     """What the multi-GPU sharding relies on: a scene's output does not depend on which other scenes
     share its batch.  Four 160k-point scenes in one batch == the same scenes one by one (rank-by-rank), bit for bit."""
