@@ -62,15 +62,14 @@ def parse(argv=None):
 def spawn_ranks(args):
     """--gpus N without a torchrun environment: start the N ranks as children (nothing in this process
     has touched the GPU yet, and nothing will), relay their stdout / stderr, return their exit status."""
-    import socket
-    port = args.master_port
-    if not port:
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # a port of our own choosing could be taken between the probe and torchrun's bind: unless one is given, torchrun's
+    # c10d rendezvous picks a free one itself (--rdzv-endpoint ...:0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus)]
+    if args.master_port:
+        cmd += ["--master-addr", "127.0.0.1", "--master-port", str(args.master_port)]
+    else:
+        cmd += ["--rdzv-backend", "c10d", "--rdzv-endpoint", "127.0.0.1:0", "--local-addr", "127.0.0.1"]
+    cmd += [os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
@@ -220,7 +219,11 @@ def main():
         sys.exit(spawn_ranks(args))  # before any GPU call of this process
     from mssvt_amd import dist as mdist
     rank, world, local_rank = mdist.env_rank_world()
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if "WORLD_SIZE" in os.environ and world != args.gpus:
+        # under a launcher (torchrun ... bench.py without --gpus) the environment is authoritative
+        if args.gpus != 1:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d: following the launcher" % (args.gpus, world), file=sys.stderr)
+        args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the hot path has no CPU fallback)"
     # MSSVT_BENCH_ONE_DEVICE=1 (debugging the N > 1 code path on a single-GPU box): every rank on cuda:0, gloo
     one_dev = os.environ.get("MSSVT_BENCH_ONE_DEVICE", "0") == "1"

@@ -132,7 +132,16 @@ class CenterPoint(nn.Module):
     def load_params_from_file(self, filename, logger=None, to_cpu=False):
         if not os.path.isfile(filename):
             raise FileNotFoundError(filename)
-        ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None, weights_only=False)
+        loc = torch.device("cpu") if to_cpu else None
+        try:
+            # tensors / plain containers only: loading a checkpoint cannot run code
+            ckpt = torch.load(filename, map_location=loc, weights_only=True)
+        except Exception as err:  # noqa: BLE001  (pickled objects beyond tensors: OpenPCDet stores e.g. numpy scalars)
+            if os.environ.get("MSSVT_TRUST_CHECKPOINTS", "0") != "1":
+                raise RuntimeError(
+                    "%s holds pickled objects beyond tensors (%s); unpickling them can execute arbitrary code. Set "
+                    "MSSVT_TRUST_CHECKPOINTS=1 to load a checkpoint you trust." % (filename, type(err).__name__)) from err
+            ckpt = torch.load(filename, map_location=loc, weights_only=False)
         state, update = self._load_state_dict(ckpt["model_state"], strict=False)
         missed = [k for k in state if k not in update]
         if logger is not None:

@@ -55,12 +55,16 @@ __device__ __forceinline__ bool inside(const Box7 &b, P2 p) {
 }
 
 __device__ __forceinline__ void corners_of(const Box7 &b, P2 (&c)[5]) {
+    // the reference's arithmetic, rounding for rounding (iou3d_nms_kernel.cu:109-111,125-128: axis-aligned corners
+    // x -+ dx/2 FIRST; :94-98 rotate_around_center subtracts the centre again) -- for large |x| the corners differ in the
+    // last bits from (-+ dx/2) rotated directly, enough to flip a pair whose IoU sits at the threshold
     const float hx = b.dx / 2, hy = b.dy / 2, cs = cosf(b.r), sn = sinf(b.r);
-    const float ox[4] = {-hx, hx, hx, -hx}, oy[4] = {-hy, -hy, hy, hy};
+    const float x1 = b.x - hx, x2 = b.x + hx, y1 = b.y - hy, y2 = b.y + hy;
+    const float px[4] = {x1, x2, x2, x1}, py[4] = {y1, y1, y2, y2};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        c[k].x = ox[k] * cs + oy[k] * (-sn) + b.x;
-        c[k].y = ox[k] * sn + oy[k] * cs + b.y;
+        c[k].x = (px[k] - b.x) * cs + (py[k] - b.y) * (-sn) + b.x;
+        c[k].y = (px[k] - b.x) * sn + (py[k] - b.y) * cs + b.y;
     }
     c[4] = c[0];
 }

@@ -493,7 +493,7 @@ def _attn_f16_ok(block, r, p):
     O <= the V' bound.  Once per parameter version (one small host sync)."""
     ts = [block.norm1.weight, block.norm1.bias, r["Wp"], r["bp"]] + list(r["Wq"]) + list(r["bq"]) + list(r["Wkv"]) + \
         list(r["bkv"]) + list(r["Wo"])
-    ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + (float(p.coord_bound),)
+    ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + (float(p.coord_bound),) + _content_key(ts)
     if r.get("f16_ver") != ver:
         g1, b1, Wp, bp = [t.detach().float() for t in ts[:4]]
         C = g1.numel()
@@ -551,13 +551,24 @@ def _ffn_refs(block):
     return r
 
 
+VERIFY_WEIGHTS = os.environ.get("MSSVT_VERIFY_WEIGHTS", "0") == "1"
+
+
+def _content_key(ts):
+    """Debug mode (MSSVT_VERIFY_WEIGHTS=1): a checksum of the parameter CONTENTS joins the cache keys, so that even a write
+    through `.data` (which leaves `_version` alone) is noticed -- at one host sync per call."""
+    if not VERIFY_WEIGHTS:
+        return ()
+    return tuple(float(t.detach().double().sum().item()) + float(t.detach().double().abs().sum().item()) * 1e-3 for t in ts)
+
+
 @torch.no_grad()
 def _ffn_f16_weights(fr):
     """The split-fp16 fragments of W1 / W2 (mssvt_ffn_pack_weights) when the operands of the split-fp16 FFN stay inside
     the fp16 range whatever the input rows are, else None: a LayerNorm output is bounded by sqrt(C) max|w| + max|b|, a
     hidden activation by max_h(|W1_h|_1 xmax + |b1_h|).  Evaluated once per parameter version (one small host sync)."""
     ts = (fr["W1"], fr["b1"], fr["W2"], fr["b2"], fr["lnw"], fr["lnb"])
-    ver = tuple(t._version for t in ts) + (fr["W1"].data_ptr(), fr["W2"].data_ptr())
+    ver = tuple(t._version for t in ts) + (fr["W1"].data_ptr(), fr["W2"].data_ptr()) + _content_key(ts)
     if fr.get("f16_ver") != ver:
         W1, b1, W2, b2, lnw, lnb = [t.detach().float() for t in ts]
         xmax = (fr["C"] ** 0.5) * lnw.abs().max() + lnb.abs().max()
@@ -1014,7 +1025,8 @@ def _compress_f16_ok(block, sp):
     ma = block.ms_attn
     ts = (block.norm1.weight, block.norm1.bias, block.pos_proj[0].weight, block.pos_proj[0].bias, block.pos_proj[2].weight,
           block.pos_proj[2].bias, ma.to_qs[0].weight, ma.to_kvs[0].weight, ma.to_kvs[0].bias, ma.projs[0].weight)
-    ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + (tuple(float(v) for v in sp.point_cloud_range),)
+    ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + (tuple(float(v) for v in sp.point_cloud_range),) + \
+        _content_key(ts)
     cache = block.__dict__.setdefault("_cmp_f16_cache", {})
     if cache.get("ver") != ver:
         g1, b1, Wp1, bp1, Wp2, bp2, Wq, Wkv, bkv, Wo = [t.detach().float() for t in ts]

@@ -20,10 +20,31 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
     n = int(order.shape[0])
     if n == 0:
         return order, None
+    if n > NMS_MAX_BOXES:
+        # beyond one launch's capacity (the reference takes any N): score-ordered chunks, the boxes kept so far put in
+        # front of the next chunk -- they outrank it and do not suppress each other, so greedy NMS keeps them and
+        # applies them to the chunk: the same result as one pass
+        kept = order[:0]
+        for lo in range(0, n, NMS_MAX_BOXES // 2):
+            chunk = order[lo:lo + NMS_MAX_BOXES // 2]
+            if kept.numel() + chunk.numel() > NMS_MAX_BOXES:
+                raise _lib.MssvtHipError("nms_gpu: more than %d boxes survive" % (NMS_MAX_BOXES // 2))
+            cand = torch.cat([kept, chunk])
+            kept = cand[_nms_sorted(boxes[cand].float().contiguous(), thresh)]
+        return kept.contiguous(), None
     b = boxes[order].float().contiguous()
+    return order[_nms_sorted(b, thresh)].contiguous(), None
+
+
+NMS_MAX_BOXES = 16384  # csrc/nms_bev.hip: one launch
+
+
+def _nms_sorted(b, thresh):
+    """Indices (into `b`, best first) that greedy rotated NMS keeps among boxes already sorted by descending score."""
+    n = int(b.shape[0])
     ws = torch.empty(int(_lib.lib().mssvt_nms_workspace_bytes(_i(n))) // 8 + 1, dtype=torch.int64, device=b.device)
     keep = torch.empty(n, dtype=torch.int32, device=b.device)
     cnt = torch.empty(1, dtype=torch.int32, device=b.device)
     _lib.call("mssvt_nms_bev", _i(n), _lib.ptr(b), ctypes.c_float(float(thresh)), _lib.ptr(ws), _lib.ptr(keep),
               _lib.ptr(cnt), _lib.stream())
-    return order[keep[:int(cnt.item())].long()].contiguous(), None
+    return keep[:int(cnt.item())].long()

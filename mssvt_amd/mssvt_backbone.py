@@ -127,6 +127,29 @@ class MixedScaleSparseTransformerBlock(nn.Module):
         tabs, n_odd, n_even = query_table.vox_query_table(win1_size, win2_size, cbs_mode or 'odd_even')
         return {k: torch.from_numpy(v) for k, v in tabs.items()}, n_odd, n_even
 
+    # -- derived-weight caches of the fused path ---------------------------------------------------------------
+    # The fused kernels keep, per parameter VERSION, the split-fp16 fragments of linear1 / linear2 and the fp16 range
+    # verdicts of the attention / CompressBlock weights (mssvt_amd/fused.py: _ffn_f16_weights, _attn_f16_ok,
+    # _compress_f16_ok), keyed on `tensor._version` + `data_ptr()`.  Every update that goes through autograd-visible
+    # in-place ops, `load_state_dict`, `.to()` / `.half()` / `.cuda()` is seen (the last three through the hooks below).
+    # An in-place write through `.data` (`p.data.copy_(ema)`, weight clipping, hand-written optimizers) is NOT: it does
+    # not bump the version counter.  Call `refresh_weights()` after such an update (MixedScaleSparseTransformer has the
+    # same method for all its blocks), or set MSSVT_VERIFY_WEIGHTS=1 to have every forward compare a checksum (one
+    # host sync per block: debugging only).
+    def refresh_weights(self):
+        for k in ("_ffn_ref_cache", "_attn_ref_cache", "_cmp_f16_cache"):
+            self.__dict__.pop(k, None)
+        return self
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.refresh_weights()
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.refresh_weights()
+
     def set_vox_query_table(self, tables):
         """Install explicit offset tables (dict of (n,3) int tensors/arrays), e.g. tables
         exported from a reference run whose tie order differs."""
@@ -395,6 +418,13 @@ class MixedScaleSparseTransformer(nn.Module):
                 rows.append((blk, nxt_norm, group, nxt_cmp))
             sched = self._sched = (len(blocks), rows)
         return sched[1]
+
+    def refresh_weights(self):
+        """Drop the derived-weight caches of every block (see MixedScaleSparseTransformerBlock.refresh_weights): needed
+        after parameters were overwritten through `.data`."""
+        for blk in self.backbone:
+            blk.refresh_weights()
+        return self
 
     def set_impl(self, impl):
         assert impl in ("fused", "ops")

@@ -98,6 +98,8 @@ class Segments(object):
                 g._cut(longest)
 
     def sum(self, src):
+        if self.idx is None or self.idx.numel() == 0:  # an empty index set: nothing to add (the C entry rejects a NULL idx)
+            return torch.zeros((self.n_dst,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         if self.pending is not None:
             self._cut(int(self.pending.item()))
         dst = _ranges_sum(src, self.start, self.end, self.idx, self.w, self.n_dst)
@@ -343,7 +345,13 @@ def block_supported(block, sp):
     return (sp.features.is_cuda and sp.features.dtype == torch.float32 and block.win2_size is not None
             and len(ma.num_heads) == 2 and sp.features.shape[1] % 4 == 0 and all(d % 4 == 0 for d in ma.scale_dims)
             and max(block.max_num_win1, block.max_num_win2) < 2048 and max(block.win2_size) <= 120
-            and max(block.win1_size) <= 60)
+            and max(block.win1_size) <= 60 and _pair_attention_covers(ma))
+
+
+def _pair_attention_covers(ma):
+    """Shapes csrc/pair_attn.hip is instantiated for: <= 128 channels per head group, head dimension 4 .. 64 (a power of
+    two); anything else trains through the operator path instead of failing inside mssvt_pair_attention_fwd."""
+    return max(ma.scale_dims) <= 128 and ma.per_head_dim in (4, 8, 16, 32, 64)
 
 
 @torch.no_grad()
@@ -467,7 +475,7 @@ def block_forward(block, sp):
 def compress_supported(block, sp):
     ma = block.ms_attn
     return (sp.features.is_cuda and sp.features.dtype == torch.float32 and ma.num_head_groups == 1
-            and sp.features.shape[1] % 4 == 0 and len(block.pos_proj) >= 3)
+            and sp.features.shape[1] % 4 == 0 and len(block.pos_proj) >= 3 and _pair_attention_covers(ma))
 
 
 @torch.no_grad()

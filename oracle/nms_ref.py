@@ -49,9 +49,13 @@ def _in_box(box, p):  # :50-61
 def _corners(box):  # :114-150
     hx, hy = box[3] / F(2), box[4] / F(2)
     c, s = F(math.cos(float(box[6]))), F(math.sin(float(box[6])))
+    # :109-111 axis-aligned corners first, :94-98 rotate_around_center subtracts the centre again (fp32 each step)
+    x1, x2, y1, y2 = F(box[0] - hx), F(box[0] + hx), F(box[1] - hy), F(box[1] + hy)
     out = []
-    for dx, dy in ((-hx, -hy), (hx, -hy), (hx, hy), (-hx, hy)):
-        out.append((F(dx * c + dy * (-s) + box[0]), F(dx * s + dy * c + box[1])))
+    for px, py in ((x1, y1), (x2, y1), (x2, y2), (x1, y2)):
+        out.append((F(F(F(px - box[0]) * c) + F(F(py - box[1]) * (-s))) + box[0],
+                    F(F(F(px - box[0]) * s) + F(F(py - box[1]) * c)) + box[1]))
+    out = [(F(a), F(b)) for a, b in out]
     return out + [out[0]]
 
 

@@ -382,3 +382,34 @@ def test_split_fp16_range_guard_keeps_the_fp32_kernels_for_large_parameters():
     with torch.no_grad():
         blk.linear1.weight.mul_(1.0 / 20000.0)
     assert fused._ffn_f16_weights(fused._ffn_refs(blk)) is not None
+
+
+def test_weight_caches_follow_state_dict_loads_and_refresh():
+    """The split-fp16 weight fragments are cached per parameter version.  load_state_dict / .to() drop them through the
+    module hooks; a write through `.data` (no version bump) needs refresh_weights() -- after which the FFN tail matches
+    torch on the new weights."""
+    from mssvt_amd import config, fused
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval()
+    blk = net.backbone[0]
+    x = torch.randn(2000, 128, device=DEV)
+
+    class SP(object):
+        _next_norm1 = None
+
+    def check():
+        with torch.no_grad():
+            y = fused._ffn_tail(blk, SP(), x)
+            want = x + blk.linear2(torch.relu(blk.linear1(blk.norm2(x))))
+        assert float((y - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+    check()
+    assert "_ffn_ref_cache" in blk.__dict__
+    sd = {k: v.clone() * 1.5 if k.endswith("linear1.weight") else v.clone() for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)                       # copies in place: same storage, and the hook drops the cache
+    assert "_ffn_ref_cache" not in blk.__dict__
+    check()
+    blk.linear2.weight.data.mul_(0.5)             # invisible to the version counter
+    net.refresh_weights()
+    assert "_ffn_ref_cache" not in blk.__dict__
+    check()
