@@ -312,7 +312,7 @@ int mssvt_block_attention_bf16(
     const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
     const float *const *host_bo, const float *Wpos, const float *bpos, float *attn, void *stream);
 
-/* The same single launch with fp32-accurate products: every MFMA operand split exactly into two fp16 halves
+/* The same single launch with fp32-accurate products: every MFMA operand split into two fp16 halves (hi + 2^-11 lo: 22 of 24 mantissa bits)
  * (hi + 2^-11 lo; 3 x v_mfma_f32_16x16x32_f16 per product sum, fp32 accumulation: the fp32 matrix instruction's error
  * against float64 at 3/16 of its cycles), keys projected in the kernel, no hand-off through HBM.  Arguments of
  * mssvt_block_attention minus qbuf.  The CALLER guarantees the fp16 range of tokens, Q' (scaled), K', V'
@@ -391,7 +391,7 @@ int mssvt_compress_attention_group(int C, int c0, int Cg, int head_dim, float sc
  * k_ind / win_vstart / win_cnt / pair_win: from mssvt_window_plan_one with disjoint_lists = 1,
  * with_pad = 0.  Wpos1 (C,6), Wpos2 (C,C), Wq (C,C), Wkv (2C,C), Wo (C,C) + biases: the module's
  * parameters.  Scratch: qp (win_capacity,C), ktok (N,C), score (N,C/head_dim), vp (N,C).
- * split_f16 != 0: the C x C products with every fp32 operand split exactly into two fp16 halves
+ * split_f16 != 0: the C x C products with every fp32 operand split into two fp16 halves (22 of 24 mantissa bits)
  * (3 x v_mfma_f32_16x16x32_f16, fp32 accumulation: the fp32 instruction's error at 3/16 of its
  * cycles); the CALLER guarantees the fp16 range of xhat, the positional hidden layer, the key
  * tokens and the V rows (mssvt_amd/fused.py bounds them from the parameters), else pass 0.
@@ -431,7 +431,7 @@ int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, c
  * x parked in y), 2 = only the second (GEMM2 + residual + next norm) -- for measurement.
  * phases 4 (num_rows_dev allowed; hidden = NULL, or the fragments written by
  * mssvt_ffn_pack_weights for these W1 / W2: saves the in-kernel split): ONE launch with register-stationary weights
- * and every fp32 operand split exactly into two fp16 halves (3 x v_mfma_f32_16x16x32_f16 per
+ * and every fp32 operand split into two fp16 halves (22 of 24 mantissa bits) (3 x v_mfma_f32_16x16x32_f16 per
  * product sum, fp32 accumulation: the fp32 kernels' error against float64 at 3/16 of the matrix
  * cycles; no hidden round trip).  The CALLER guarantees the fp16 range: sqrt(C) max|norm_w| +
  * max|norm_b| and max_h(|W1_h|_1 * that + |b1_h|) below 3e4 (mssvt_amd/fused.py checks the

@@ -94,7 +94,7 @@ __device__ __forceinline__ void cf_gemm(f32x4 (&acc)[NT], const float *W_l, cons
     }
 }
 
-// ---- the same products with every fp32 operand split exactly into two fp16 halves (see ffn.hip, k_ffn_ws): hi =
+// ---- the same products with every fp32 operand split into two fp16 halves (22 of 24 mantissa bits) (see ffn.hip, k_ffn_ws): hi =
 // fp16(v), lo = fp16((v - hi) 2^11); sum a b = sum a_hi b_hi + 2^-11 (sum a_hi b_lo + sum a_lo b_hi), three
 // v_mfma_f32_16x16x32_f16 with fp32 accumulation: the fp32 instruction's error against float64 at 3/16 of its cycles.
 // LDS row of a weight matrix: C halves hi | C halves lo (+ 16 bytes: the same (C + 4)-float stride, conflict free);

@@ -740,14 +740,15 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
 // Single-launch FFN tail, weights stationary in registers, fp32 operands split into two fp16 halves
 // =====================================================================================================
 // The fp32 matrix instruction above runs at 1/16 of the 16-bit rate, and at 62 us per FFN (both launches) it bounds
-// the frame.  Here every fp32 operand v is split exactly into  hi = fp16(v)  and  lo = fp16((v - hi) * 2^11)  (22+
+// the frame.  Here every fp32 operand v is split into  hi = fp16(v)  and  lo = fp16((v - hi) * 2^11)  (round toward zero: 22+
 // mantissa bits together; the lo half is scaled so that it stays out of the fp16 subnormals) and a product sum is three
 // v_mfma_f32_16x16x32_f16 with fp32 accumulation:
 //        sum a b  =  sum a_hi b_hi  +  2^-11 (sum a_hi b_lo + sum a_lo b_hi)            (a_lo b_lo ~ 2^-22: dropped)
 // 3/16 of the fp32 instruction's cycles for the same result to ~2^-21 relative per operand (measured against float64:
 // the same max error as the fp32 kernels).  The caller checks the fp16 RANGE of the operands from
-// the parameters (|LayerNorm output| <= sqrt(C) max|w| + max|b|, |hidden| <= max_h(|W1_h|_1 xmax + |b1_h|) < 3e4) and
-// keeps the fp32 kernels otherwise.
+// the parameters (|LayerNorm output| <= sqrt(C) max|w| + max|b|, |hidden| <= max_h(|W1_h|_1 xmax + |b1_h|) < 6e4 = fused.FFN_F16_LIMIT) and
+// keeps the fp32 kernels otherwise.  (Not exact: hi + 2^-11 lo drops the last ~2 mantissa bits of v and the product sum drops
+// a_lo b_lo; both ~2^-22 relative.)
 //
 // With the matrix work that cheap the layout changes: one workgroup of FF/32 = C/16 waves per CU; wave w keeps, as
 // MFMA A-fragments in REGISTERS for the whole launch (2 x 64 VGPRs at C = 128), the W1 rows of hidden units

@@ -1,21 +1,22 @@
 """Module fast path: window plan + fused HIP block kernels (``impl="fused"``).
 
 What the reference does per Block with ~100 launches and >= 5B+2 host syncs
- becomes, per forward,
+ becomes, per forward (every launch a kernel of libmssvt_hip.so),
 
-    once per voxel set   K1 hash map (SparseTensor) + per-sample counts
-    once per window cfg  K2 window discovery (device-compacted) + ONE fused plan kernel
-                         (K3 + 2xK7 + 2xK8 + key masks), shared by consecutive Blocks
-    per Block            LayerNorm, one fused attention kernel per head group,
-                         one interpolation/scatter/residual kernel, the FFN
+    once per voxel set   level set-up: counts, occupancy columns, column bases, window partitions (csrc/level_sorted.hip
+                         for the (b,x,y,z)-sorted lists DynamicVFE emits -- verified on the device, speculative in the
+                         backbone; csrc/hash_build.hip for any other order), the first norm1
+    once per window cfg  ONE fused plan kernel (K3 + 2xK7 + 2xK8 + key masks + resolved metadata), work orders and
+                         interpolation tables, shared by consecutive Blocks
+    per Block            window attention (k_attn_q / k_attn_kv / k_attn_o, or k_attn_bf16), the FFN tail in one launch
+                         (k_ffn_ws: interpolation + scatter + residual + norm2 + linear1 + ReLU + linear2 + next norm1)
+    CompressBlock        its plan, k_cmp_query_keys / k_cmp_kv / k_cmp_out, the FFN tail
 
-with no host synchronisation: window counts stay in device memory, per-window buffers
-are sized by their capacity (#voxels) and kernels read the live count.  Only the
-CompressBlock's data-dependent output shape costs one sync per forward.
+with no host synchronisation until the end: window counts stay in device memory, per-window buffers
+are sized by their capacity (#voxels) and kernels read the live count.  The CompressBlock's data-dependent
+output shape is the one host wait per forward (an early async copy; status words ride along).
 
-Everything that touches voxels or windows is hand-written HIP behind the C ABI
-(include/mssvt_hip.h, part 2); torch supplies memory, streams, LayerNorm and the
-per-voxel FFN GEMMs.
+torch supplies memory and streams; no framework kernel (LayerNorm, GEMM, bincount) runs on the benchmark configuration.
 """
 import ctypes
 
@@ -479,8 +480,8 @@ def _attn_refs(block, groups):
     return r
 
 
-# arithmetic of the fp32 attention: "f16x3" = ONE launch, keys projected in the kernel, every MFMA operand split exactly
-# into two fp16 halves (csrc/block_attn_f16x3.hip: the fp32 instruction's error, no hand-off through HBM); "f32" = the
+# arithmetic of the fp32 attention: "f16x3" = ONE launch, keys projected in the kernel, every MFMA operand split
+# into two fp16 halves (22 of 24 mantissa bits kept) (csrc/block_attn_f16x3.hip: the fp32 instruction's error, no hand-off through HBM); "f32" = the
 # three fp32-MFMA launches of csrc/block_attn.hip.  Operands outside the fp16 range always take "f32".
 ATTN_ARITH = os.environ.get("MSSVT_ATTN_ARITH", "f32")
 
@@ -531,7 +532,7 @@ FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
 FFN_SPLIT = os.environ.get("MSSVT_FFN_SPLIT", "1") != "0"
 CMP_FUSED = os.environ.get("MSSVT_CMP_FUSED", "1") != "0"
 FFN_TIMER = None  # bench.py sets this to a list to time k_ffn_up live (see _ffn_tail)
-# arithmetic of the FFN's matrix products: "f16x3" = every fp32 operand split exactly into two fp16 halves, three
+# arithmetic of the FFN's matrix products: "f16x3" = every fp32 operand split into two fp16 halves (hi + 2^-11 lo: 22 of 24 mantissa bits), three
 # 16-bit MFMAs per product sum, fp32 accumulation (k_ffn_ws: same error against float64 as the fp32 instruction, 3/16 of
 # its cycles, one launch); "f32" = v_mfma_f32_16x16x4_f32 (k_ffn_up + k_ffn_down).  A module attribute `ffn_arith`
 # overrides it; operands outside the fp16 range (checked from the parameters) always take "f32".
@@ -1182,6 +1183,49 @@ def ffn_timer_summary(samples):
     return out
 
 
+def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
+    """One Block's window attention on the bench frame against both roofs: algorithmic bytes (window metadata, valid key
+    rows Cg wide, query rows in + attention rows out C wide -- the Q~ / Xbar hand-off of the fp32 launches is this
+    implementation's own traffic, not counted) / time vs 8 TB/s, and the reference's FLOP (keys projected) / time vs the
+    matrix peak of the operand type."""
+    p = two_scale_plan(blk, sp)
+    x_in = sp.features.contiguous()
+    C = x_in.shape[1]
+    q_ind, nq, _ = _query(blk, p)
+    attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
+    od = _work_order(blk, p, nq, x_in.shape[0])
+    ma = blk.ms_attn
+    qbuf = _query_scratch(p, od["row_cap"], ma, x_in.device)
+    ms = event_time_ms(lambda: _attention_call(blk, p, od, C, nq, xhat, qbuf, attn), 20)
+    nw = int(p.num_wins.item())
+    K = blk.key_num_sample
+    keys = [int((p.k_mask[g][:nw] == 0).sum()) for g in range(2)]
+    n_q = int((q_ind[:nw] >= 0).sum())
+    alg = nw * (16 + 16 * (nq + 2 * K)) + sum(k * 4 * cg for k, cg in zip(keys, ma.scale_dims)) + 2 * n_q * 4 * C
+    # reference arithmetic per window and group: Wq, Wo on the valid queries, Wkv on the valid keys, QK^T and PV
+    nqv = (q_ind[:nw] >= 0).sum(1).double()
+    flop = 0.0
+    for g, cg in enumerate(ma.scale_dims):
+        kg = (p.k_mask[g][:nw] == 0).sum(1).double()
+        flop += float((4.0 * nqv * cg * cg + 4.0 * kg * cg * cg + 4.0 * nqv * kg * cg).sum()) + 12.0 * cg * float((nqv + kg).sum())
+    bf16 = getattr(blk, "attn_dtype", "f32") == "bf16" and _attn_refs(blk, None)["bf16_ok"]
+    names = ["k_attn_bf16"] if bf16 else ["k_attn_q", "k_attn_kv", "k_attn_o"]
+    peak_tf = MFMA_F16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+    gbs = alg / (ms * 1e-3) / 1e9
+    counters = {k: {kk: v.get(kk) for kk in ("hbm_bytes_per_launch", "mfma_busy_frac", "valu_issue_frac", "cycles_per_launch")}
+                for k, v in (pmc or {}).items() if isinstance(v, dict) and any(k.startswith(n) for n in names)}
+    return {"bound": "hbm", "cbs_pattern": int(blk.cbs_pattern),
+            "kernel": ("mssvt_block_attention_bf16 (k_attn_bf16: one launch, keys projected in the kernel, bf16 operands)" if bf16
+                       else "mssvt_block_attention, both head groups (k_attn_q + k_attn_kv + k_attn_o, grid.y = group)"),
+            "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs, "algorithmic_bytes_per_launch": alg,
+            "avg_launch_us": ms * 1e3, "units_per_launch": {"windows": nw, "valid_key_rows": sum(keys), "valid_query_rows": n_q},
+            "matrix": {"algorithmic_flop_per_launch": flop, "tflops": flop / (ms * 1e-3) / 1e12, "peak_tflops": peak_tf,
+                       "frac": flop / (ms * 1e-3) / 1e12 / peak_tf, "operands": "bf16" if bf16 else "f32"},
+            "pmc": counters or None,
+            "note": "algorithmic bytes exclude the Q~ / Xbar hand-off between the fp32 launches; pmc = per-launch means of "
+                    "profiles/pmc_frame.json (HBM bytes = 2 FETCH + WRITE, MFMA-pipe and VALU-issue busy fractions)"}
+
+
 def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
     """Roofline of the dominant kernel of the frame on the bench inputs.
 
@@ -1190,34 +1234,32 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
     block's LayerNorm of y, when the launch emits it -- it replaces that block's own read + write pass); the 3 attention
     rows interpolated into the input are NOT counted (17 MB per launch, L2 / Infinity-Cache resident), so the figure is
     conservative.  fp32 arithmetic (ffn_arith = "f32"): k_ffn_up, fp32 MFMA bound, 2 C FF FLOP per row.
-    The attention call of a Block (3 launches; gather-latency bound) is reported beside it."""
+    The attention call of a Block is reported beside it for BOTH query patterns (the heavy odd one and the light even one),
+    with the bf16-operand kernel in place of the fp32 launches when the module runs it (configs[2])."""
     import json
     from .mssvt_utils import SparseTensor
     blk = net.backbone[0]
+    pmc_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_frame.json")
+    counters = {}
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            counters = json.load(f)
     with torch.no_grad():
         sp = SparseTensor(features=feats, indices=vc.int().contiguous(), spatial_shape=net.grid_size,
                           voxel_size=net.voxel_size, point_cloud_range=net.point_cloud_range,
                           batch_size=batch, hash_size=net.hash_size)
+        sp._plan_group = [b for b in net.backbone if b.plan_key() == blk.plan_key()] if hasattr(blk, "plan_key") else None
         p = two_scale_plan(blk, sp)
         x_in = sp.features.contiguous()
         C = x_in.shape[1]
         xhat = layer_norm(x_in, blk.norm1)
+        attn_lines, seen = [], set()
+        for b2 in net.backbone:
+            if hasattr(b2, "plan_key") and b2.plan_key() == blk.plan_key() and supported(b2, sp) and b2.cbs_pattern not in seen:
+                seen.add(b2.cbs_pattern)
+                attn_lines.append(_attention_roofline(net, b2, sp, xhat, event_time_ms, peak_gbs, counters))
         q_ind, nq, _ = _query(blk, p)
-        attn = torch.empty((p.cap, nq, C), dtype=torch.float32, device=x_in.device)
-        od = _work_order(blk, p, nq, x_in.shape[0])
-        ma = blk.ms_attn
-        qbuf = _query_scratch(p, od["row_cap"], ma, x_in.device)
         vs3, mn3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3])
-
-        def launch_attn():
-            _attention_call(blk, p, od, C, nq, xhat, qbuf, attn)
-
-        ms_attn = event_time_ms(launch_attn, 20)
-        nw = int(p.num_wins.item())
-        K = blk.key_num_sample
-        n_keys = sum(int((p.k_mask[g][:nw] == 0).sum()) for g in range(2))
-        cg = ma.scale_dims[0]
-        n_q = int((q_ind[:nw] >= 0).sum())
         interp = 1 if blk.use_feature_interpolation else 0
         upd_ind, n_upd, owner = (p.ind_win1, blk.max_num_win1, p.owner_win1) if interp else (q_ind, nq, _query(blk, p)[2])
         tab = _interp_table(blk, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, mn3)
@@ -1234,23 +1276,12 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
             ms_down = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf), phases=2), 20)
     N, FF = x_in.shape[0], blk.linear1.out_features
     flop = 2.0 * C * FF * N
-    # window metadata + valid key rows (Cg wide) + query rows in and attention rows out (C wide); the Q~ / Xbar
-    # hand-off between the three launches is NOT algorithmic (it is this implementation's own traffic)
-    alg = nw * (16 + 16 * (nq + 2 * K)) + n_keys * 4 * cg + 2 * n_q * 4 * C
-    gbs = alg / (ms_attn * 1e-3) / 1e9
-    # HBM bytes per launch of the FFN kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for
-    # 16-B-per-lane reads on gfx950); bench.py cannot collect counters itself
-    traffic, attn_pmc = None, None
-    pmc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        with open(pmc) as f:
-            counters = json.load(f)
-        traffic = counters.get("k_ffn_ws<128,256>" if split16 else "k_ffn_up<128,256>", {}).get("hbm_bytes_per_launch")
-        # the window-attention kernels' measured HBM bytes and MFMA-pipe busy fraction (same PMC passes)
-        attn_pmc = {k: {"hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"),
-                        "mfma_busy_frac": v.get("mfma_busy_frac_of_gpu_active")}
-                    for k, v in counters.items() if isinstance(v, dict) and k.startswith("k_attn_")}
+    # HBM bytes per launch of the FFN kernel from the PMC passes committed under profiles/ (tools/pmc_frame.sh: rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE in separate runs over whole forwards of this frame, FETCH doubled as MI355X_MICROARCH.md
+    # prescribes for 16-B-per-lane reads on gfx950); bench.py cannot collect counters itself
+    traffic = (counters.get("k_ffn_ws<%d, %d, true, true>" % (C, FF) if split16 else "k_ffn_up<%d, %d>" % (C, FF)) or {}).get(
+        "hbm_bytes_per_launch")
+    pmc = pmc_path
     # what the box delivers on bare loops (tools/peaks/run.py; `peak` below stays the guide's number)
     ceilings = None
     cpath = os.path.join(os.path.dirname(pmc), "r01_measured_ceilings.json")
@@ -1315,13 +1346,6 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
         other.append({"bound": "mfma", "kernel": "k_ffn_down<128,256> (GEMM2 + residual + next norm1)", "achieved": tf_down,
                       "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_down / MFMA_F32_PEAK_TFLOPS,
                       "algorithmic_flop_per_launch": flop, "avg_launch_us": ms_down * 1e3})
-    other.append(
-                {"bound": "hbm", "kernel": "mssvt_block_attention, both head groups (k_attn_q + k_attn_kv + k_attn_o, grid.y = group)",
-                 "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs,
-                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": ms_attn * 1e3,
-                 "units_per_launch": {"windows": nw, "valid_key_rows": n_keys, "valid_query_rows": n_q},
-                 "pmc": attn_pmc,
-                 "note": "algorithmic bytes exclude the Q~ / Xbar hand-off between the launches; pmc = HBM bytes "
-                         "(2 FETCH + WRITE) and MFMA-pipe busy fraction per launch from profiles/pmc_traffic.json"})
+    other += attn_lines
     res["other_kernels"] = other
     return res
