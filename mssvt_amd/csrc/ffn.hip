@@ -775,13 +775,25 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 #define FFW_SCALE 2048.0f
 #define FFW_INV (1.0f / 2048.0f)
 
+// Row-wise arithmetic on PAIRS: the phases between the matrix products are VALU-issue bound (~350 vector instructions per
+// wave and 16-row tile against 48 MFMAs), and v_pk_mul / v_pk_add / v_pk_fma_f32 do two lanes' worth of the same IEEE
+// operation per issue slot.  Same operations in the same order per element: results are bit-identical to the scalar form.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk2(float a, float b) { return f32x2{a, b}; }
+__device__ __forceinline__ f32x2 pk1(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 ffw_relu2(f32x2 v) { return f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)}; }
+
 // v -> (hi, lo) halves of 4 floats
-__device__ __forceinline__ void ffw_split4(const float v0, const float v1, const float v2, const float v3, h16x4 &hi, h16x4 &lo) {
-    const fp16x2 a = __builtin_amdgcn_cvt_pkrtz(v0, v1), b = __builtin_amdgcn_cvt_pkrtz(v2, v3);
-    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz((v0 - (float)a[0]) * FFW_SCALE, (v1 - (float)a[1]) * FFW_SCALE);
-    const fp16x2 d = __builtin_amdgcn_cvt_pkrtz((v2 - (float)b[0]) * FFW_SCALE, (v3 - (float)b[1]) * FFW_SCALE);
+__device__ __forceinline__ void ffw_split4(const f32x2 v01, const f32x2 v23, h16x4 &hi, h16x4 &lo) {
+    const fp16x2 a = __builtin_amdgcn_cvt_pkrtz(v01[0], v01[1]), b = __builtin_amdgcn_cvt_pkrtz(v23[0], v23[1]);
+    const f32x2 r01 = (v01 - pk2((float)a[0], (float)a[1])) * pk1(FFW_SCALE), r23 = (v23 - pk2((float)b[0], (float)b[1])) * pk1(FFW_SCALE);
+    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz(r01[0], r01[1]), d = __builtin_amdgcn_cvt_pkrtz(r23[0], r23[1]);
     hi = h16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
     lo = h16x4{(_Float16)c[0], (_Float16)c[1], (_Float16)d[0], (_Float16)d[1]};
+}
+__device__ __forceinline__ void ffw_split4(const float v0, const float v1, const float v2, const float v3, h16x4 &hi, h16x4 &lo) {
+    ffw_split4(pk2(v0, v1), pk2(v2, v3), hi, lo);
 }
 __device__ __forceinline__ h16x8 ffw_cat(const h16x4 a, const h16x4 b) {
     return h16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -911,12 +923,12 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     }
 #define FFW_COMBINE(x_)                                                                                     \
     if (TABBED) {                                                                                           \
-        x_.x = ((r1.x * w1 + r2.x * w2) + r3.x * w3) + rx.x * wx;                                           \
-        x_.y = ((r1.y * w1 + r2.y * w2) + r3.y * w3) + rx.y * wx;                                           \
-        x_.z = ((r1.z * w1 + r2.z * w2) + r3.z * w3) + rx.z * wx;                                           \
-        x_.w = ((r1.w * w1 + r2.w * w2) + r3.w * w3) + rx.w * wx;                                           \
+        const f32x2 a_ = ((pk2(r1.x, r1.y) * pk1(w1) + pk2(r2.x, r2.y) * pk1(w2)) + pk2(r3.x, r3.y) * pk1(w3)) + pk2(rx.x, rx.y) * pk1(wx); \
+        const f32x2 b_ = ((pk2(r1.z, r1.w) * pk1(w1) + pk2(r2.z, r2.w) * pk1(w2)) + pk2(r3.z, r3.w) * pk1(w3)) + pk2(rx.z, rx.w) * pk1(wx); \
+        x_ = make_float4(a_[0], a_[1], b_[0], b_[1]);                                                       \
     } else {                                                                                                \
-        x_ = make_float4(rx.x * wx, rx.y * wx, rx.z * wx, rx.w * wx);                                       \
+        const f32x2 a_ = pk2(rx.x, rx.y) * pk1(wx), b_ = pk2(rx.z, rx.w) * pk1(wx);                          \
+        x_ = make_float4(a_[0], a_[1], b_[0], b_[1]);                                                       \
     }
     // LayerNorm (norm2) over the row's LPR lanes, split, B fragments of GEMM1.  channel 4 q = 32 P + 8 gq + j0: fragment
     // P, lane (la = r, g = gq), halves j0 .. j0 + 3.  Slot of lane (la, g) inside a fragment: 16 g + ((la + 4 g + P) & 15)
@@ -925,13 +937,13 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
 #define FFW_NORM_TO_BFRAG(x_)                                                                               \
     {                                                                                                       \
         const float mean_ = ffw_row_sum<LPR>((x_.x + x_.y) + (x_.z + x_.w)) * (1.0f / C);                   \
-        const float d0_ = x_.x - mean_, d1_ = x_.y - mean_, d2_ = x_.z - mean_, d3_ = x_.w - mean_;         \
+        const f32x2 d01_ = pk2(x_.x, x_.y) - pk1(mean_), d23_ = pk2(x_.z, x_.w) - pk1(mean_);               \
         const float var_ = ffw_row_sum<LPR>(                                                                \
-            __builtin_fmaf(d3_, d3_, __builtin_fmaf(d2_, d2_, __builtin_fmaf(d1_, d1_, d0_ * d0_))));       \
+            __builtin_fmaf(d23_[1], d23_[1], __builtin_fmaf(d23_[0], d23_[0], __builtin_fmaf(d01_[1], d01_[1], d01_[0] * d01_[0])))); \
         const float rstd_ = rsqrtf(var_ * (1.0f / C) + a.eps);                                              \
         h16x4 hi_, lo_;                                                                                     \
-        ffw_split4(d0_ * rstd_ * lnw.x + lnb.x, d1_ * rstd_ * lnw.y + lnb.y, d2_ * rstd_ * lnw.z + lnb.z,   \
-                   d3_ * rstd_ * lnw.w + lnb.w, hi_, lo_);                                                  \
+        ffw_split4(d01_ * pk1(rstd_) * pk2(lnw.x, lnw.y) + pk2(lnb.x, lnb.y),                               \
+                   d23_ * pk1(rstd_) * pk2(lnw.z, lnw.w) + pk2(lnb.z, lnb.w), hi_, lo_);                     \
         const int P_ = q >> 3, gq_ = (q >> 1) & 3, j0_ = (q & 1) * 4;                                       \
         h16x4 *dst_ = reinterpret_cast<h16x4 *>(bfrag + (P_ * 2) * 64 + 16 * gq_ + ((r + 4 * gq_ + P_) & 15)) + (j0_ >> 2); \
         dst_[0] = hi_;                                                                                      \
@@ -958,12 +970,15 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
             _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(uk_[T], W1l[T][P], bh_[P]);               \
         }                                                                                                   \
         h16x4 h0_, l0_, h1_, l1_;                                                                           \
-        ffw_split4(FFW_U(0, 0), FFW_U(0, 1), FFW_U(0, 2), FFW_U(0, 3), h0_, l0_);                           \
-        ffw_split4(FFW_U(1, 0), FFW_U(1, 1), FFW_U(1, 2), FFW_U(1, 3), h1_, l1_);                           \
+        ffw_split4(FFW_U2(0, 0), FFW_U2(0, 2), h0_, l0_);                                                   \
+        ffw_split4(FFW_U2(1, 0), FFW_U2(1, 2), h1_, l1_);                                                   \
         ufrag[(wv * 2) * 64 + lane] = ffw_cat(h0_, h1_);                                                    \
         ufrag[(wv * 2 + 1) * 64 + lane] = ffw_cat(l0_, l1_);                                                \
     }
 #define FFW_U(T_, i_) fmaxf(__builtin_fmaf(ul_[T_][i_] + uk_[T_][i_], FFW_INV, um_[T_][i_]), 0.f)
+    // elements i_, i_ + 1 at once: relu(fma(ul + uk, 2^-11, um))
+#define FFW_U2(T_, i_) ffw_relu2(pk_fma(pk2(ul_[T_][i_], ul_[T_][i_ + 1]) + pk2(uk_[T_][i_], uk_[T_][i_ + 1]), pk1(FFW_INV), \
+                                        pk2(um_[T_][i_], um_[T_][i_ + 1])))
 
     // ---- the first tile's rows are requested before the weights (both pure latency) -------------------------
     FFW_TAB(tile, tr, tw, own)
@@ -1048,9 +1063,11 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                 FFW_TAB(min(t2 + (int)gridDim.x, tiles - 1), trn, twn, ownn)
             }
             FFW_NORM_TO_BFRAG(xn)
-            *reinterpret_cast<float4 *>(ytile + la * PS + 16 * wv + 4 * g) =
-                make_float4(__builtin_fmaf(l[0] + k[0], FFW_INV, m[0]), __builtin_fmaf(l[1] + k[1], FFW_INV, m[1]),
-                            __builtin_fmaf(l[2] + k[2], FFW_INV, m[2]), __builtin_fmaf(l[3] + k[3], FFW_INV, m[3]));
+            {
+                const f32x2 y01 = pk_fma(pk2(l[0], l[1]) + pk2(k[0], k[1]), pk1(FFW_INV), pk2(m[0], m[1])),
+                            y23 = pk_fma(pk2(l[2], l[3]) + pk2(k[2], k[3]), pk1(FFW_INV), pk2(m[2], m[3]));
+                *reinterpret_cast<float4 *>(ytile + la * PS + 16 * wv + 4 * g) = make_float4(y01[0], y01[1], y23[0], y23[1]);
+            }
         }
         WSTAMP(2)
         __syncthreads();
@@ -1058,17 +1075,18 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         // ---- I1: D(t): y = x + (W2 u + b2), the next block's LayerNorm, whole rows out | GEMM1(t1) ------------------
         {
             const size_t row = (size_t)min(tile * 16 + r, n - 1);
-            float4 y = *reinterpret_cast<const float4 *>(ytile + r * PS + 4 * q);
-            y.x += xc.x; y.y += xc.y; y.z += xc.z; y.w += xc.w;
-            *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = y;
+            const float4 yt = *reinterpret_cast<const float4 *>(ytile + r * PS + 4 * q);
+            const f32x2 y01 = pk2(yt.x, yt.y) + pk2(xc.x, xc.y), y23 = pk2(yt.z, yt.w) + pk2(xc.z, xc.w);
+            *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = make_float4(y01[0], y01[1], y23[0], y23[1]);
             if (NORM2) {
-                const float mean = ffw_row_sum<LPR>((y.x + y.y) + (y.z + y.w)) * (1.0f / C);
-                const float d0 = y.x - mean, d1 = y.y - mean, d2 = y.z - mean, d3 = y.w - mean;
-                const float var = ffw_row_sum<LPR>(__builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0))));
+                const float mean = ffw_row_sum<LPR>((y01[0] + y01[1]) + (y23[0] + y23[1])) * (1.0f / C);
+                const f32x2 d01 = y01 - pk1(mean), d23 = y23 - pk1(mean);
+                const float var = ffw_row_sum<LPR>(
+                    __builtin_fmaf(d23[1], d23[1], __builtin_fmaf(d23[0], d23[0], __builtin_fmaf(d01[1], d01[1], d01[0] * d01[0]))));
                 const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
-                *reinterpret_cast<float4 *>(a.y_norm + row * C + 4 * q) =
-                    make_float4(d0 * rstd * ln2w.x + ln2b.x, d1 * rstd * ln2w.y + ln2b.y, d2 * rstd * ln2w.z + ln2b.z,
-                                d3 * rstd * ln2w.w + ln2b.w);
+                const f32x2 n01 = d01 * pk1(rstd) * pk2(ln2w.x, ln2w.y) + pk2(ln2b.x, ln2b.y),
+                            n23 = d23 * pk1(rstd) * pk2(ln2w.z, ln2w.w) + pk2(ln2b.z, ln2b.w);
+                *reinterpret_cast<float4 *>(a.y_norm + row * C + 4 * q) = make_float4(n01[0], n01[1], n23[0], n23[1]);
             }
             FFW_GEMM1()
         }
@@ -1087,6 +1105,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
 #undef FFW_NORM_TO_BFRAG
 #undef FFW_GEMM1
 #undef FFW_U
+#undef FFW_U2
 #ifdef MSSVT_STAMPS
     if (lane == 0 && blockIdx.x < 4) {
         for (int k = 0; k < 7; ++k) g_ws_stamps[(blockIdx.x * 8 + (wv & 7)) * 16 + k] = ws_acc[k];
