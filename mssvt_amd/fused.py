@@ -118,7 +118,7 @@ def _level_partitions(blocks):
 
 
 @torch.no_grad()
-def _sorted_level(blocks, indices, B, H, spatial_shape):
+def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     """Level state from `mssvt_level_setup_sorted` (counts, occupancy columns, column bases, window partitions of
     `blocks`), or None when not applicable.  The caller checks st["level_status"] for ST_UNSORTED."""
     from .mssvt_backbone import MixedScaleSparseTransformerCompressBlock as Compress
@@ -154,9 +154,35 @@ def _sorted_level(blocks, indices, B, H, spatial_shape):
               ints(shapes), ints([b.win1_size for b in todo]),
               (ctypes.c_int * max(k, 1))(*[int(b.max_num_wins) for b in todo]), ptrs(wins), ptrs(tables),
               ptrs([vcounts[i] for i in range(k)]), ptrs(hdrs), _P(scratch), _lib.stream())
-    return {"indices": indices, "v_bs_cnt": cnt, "plans": {}, "occ": occ, "vbase": vbase, "level_status": status,
-            "sorted": True, "status_words": [status], "_zero": zero,
-            "partitions": {_partition_key(b): (wins[i], tables[i], vcounts[i], hdrs[i]) for i, b in enumerate(todo)}}
+    st = {"indices": indices, "v_bs_cnt": cnt, "plans": {}, "occ": occ, "vbase": vbase, "level_status": status,
+          "sorted": True, "status_words": [status], "_zero": zero,
+          "partitions": {_partition_key(b): (wins[i], tables[i], vcounts[i], hdrs[i]) for i, b in enumerate(todo)}}
+    if early_readback:
+        # Every word the host will want from this level -- the level's status, each partition's status and window count
+        # (the output shape of the CompressBlock that ends it) -- is final once these three launches are done, i.e. at the
+        # very start of the frame: copy them out NOW.  When the host reaches the CompressBlock a frame's worth of launches
+        # later the copy has long landed, the forward never blocks on the GPU, and the host runs ahead of it (the frame's
+        # front -- a dozen short launches -- was host bound: the GPU idled ~80 us per frame waiting for them).
+        n = 64 * (k + 1)
+        host = _pinned_words(n, dev)
+        host.copy_(zero[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["early"] = (host, ev, {_partition_key(b): 64 * (i + 1) for i, b in enumerate(todo)})
+    return st
+
+
+_pinned = {}
+
+
+def _pinned_words(n, dev):
+    """A pinned int32 buffer of >= n words per device, reused by every forward (each forward reads its words before it
+    returns, so one is enough; allocating pinned memory per frame costs more than the frame's front)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    t = _pinned.get(key)
+    if t is None:
+        t = _pinned[key] = torch.empty(n, dtype=torch.int32, pin_memory=True)
+    return t
 
 
 PARTITION_GROUPS = True  # a Block's window partition and the next CompressBlock's share their launches
@@ -206,7 +232,7 @@ def setup_input_level(blocks, sp_kwargs, assume_sorted=True):
     X, Y, Z = (int(v) for v in sp_kwargs["spatial_shape"])
     if assume_sorted and SORTED_LEVELS:
         # speculative: no host sync here, the verdict (ST_UNSORTED) is read with the frame's other status words
-        st = _sorted_level(blocks, indices, B, H, sp_kwargs["spatial_shape"])
+        st = _sorted_level(blocks, indices, B, H, sp_kwargs["spatial_shape"], early_readback=True)
         if st is not None:
             sp = SparseTensor(lazy_map_table=True, **sp_kwargs)
             sp.v_bs_cnt, sp._cnt_of, sp.map_status = st["v_bs_cnt"], sp.indices, None
@@ -941,13 +967,23 @@ def one_scale_plan(block, sp, sync=True):
         # host memory now and wait for THAT copy later (not for the stream) -- the forward returns while
         # the GPU still runs the block's tail and the next frame's launches queue up behind it
         # ... together with the status words of the voxel table and of the Block plans of this level
+        early = st.get("early")
+        off = early[2].get(_partition_key(block)) if early is not None else None
+        if off is not None and p.disjoint and getattr(sp, "map_status", None) is None and \
+                all(w.data_ptr() == st["_zero"].data_ptr() or any(w.data_ptr() == st["_zero"].data_ptr() + 4 * o for o in early[2].values())
+                    for w in st.get("status_words", [])):
+            # (every status word of the level sits in the block copied out at the start of the frame)
+            host_t, p.host_ev = early[0], early[1]
+            p.host_words = lambda: (lambda h: [h[off], h[off + 1], h[off + 2], h[0]] + [h[o] for o in early[2].values()])(host_t.tolist())
+            return p
         words = [ws[:3]] + list(st.get("status_words", []))
         if getattr(sp, "map_status", None) is not None:
             words.append(sp.map_status)
-        p.host_ws = torch.empty(3 + len(words) - 1, dtype=torch.int32, pin_memory=True)
-        p.host_ws.copy_(torch.cat(words) if len(words) > 1 else ws[:3], non_blocking=True)
+        host_t = torch.empty(3 + len(words) - 1, dtype=torch.int32, pin_memory=True)
+        host_t.copy_(torch.cat(words) if len(words) > 1 else ws[:3], non_blocking=True)
         p.host_ev = torch.cuda.Event()
         p.host_ev.record()
+        p.host_words = host_t.tolist
         return p
     # the forward's single host sync; the status words of the voxel table and of this level's Block plans
     # ride along (an overflow there must not pass silently either)
@@ -1075,7 +1111,7 @@ def _compress_forward_fused(block, sp, xhat, x_in):
               _i(1 if getattr(block, "ffn_arith", FFN_ARITH) == "f16x3" and _compress_f16_ok(block, sp) else 0), _lib.stream())
     y = _ffn_tail(block, sp, new, n_rows_dev=p.num_wins, apply_out=False)  # no residual to the block input (ref :383-385)
     p.host_ev.synchronize()  # the forward's single host wait: the output shape (copied out long ago)
-    host = p.host_ws.tolist()
+    host = p.host_words()
     status, nw = host[0], host[1]
     _raise_if_unsorted(getattr(sp, "_level", None), host[3:])
     for extra in host[3:]:  # voxel hash table / Block plans: overflow must not pass silently
