@@ -462,12 +462,12 @@ class MixedScaleSparseTransformer(nn.Module):
     _unsorted_backoff = 64
 
     def _forward(self, batch_dict, assume_sorted):
+        from . import fused
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         fused_path = feats.is_cuda and any(getattr(b, 'impl', None) == 'fused' for b in self.backbone)
         # index work of the frame on a side stream (mssvt_amd/fused.py, "Index work of a frame on a second HIP stream")
         side = main = None
         if fused_path and self.async_index and not torch.is_grad_enabled():
-            from . import fused
             main, side = torch.cuda.current_stream(feats.device), fused.side_stream(feats.device)
             ready = batch_dict.get('voxel_coords_ready')  # optional event: the indices are complete behind it
             if ready is not None:
@@ -485,8 +485,9 @@ class MixedScaleSparseTransformer(nn.Module):
                           voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
                           batch_size=batch_dict['batch_size'], hash_size=self.hash_size, gather_dict=None)
                 sp = None
-                if arena is not None and not torch.is_grad_enabled():
-                    from . import fused  # one call sets up the whole input level for the fused blocks
+                if arena is not None and (not torch.is_grad_enabled() or fused.TRAIN_COMPACT):
+                    # one call sets up the whole input level for the fused blocks (index work only: the compact
+                    # training path builds on the same plans)
                     sp = fused.setup_input_level(self.backbone, kw, assume_sorted)
                 if sp is None:
                     sp = SparseTensor(map_table=None, **kw)
@@ -507,7 +508,7 @@ class MixedScaleSparseTransformer(nn.Module):
                 sp._next_compress = nxt_cmp
                 sp = blk(sp, block_idx=i)
             if getattr(sp, "_level", None) is not None and arena is not None:
-                from . import fused  # a level that no fused CompressBlock closed: read its overflow words now
+                # a level that no fused CompressBlock closed: read its overflow words now
                 fused.check_level_status(sp)
         finally:
             mssvt_ops.FillArena.current = None

@@ -57,7 +57,7 @@ def test_bench_ffn_arith_flag_and_roofline_object():
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, env=e, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert "split exactly into two fp16 halves" in res["config"]["ffn_arith"]
+    assert "split into two fp16 halves" in res["config"]["ffn_arith"]
     rf = res["roofline"]
     assert rf["bound"] == "hbm" and "k_ffn_ws" in rf["kernel"] and 0 < rf["frac"] < 1 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["frame"]["frac"] > 0
