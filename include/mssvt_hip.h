@@ -349,7 +349,9 @@ int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_interpolation, 
  * first row.  With disjoint lists counters[0] is not touched.
  * occ_columns / column_vbase / level_status_dev (optional, all or none; mssvt_level_setup_sorted): sorted voxel
  * list -> occupancy bit = hit, column base + popcount below z = voxel index, the hash is not probed
- * (xyz_to_vidx may be NULL) unless level_status_dev[0] has ST_UNSORTED (8) set.                    */
+ * (xyz_to_vidx may be NULL) unless level_status_dev[0] has ST_UNSORTED (8) set.
+ * disjoint_lists == 2: disjoint AND every table offset has x = y = 0 (the caller checked): with x_ws = y_ws = 1 on a
+ * sorted level the lists are built one LANE per window from the column words (pillar windows).        */
 int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws,
                           int max_num_win1, int hash_size, int num_win1, const int *vox_query_win1,
                           const int *win_indices, const int *num_wins_dev, int win_capacity,

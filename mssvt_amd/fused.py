@@ -938,7 +938,10 @@ def one_scale_plan(block, sp, sync=True):
         lo = torch.tensor([-(w // 2) for w in block.win1_size])
         hi = torch.tensor([w - w // 2 - 1 for w in block.win1_size])
         tcpu = tw.cpu()
-        cached = block._disjoint_cache = (tw, 1 if bool(((tcpu >= lo) & (tcpu <= hi)).all()) else 0)
+        dis = 1 if bool(((tcpu >= lo) & (tcpu <= hi)).all()) else 0
+        if dis and bool((tcpu[:, :2] == 0).all()):
+            dis = 2  # ... and every offset stays in the window's own (x, y) column (pillar windows: a lane per window)
+        cached = block._disjoint_cache = (tw, dis)
     p.disjoint = cached[1]
     overlap = 1 if p.disjoint else 8
     row_cap = cap * overlap + (cap if p.with_pad else 0)
