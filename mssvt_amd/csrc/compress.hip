@@ -117,21 +117,23 @@ __global__ void __launch_bounds__(256)
     k_window_plan_pillars(int x_max, int y_max, int z_max, int z_ws, int max_win1, int n_win1, const int *q_win1,
                           const int *win_indices, const int *num_wins, const int *v_bs_cnt, int *k_ind, int *win_vstart,
                           int *win_cnt, int *pair_base, int *pair_win, int *pair_vox, const unsigned long long *occ,
-                          const int *col_vbase, const int *level_status) {
+                          const int *col_vbase, const int *level_status, int win_capacity) {
+    // the table's z offsets (<= 64, the caller checked) in the lanes of a register: no load inside the walk
+    const int oz_lane = q_win1[min(lane_id(), n_win1 - 1) * 3 + 2];
     const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= *num_wins || (level_status[0] & ST_UNSORTED)) return;
-    const int4 wi = reinterpret_cast<const int4 *>(win_indices)[w];  // [b, wz, wy, wx]
+    const int4 wi = reinterpret_cast<const int4 *>(win_indices)[min(w, win_capacity - 1)];  // [b, wz, wy, wx]
+    const bool live = w < *num_wins && !(level_status[0] & ST_UNSORTED);
     int vstart = 0;
-    for (int k = 0; k < wi.x; ++k) vstart += v_bs_cnt[k];
+    for (int k = 0; k < (live ? wi.x : 0); ++k) vstart += v_bs_cnt[k];
     const int cz = wi.y * z_ws + z_ws / 2;
-    const size_t col = ((size_t)wi.x * x_max + wi.w) * y_max + wi.z;
-    const unsigned long long word = occ[col];
+    const size_t col = live ? ((size_t)wi.x * x_max + wi.w) * y_max + wi.z : 0;
+    const unsigned long long word = live ? occ[col] : 0ull;
     const int base = col_vbase[col];
     int *row = k_ind + (size_t)w * max_win1;
     int cnt = 0;
-    for (int q = 0; q < n_win1; ++q) {
-        const int sz = cz + q_win1[q * 3 + 2];  // (wave-uniform offset: a scalar load)
-        if ((unsigned int)sz < (unsigned int)z_max && ((word >> sz) & 1ull)) {
+    for (int q = 0; q < n_win1; ++q) {  // (every lane of the wave takes part: readlane)
+        const int sz = cz + __builtin_amdgcn_readlane(oz_lane, q);
+        if (live && (unsigned int)sz < (unsigned int)z_max && ((word >> sz) & 1ull)) {
             if (cnt < max_win1) {
                 const int sv = base + __popcll(word & ((1ull << sz) - 1ull));
                 row[cnt] = sv;
@@ -141,6 +143,7 @@ __global__ void __launch_bounds__(256)
             ++cnt;
         }
     }
+    if (!live) return;
     const int nk = cnt < max_win1 ? cnt : max_win1;
     for (int k = nk; k < max_win1; ++k) row[k] = -1;
     win_vstart[w] = vstart;
@@ -289,10 +292,10 @@ extern "C" int mssvt_window_plan_one(int x_max, int y_max, int z_max, int x_ws, 
         hipError_t e = hipMemsetAsync(counters, 0, sizeof(int), (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    if (ranked && disjoint_lists == 2 && !with_pad && x_ws == 1 && y_ws == 1) {
+    if (ranked && disjoint_lists == 2 && !with_pad && x_ws == 1 && y_ws == 1 && num_win1 >= 1 && num_win1 <= MSSVT_WAVE) {
         k_window_plan_pillars<<<divup(win_capacity, 256), 256, 0, (hipStream_t)stream>>>(
             x_max, y_max, z_max, z_ws, max_num_win1, num_win1, vox_query_win1, win_indices, num_wins_dev, v_bs_cnt, k_ind,
-            win_vstart, win_cnt, pair_base, pair_win, pair_vox, occ_columns, column_vbase, level_status_dev);
+            win_vstart, win_cnt, pair_base, pair_win, pair_vox, occ_columns, column_vbase, level_status_dev, win_capacity);
         return mssvt_launch_status();
     }
     k_window_plan_one<<<divup(win_capacity, CP_WPB), CP_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(
