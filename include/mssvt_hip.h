@@ -230,7 +230,12 @@ int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_ma
  * by (b,x,y,z) the index of an occupied cell is column_vbase + popcount(column word below z) and the hash is not
  * probed at all (xyz_to_vidx may then be NULL); when level_status_dev[0] has ST_UNSORTED (8) set the hash is used.
  * win_counts_dev (optional, B ints: windows per sample, as the window partition reports them): the windows are
- * then processed centre-out inside every sample (heaviest first on lidar scenes); the outputs do not depend on it. */
+ * accepted and unused (a centre-out work order was measured: no gain).
+ * num_tabs (0..4) interpolation tables built in the same launch (what mssvt_block_interp_table_multi builds from the
+ * finished lists; requires kmeta1 and window lists that cannot overlap, i.e. every voxel owned by one window -- the
+ * caller checks the tables): host_tab_list[t] = query list (0 odd, 1 even, 2 win1), host_tab_interp[t] = the Block's
+ * use_feature_interpolation, host_tab_zero_row[t] = a row of the attention buffer that holds zeros, host_tab_row[t]
+ * (N,4) int32 pre-filled with -1 / host_tab_w[t] (N,4) f32 as for mssvt_block_interp_table.                    */
 int mssvt_window_plan_two(
     int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
     int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
@@ -243,7 +248,8 @@ int mssvt_window_plan_two(
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
     float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
     const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
-    const int *win_counts_dev, void *stream);
+    const int *win_counts_dev, int num_tabs, const int *host_tab_list, const int *host_tab_interp,
+    const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, void *stream);
 
 /* Occupancy columns of a voxel set (z_max <= 64): columns (B*x_max*y_max) 64-bit words, bit z of
  * word (b*x_max + x)*y_max + y set when cell (b,x,y,z) holds a voxel.  Optional input of

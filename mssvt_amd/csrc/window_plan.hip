@@ -62,6 +62,16 @@ struct PlanArgs {
     // is not probed at all; level_status = the device word in which mssvt_level_setup_sorted reports ST_UNSORTED
     const int *col_vbase, *level_status;
     const int *win_counts;  // (unused: a centre-out work order was measured and bought nothing)
+    // interpolation tables (ref K9 + K10 + weights, mssvt_backbone.py:298-311; csrc/block_attn.hip k_block_scatter is the
+    // stand-alone form): per voxel the three attention rows + weights its update comes from, for up to PLAN_MAX_TABS
+    // (query list, interpolation) variants -- built here, where the window's lists sit in LDS, when the lists of
+    // different windows cannot overlap (every voxel then has one owner: this window)
+    int n_tabs, tab_q;  // tab_q: candidate slots per wave (largest query list + 3)
+    struct PlanTab {
+        int list, maxn, interp, zero_row;  // list: 0 odd, 1 even, 2 win1 (the queries); zero_row: attention row of zeros
+        int4 *tab_row;
+        float4 *tab_w;
+    } tabs[4];
 };
 
 __device__ __forceinline__ float plan_centre(int idx, float cell, float lo) {
@@ -321,6 +331,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
     unsigned long long *colw = reinterpret_cast<unsigned long long *>(fps_out + ((K + 1) & ~1));  // 8-byte aligned
     const int ncols = a.fnx * a.fny;
     int *cbase = reinterpret_cast<int *>(colw + ncols);
+    float *cand = reinterpret_cast<float *>(cbase + ncols);  // 4 x tab_q words: x, y, z, (slot << 1 | valid)
 
     const slot_t *tab = a.table + (size_t)wi.x * a.hash_size;
     int vstart = 0;
@@ -490,6 +501,92 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
         }
     }
 
+    // ---- interpolation tables (see PlanArgs::tabs) ----------------------------------------------------------
+    // Lanes are dealt to (table, win1 slot) pairs: with n1 <= 32 entries two tables go through the 3-NN search side by
+    // side (lanes 0-31 / 32-63), with n1 <= 16 four; the candidates of table t sit in cand + 4 t tab_q.
+    if (a.n_tabs > 0) {
+        const int per = n1 <= 16 ? 16 : n1 <= 32 ? 32 : 64, side = MSSVT_WAVE / per;  // lanes per table, tables side by side
+        for (int t0 = 0; t0 < a.n_tabs; t0 += side) {
+            // candidates of tables t0 .. t0 + side - 1: known points = ALL query slots; empty slots sit at the world origin
+            // with zero features (ref :302).  In slot order: every valid slot (they come first), and of the EMPTY slots
+            // only the first three -- all of them are the same point, the search keeps the first seen on ties (strict <):
+            // a fourth can never enter the best three
+            int nc_mine = 0, first_mine = 0, maxn_mine = 1, zero_mine = 0, interp_mine = 0, nvl_mine = 0;
+            int4 *row_mine = nullptr;
+            float4 *w_mine = nullptr;
+            const int tl = lane / per;  // this lane's table (relative to t0)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                if (ti < t0 || ti >= t0 + side || ti >= a.n_tabs) continue;
+                const int first = a.tabs[ti].list == 1 ? cnt_odd : 0;
+                const int nvl = a.tabs[ti].list == 0 ? nO : a.tabs[ti].list == 1 ? nE : n1, maxn = a.tabs[ti].maxn;
+                const int ncand = a.tabs[ti].interp ? nvl + min(3, maxn - nvl) : 0;
+                float *kx = cand + 4 * (ti - t0) * a.tab_q, *ky = kx + a.tab_q, *kz = ky + a.tab_q;
+                int *kvalid = reinterpret_cast<int *>(kz + a.tab_q);
+                for (int k = lane; k < ncand; k += MSSVT_WAVE) {
+                    float x = 0.f, y = 0.f, z = 0.f;
+                    if (k < nvl) {
+                        int ox, oy, oz;
+                        fps_unpack(hpk[first + k], ox, oy, oz);
+                        x = plan_centre(cx + ox, a.vsx, a.minx);
+                        y = plan_centre(cy + oy, a.vsy, a.miny);
+                        z = plan_centre(cz + oz, a.vsz, a.minz);
+                    }
+                    kx[k] = x; ky[k] = y; kz[k] = z;
+                    kvalid[k] = (k << 1) | (k < nvl ? 1 : 0);  // slot, valid bit
+                }
+                if (tl == ti - t0) {
+                    nc_mine = ncand; first_mine = first; maxn_mine = maxn; zero_mine = a.tabs[ti].zero_row;
+                    interp_mine = a.tabs[ti].interp; nvl_mine = nvl;
+                    row_mine = a.tabs[ti].tab_row; w_mine = a.tabs[ti].tab_w;
+                }
+            }
+            wave_lds_sync();
+            const float *kx = cand + 4 * tl * a.tab_q, *ky = kx + a.tab_q, *kz = ky + a.tab_q;
+            const int *kvalid = reinterpret_cast<const int *>(kz + a.tab_q);
+            if (row_mine != nullptr && !interp_mine) {  // ref mssvt_backbone.py:327-330: only the query voxels are updated
+                for (int k = lane % per; k < nvl_mine; k += per) {
+                    const int v = hsv[first_mine + k];
+                    row_mine[vstart + v] = make_int4(w * maxn_mine + k, zero_mine, zero_mine, 0);
+                    w_mine[vstart + v] = make_float4(1.f, 0.f, 0.f, 0.f);
+                }
+            } else if (row_mine != nullptr) {
+                for (int sl = lane % per; sl < n1; sl += per) {  // K9 (ref interpolate_gpu.cu:16-59) + weights (ref :305-307)
+                    const int v = hsv[sl];
+                    int ox, oy, oz;
+                    fps_unpack(hpk[sl], ox, oy, oz);
+                    const float ux = plan_centre(cx + ox, a.vsx, a.minx), uy = plan_centre(cy + oy, a.vsy, a.miny),
+                                uz = plan_centre(cz + oz, a.vsz, a.minz);
+                    // the reference keeps the running bests in double (initial 1e40) and compares float distances against
+                    // them: the same order as float compares against +inf
+                    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+                    int c1 = -1, c2 = -1, c3 = -1;
+                    for (int k = 0; k < nc_mine; ++k) {
+                        const float dx = ux - kx[k], dy = uy - ky[k], dz = uz - kz[k];
+                        const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        if (d < b1) { b3 = b2; c3 = c2; b2 = b1; c2 = c1; b1 = d; c1 = k; }
+                        else if (d < b2) { b3 = b2; c3 = c2; b2 = d; c2 = k; }
+                        else if (d < b3) { b3 = d; c3 = k; }
+                    }
+                    // fewer than three candidates (nq < 3): the reference leaves index 0 / distance 1e40 -> weight ~0
+                    const int m1 = c1 >= 0 ? kvalid[c1] : 0, m2 = c2 >= 0 ? kvalid[c2] : 0, m3 = c3 >= 0 ? kvalid[c3] : 0;
+                    const float d1 = fmaxf(c1 >= 0 ? sqrtf(b1) : INFINITY, 1e-10f), d2 = fmaxf(c2 >= 0 ? sqrtf(b2) : INFINITY, 1e-10f),
+                                d3 = fmaxf(c3 >= 0 ? sqrtf(b3) : INFINITY, 1e-10f);
+                    float w1 = 1.0f / d1, w2 = 1.0f / d2, w3 = 1.0f / d3;
+                    const float norm = (w1 + w2) + w3;
+                    w1 /= norm; w2 /= norm; w3 /= norm;
+                    if (!(m1 & 1) || c1 < 0) w1 = 0.f;  // empty slots carry zero features
+                    if (!(m2 & 1) || c2 < 0) w2 = 0.f;
+                    if (!(m3 & 1) || c3 < 0) w3 = 0.f;
+                    row_mine[vstart + v] = make_int4(w1 != 0.f ? w * maxn_mine + (m1 >> 1) : zero_mine,
+                                                     w2 != 0.f ? w * maxn_mine + (m2 >> 1) : zero_mine,
+                                                     w3 != 0.f ? w * maxn_mine + (m3 >> 1) : zero_mine, 0);
+                    w_mine[vstart + v] = make_float4(w1, w2, w3, 0.f);
+                }
+            }
+            wave_lds_sync();
+        }
+    }
     PSTAMP()
     // ---- K7 + K8 + masks for both scales (ref mssvt_backbone.py:247-258) -----------
     const float4 none = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
@@ -587,7 +684,8 @@ extern "C" int mssvt_window_plan_two(
     const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
     float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
     const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
-    const int *win_counts_dev, void *stream) {
+    const int *win_counts_dev, int num_tabs, const int *host_tab_list, const int *host_tab_interp,
+    const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, void *stream) {
     if (!win_indices || !num_wins_dev || !v_bs_cnt || !ind_odd || !ind_even ||
         !ind_win1 || !k_ind1 || !k_ind2 || !k_mask1 || !k_mask2 || !win_vstart || !owner_win1 ||
         !owner_odd || !owner_even || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
@@ -646,6 +744,24 @@ extern "C" int mssvt_window_plan_two(
     a.occ = nullptr;
     a.col_vbase = a.level_status = nullptr;
     a.win_counts = win_counts_dev;
+    a.n_tabs = 0;
+    a.tab_q = 0;
+    if (num_tabs < 0 || num_tabs > 4) return MSSVT_E_TOOLARGE;
+    if (num_tabs > 0) {
+        if (!kmeta1 || !host_tab_list || !host_tab_interp || !host_tab_zero_row || !host_tab_row || !host_tab_w) return MSSVT_E_BADARG;
+        for (int t = 0; t < num_tabs; ++t) {
+            if (host_tab_list[t] < 0 || host_tab_list[t] > 2 || !host_tab_row[t] || !host_tab_w[t]) return MSSVT_E_BADARG;
+            a.tabs[t].list = host_tab_list[t];
+            a.tabs[t].maxn = host_tab_list[t] == 0 ? max_num_odd : host_tab_list[t] == 1 ? max_num_even : max_num_win1;
+            a.tabs[t].interp = host_tab_interp[t];
+            a.tabs[t].zero_row = host_tab_zero_row[t];
+            a.tabs[t].tab_row = reinterpret_cast<int4 *>(host_tab_row[t]);
+            a.tabs[t].tab_w = reinterpret_cast<float4 *>(host_tab_w[t]);
+            if (a.tabs[t].maxn + 3 > a.tab_q) a.tab_q = a.tabs[t].maxn + 3;
+        }
+        a.tab_q = (a.tab_q + 1) & ~1;
+        a.n_tabs = num_tabs;
+    }
     a.fx0 = a.fy0 = a.fnx = a.fny = a.fny_magic = 0;
     a.q_packed = packed_offsets;
     if (occ_columns && host_footprint4 && packed_offsets && z_max <= 64 && host_footprint4[2] > 0 &&
@@ -665,6 +781,8 @@ extern "C" int mssvt_window_plan_two(
         return MSSVT_E_BADARG;
     }
     if (!a.col_vbase && !xyz_to_vidx) return MSSVT_E_BADARG;  // the hash is the only source of voxel indices then
+    a.lds_words_per_wave += 4 * a.tab_q * 4;  // candidates of up to four tables side by side
+    a.lds_words_per_wave += a.lds_words_per_wave & 1;
     // waves (windows) per workgroup: the count that puts the most waves on a CU (160 KiB of LDS,
     // workgroups <= 64 KiB), ties -> larger workgroups (fewer of them to dispatch)
     int wpb = 1, best_waves = 0;

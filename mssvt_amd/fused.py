@@ -286,6 +286,52 @@ def occupancy_columns(sp, st):
     return st["occ"]
 
 
+PLAN_TABLES = os.environ.get("MSSVT_PLAN_TABLES", "1") != "0"
+
+
+def _lists_disjoint(block):
+    """True when the win1 lists (hence the odd / even lists) of different windows cannot share a voxel: every offset of
+    the three tables inside the window's own cells.  Then each listed voxel is owned by its window and the plan kernel
+    can write the interpolation tables itself (host check on the tables, cached; custom tables stay correct)."""
+    t = block.vox_query_table
+    c = block.__dict__.get("_own_cache")
+    if c is None or c[0] is not t['win1']:
+        lo = torch.tensor([-(w // 2) for w in block.win1_size])
+        hi = torch.tensor([w - w // 2 - 1 for w in block.win1_size])
+        allt = torch.cat([t[k].reshape(-1, 3).cpu() for k in ('odd', 'even', 'win1')], 0)
+        c = block.__dict__["_own_cache"] = (t['win1'], bool(((allt >= lo) & (allt <= hi)).all()))
+    return c[1]
+
+
+def _plan_tables(block, sp, p, key, dev, N):
+    """ctypes arguments (num_tabs, lists, interps, zero rows, tab_row / tab_w pointers) of mssvt_window_plan_two for the
+    (query list, interpolation) variants of the Blocks that share the plan, and their keys in p.tables."""
+    none = (_i(0), None, None, None, None, None)
+    p.tables = {}
+    group = [b for b in (getattr(sp, "_plan_group", None) or [block]) if b.plan_key() == key and supported(b, sp)]
+    if not PLAN_TABLES or not group or not _lists_disjoint(block):
+        return none, []
+    todo, seen = [], set()
+    for b in group:
+        C, FF = b.linear1.in_features, b.linear1.out_features
+        k = (b.cbs_pattern, 1 if b.use_feature_interpolation else 0, _query(b, p)[1], C)
+        if k not in seen and (C, FF) in FFN_SHAPES and len(todo) < 4:
+            seen.add(k)
+            todo.append((b, k))
+    if not todo:
+        return none, []
+    _attn_buffers_alloc(p, [(k[2], k[3]) for _, k in todo], dev)
+    n = len(todo)
+    p._tab_rows = mssvt_ops.full_neg1((n, max(N, 1), 4), dev)
+    p._tab_ws = torch.empty((n, max(N, 1), 4), dtype=torch.float32, device=dev)  # written with tab_row
+    ia = lambda v: (ctypes.c_int * n)(*[int(x) for x in v])  # noqa: E731
+    pa = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+    lists = [{1: 0, 0: 1, 2: 2}[k[0]] for _, k in todo]  # cbs_pattern -> list: 1 odd, 0 even, 2 win1
+    args = (_i(n), ia(lists), ia([k[1] for _, k in todo]), ia([p.attn_zero[(k[2], k[3])] for _, k in todo]),
+            pa([p._tab_rows[i] for i in range(n)]), pa([p._tab_ws[i] for i in range(n)]))
+    return args, [k for _, k in todo]
+
+
 def _voxel_table(sp, st, occ):
     """The voxel hash table for a plan kernel -- or None on a sorted level (column bases instead): the table of such a
     level is only built when somebody asks for `sp.map_table`."""
@@ -376,7 +422,11 @@ def two_scale_plan(block, sp, all_lists=False):
               _P(p.kmeta[1]), _P(p.wcentre), _P(p.nq_valid), _P(occ),
               fp4, _P(packed), _P(st.get("vbase") if occ is not None else None),
               _P(st.get("level_status") if occ is not None else None), _P(p.k_bs_cnt))
-    _lib.call("mssvt_window_plan_two", *p._plan_args, _lib.stream())
+    # the interpolation tables of the Blocks that share this plan: in the same launch when every voxel has ONE owner
+    tab_args, tab_keys = _plan_tables(block, sp, p, key, dev, N)
+    _lib.call("mssvt_window_plan_two", *p._plan_args, *tab_args, _lib.stream())
+    for i, k in enumerate(tab_keys):
+        p.tables[k] = (p._tab_rows[i], p._tab_ws[i])
     st["plans"][key] = p
     return p
 

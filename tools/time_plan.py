@@ -1,6 +1,6 @@
 """Time the window-plan kernel ALONE on the bench scene (investigation helper; safe for timing-only ablation builds:
 nothing consumes its outputs here).  usage: python tools/time_plan.py [batch]"""
-import os, sys
+import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -35,4 +35,4 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-print("mssvt_window_plan_two alone: %.1f us" % t(lambda: _lib.call("mssvt_window_plan_two", *p._plan_args, _lib.stream())))
+print("mssvt_window_plan_two alone: %.1f us" % t(lambda: _lib.call("mssvt_window_plan_two", *p._plan_args, ctypes.c_int(0), None, None, None, None, None, _lib.stream())))
