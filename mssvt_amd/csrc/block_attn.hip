@@ -85,6 +85,39 @@ struct AttnPack {
 #define MFMA4(acc, av, bv)                                                    \
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
 
+// ---- split-fp16 operands (kv16 form of launch B, see k_attn_kvh) ---------------------------------------------
+// v = hi + 2^-11 lo with hi = fp16(v), lo = fp16((v - hi) 2^11), both rounded toward zero: 22 mantissa bits; a product
+// sum is three v_mfma_f32_16x16x32_f16 (hi hi, hi lo, lo hi) accumulated in fp32 -- the arithmetic of csrc/ffn.hip
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16v4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define MFMA_H(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16((av), (bv), acc, 0, 0, 0)
+#define H16_SCALE 2048.0f
+#define H16_INV (1.0f / 2048.0f)
+__device__ __forceinline__ void h16_split4(const f32x4 v, h16x4 &hi, h16x4 &lo) {
+    const fp16x2 a = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), b = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)a[0]) * H16_SCALE, (v[1] - (float)a[1]) * H16_SCALE),
+                 d = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)b[0]) * H16_SCALE, (v[3] - (float)b[1]) * H16_SCALE);
+    hi = h16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
+    lo = h16x4{(_Float16)c[0], (_Float16)c[1], (_Float16)d[0], (_Float16)d[1]};
+}
+__device__ __forceinline__ h16x8 h16_cat(const h16x4 a, const h16x4 b) {
+    return h16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// (hi, lo) fragments of 8 values held as two accumulator-layout quads
+__device__ __forceinline__ void h16_split8(const f32x4 v0, const f32x4 v1, h16x8 &hi, h16x8 &lo) {
+    h16x4 h0, l0, h1, l1;
+    h16_split4(v0, h0, l0);
+    h16_split4(v1, h1, l1);
+    hi = h16_cat(h0, h1);
+    lo = h16_cat(l0, l1);
+}
+// channel of k slot (g, j) of 32-channel step P in the kv16 operand order: 32 P + 8 g + j.  A 16-row MFMA tile u = 2 P + h
+// whose A row m stands for channel kv16_chan(u, m) leaves lane (., g) with channels 32 P + 8 g + 4 h + i in registers i:
+// tiles 2 P and 2 P + 1 together are the lane's 8 consecutive channels of step P
+__device__ __forceinline__ int kv16_chan(int u, int m) { return 32 * (u >> 1) + 8 * (m >> 2) + 4 * (u & 1) + (m & 3); }
+
 // Store of the Q~ / Xbar hand-off rows.  (Measured: written through with `sc1` instead of left dirty for the
 // write-back at the kernel boundary, the 67 MB per launch cost the same ~11 us -- k_attn_q 20.6 -> 19.2 us,
 // k_attn_kv 46.0 -> 47.2 us: it is the bytes, not when they leave the L2.)
@@ -100,8 +133,12 @@ extern "C" int mssvt_debug_read_attn_q_stamps(unsigned long long *host) {
 #define QSTAMP(k_)
 #endif
 // ---- A: queries -> Qt --------------------------------------------------------------------------
-template <int CG, int HD, int HP>
+// KV16: Qt rows leave as (hi, lo) fp16 fragments in the operand order of k_attn_kvh (same bytes per row): per head,
+// [step P][g][hi x 8 | lo x 8] of channels 32 P + 8 g + j.  The rows of Wk^T are staged permuted so that output tile
+// u, A row m is channel kv16_chan(u, m) and a lane ends up with 8 consecutive channels (one 16-byte store per half)
+template <int CG, int HD, int HP, bool KV16>
 __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_q(AttnPack pack) {
+    static_assert(!KV16 || CG % 32 == 0, "kv16 operand order: 32-channel steps");
     const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int CGP = (CG + 15) / 16 * 16, NT = CGP / 16, LS = CGP + 4, NH = CG / HD, QROW = HP * CG;
     extern __shared__ float4 lds4[];
@@ -138,7 +175,9 @@ __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_q(AttnPack p
             const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
             if (e < CGP * CGP) {
                 Wq_l[o * LS + c] = vq[u];
-                WkT_l[c * LS + o] = vk[u];
+                // kv16: channel c sits in the row that tile u = 2 (c / 32) + (c % 8) / 4 reads as m = 4 ((c % 32) / 8) + c % 4
+                const int crow = KV16 ? 16 * (2 * (c >> 5) + ((c & 7) >> 2)) + 4 * ((c & 31) >> 3) + (c & 3) : c;
+                WkT_l[crow * LS + o] = vk[u];
             }
         }
     }
@@ -231,6 +270,19 @@ __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_q(AttnPack p
 #pragma unroll
                 for (int u = 0; u < NT; ++u) MFMA4(acc[u], w[u].w, bq4[3]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (KV16) {
+                h16x8 *dsth = reinterpret_cast<h16x8 *>(dst + h * CG);
+#pragma unroll
+                for (int P = 0; P < NT / 2; ++P) {
+                    h16x8 hi, lo;
+                    h16_split8(acc[2 * P] * a.scale, acc[2 * P + 1] * a.scale, hi, lo);
+                    if (row_ok) {
+                        dsth[(P * 4 + g) * 2] = hi;
+                        dsth[(P * 4 + g) * 2 + 1] = lo;
+                    }
+                }
+                continue;
             }
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
@@ -639,8 +691,228 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
 }
 
 
+// ---- B, kv16 form: the same launch with split-fp16 matrix operands --------------------------------------------
+// Launch B above is bound by the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, 32 cycles for a 16 x 16 x 4 tile: 72 of
+// them per window, pass and head group at K = 32 -- ~2.3 k of the ~3.2 k cycles a window keeps its SIMD busy).  Here every
+// product sum is three v_mfma_f32_16x16x32_f16 on (hi, lo) halves (see h16_split4; fp32 accumulation, the error of the fp32
+// instruction as in csrc/ffn.hip): 12 + 12 sixteen-cycle instructions per window and pass instead of 32 + 32 thirty-two-cycle
+// ones.  What makes it cheaper here than in the single-launch k_attn_f16x3 (which split ~20 fragments per window): the
+// key tokens are the only operand split in this kernel, ONCE per window (Qt arrives split from k_attn_q<KV16>, P is 8
+// values per lane and pass), and the transposed operand of the second product comes out of the LDS image by
+// ds_read_b64_tr_b16 instead of 32 scalar column reads.
+//   channels: k slot (g, j) of step P <-> channel 32 P + 8 g + j in BOTH operands of the score product (the key rows are
+//             gathered as 2 x 16 bytes per step, Qt is stored in that order by k_attn_q);
+//   keys:     k slot (g, j) of step s <-> key 32 s + 16 (j / 4) + 4 g + j % 4 = the accumulator layout of two score tiles,
+//             so the normalised scores are the B operand of the second product as they stand.
+// LDS image per wave: [hi | lo][key][channel] fp16, rows of 2 CG + 32 bytes (conflict-free transposed reads: the 8 rows
+// a 32-lane half touches start 40 banks apart).  Unused key tiles hold zeros (their P is 0, but the product needs finite
+// operands).  The caller guarantees the fp16 range of tokens and Qt (fused._attn_kv16_ok).
+__device__ __forceinline__ h16x4 lds_read_tr16(const char *p) {
+    return __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+        (__attribute__((address_space(3))) fp16v4 *)(p)));
+}
+template <int CG, int HD, int HP, int KT>
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kvh(AttnPack pack) {
+    static_assert(CG % 32 == 0 && KT % 2 == 0, "32-channel and 32-key steps");
+    const AttnArgs &a = pack.g[blockIdx.y];
+    constexpr int NT = CG / 16, NP = CG / 32, NS = KT / 2, NH = CG / HD, QROW = HP * CG, QPP = 16 / HP;
+    constexpr int RS = 2 * CG + 32, IMG = KT * 16 * RS;  // bytes: image row, one (hi or lo) image
+    extern __shared__ float4 lds4[];
+    const int lane = lane_id(), la = lane & 15, g = lane >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    char *Ti = reinterpret_cast<char *>(lds4) + (size_t)wv * 2 * IMG;
+    // positional MLP operand of this lane: A row la of tile u <-> channel kv16_chan(u, la), input g
+    float wconst[NT], w3[NT], w4[NT], w5[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int c = kv16_chan(u, la);
+        const float *wp = a.Wp + (size_t)(a.c0 + c) * 6;
+        wconst[u] = g < 3 ? wp[g] : a.bp[a.c0 + c];
+        w3[u] = g == 3 ? wp[3] : 0.f;
+        w4[u] = g == 3 ? wp[4] : 0.f;
+        w5[u] = g == 3 ? wp[5] : 0.f;
+    }
+    const int n_act = __builtin_amdgcn_readfirstlane(*a.num_wins);
+    const int wstep = gridDim.x * ATTN_ROW_WAVES;
+    const int K = a.K;
+    int wi = __builtin_amdgcn_readfirstlane(blockIdx.x * ATTN_ROW_WAVES + wv);
+    if (wi >= n_act) return;
+    const __amdgpu_buffer_rsrc_t xr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.xhat), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t km_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(a.kmeta), 0, -1, 0x00020000);
+    const unsigned row_bytes = (unsigned)a.C * 4u, lane_off = ((unsigned)a.c0 + 8u * g) * 4u;
+    // piece S of a row: channels 32 (S / 2) + 8 g + 4 (S % 2) + i
+#define KVH_ROW4(off_, S_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_rs, (off_) + 128u * ((S_) >> 1) + 16u * ((S_) & 1), 0, 0))
+    // the software pipeline of k_attn_kv: window ids three steps ahead, metadata two, raw rows one; every load unconditional
+    int w_p;
+    float4 wc_m, km_m[KT];
+    int nqv_m, qbase_m;
+#define KVH_LOAD_META()                                                                    \
+    {                                                                                      \
+        wc_m = a.wcentre[w_p];                                                             \
+        nqv_m = a.nq_valid[w_p];                                                           \
+        qbase_m = a.q_off[w_p];                                                            \
+        _Pragma("unroll") for (int t = 0; t < KT; ++t)                                     \
+            km_m[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(    \
+                km_rs, ((unsigned)w_p * (unsigned)K + (unsigned)min(16 * t + la, K - 1)) * 16u, 0, 0)); \
+    }
+    float4 wc_r;
+    int nqv_r, qbase_r;
+    float rel_r[KT];
+    unsigned vmask_r, used_r;
+    f32x4 T1n[KT][NT];
+#define KVH_ISSUE_ROWS()                                                                   \
+    {                                                                                      \
+        wc_r = wc_m; nqv_r = nqv_m; qbase_r = qbase_m;                                     \
+        vmask_r = 0; used_r = 0;                                                           \
+        _Pragma("unroll") for (int t = 0; t < KT; ++t) {                                   \
+            const int r_ = __builtin_bit_cast(int, km_m[t].w);                             \
+            const bool ok_ = 16 * t + la < K && r_ >= 0;                                   \
+            const unsigned long long bal_ = __ballot(ok_);                                 \
+            vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
+            used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
+            rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
+            const unsigned ro_ = (unsigned)__umul24((unsigned)(ok_ ? r_ : 0), row_bytes) + lane_off; \
+            _Pragma("unroll") for (int S = 0; S < NT; ++S) T1n[t][S] = KVH_ROW4(ro_, S);   \
+        }                                                                                  \
+    }
+    const int w_last = n_act - 1;
+    w_p = a.perm[wi];
+    KVH_LOAD_META()
+    w_p = a.perm[min(wi + wstep, w_last)];
+    KVH_ISSUE_ROWS()
+    KVH_LOAD_META()
+    w_p = a.perm[min(wi + 2 * wstep, w_last)];
+    // transposed reads: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of its 4 x 16 block
+    const char *tr_base = Ti + (4 * g + (la >> 2)) * RS + 8 * (la & 3);
+    const int hh = la % HP;
+    const bool head_ok = hh < NH;
+    for (; wi < n_act; wi += wstep) {
+        const float4 wc = wc_r;
+        const int nqv = qbase_r + nqv_r <= a.row_capacity ? nqv_r : 0;
+        const size_t qbase = (size_t)qbase_r;
+        const unsigned vmask = vmask_r, used = used_r;
+        // key tokens = row + relu(positional MLP), split once: A operands of the score product
+        h16x8 Th[KT][NP], Tl[KT][NP];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            if (!(used >> t & 1)) {
+#pragma unroll
+                for (int P = 0; P < NP; ++P) Th[t][P] = Tl[t][P] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                continue;
+            }
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                f32x4 tk[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int u = 2 * P + h;
+                    const float wu = ((wconst[u] + w3[u] * wc.x) + w4[u] * wc.y) + w5[u] * wc.z;
+                    f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    MFMA4(p1, wu, rel_r[t]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tk[h][i] = T1n[t][u][i] + fmaxf(p1[i], 0.0f);
+                }
+                h16_split8(tk[0], tk[1], Th[t][P], Tl[t][P]);
+            }
+        }
+        // first query pass: its Qt fragments travel while the image is written
+        const h16x8 *qrow = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + min(la / HP, nqv - 1)) * QROW + (head_ok ? hh : 0) * CG);
+        h16x8 qh[NP], ql[NP];
+#pragma unroll
+        for (int P = 0; P < NP; ++P) {
+            qh[P] = qrow[(P * 4 + g) * 2];
+            ql[P] = qrow[(P * 4 + g) * 2 + 1];
+        }
+        KVH_ISSUE_ROWS()
+        KVH_LOAD_META()
+        w_p = a.perm[min(wi + 3 * wstep, w_last)];
+        // image: key row 16 t + la, channels 32 P + 8 g .. + 7
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                char *dst = Ti + (16 * t + la) * RS + 64 * P + 16 * g;
+                *reinterpret_cast<h16x8 *>(dst) = Th[t][P];
+                *reinterpret_cast<h16x8 *>(dst + IMG) = Tl[t][P];
+            }
+        wave_lds_sync();
+        for (int q0 = 0; q0 < nqv; q0 += QPP) {
+            const int q = q0 + la / HP;
+            const bool q_ok = q < nqv && head_ok;
+            float *xrow = a.qbuf + (qbase + min(q, nqv - 1)) * QROW + (head_ok ? hh : 0) * CG;
+            if (q0 > 0) {
+                qrow = reinterpret_cast<const h16x8 *>(xrow);
+#pragma unroll
+                for (int P = 0; P < NP; ++P) {
+                    qh[P] = qrow[(P * 4 + g) * 2];
+                    ql[P] = qrow[(P * 4 + g) * 2 + 1];
+                }
+            }
+            // scores S[key][col] = sum_c T[key][c] Qt[col][c]
+            f32x4 sc[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(used >> t & 1)) continue;
+                f32x4 mm = sc[t], ml = sc[t], lm = sc[t];
+#pragma unroll
+                for (int P = 0; P < NP; ++P) {
+                    MFMA_H(mm, Th[t][P], qh[P]);
+                    MFMA_H(ml, Th[t][P], ql[P]);
+                    MFMA_H(lm, Tl[t][P], qh[P]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[t][i] = __builtin_fmaf(ml[i] + lm[i], H16_INV, mm[i]);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, (vmask >> (4 * t + i) & 1) ? sc[t][i] : -INFINITY);
+            mx = fmaxf(mx, lane_xor16(mx));
+            mx = fmaxf(mx, lane_xor32(mx));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = (vmask >> (4 * t + i) & 1) ? __expf(sc[t][i] - mx) : 0.0f;
+                    sc[t][i] = e;
+                    sum += e;
+                }
+            sum += lane_xor16(sum);
+            sum += lane_xor32(sum);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            // Xbar^T[c][col] = sum_key T[key][c] P[key][col]
+            h16x8 ph[NS], pl[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) h16_split8(sc[2 * s] * inv, sc[2 * s + 1] * inv, ph[s], pl[s]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, ml = mm, lm = mm;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const char *blk = tr_base + 32 * s * RS + 32 * u;
+                    const h16x8 ah = h16_cat(lds_read_tr16(blk), lds_read_tr16(blk + 16 * RS));
+                    const h16x8 al = h16_cat(lds_read_tr16(blk + IMG), lds_read_tr16(blk + IMG + 16 * RS));
+                    MFMA_H(mm, ah, ph[s]);
+                    MFMA_H(ml, ah, pl[s]);
+                    MFMA_H(lm, al, ph[s]);
+                }
+                if (q_ok)  // xbar replaces qt in place (this lane's own bytes of the row)
+                    store_handoff(xrow + 16 * u + 4 * g, f32x4{__builtin_fmaf(ml[0] + lm[0], H16_INV, mm[0]), __builtin_fmaf(ml[1] + lm[1], H16_INV, mm[1]),
+                                                               __builtin_fmaf(ml[2] + lm[2], H16_INV, mm[2]), __builtin_fmaf(ml[3] + lm[3], H16_INV, mm[3])});
+            }
+        }
+        wave_lds_sync();  // the next window rewrites the image
+    }
+#undef KVH_LOAD_META
+#undef KVH_ISSUE_ROWS
+#undef KVH_ROW4
+}
+
 template <int CG, int HD, int HP>
-static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hipStream_t stream) {
+static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, bool kv16, hipStream_t stream) {
     constexpr int CGP = (CG + 15) / 16 * 16, LS = CGP + 4;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
@@ -649,11 +921,30 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hip
     // A / C: persistent over 16-row tiles, one 16-wave workgroup per CU and head group at most
     const int tiles_cap = (row_capacity + 15) / 16;
     int row_grid = tiles_cap;
-    if (row_grid > cus * 2 / ng) row_grid = cus * 2 / ng;
+    static const int qo_wgs = getenv("MSSVT_ATTN_QO_WGS") ? atoi(getenv("MSSVT_ATTN_QO_WGS")) : 2;
+    if (row_grid > cus * qo_wgs / (2 * ng)) row_grid = cus * qo_wgs / (2 * ng);
     if (row_grid < 1) row_grid = 1;
     const size_t lds_q = ((size_t)2 * CGP * LS + CGP * 8 + CGP) * 4, lds_o = ((size_t)2 * CGP * LS + 2 * CGP) * 4;
     const int K = pack.g[0].K;
-    k_attn_q<CG, HD, HP><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
+    if constexpr (CG % 32 == 0) {
+        if (kv16 && K > 16 && K <= 64) {  // split-fp16 operands in launch B (k_attn_kvh); A writes Qt pre-split
+            constexpr int RS = 2 * CG + 32;
+            const dim3 kv_grid(cus * 3 / ng > 0 ? cus * 3 / ng : 1, ng);
+            const size_t img = (size_t)ATTN_ROW_WAVES * 2 * 16 * RS;  // per key tile of 16 slots, all waves, hi + lo
+            k_attn_q<CG, HD, HP, true><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
+            if (K <= 32)
+                k_attn_kvh<CG, HD, HP, 2><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 2 * img, stream>>>(pack);
+            else {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_kvh<CG, HD, HP, 4>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * img));
+                if (e != hipSuccess) return (int)e;
+                k_attn_kvh<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 4 * img, stream>>>(pack);
+            }
+            k_attn_o<CG, HD, HP><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_o, stream>>>(pack);
+            return mssvt_launch_status();
+        }
+    }
+    k_attn_q<CG, HD, HP, false><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
     // B: persistent over the work order with exactly the waves that are resident (3 workgroups of 4 waves per CU at the
     // 164 VGPRs of the K = 32 instantiation): every further workgroup would run in a later round and pay the prologue
     // (positional weights, three dependent metadata round trips: ~9 k cycles, as much as one window) again for its few
@@ -678,10 +969,10 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, hip
     return mssvt_launch_status();
 }
 
-static int dispatch_block_attn(const AttnPack &pack, int ng, int Cg, int head_dim, int row_capacity, hipStream_t st) {
+static int dispatch_block_attn(const AttnPack &pack, int ng, int Cg, int head_dim, int row_capacity, bool kv16, hipStream_t st) {
 #define MSSVT_ATTN_CASE(cg, hd)                                   \
     if (Cg == cg && head_dim == hd)                               \
-        return launch_block_attn<cg, hd, ((cg / hd + 3) / 4) * 4>(pack, ng, row_capacity, st);
+        return launch_block_attn<cg, hd, ((cg / hd + 3) / 4) * 4>(pack, ng, row_capacity, kv16, st);
     MSSVT_ATTN_CASE(8, 8)
     MSSVT_ATTN_CASE(16, 8)
     MSSVT_ATTN_CASE(16, 16)
@@ -697,13 +988,13 @@ static int dispatch_block_attn(const AttnPack &pack, int ng, int Cg, int head_di
 #undef MSSVT_ATTN_CASE
 }
 
-extern "C" int mssvt_block_attention(
+static int block_attention_impl(
     int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
     int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
     const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
     const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
     const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
-    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream) {
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, bool kv16, void *stream) {
     if (!host_c0 || !host_cg || !host_heads || !xhat || !num_active_dev || !perm || !q_off || !nq_valid ||
         !num_rows_dev || !qrow_meta || !qrow_src || !host_kmeta || !wcentre || !host_Wq || !host_bq || !host_Wkv ||
         !host_bkv || !host_Wo || !host_bo || !Wpos || !bpos || !qbuf || !attn || C <= 0 || num_groups <= 0 ||
@@ -744,14 +1035,30 @@ extern "C" int mssvt_block_attention(
         } else {  // unequal group widths: one launch triple per group
             AttnPack one;
             for (int i = 0; i < ATTN_MAX_GROUPS; ++i) one.g[i] = a;
-            const int rc = dispatch_block_attn(one, 1, Cg, head_dim, row_capacity, st);
+            const int rc = dispatch_block_attn(one, 1, Cg, head_dim, row_capacity, kv16, st);
             if (rc) return rc;
         }
     }
     if (!same) return MSSVT_OK;
     for (int g = num_groups; g < ATTN_MAX_GROUPS; ++g) pack.g[g] = pack.g[0];
-    return dispatch_block_attn(pack, num_groups, host_cg[0], head_dim, row_capacity, st);
+    return dispatch_block_attn(pack, num_groups, host_cg[0], head_dim, row_capacity, kv16, st);
 }
+
+#define ATTN_ENTRY_PARAMS                                                                                              \
+    int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,   \
+    int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,       \
+    const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,       \
+    const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,    \
+    const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,                           \
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream
+#define ATTN_ENTRY_ARGS                                                                                                \
+    C, num_groups, host_c0, host_cg, host_heads, head_dim, scale, nq, key_num_sample, xhat, num_active_dev, perm,      \
+    q_off, nq_valid, num_rows_dev, row_capacity, qrow_meta, qrow_src, host_kmeta, wcentre, host_Wq, host_bq, host_Wkv, \
+    host_bkv, host_Wo, host_bo, Wpos, bpos, qbuf, attn
+extern "C" int mssvt_block_attention(ATTN_ENTRY_PARAMS) { return block_attention_impl(ATTN_ENTRY_ARGS, false, stream); }
+// launch B with split-fp16 matrix operands (k_attn_kvh) where the shape allows (Cg % 32 == 0, 16 < K <= 64), the fp32
+// form otherwise; the CALLER guarantees the fp16 range of key tokens and Qt
+extern "C" int mssvt_block_attention_kv16(ATTN_ENTRY_PARAMS) { return block_attention_impl(ATTN_ENTRY_ARGS, true, stream); }
 
 // cell centre in metres, one rounding per op like the reference's torch expression
 // (ref: with_coords, mssvt_backbone.py:132-137)

@@ -587,6 +587,35 @@ def _attn_f16_ok(block, r, p):
     return r["f16_ok"]
 
 
+# launch B of the fp32 attention (scores, softmax, weighted key sum per window) with split-fp16 matrix operands
+# (csrc/block_attn.hip, k_attn_kvh: hi + 2^-11 lo halves, 3 x v_mfma_f32_16x16x32_f16 per product sum, fp32 accumulation --
+# the FFN's arithmetic); "0" keeps the fp32 matrix instruction.  Operands outside the fp16 range always take the fp32 form.
+ATTN_KV16 = os.environ.get("MSSVT_ATTN_KV16", "1") != "0"
+
+
+@torch.no_grad()
+def _attn_kv16_ok(block, r, p):
+    """True when the matrix operands of k_attn_kvh stay inside the fp16 range whatever the input is: key tokens
+    |xhat| + positional term (as _attn_f16_ok) and Qt = scale Wk_h^T q'_h with |q'_o| <= |Wq_o|_1 tmax + |bq_o|,
+    |Qt_c| <= scale sum_o |Wk_oc| |q'_o|.  Once per parameter version (one small host sync)."""
+    ts = [block.norm1.weight, block.norm1.bias, r["Wp"], r["bp"]] + list(r["Wq"]) + list(r["bq"]) + list(r["Wkv"])
+    ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + (float(p.coord_bound),) + _content_key(ts)
+    if r.get("kv16_ver") != ver:
+        g1, b1, Wp, bp = [t.detach().float() for t in ts[:4]]
+        C = g1.numel()
+        xmax = (C ** 0.5) * g1.abs().max() + b1.abs().max()
+        tmax = xmax + (Wp.reshape(C, -1).abs().sum(1) * p.coord_bound + bp.abs()).max()
+        worst = [tmax]
+        for Wq, bq, Wkv in zip(r["Wq"], r["bq"], r["Wkv"]):
+            cg = Wq.shape[0]
+            qmax = Wq.detach().abs().sum(1) * tmax + bq.detach().abs()  # (cg) bound of |q'_o|
+            worst.append((Wkv.detach()[:cg].abs() * qmax[:, None]).sum(0).max() * abs(r["scale"]))
+        worst = torch.stack([w.float() for w in worst]).max()
+        r["kv16_ok"] = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
+        r["kv16_ver"] = ver
+    return r["kv16_ok"]
+
+
 def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
     """mssvt_block_attention (or its bf16-operand form) for the given head groups (default: all)."""
     r = _attn_refs(block, groups)
@@ -600,6 +629,8 @@ def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
         _lib.call("mssvt_block_attention_bf16", *head, _P(attn), _lib.stream())
     elif r["bf16_ok"] and getattr(block, "attn_arith", ATTN_ARITH) == "f16x3" and _attn_f16_ok(block, r, p):
         _lib.call("mssvt_block_attention_f16x3", *head, _P(attn), _lib.stream())
+    elif getattr(block, "attn_kv16", ATTN_KV16) and _attn_kv16_ok(block, r, p):
+        _lib.call("mssvt_block_attention_kv16", *head, _P(qbuf), _P(attn), _lib.stream())
     else:
         _lib.call("mssvt_block_attention", *head, _P(qbuf), _P(attn), _lib.stream())
 

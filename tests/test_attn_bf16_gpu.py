@@ -127,6 +127,7 @@ def test_bf16_attention_rows_vs_fp32_kernels():
         od = fused._work_order(blk, p, nq, feats.shape[0])
         qbuf = fused._query_scratch(p, od["row_cap"], blk.ms_attn, feats.device)
         rows = {}
+        blk.attn_kv16 = False  # "f32" = the fp32 matrix instruction
         for dt in ("f32", "bf16"):
             blk.attn_dtype = dt
             attn = torch.zeros((p.cap * nq + 1, 128), dtype=torch.float32, device=DEV)
@@ -166,6 +167,7 @@ def test_split_f16_single_launch_attention_rows_vs_fp32_kernels():
             qbuf = fused._query_scratch(p, od["row_cap"], blk.ms_attn, feats.device)
             assert fused._attn_f16_ok(blk, fused._attn_refs(blk, None), p)
             rows = {}
+            blk.attn_kv16 = False  # "f32" = the fp32 matrix instruction in all three launches
             for arith in ("f32", "f16x3"):
                 blk.attn_arith = arith
                 attn = torch.zeros((p.cap * nq + 1, 128), dtype=torch.float32, device=DEV)
@@ -178,3 +180,58 @@ def test_split_f16_single_launch_attention_rows_vs_fp32_kernels():
             assert torch.equal(rows["f32"][:nw * nq][~valid], rows["f16x3"][:nw * nq][~valid])
             tol = 1e-5 * float(a.abs().max()) + 1e-4 * a.abs()
             assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
+
+
+@pytest.mark.parametrize("seed,points,batch", [(9, 40000, 1), (4, 30000, 2)])
+def test_split_f16_window_launch_attention_rows_vs_fp32_kernels(seed, points, batch):
+    """mssvt_block_attention_kv16 (the default of the fp32 path): launch B with split-fp16 matrix operands (k_attn_kvh),
+    Qt pre-split by launch A.  Same plan, against the three fp32-MFMA launches, with the fp32 parity path's tolerance
+    |diff| <= 1e-5 max|ref| + 1e-4 |ref|; rows of invalid queries stay untouched; both query patterns."""
+    from mssvt_amd import config, fused
+    from mssvt_amd.mssvt_utils import SparseTensor
+    pts = synthetic.make_batch_points(points, batch, seed)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval()
+    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(2)).to(DEV)
+    with torch.no_grad():
+        sp = SparseTensor(features=feats, indices=torch.from_numpy(vc).to(DEV).int().contiguous(),
+                          spatial_shape=net.grid_size, voxel_size=net.voxel_size,
+                          point_cloud_range=net.point_cloud_range, batch_size=batch, hash_size=net.hash_size)
+        for blk in (net.backbone[0], net.backbone[1]):
+            p = fused.two_scale_plan(blk, sp)
+            xhat = fused.layer_norm(feats, blk.norm1)
+            q_ind, nq, _ = fused._query(blk, p)
+            od = fused._work_order(blk, p, nq, feats.shape[0])
+            qbuf = fused._query_scratch(p, od["row_cap"], blk.ms_attn, feats.device)
+            assert fused._attn_kv16_ok(blk, fused._attn_refs(blk, None), p)
+            rows = {}
+            for kv16 in (False, True):
+                blk.attn_kv16 = kv16
+                attn = torch.zeros((p.cap * nq + 1, 128), dtype=torch.float32, device=DEV)
+                fused._attention_call(blk, p, od, 128, nq, xhat, qbuf, attn)
+                rows[kv16] = attn
+            nw = int(p.num_wins.item())
+            valid = (q_ind[:nw] >= 0).reshape(-1)
+            a, b = rows[False][:nw * nq][valid], rows[True][:nw * nq][valid]
+            assert a.shape[0] > 1000 and not torch.equal(a, b)
+            assert torch.equal(rows[False][:nw * nq][~valid], rows[True][:nw * nq][~valid])
+            tol = 1e-5 * float(a.abs().max()) + 1e-4 * a.abs()
+            assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
+            print("kv16 vs fp32 launches: max |diff| / max |ref| = %.2e" % (float((a - b).abs().max()) / float(a.abs().max())))
+
+
+def test_split_f16_window_launch_range_guard():
+    """Key tokens or Qt that could leave the fp16 range (bound from the parameters) keep the fp32 launch."""
+    from mssvt_amd import config, fused
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg().to(DEV).eval()
+    blk = net.backbone[0]
+
+    class P(object):
+        coord_bound = 80.0
+    r = fused._attn_refs(blk, None)
+    assert fused._attn_kv16_ok(blk, r, P)
+    with torch.no_grad():
+        blk.ms_attn.to_qs[0].weight.mul_(3.0e4)
+    assert not fused._attn_kv16_ok(blk, fused._attn_refs(blk, None), P)
