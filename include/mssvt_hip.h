@@ -304,18 +304,29 @@ int mssvt_block_attention(
     const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
     const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream);
 
-/* mssvt_block_attention with split-fp16 matrix operands in its per-window launch (k_attn_kvh): scores and the weighted
- * key sum as three v_mfma_f32_16x16x32_f16 on (hi, lo = 2^11 (v - hi)) fp16 halves, fp32 accumulation -- the fp32
- * instruction's error at ~1/4 of its cycles; Qt crosses qbuf pre-split (same bytes).  Same arguments and results (to
+/* mssvt_block_attention with split-fp16 matrix operands: every product sum as three v_mfma_f32_16x16x32_f16 on
+ * (hi, lo = 2^11 (v - hi)) fp16 halves with fp32 accumulation -- the fp32 instruction's error at ~1/4 of its cycles.
+ * The per-window launch (k_attn_kvh: scores, weighted key sum; Qt crosses qbuf pre-split, same bytes) always; the
+ * two row-tiled launches (k_attn_q16 / k_attn_o16) when host_packed gives one mssvt_attn_pack_weights blob per head
+ * group (head_dim 16), else they keep the fp32 instruction (host_packed may be NULL).  Same arguments and results (to
  * the fp32 tolerance) as mssvt_block_attention; shapes outside Cg % 32 == 0, 16 < key_num_sample <= 64 run the fp32
- * form.  The CALLER guarantees the fp16 range of key tokens and Qt (mssvt_amd/fused.py, _attn_kv16_ok).            */
+ * form.  The CALLER guarantees the fp16 range of key tokens, Q', Qt, Xbar, V (mssvt_amd/fused.py, _attn_kv16_ok). */
 int mssvt_block_attention_kv16(
     int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
     int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
     const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
     const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
     const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
-    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, void *stream);
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn,
+    const void *const *host_packed, void *stream);
+
+/* Split-fp16 fragments of one head group's projections for mssvt_block_attention_kv16, in MFMA operand order: Wq
+ * (Cg,Cg), Wkv (2Cg,Cg: K rows then V rows, the softmax scale folded into K), Wo (Cg,Cg) -- nn.Linear layouts of
+ * ref mssvt_utils.py:92-103.  Once per parameter version.  mssvt_attn_packed_bytes: size of `packed`, 0 = shape not
+ * instantiated (head_dim 16, Cg 32 / 64).                                                                          */
+long long mssvt_attn_packed_bytes(int Cg, int head_dim);
+int mssvt_attn_pack_weights(int Cg, int head_dim, float scale, const float *Wq, const float *Wkv, const float *Wo,
+                            void *packed, void *stream);
 
 /* mssvt_block_attention with bf16 matrix-core operands (BASELINE configs[2]; an extension of this build -- the
  * reference's MixedScaleAttention computes in fp32, ref mssvt_utils.py:112-150): ONE launch, one wavefront per

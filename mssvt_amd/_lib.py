@@ -34,6 +34,7 @@ def lib():
         _lib.mssvt_csr_transpose_workspace_bytes.restype = ctypes.c_longlong
         _lib.mssvt_ffn_packed_bytes.restype = ctypes.c_longlong
         _lib.mssvt_level_sorted_scratch_ints.restype = ctypes.c_longlong
+        _lib.mssvt_attn_packed_bytes.restype = ctypes.c_longlong
     return _lib
 
 

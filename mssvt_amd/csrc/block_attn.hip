@@ -73,6 +73,7 @@ struct AttnArgs {
     float *qbuf;  // (query rows, HP*CG): Qt after A, Xbar after B
     float *attn;
     int row_capacity;  // rows of qbuf / the compact row arrays
+    const void *packed;  // split-fp16 weight fragments of this group (mssvt_attn_pack_weights) or null
 };
 
 // head groups of equal shape run in ONE launch: blockIdx.y = group (their work is independent: channel
@@ -113,10 +114,9 @@ __device__ __forceinline__ void h16_split8(const f32x4 v0, const f32x4 v1, h16x8
     hi = h16_cat(h0, h1);
     lo = h16_cat(l0, l1);
 }
-// channel of k slot (g, j) of 32-channel step P in the kv16 operand order: 32 P + 8 g + j.  A 16-row MFMA tile u = 2 P + h
-// whose A row m stands for channel kv16_chan(u, m) leaves lane (., g) with channels 32 P + 8 g + 4 h + i in registers i:
-// tiles 2 P and 2 P + 1 together are the lane's 8 consecutive channels of step P
-__device__ __forceinline__ int kv16_chan(int u, int m) { return 32 * (u >> 1) + 8 * (m >> 2) + 4 * (u & 1) + (m & 3); }
+// kv16 operand order: k slot (g, j) of a 32-wide step P <-> index 32 P + 16 (j / 4) + 4 g + j % 4 -- what a lane holds after
+// two DENSE 16-byte row pieces S = 2 P, 2 P + 1 (piece S of lane (., g) = indices 16 S + 4 g .. + 3: the four g lanes of a
+// row read 64 contiguous bytes), and equally the accumulator registers of two consecutive 16-row output tiles
 
 // Store of the Q~ / Xbar hand-off rows.  (Measured: written through with `sc1` instead of left dirty for the
 // write-back at the kernel boundary, the 67 MB per launch cost the same ~11 us -- k_attn_q 20.6 -> 19.2 us,
@@ -134,8 +134,7 @@ extern "C" int mssvt_debug_read_attn_q_stamps(unsigned long long *host) {
 #endif
 // ---- A: queries -> Qt --------------------------------------------------------------------------
 // KV16: Qt rows leave as (hi, lo) fp16 fragments in the operand order of k_attn_kvh (same bytes per row): per head,
-// [step P][g][hi x 8 | lo x 8] of channels 32 P + 8 g + j.  The rows of Wk^T are staged permuted so that output tile
-// u, A row m is channel kv16_chan(u, m) and a lane ends up with 8 consecutive channels (one 16-byte store per half)
+// [step P][g][hi x 8 | lo x 8], the 8 = this lane's accumulator registers of output tiles 2 P and 2 P + 1
 template <int CG, int HD, int HP, bool KV16>
 __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_q(AttnPack pack) {
     static_assert(!KV16 || CG % 32 == 0, "kv16 operand order: 32-channel steps");
@@ -175,9 +174,7 @@ __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_q(AttnPack p
             const int e = e0 + u * blockDim.x, o = e / CGP, c = e % CGP;
             if (e < CGP * CGP) {
                 Wq_l[o * LS + c] = vq[u];
-                // kv16: channel c sits in the row that tile u = 2 (c / 32) + (c % 8) / 4 reads as m = 4 ((c % 32) / 8) + c % 4
-                const int crow = KV16 ? 16 * (2 * (c >> 5) + ((c & 7) >> 2)) + 4 * ((c & 31) >> 3) + (c & 3) : c;
-                WkT_l[crow * LS + o] = vk[u];
+                WkT_l[c * LS + o] = vk[u];
             }
         }
     }
@@ -410,6 +407,279 @@ __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_o(AttnPack p
                 *reinterpret_cast<float4 *>(dst + c) = make_float4(out[u][0], out[u][1], out[u][2], out[u][3]);
         }
     }
+}
+
+// ---- A and C with split-fp16 operands (kv16 form) ---------------------------------------------------------------
+// The row-tiled launches above are bound by the fp32 matrix instruction too: 128 v_mfma_f32_16x16x4_f32 = 4 096 pipe cycles
+// per 16-row tile, four waves per SIMD.  Here the four Cg x Cg matrices are split ONCE per parameter version into (hi, lo)
+// fp16 fragments in MFMA operand order (k_attn_pack; the softmax scale folded into Wk), staged by a straight 16-byte copy
+// (32 KiB per launch and workgroup instead of 37 KiB of element-wise transposes), and a tile costs 72 (A) / 48 (C)
+// sixteen-cycle instructions.  Workgroups are 8 waves so that BOTH head groups of a launch are resident side by side
+// (the 16-wave form ran its two groups one after the other: 90 VGPRs allow one such workgroup per CU).
+// Fragment blob of one head group (bytes; NT = Cg / 16 output tiles, NP = Cg / 32 steps; HD = 16: head h = tile h):
+//   WqF [t][P][hi | lo][lane] x 16 B   A rows o = 16 t + m,        k slot (g, j) <-> channel 32 P + 16 (j / 4) + 4 g + j % 4
+//   WkF [h][u][hi | lo][lane] x  8 B   A rows c = (16 * u + m), k slot (g, j) <-> o = 16 h + 4 g + j   (x scale)
+//   WvF [t][P][hi | lo][lane] x 16 B   A rows o = 16 t + m,        k slot (g, j) <-> the same channel of Xbar_t
+//   WoF [u][s][hi | lo][lane] x 16 B   A rows p = 16 u + m,        k slot (g, j) <-> o = 32 s + 16 (j / 4) + 4 g + j % 4
+#define ATTN_QO16_WAVES 8
+#define MFMA_H16(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x16f16((av), (bv), acc, 0, 0, 0)
+template <int CG>
+struct AttnBlob {
+    static constexpr int NT = CG / 16, NP = CG / 32;
+    static constexpr int WQ = 0, WK = WQ + NT * NP * 2 * 64 * 16, WV = WK + NT * NT * 2 * 64 * 8, WO = WV + NT * NP * 2 * 64 * 16,
+                         BYTES = WO + NT * NP * 2 * 64 * 16;
+};
+
+template <int CG>
+__global__ void __launch_bounds__(MSSVT_WAVE) k_attn_pack(const float *Wq, const float *Wkv, const float *Wo, float scale, char *blob) {
+    using L = AttnBlob<CG>;
+    constexpr int NT = L::NT, NP = L::NP;
+    const int lane = lane_id(), m = lane & 15, g = lane >> 4, f = blockIdx.x;  // fragment index within its matrix
+    const int which = blockIdx.y;                                              // 0 Wq, 1 Wk, 2 Wv, 3 Wo
+    if (which == 1) {
+        if (f >= NT * NT) return;
+        const int h = f / NT, u = f % NT;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = Wkv[(size_t)(16 * h + 4 * g + j) * CG + (16 * u + m)] * scale;
+        h16x4 hi, lo;
+        h16_split4(v, hi, lo);
+        h16x4 *dst = reinterpret_cast<h16x4 *>(blob + L::WK) + (size_t)f * 2 * 64 + lane;
+        dst[0] = hi;
+        dst[64] = lo;
+        return;
+    }
+    if (f >= NT * NP) return;
+    const int t = f / NP, P = f % NP;
+    // 8 k slots of a lane = two runs of 4 consecutive columns, 16 apart (kv16 operand order)
+    const float *rowp = (which == 0 ? Wq + (size_t)(16 * t + m) * CG : which == 2 ? Wkv + (size_t)(CG + 16 * t + m) * CG
+                                                                                  : Wo + (size_t)(16 * t + m) * CG) + 32 * P + 4 * g;
+    const float4 w0 = *reinterpret_cast<const float4 *>(rowp), w1 = *reinterpret_cast<const float4 *>(rowp + 16);
+    h16x8 hi, lo;
+    h16_split8(f32x4{w0.x, w0.y, w0.z, w0.w}, f32x4{w1.x, w1.y, w1.z, w1.w}, hi, lo);
+    h16x8 *dst = reinterpret_cast<h16x8 *>(blob + (which == 0 ? L::WQ : which == 2 ? L::WV : L::WO)) + (size_t)f * 2 * 64 + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+}
+
+// straight copy of n16 16-byte pieces into the LDS, every load of a thread in flight before its first store
+template <int N16, int THREADS>
+__device__ __forceinline__ void attn_stage16(float4 *lds, const float4 *src) {
+    constexpr int PER = (N16 + THREADS - 1) / THREADS;
+    float4 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = threadIdx.x + k * THREADS;
+        if (N16 % THREADS == 0 || e < N16) v[k] = src[e];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = threadIdx.x + k * THREADS;
+        if (N16 % THREADS == 0 || e < N16) lds[e] = v[k];
+    }
+}
+
+// ---- A, kv16 form: rows -> Qt.  KV16OUT: Qt as (hi, lo) fragments for k_attn_kvh, else fp32 for k_attn_kv
+// (sched_barriers: without them the scheduler hoists the fragment reads of every step and spills ~100 registers)
+template <int CG, int HP, bool KV16OUT>
+__global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_q16(AttnPack pack) {
+    const AttnArgs &a = pack.g[blockIdx.y];
+    using L = AttnBlob<CG>;
+    constexpr int NT = CG / 16, NP = CG / 32, QROW = HP * CG;
+    extern __shared__ float4 lds4[];
+    const h16x8 *WqF = reinterpret_cast<const h16x8 *>(lds4);
+    const h16x4 *WkF = reinterpret_cast<const h16x4 *>(reinterpret_cast<const char *>(lds4) + L::WK);
+    float *bq_l = reinterpret_cast<float *>(reinterpret_cast<char *>(lds4) + L::WV);
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    if ((int)blockIdx.x >= tiles) return;
+    int tile = wv * gridDim.x + blockIdx.x;
+    float4 rm = a.qrow_meta[min(tile * 16 + r, rows - 1)];
+    int2 src = a.qrow_src[min(tile * 16 + r, rows - 1)];
+    attn_stage16<L::WV / 16, ATTN_QO16_WAVES * MSSVT_WAVE>(lds4, reinterpret_cast<const float4 *>(a.packed));
+    if (threadIdx.x < CG) bq_l[threadIdx.x] = a.bq[threadIdx.x];
+    // positional MLP as two K = 4 products (relative offset | 1, window centre): A row r of tile u <-> channel (16 * u + r)
+    float wrel[NT], wctr[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const float *wp = a.Wp + (size_t)(a.c0 + (16 * u + r)) * 6;
+        wrel[u] = g < 3 ? wp[g] : a.bp[a.c0 + (16 * u + r)];
+        wctr[u] = g < 3 ? wp[3 + g] : 0.f;
+    }
+    float4 wc = a.wcentre[src.x];
+    f32x4 xq[NT];  // piece S: channels 16 S + 4 g + i of the row
+#define ATTN_Q16_ROWS()                                                                                   \
+    {                                                                                                     \
+        const float *xrow_ = a.xhat + (size_t)__builtin_bit_cast(int, rm.w) * a.C + a.c0 + 4 * g;         \
+        _Pragma("unroll") for (int S = 0; S < NT; ++S) {                                                  \
+            const float4 v_ = *reinterpret_cast<const float4 *>(xrow_ + 16 * S);                          \
+            xq[S] = f32x4{v_.x, v_.y, v_.z, v_.w};                                                        \
+        }                                                                                                 \
+    }
+    ATTN_Q16_ROWS()
+    __syncthreads();
+    for (bool first = true; tile < tiles; tile += gridDim.x * ATTN_QO16_WAVES, first = false) {
+        const int row = min(tile * 16 + r, rows - 1);
+        if (!first) {
+            rm = a.qrow_meta[row];
+            src = a.qrow_src[row];
+            wc = a.wcentre[src.x];
+            ATTN_Q16_ROWS()
+        }
+        const float relb = g == 0 ? rm.x : (g == 1 ? rm.y : (g == 2 ? rm.z : 1.0f));
+        const float ctrb = g == 0 ? wc.x : (g == 1 ? wc.y : (g == 2 ? wc.z : 0.0f));
+        h16x8 xh[NP], xl[NP];
+#pragma unroll
+        for (int P = 0; P < NP; ++P) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                MFMA4(p1, wrel[2 * P + h], relb);
+                MFMA4(p1, wctr[2 * P + h], ctrb);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xq[2 * P + h][i] += fmaxf(p1[i], 0.0f);
+            }
+            h16_split8(xq[2 * P], xq[2 * P + 1], xh[P], xl[P]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // GEMM1^T: Q'^T[o][row] = sum_c Wq[o][c] xq[row][c] + bq[o]; accumulator (row, g), i <-> o = 16 t + 4 g + i
+        h16x4 qh[NT], ql[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 b = *reinterpret_cast<const float4 *>(bq_l + 16 * t + 4 * g);
+            f32x4 mm = f32x4{b.x, b.y, b.z, b.w}, cr = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                const h16x8 wh = WqF[((t * NP + P) * 2) * 64 + lane], wl = WqF[((t * NP + P) * 2 + 1) * 64 + lane];
+                MFMA_H(mm, wh, xh[P]);
+                MFMA_H(cr, wh, xl[P]);
+                MFMA_H(cr, wl, xh[P]);
+            }
+            h16_split4(f32x4{__builtin_fmaf(cr[0], H16_INV, mm[0]), __builtin_fmaf(cr[1], H16_INV, mm[1]),
+                             __builtin_fmaf(cr[2], H16_INV, mm[2]), __builtin_fmaf(cr[3], H16_INV, mm[3])}, qh[t], ql[t]);
+            if (t & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        // GEMM2^T per head (= tile h): Qt_h^T[c][row] = sum_{o in head h} (scale Wk[o][c]) Q'[row][o]
+        const bool row_ok = tile * 16 + r < rows;
+        float *dst = a.qbuf + (size_t)(tile * 16 + r) * QROW;
+#pragma unroll
+        for (int h = 0; h < NT; ++h) {
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                f32x4 acc[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int u = 2 * P + e;
+                    const h16x4 wh = WkF[((h * NT + u) * 2) * 64 + lane], wl = WkF[((h * NT + u) * 2 + 1) * 64 + lane];
+                    f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
+                    MFMA_H16(mm, wh, qh[h]);
+                    MFMA_H16(cr, wh, ql[h]);
+                    MFMA_H16(cr, wl, qh[h]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[e][i] = __builtin_fmaf(cr[i], H16_INV, mm[i]);
+                }
+                if (KV16OUT) {
+                    h16x8 *dsth = reinterpret_cast<h16x8 *>(dst + h * CG);
+                    h16x8 hi, lo;
+                    h16_split8(acc[0], acc[1], hi, lo);
+                    if (row_ok) {
+                        dsth[(P * 4 + g) * 2] = hi;
+                        dsth[(P * 4 + g) * 2 + 1] = lo;
+                    }
+                } else if (row_ok) {
+                    store_handoff(dst + h * CG + (32 * P + 4 * g), acc[0]);
+                    store_handoff(dst + h * CG + (32 * P + 16 + 4 * g), acc[1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef ATTN_Q16_ROWS
+}
+
+// ---- C, kv16 form: Xbar -> attention output rows
+template <int CG, int HP>
+__global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_o16(AttnPack pack) {
+    const AttnArgs &a = pack.g[blockIdx.y];
+    using L = AttnBlob<CG>;
+    constexpr int NT = CG / 16, NP = CG / 32, QROW = HP * CG;
+    extern __shared__ float4 lds4[];
+    const h16x8 *WvF = reinterpret_cast<const h16x8 *>(lds4);
+    const h16x8 *WoF = reinterpret_cast<const h16x8 *>(reinterpret_cast<const char *>(lds4) + (L::WO - L::WV));
+    float *bv_l = reinterpret_cast<float *>(reinterpret_cast<char *>(lds4) + (L::BYTES - L::WV)), *bo_l = bv_l + CG;
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
+    const int wv = threadIdx.x / MSSVT_WAVE;
+    if ((int)blockIdx.x >= tiles) return;
+    int tile = wv * gridDim.x + blockIdx.x;
+    f32x4 x[NT], xn[NT];  // piece S of one head's Xbar row: channels 16 S + 4 g + i
+#define ATTN_O16_ROWS(dst_, row_, h_)                                                                     \
+    {                                                                                                     \
+        const float *xb_ = a.qbuf + (size_t)(row_) * QROW + (h_) * CG + 4 * g;                            \
+        _Pragma("unroll") for (int S = 0; S < NT; ++S) {                                                  \
+            const float4 t4_ = *reinterpret_cast<const float4 *>(xb_ + 16 * S);                           \
+            dst_[S] = f32x4{t4_.x, t4_.y, t4_.z, t4_.w};                                                  \
+        }                                                                                                 \
+    }
+    ATTN_O16_ROWS(x, min(tile * 16 + r, rows - 1), 0)
+    attn_stage16<(L::BYTES - L::WV) / 16, ATTN_QO16_WAVES * MSSVT_WAVE>(
+        lds4, reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.packed) + L::WV));
+    if (threadIdx.x < CG) {
+        bv_l[threadIdx.x] = a.bkv[CG + threadIdx.x];
+        bo_l[threadIdx.x] = a.bo[threadIdx.x];
+    }
+    __syncthreads();
+    for (bool first = true; tile < tiles; tile += gridDim.x * ATTN_QO16_WAVES, first = false) {
+        const int row = min(tile * 16 + r, rows - 1);
+        const bool row_ok = tile * 16 + r < rows;
+        const int dest = a.qrow_src[row].y;
+        if (!first) ATTN_O16_ROWS(x, row, 0)
+        // GEMM3^T: V^T[o][row] = sum_c Wv[o][c] Xbar_{head(o)}[row][c] + bv[o]  (head of tile t = t)
+        f32x4 v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) ATTN_O16_ROWS(xn, row, t + 1)  // the next head's row pieces under this head's products
+            const float4 b = *reinterpret_cast<const float4 *>(bv_l + 16 * t + 4 * g);
+            f32x4 mm = f32x4{b.x, b.y, b.z, b.w}, cr = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                h16x8 xh, xl;
+                h16_split8(x[2 * P], x[2 * P + 1], xh, xl);
+                const h16x8 wh = WvF[((t * NP + P) * 2) * 64 + lane], wl = WvF[((t * NP + P) * 2 + 1) * 64 + lane];
+                MFMA_H(mm, wh, xh);
+                MFMA_H(cr, wh, xl);
+                MFMA_H(cr, wl, xh);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[t][i] = __builtin_fmaf(cr[i], H16_INV, mm[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int S = 0; S < NT; ++S) x[S] = xn[S];
+        }
+        // GEMM4^T: out^T[p][row] = sum_o Wo[p][o] V[row][o] + bo[p]; two V tiles = one 32-wide step of the B operand
+        h16x8 vh[NP], vl[NP];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) h16_split8(v[2 * s], v[2 * s + 1], vh[s], vl[s]);
+        float *dst = a.attn + (size_t)dest * a.C + a.c0 + 4 * g;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 b = *reinterpret_cast<const float4 *>(bo_l + 16 * u + 4 * g);
+            f32x4 mm = f32x4{b.x, b.y, b.z, b.w}, cr = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const h16x8 wh = WoF[((u * NP + s) * 2) * 64 + lane], wl = WoF[((u * NP + s) * 2 + 1) * 64 + lane];
+                MFMA_H(mm, wh, vh[s]);
+                MFMA_H(cr, wh, vl[s]);
+                MFMA_H(cr, wl, vh[s]);
+            }
+            if (row_ok)
+                *reinterpret_cast<float4 *>(dst + 16 * u) = make_float4(__builtin_fmaf(cr[0], H16_INV, mm[0]), __builtin_fmaf(cr[1], H16_INV, mm[1]),
+                                                                        __builtin_fmaf(cr[2], H16_INV, mm[2]), __builtin_fmaf(cr[3], H16_INV, mm[3]));
+            if (u & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef ATTN_O16_ROWS
 }
 
 // ---- B: keys, scores, softmax, xbar (one wavefront per window) ------------------------------------
@@ -700,37 +970,39 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
 // key tokens are the only operand split in this kernel, ONCE per window (Qt arrives split from k_attn_q<KV16>, P is 8
 // values per lane and pass), and the transposed operand of the second product comes out of the LDS image by
 // ds_read_b64_tr_b16 instead of 32 scalar column reads.
-//   channels: k slot (g, j) of step P <-> channel 32 P + 8 g + j in BOTH operands of the score product (the key rows are
-//             gathered as 2 x 16 bytes per step, Qt is stored in that order by k_attn_q);
+//   channels: k slot (g, j) of step P <-> channel 32 P + 16 (j / 4) + 4 g + j % 4 in BOTH operands of the score product (two
+//             dense 16-byte pieces of a key row per step; Qt is stored in that order by launch A); the image keeps the
+//             lane's 8 slots together (column 32 P + 8 g + j), so the second product's output rows come out in slot
+//             order and the Xbar store undoes the permutation in its address;
 //   keys:     k slot (g, j) of step s <-> key 32 s + 16 (j / 4) + 4 g + j % 4 = the accumulator layout of two score tiles,
 //             so the normalised scores are the B operand of the second product as they stand.
-// LDS image per wave: [hi | lo][key][channel] fp16, rows of 2 CG + 32 bytes (conflict-free transposed reads: the 8 rows
-// a 32-lane half touches start 40 banks apart).  Unused key tiles hold zeros (their P is 0, but the product needs finite
+// LDS image per wave: [hi | lo][key][channel] fp16, rows of 2 CG + 16 bytes (36 KiB per workgroup at K = 32: four
+// workgroups = 4 waves / SIMD per CU; the 8 rows a 32-lane half of a transposed read touches start 36 banks apart).  Unused key tiles hold zeros (their P is 0, but the product needs finite
 // operands).  The caller guarantees the fp16 range of tokens and Qt (fused._attn_kv16_ok).
+#define KVH_RS(cg) (2 * (cg) + 16)  // bytes per image row: 16-byte aligned, 36 banks at Cg = 64 (transposed reads: one 2-way pair per half)
 __device__ __forceinline__ h16x4 lds_read_tr16(const char *p) {
     return __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
         (__attribute__((address_space(3))) fp16v4 *)(p)));
 }
 template <int CG, int HD, int HP, int KT>
-__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kvh(AttnPack pack) {
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k_attn_kvh(AttnPack pack) {
     static_assert(CG % 32 == 0 && KT % 2 == 0, "32-channel and 32-key steps");
     const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int NT = CG / 16, NP = CG / 32, NS = KT / 2, NH = CG / HD, QROW = HP * CG, QPP = 16 / HP;
-    constexpr int RS = 2 * CG + 32, IMG = KT * 16 * RS;  // bytes: image row, one (hi or lo) image
+    constexpr int RS = KVH_RS(CG), IMG = KT * 16 * RS;  // bytes: image row, one (hi or lo) image
     extern __shared__ float4 lds4[];
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = threadIdx.x / MSSVT_WAVE;
     char *Ti = reinterpret_cast<char *>(lds4) + (size_t)wv * 2 * IMG;
-    // positional MLP operand of this lane: A row la of tile u <-> channel kv16_chan(u, la), input g
-    float wconst[NT], w3[NT], w4[NT], w5[NT];
+    // positional MLP operand of this lane: A row la of tile u <-> channel (16 * u + la), input g: the weight of the
+    // relative offset (g < 3) | bias + window-centre part (g = 3: summed over the three lanes that hold its weights)
+    float wrel[NT], wctr[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-        const int c = kv16_chan(u, la);
+        const int c = (16 * u + la);
         const float *wp = a.Wp + (size_t)(a.c0 + c) * 6;
-        wconst[u] = g < 3 ? wp[g] : a.bp[a.c0 + c];
-        w3[u] = g == 3 ? wp[3] : 0.f;
-        w4[u] = g == 3 ? wp[4] : 0.f;
-        w5[u] = g == 3 ? wp[5] : 0.f;
+        wrel[u] = g < 3 ? wp[g] : a.bp[a.c0 + c];
+        wctr[u] = g < 3 ? wp[3 + g] : 0.f;
     }
     const int n_act = __builtin_amdgcn_readfirstlane(*a.num_wins);
     const int wstep = gridDim.x * ATTN_ROW_WAVES;
@@ -739,9 +1011,9 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kvh(Attn
     if (wi >= n_act) return;
     const __amdgpu_buffer_rsrc_t xr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.xhat), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t km_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(a.kmeta), 0, -1, 0x00020000);
-    const unsigned row_bytes = (unsigned)a.C * 4u, lane_off = ((unsigned)a.c0 + 8u * g) * 4u;
-    // piece S of a row: channels 32 (S / 2) + 8 g + 4 (S % 2) + i
-#define KVH_ROW4(off_, S_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_rs, (off_) + 128u * ((S_) >> 1) + 16u * ((S_) & 1), 0, 0))
+    const unsigned row_bytes = (unsigned)a.C * 4u, lane_off = ((unsigned)a.c0 + 4u * g) * 4u;
+    // piece S of a row: channels 16 S + 4 g + i (dense: the four g lanes of a key read 64 contiguous bytes)
+#define KVH_ROW4(off_, S_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_rs, (off_) + 64u * (S_), 0, 0))
     // the software pipeline of k_attn_kv: window ids three steps ahead, metadata two, raw rows one; every load unconditional
     int w_p;
     float4 wc_m, km_m[KT];
@@ -791,28 +1063,33 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kvh(Attn
         const int nqv = qbase_r + nqv_r <= a.row_capacity ? nqv_r : 0;
         const size_t qbase = (size_t)qbase_r;
         const unsigned vmask = vmask_r, used = used_r;
-        // key tokens = row + relu(positional MLP), split once: A operands of the score product
-        h16x8 Th[KT][NP], Tl[KT][NP];
+        const float ctrb = g == 0 ? wc.x : (g == 1 ? wc.y : wc.z);  // wctr is 0 for g = 3
+        // key tokens = row + relu(positional MLP), split once, straight into the image (both products read it: the score
+        // product row-wise, the second one transposed -- no token registers live across the passes: 4 waves / SIMD)
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-            if (!(used >> t & 1)) {
-#pragma unroll
-                for (int P = 0; P < NP; ++P) Th[t][P] = Tl[t][P] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                continue;
-            }
 #pragma unroll
             for (int P = 0; P < NP; ++P) {
-                f32x4 tk[2];
+                h16x8 th = h16x8{0, 0, 0, 0, 0, 0, 0, 0}, tl = th;
+                if (used >> t & 1) {
+                    f32x4 tk[2];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int u = 2 * P + h;
-                    const float wu = ((wconst[u] + w3[u] * wc.x) + w4[u] * wc.y) + w5[u] * wc.z;
-                    f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    MFMA4(p1, wu, rel_r[t]);
+                    for (int h = 0; h < 2; ++h) {
+                        const int u = 2 * P + h;
+                        float cs = wctr[u] * ctrb;
+                        cs += lane_xor16(cs);
+                        cs += lane_xor32(cs);
+                        const float wu = g == 3 ? wrel[u] + cs : wrel[u];
+                        f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        MFMA4(p1, wu, rel_r[t]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tk[h][i] = T1n[t][u][i] + fmaxf(p1[i], 0.0f);
+                        for (int i = 0; i < 4; ++i) tk[h][i] = T1n[t][u][i] + fmaxf(p1[i], 0.0f);
+                    }
+                    h16_split8(tk[0], tk[1], th, tl);
                 }
-                h16_split8(tk[0], tk[1], Th[t][P], Tl[t][P]);
+                char *dst = Ti + (16 * t + la) * RS + 64 * P + 16 * g;  // key row 16 t + la, the lane's 8 k slots of step P
+                *reinterpret_cast<h16x8 *>(dst) = th;
+                *reinterpret_cast<h16x8 *>(dst + IMG) = tl;
             }
         }
         // first query pass: its Qt fragments travel while the image is written
@@ -826,15 +1103,6 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kvh(Attn
         KVH_ISSUE_ROWS()
         KVH_LOAD_META()
         w_p = a.perm[min(wi + 3 * wstep, w_last)];
-        // image: key row 16 t + la, channels 32 P + 8 g .. + 7
-#pragma unroll
-        for (int t = 0; t < KT; ++t)
-#pragma unroll
-            for (int P = 0; P < NP; ++P) {
-                char *dst = Ti + (16 * t + la) * RS + 64 * P + 16 * g;
-                *reinterpret_cast<h16x8 *>(dst) = Th[t][P];
-                *reinterpret_cast<h16x8 *>(dst + IMG) = Tl[t][P];
-            }
         wave_lds_sync();
         for (int q0 = 0; q0 < nqv; q0 += QPP) {
             const int q = q0 + la / HP;
@@ -854,15 +1122,17 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kvh(Attn
             for (int t = 0; t < KT; ++t) {
                 sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (!(used >> t & 1)) continue;
-                f32x4 mm = sc[t], ml = sc[t], lm = sc[t];
+                f32x4 mm = sc[t], cr = sc[t];
 #pragma unroll
                 for (int P = 0; P < NP; ++P) {
-                    MFMA_H(mm, Th[t][P], qh[P]);
-                    MFMA_H(ml, Th[t][P], ql[P]);
-                    MFMA_H(lm, Tl[t][P], qh[P]);
+                    const char *src = Ti + (16 * t + la) * RS + 64 * P + 16 * g;
+                    const h16x8 th = *reinterpret_cast<const h16x8 *>(src), tl = *reinterpret_cast<const h16x8 *>(src + IMG);
+                    MFMA_H(mm, th, qh[P]);
+                    MFMA_H(cr, th, ql[P]);
+                    MFMA_H(cr, tl, qh[P]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sc[t][i] = __builtin_fmaf(ml[i] + lm[i], H16_INV, mm[i]);
+                for (int i = 0; i < 4; ++i) sc[t][i] = __builtin_fmaf(cr[i], H16_INV, mm[i]);
             }
             float mx = -INFINITY;
 #pragma unroll
@@ -889,19 +1159,20 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kvh(Attn
             for (int s = 0; s < NS; ++s) h16_split8(sc[2 * s] * inv, sc[2 * s + 1] * inv, ph[s], pl[s]);
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
-                f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, ml = mm, lm = mm;
+                f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const char *blk = tr_base + 32 * s * RS + 32 * u;
                     const h16x8 ah = h16_cat(lds_read_tr16(blk), lds_read_tr16(blk + 16 * RS));
                     const h16x8 al = h16_cat(lds_read_tr16(blk + IMG), lds_read_tr16(blk + IMG + 16 * RS));
                     MFMA_H(mm, ah, ph[s]);
-                    MFMA_H(ml, ah, pl[s]);
-                    MFMA_H(lm, al, ph[s]);
+                    MFMA_H(cr, ah, pl[s]);
+                    MFMA_H(cr, al, ph[s]);
                 }
                 if (q_ok)  // xbar replaces qt in place (this lane's own bytes of the row)
-                    store_handoff(xrow + 16 * u + 4 * g, f32x4{__builtin_fmaf(ml[0] + lm[0], H16_INV, mm[0]), __builtin_fmaf(ml[1] + lm[1], H16_INV, mm[1]),
-                                                               __builtin_fmaf(ml[2] + lm[2], H16_INV, mm[2]), __builtin_fmaf(ml[3] + lm[3], H16_INV, mm[3])});
+                    // image column 16 u + 4 g + i is k slot (2 (u % 2) + g / 2, 4 (g % 2) + i) of step u / 2 (see above)
+                    store_handoff(xrow + 32 * (u >> 1) + 16 * (g & 1) + 8 * (u & 1) + 4 * (g >> 1), f32x4{__builtin_fmaf(cr[0], H16_INV, mm[0]), __builtin_fmaf(cr[1], H16_INV, mm[1]),
+                                                               __builtin_fmaf(cr[2], H16_INV, mm[2]), __builtin_fmaf(cr[3], H16_INV, mm[3])});
             }
         }
         wave_lds_sync();  // the next window rewrites the image
@@ -928,10 +1199,24 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, boo
     const int K = pack.g[0].K;
     if constexpr (CG % 32 == 0) {
         if (kv16 && K > 16 && K <= 64) {  // split-fp16 operands in launch B (k_attn_kvh); A writes Qt pre-split
-            constexpr int RS = 2 * CG + 32;
-            const dim3 kv_grid(cus * 3 / ng > 0 ? cus * 3 / ng : 1, ng);
+            constexpr int RS = KVH_RS(CG);
+            static const int kvh_wgs = getenv("MSSVT_ATTN_KVH_WGS") ? atoi(getenv("MSSVT_ATTN_KVH_WGS")) : 0;
+            const int wgs = kvh_wgs > 0 ? kvh_wgs : (K <= 32 ? 4 : 2);  // resident workgroups per CU
+            const dim3 kv_grid(cus * wgs / ng > 0 ? cus * wgs / ng : 1, ng);
             const size_t img = (size_t)ATTN_ROW_WAVES * 2 * 16 * RS;  // per key tile of 16 slots, all waves, hi + lo
-            k_attn_q<CG, HD, HP, true><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
+            bool packed = HD == 16;
+            for (int g = 0; g < ng; ++g) packed = packed && pack.g[g].packed != nullptr;
+            int grid16 = tiles_cap;  // 8-wave workgroups, two per CU
+            if (grid16 > cus * 2 / ng) grid16 = cus * 2 / ng;
+            if (grid16 < 1) grid16 = 1;
+            static const int qo16 = getenv("MSSVT_ATTN_QO16_MASK") ? atoi(getenv("MSSVT_ATTN_QO16_MASK")) : 3;  // 1: A, 2: C
+            const bool q16 = packed && (qo16 & 1), o16 = packed && (qo16 & 2);
+            if constexpr (HD == 16) {
+                if (q16)
+                    k_attn_q16<CG, HP, true><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, AttnBlob<CG>::WV + CG * 4, stream>>>(pack);
+            }
+            if (!q16)
+                k_attn_q<CG, HD, HP, true><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
             if (K <= 32)
                 k_attn_kvh<CG, HD, HP, 2><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 2 * img, stream>>>(pack);
             else {
@@ -940,7 +1225,12 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, boo
                 if (e != hipSuccess) return (int)e;
                 k_attn_kvh<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 4 * img, stream>>>(pack);
             }
-            k_attn_o<CG, HD, HP><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_o, stream>>>(pack);
+            if constexpr (HD == 16) {
+                if (o16)
+                    k_attn_o16<CG, HP><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, AttnBlob<CG>::BYTES - AttnBlob<CG>::WV + 2 * CG * 4, stream>>>(pack);
+            }
+            if (!o16)
+                k_attn_o<CG, HD, HP><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_o, stream>>>(pack);
             return mssvt_launch_status();
         }
     }
@@ -994,7 +1284,8 @@ static int block_attention_impl(
     const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
     const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
     const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
-    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, bool kv16, void *stream) {
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn, bool kv16,
+    const void *const *host_packed, void *stream) {
     if (!host_c0 || !host_cg || !host_heads || !xhat || !num_active_dev || !perm || !q_off || !nq_valid ||
         !num_rows_dev || !qrow_meta || !qrow_src || !host_kmeta || !wcentre || !host_Wq || !host_bq || !host_Wkv ||
         !host_bkv || !host_Wo || !host_bo || !Wpos || !bpos || !qbuf || !attn || C <= 0 || num_groups <= 0 ||
@@ -1029,6 +1320,7 @@ static int block_attention_impl(
         a.qbuf = qbuf + qoff;
         a.attn = attn;
         a.row_capacity = row_capacity;
+        a.packed = host_packed ? host_packed[g] : nullptr;
         qoff += (size_t)row_capacity * (((heads + 3) / 4) * 4) * Cg;
         if (same) {
             pack.g[g] = a;
@@ -1055,244 +1347,35 @@ static int block_attention_impl(
     C, num_groups, host_c0, host_cg, host_heads, head_dim, scale, nq, key_num_sample, xhat, num_active_dev, perm,      \
     q_off, nq_valid, num_rows_dev, row_capacity, qrow_meta, qrow_src, host_kmeta, wcentre, host_Wq, host_bq, host_Wkv, \
     host_bkv, host_Wo, host_bo, Wpos, bpos, qbuf, attn
-extern "C" int mssvt_block_attention(ATTN_ENTRY_PARAMS) { return block_attention_impl(ATTN_ENTRY_ARGS, false, stream); }
+extern "C" int mssvt_block_attention(ATTN_ENTRY_PARAMS) { return block_attention_impl(ATTN_ENTRY_ARGS, false, nullptr, stream); }
 // launch B with split-fp16 matrix operands (k_attn_kvh) where the shape allows (Cg % 32 == 0, 16 < K <= 64), the fp32
-// form otherwise; the CALLER guarantees the fp16 range of key tokens and Qt
-extern "C" int mssvt_block_attention_kv16(ATTN_ENTRY_PARAMS) { return block_attention_impl(ATTN_ENTRY_ARGS, true, stream); }
-
-// cell centre in metres, one rounding per op like the reference's torch expression
-// (ref: with_coords, mssvt_backbone.py:132-137)
-__device__ __forceinline__ float centre_of(int idx, float cell, float lo) {
-    return __fadd_rn(__fmul_rn(__fadd_rn((float)idx, 0.5f), cell), lo);
+// form otherwise; with host_packed (one mssvt_attn_pack_weights blob per group; head_dim 16) launches A and C run on the
+// pre-split fragments too.  The CALLER guarantees the fp16 range of key tokens, Q', Qt, Xbar and V
+extern "C" int mssvt_block_attention_kv16(
+    int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
+    int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
+    const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
+    const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
+    const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
+    const float *const *host_bo, const float *Wpos, const float *bpos, float *qbuf, float *attn,
+    const void *const *host_packed, void *stream) {
+    return block_attention_impl(ATTN_ENTRY_ARGS, true, host_packed, stream);
 }
 
-// ---------------------------------------------------------------------------------
-// interpolation (3-NN, inverse distance) + scatter + first residual
-// ---------------------------------------------------------------------------------
-struct ScatterArgs {
-    int C, nq, n1, interp;
-    const float *attn, *x_in;
-    float *x_new;
-    const int *indices, *win_ind, *num_wins, *win_vstart, *q_ind, *upd_ind, *owner;
-    float vsx, vsy, vsz, minx, miny, minz;
-    // table mode (tab_row != null): nothing is gathered; per owned voxel the three attention
-    // rows and weights are recorded so that a consumer (the fused FFN) can apply them
-    int4 *tab_row;
-    float4 *tab_w;
-    int zero_row;  // row of `attn` that holds zeros: target of empty slots / zero weights
-};
-
-#define SC_WPB 4
-#define SC_MAXQ 256
-#define SC_MAX_SETS 4
-struct ScatterPack {
-    ScatterArgs s[SC_MAX_SETS];
-};
-
-// blockIdx.y = set: the interpolation tables of all (cbs_pattern, interp) variants of a plan in one launch
-__global__ void __launch_bounds__(SC_WPB *MSSVT_WAVE) k_block_scatter(ScatterPack pack) {
-    const ScatterArgs &a = pack.s[blockIdx.y];
-    __shared__ float kx[SC_WPB][SC_MAXQ], ky[SC_WPB][SC_MAXQ], kz[SC_WPB][SC_MAXQ];
-    __shared__ int kvalid[SC_WPB][SC_MAXQ];
-    const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
-    const int nw = *a.num_wins;
-    for (int w = blockIdx.x * SC_WPB + wv; w < nw; w += gridDim.x * SC_WPB) {
-        const int vstart = a.win_vstart[w];
-        if (!a.interp) {  // ref mssvt_backbone.py:327-330: only the query voxels are updated
-            for (int i = 0; i < a.nq; ++i) {
-                const int v = a.q_ind[(size_t)w * a.nq + i];
-                if (v < 0 || a.owner[vstart + v] != w * a.nq + i) continue;
-                if (a.tab_row) {
-                    if (lane == 0) {
-                        a.tab_row[vstart + v] = make_int4(w * a.nq + i, a.zero_row, a.zero_row, 0);
-                        a.tab_w[vstart + v] = make_float4(1.f, 0.f, 0.f, 0.f);
-                    }
-                    continue;
-                }
-                const float *src = a.attn + ((size_t)w * a.nq + i) * a.C;
-                const size_t row = (size_t)(vstart + v) * a.C;
-                for (int c = lane; c < a.C; c += MSSVT_WAVE) a.x_new[row + c] = src[c] + a.x_in[row + c];
-            }
-            continue;
-        }
-        // known points = ALL nq query slots; empty slots sit at the world origin with zero
-        // features (ref :302 gathers coordinates with -1 -> 0 fill) -- kept as is
-        // Candidate list for the 3-NN search, in slot order: every valid slot, and of the EMPTY slots only the
-        // first three -- all empty slots are the same point (the origin), the search keeps the first seen on
-        // ties (strict <), so a fourth one can never enter the best three.  ~5 candidates instead of nq.
-        int ncand = 0, nempty = 0;
-        for (int i0 = 0; i0 < a.nq; i0 += MSSVT_WAVE) {
-            const int i = i0 + lane;
-            int v = -1;
-            float x = 0.f, y = 0.f, z = 0.f;
-            if (i < a.nq) {
-                v = a.q_ind[(size_t)w * a.nq + i];
-                if (v >= 0) {
-                    const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + v];
-                    x = centre_of(vi.w, a.vsx, a.minx);
-                    y = centre_of(vi.z, a.vsy, a.miny);
-                    z = centre_of(vi.y, a.vsz, a.minz);
-                }
-            }
-            const bool empty = i < a.nq && v < 0;
-            const unsigned long long me = __ballot(empty);
-            const bool keep = i < a.nq && (v >= 0 || nempty + __popcll(me & ((1ull << lane) - 1ull)) < 3);
-            const unsigned long long mk = __ballot(keep);
-            if (keep) {
-                const int p = ncand + __popcll(mk & ((1ull << lane) - 1ull));
-                kx[wv][p] = x; ky[wv][p] = y; kz[wv][p] = z;
-                kvalid[wv][p] = (i << 1) | (v >= 0 ? 1 : 0);  // original slot, valid bit
-            }
-            ncand += __popcll(mk);
-            nempty += __popcll(me);
-        }
-        wave_lds_sync();
-        for (int s0 = 0; s0 < a.n1; s0 += MSSVT_WAVE) {
-            const int s = s0 + lane;
-            int v = -1;
-            if (s < a.n1) {
-                v = a.upd_ind[(size_t)w * a.n1 + s];
-                if (v >= 0 && a.owner[vstart + v] != w * a.n1 + s) v = -1;  // another slot owns this voxel
-            }
-            int i1 = 0, i2 = 0, i3 = 0;
-            float w1 = 0.f, w2 = 0.f, w3 = 0.f;
-            if (v >= 0) {  // K9 (ref interpolate_gpu.cu:16-59) + weights (ref mssvt_backbone.py:305-307)
-                const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + v];
-                const float ux = centre_of(vi.w, a.vsx, a.minx), uy = centre_of(vi.z, a.vsy, a.miny),
-                            uz = centre_of(vi.y, a.vsz, a.minz);
-                // the reference keeps the running bests in double (initial 1e40) and compares float distances
-                // against them: the same order as float compares against +inf
-                float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
-                int c1 = -1, c2 = -1, c3 = -1;  // candidate positions
-                for (int k = 0; k < ncand; ++k) {
-                    const float dx = ux - kx[wv][k], dy = uy - ky[wv][k], dz = uz - kz[wv][k];
-                    const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    if (d < b1) { b3 = b2; c3 = c2; b2 = b1; c2 = c1; b1 = d; c1 = k; }
-                    else if (d < b2) { b3 = b2; c3 = c2; b2 = d; c2 = k; }
-                    else if (d < b3) { b3 = d; c3 = k; }
-                }
-                // fewer than three candidates (nq < 3): the reference leaves index 0 / distance 1e40 -> weight ~0
-                const int m1 = c1 >= 0 ? kvalid[wv][c1] : 0, m2 = c2 >= 0 ? kvalid[wv][c2] : 0,
-                          m3 = c3 >= 0 ? kvalid[wv][c3] : 0;
-                i1 = m1 >> 1; i2 = m2 >> 1; i3 = m3 >> 1;
-                const float d1 = fmaxf(c1 >= 0 ? sqrtf(b1) : INFINITY, 1e-10f), d2 = fmaxf(c2 >= 0 ? sqrtf(b2) : INFINITY, 1e-10f),
-                            d3 = fmaxf(c3 >= 0 ? sqrtf(b3) : INFINITY, 1e-10f);
-                w1 = 1.0f / d1; w2 = 1.0f / d2; w3 = 1.0f / d3;
-                const float norm = (w1 + w2) + w3;
-                w1 /= norm; w2 /= norm; w3 /= norm;
-                if (!(m1 & 1) || c1 < 0) w1 = 0.f;  // empty slots carry zero features
-                if (!(m2 & 1) || c2 < 0) w2 = 0.f;
-                if (!(m3 & 1) || c3 < 0) w3 = 0.f;
-            }
-            if (a.tab_row) {
-                if (v >= 0) {
-                    a.tab_row[vstart + v] = make_int4(w1 != 0.f ? w * a.nq + i1 : a.zero_row,
-                                                      w2 != 0.f ? w * a.nq + i2 : a.zero_row,
-                                                      w3 != 0.f ? w * a.nq + i3 : a.zero_row, 0);
-                    a.tab_w[vstart + v] = make_float4(w1, w2, w3, 0.f);
-                }
-                continue;
-            }
-            unsigned long long todo = __ballot(v >= 0);
-            while (todo) {  // one covered voxel at a time, lanes sweep its channels
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int vv = __shfl(v, src);
-                const int j1 = __shfl(i1, src), j2 = __shfl(i2, src), j3 = __shfl(i3, src);
-                const float f1 = __shfl(w1, src), f2 = __shfl(w2, src), f3 = __shfl(w3, src);
-                const float *r1 = a.attn + ((size_t)w * a.nq + j1) * a.C;
-                const float *r2 = a.attn + ((size_t)w * a.nq + j2) * a.C;
-                const float *r3 = a.attn + ((size_t)w * a.nq + j3) * a.C;
-                const size_t row = (size_t)(vstart + vv) * a.C;
-                for (int c = lane; c < a.C; c += MSSVT_WAVE) {
-                    float acc = 0.f;  // a zero weight never touches the (unwritten) row of an empty slot
-                    if (f1 != 0.f) acc = r1[c] * f1;
-                    if (f2 != 0.f) acc += r2[c] * f2;
-                    if (f3 != 0.f) acc += r3[c] * f3;
-                    a.x_new[row + c] = acc + a.x_in[row + c];
-                }
-            }
-        }
-        wave_lds_sync();
-    }
+extern "C" long long mssvt_attn_packed_bytes(int Cg, int head_dim) {
+    if (head_dim != 16) return 0;
+    if (Cg == 64) return AttnBlob<64>::BYTES;
+    if (Cg == 32) return AttnBlob<32>::BYTES;
+    return 0;
 }
 
-extern "C" int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_interpolation,
-                                          const float *attn, const float *x_in, float *x_new,
-                                          const int *indices, const int *win_ind,
-                                          const int *num_wins_dev, int win_capacity,
-                                          const int *win_vstart, const int *q_ind,
-                                          const int *upd_ind, const int *owner,
-                                          const float *host_voxel_size3,
-                                          const float *host_range_min3, void *stream) {
-    if (!attn || !x_in || !x_new || !indices || !win_ind || !num_wins_dev || !win_vstart || !q_ind ||
-        !owner || !host_voxel_size3 || !host_range_min3 || C <= 0 || nq <= 0)
-        return MSSVT_E_BADARG;
-    if (use_interpolation && (!upd_ind || n_upd <= 0)) return MSSVT_E_BADARG;
-    if (nq > SC_MAXQ) return MSSVT_E_TOOLARGE;
-    if (win_capacity <= 0) return MSSVT_OK;
-    ScatterArgs a;
-    a.C = C; a.nq = nq; a.n1 = n_upd; a.interp = use_interpolation;
-    a.attn = attn; a.x_in = x_in; a.x_new = x_new;
-    a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev; a.win_vstart = win_vstart;
-    a.q_ind = q_ind; a.upd_ind = upd_ind; a.owner = owner;
-    a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
-    a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
-    a.tab_row = nullptr; a.tab_w = nullptr; a.zero_row = 0;
-    int grid = divup(win_capacity, SC_WPB);
-    if (grid > 4096) grid = 4096;  // grid-stride over the windows actually present
-    ScatterPack pack;
-    for (int i = 0; i < SC_MAX_SETS; ++i) pack.s[i] = a;
-    k_block_scatter<<<grid, SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(pack);
+extern "C" int mssvt_attn_pack_weights(int Cg, int head_dim, float scale, const float *Wq, const float *Wkv, const float *Wo,
+                                       void *packed, void *stream) {
+    if (!Wq || !Wkv || !Wo || !packed) return MSSVT_E_BADARG;
+    if (head_dim != 16) return MSSVT_E_TOOLARGE;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cg == 64) k_attn_pack<64><<<dim3(16, 4), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
+    else if (Cg == 32) k_attn_pack<32><<<dim3(4, 4), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
+    else return MSSVT_E_TOOLARGE;
     return mssvt_launch_status();
-}
-
-// Table form of mssvt_block_interp_scatter: records, per voxel owned by a list slot, the
-// (up to) three attention rows and inverse-distance weights instead of applying them.
-extern "C" int mssvt_block_interp_table_multi(int num_sets, const int *host_nq, const int *host_n_upd,
-                                              const int *host_interp, const int *indices, const int *win_ind,
-                                              const int *num_wins_dev, int win_capacity, const int *win_vstart,
-                                              const int *const *host_q_ind, const int *const *host_upd_ind,
-                                              const int *const *host_owner, const float *host_voxel_size3,
-                                              const float *host_range_min3, const int *host_zero_row,
-                                              int *const *host_tab_row, float *const *host_tab_w, void *stream) {
-    if (num_sets <= 0 || num_sets > SC_MAX_SETS) return num_sets <= 0 ? MSSVT_E_BADARG : MSSVT_E_TOOLARGE;
-    if (!host_nq || !host_n_upd || !host_interp || !indices || !win_ind || !num_wins_dev || !win_vstart ||
-        !host_q_ind || !host_upd_ind || !host_owner || !host_voxel_size3 || !host_range_min3 || !host_zero_row ||
-        !host_tab_row || !host_tab_w)
-        return MSSVT_E_BADARG;
-    if (win_capacity <= 0) return MSSVT_OK;
-    ScatterPack pack;
-    for (int i = 0; i < SC_MAX_SETS; ++i) {
-        const int k = i < num_sets ? i : 0;
-        if (!host_q_ind[k] || !host_owner[k] || !host_tab_row[k] || !host_tab_w[k] || host_nq[k] <= 0)
-            return MSSVT_E_BADARG;
-        if (host_interp[k] && (!host_upd_ind[k] || host_n_upd[k] <= 0)) return MSSVT_E_BADARG;
-        if (host_nq[k] > SC_MAXQ) return MSSVT_E_TOOLARGE;
-        ScatterArgs &a = pack.s[i];
-        a.C = 0; a.nq = host_nq[k]; a.n1 = host_n_upd[k]; a.interp = host_interp[k];
-        a.attn = nullptr; a.x_in = nullptr; a.x_new = nullptr;
-        a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev; a.win_vstart = win_vstart;
-        a.q_ind = host_q_ind[k]; a.upd_ind = host_upd_ind[k]; a.owner = host_owner[k];
-        a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
-        a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
-        a.tab_row = reinterpret_cast<int4 *>(host_tab_row[k]);
-        a.tab_w = reinterpret_cast<float4 *>(host_tab_w[k]);
-        a.zero_row = host_zero_row[k];
-    }
-    int grid = divup(win_capacity, SC_WPB);
-    if (grid > 16384 / num_sets) grid = 16384 / num_sets;  // ~1 window per wave: the per-window chain is 3 dependent round trips
-    k_block_scatter<<<dim3(grid, num_sets), SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(pack);
-    return mssvt_launch_status();
-}
-
-extern "C" int mssvt_block_interp_table(int nq, int n_upd, int use_interpolation, const int *indices,
-                                        const int *win_ind, const int *num_wins_dev, int win_capacity,
-                                        const int *win_vstart, const int *q_ind, const int *upd_ind,
-                                        const int *owner, const float *host_voxel_size3,
-                                        const float *host_range_min3, int zero_row, int *tab_row,
-                                        float *tab_w, void *stream) {
-    return mssvt_block_interp_table_multi(1, &nq, &n_upd, &use_interpolation, indices, win_ind, num_wins_dev,
-                                          win_capacity, win_vstart, &q_ind, &upd_ind, &owner, host_voxel_size3,
-                                          host_range_min3, &zero_row, &tab_row, &tab_w, stream);
 }

@@ -591,14 +591,19 @@ def _attn_f16_ok(block, r, p):
 # (csrc/block_attn.hip, k_attn_kvh: hi + 2^-11 lo halves, 3 x v_mfma_f32_16x16x32_f16 per product sum, fp32 accumulation --
 # the FFN's arithmetic); "0" keeps the fp32 matrix instruction.  Operands outside the fp16 range always take the fp32 form.
 ATTN_KV16 = os.environ.get("MSSVT_ATTN_KV16", "1") != "0"
+# ... and the two row-tiled launches on pre-split weight fragments (k_attn_q16 / k_attn_o16); "0": fp32 matrix instruction
+ATTN_QO16 = os.environ.get("MSSVT_ATTN_QO16", "1") != "0"
 
 
 @torch.no_grad()
 def _attn_kv16_ok(block, r, p):
-    """True when the matrix operands of k_attn_kvh stay inside the fp16 range whatever the input is: key tokens
-    |xhat| + positional term (as _attn_f16_ok) and Qt = scale Wk_h^T q'_h with |q'_o| <= |Wq_o|_1 tmax + |bq_o|,
-    |Qt_c| <= scale sum_o |Wk_oc| |q'_o|.  Once per parameter version (one small host sync)."""
-    ts = [block.norm1.weight, block.norm1.bias, r["Wp"], r["bp"]] + list(r["Wq"]) + list(r["bq"]) + list(r["Wkv"])
+    """True when the matrix operands of the split-fp16 attention launches stay inside the fp16 range whatever the input
+    is: key / query tokens |xhat| + positional term (as _attn_f16_ok), Q' by |Wq_o|_1 tmax + |bq_o|, Qt = scale Wk_h^T q'_h
+    by scale sum_o |Wk_oc| |q'_o|, Xbar (a convex combination of key tokens) by tmax, V by |Wv_o|_1 tmax + |bv_o|, and the
+    weights themselves.  Once per parameter version (one small host sync); the same pass packs the projections into
+    MFMA fragments (mssvt_attn_pack_weights -> r["kv16_packed"], a ctypes pointer array, or None: shape not instantiated)."""
+    ts = [block.norm1.weight, block.norm1.bias, r["Wp"], r["bp"]] + list(r["Wq"]) + list(r["bq"]) + list(r["Wkv"]) + \
+        list(r["bkv"]) + list(r["Wo"])
     ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + (float(p.coord_bound),) + _content_key(ts)
     if r.get("kv16_ver") != ver:
         g1, b1, Wp, bp = [t.detach().float() for t in ts[:4]]
@@ -606,12 +611,26 @@ def _attn_kv16_ok(block, r, p):
         xmax = (C ** 0.5) * g1.abs().max() + b1.abs().max()
         tmax = xmax + (Wp.reshape(C, -1).abs().sum(1) * p.coord_bound + bp.abs()).max()
         worst = [tmax]
-        for Wq, bq, Wkv in zip(r["Wq"], r["bq"], r["Wkv"]):
+        for Wq, bq, Wkv, bkv, Wo in zip(r["Wq"], r["bq"], r["Wkv"], r["bkv"], r["Wo"]):
             cg = Wq.shape[0]
-            qmax = Wq.detach().abs().sum(1) * tmax + bq.detach().abs()  # (cg) bound of |q'_o|
-            worst.append((Wkv.detach()[:cg].abs() * qmax[:, None]).sum(0).max() * abs(r["scale"]))
+            Wq, bq, Wkv, bkv, Wo = [t.detach().float() for t in (Wq, bq, Wkv, bkv, Wo)]
+            qmax = Wq.abs().sum(1) * tmax + bq.abs()  # (cg) bound of |q'_o|
+            worst += [qmax.max(), (Wkv[:cg].abs() * qmax[:, None]).sum(0).max() * abs(r["scale"]),
+                      (Wkv[cg:].abs().sum(1) * tmax + bkv[cg:].abs()).max(), Wq.abs().max(),
+                      Wkv.abs().max() * max(1.0, abs(r["scale"])), Wo.abs().max()]
         worst = torch.stack([w.float() for w in worst]).max()
         r["kv16_ok"] = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
+        r["kv16_packed"] = None
+        if r["kv16_ok"]:
+            sizes = [int(_lib.lib().mssvt_attn_packed_bytes(_i(int(cg)), _i(r["hd"]))) for cg in r["cg"]]
+            if all(n > 0 for n in sizes):
+                blobs = [torch.empty((n,), dtype=torch.uint8, device=g1.device) for n in sizes]
+                for cg, Wq, Wkv, Wo, blob in zip(r["cg"], r["Wq"], r["Wkv"], r["Wo"], blobs):
+                    _lib.call("mssvt_attn_pack_weights", _i(int(cg)), _i(r["hd"]), _f(r["scale"]),
+                              _lib.ptr(Wq.detach().contiguous()), _lib.ptr(Wkv.detach().contiguous()),
+                              _lib.ptr(Wo.detach().contiguous()), _lib.ptr(blob), _lib.stream())
+                r["kv16_blobs"] = blobs  # keeps the buffers alive
+                r["kv16_packed"] = (ctypes.c_void_p * len(blobs))(*[b.data_ptr() for b in blobs])
         r["kv16_ver"] = ver
     return r["kv16_ok"]
 
@@ -630,7 +649,8 @@ def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
     elif r["bf16_ok"] and getattr(block, "attn_arith", ATTN_ARITH) == "f16x3" and _attn_f16_ok(block, r, p):
         _lib.call("mssvt_block_attention_f16x3", *head, _P(attn), _lib.stream())
     elif getattr(block, "attn_kv16", ATTN_KV16) and _attn_kv16_ok(block, r, p):
-        _lib.call("mssvt_block_attention_kv16", *head, _P(qbuf), _P(attn), _lib.stream())
+        _lib.call("mssvt_block_attention_kv16", *head, _P(qbuf), _P(attn),
+                  r["kv16_packed"] if getattr(block, "attn_qo16", ATTN_QO16) else None, _lib.stream())
     else:
         _lib.call("mssvt_block_attention", *head, _P(qbuf), _P(attn), _lib.stream())
 

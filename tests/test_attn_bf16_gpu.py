@@ -127,7 +127,7 @@ def test_bf16_attention_rows_vs_fp32_kernels():
         od = fused._work_order(blk, p, nq, feats.shape[0])
         qbuf = fused._query_scratch(p, od["row_cap"], blk.ms_attn, feats.device)
         rows = {}
-        blk.attn_kv16 = False  # "f32" = the fp32 matrix instruction
+        blk.attn_kv16 = blk.attn_qo16 = False  # "f32" = the fp32 matrix instruction
         for dt in ("f32", "bf16"):
             blk.attn_dtype = dt
             attn = torch.zeros((p.cap * nq + 1, 128), dtype=torch.float32, device=DEV)
@@ -205,20 +205,24 @@ def test_split_f16_window_launch_attention_rows_vs_fp32_kernels(seed, points, ba
             od = fused._work_order(blk, p, nq, feats.shape[0])
             qbuf = fused._query_scratch(p, od["row_cap"], blk.ms_attn, feats.device)
             assert fused._attn_kv16_ok(blk, fused._attn_refs(blk, None), p)
+            assert fused._attn_refs(blk, None)["kv16_packed"] is not None
             rows = {}
-            for kv16 in (False, True):
-                blk.attn_kv16 = kv16
+            for mode in ("f32", "kv16", "kv16+qo16"):  # window launch alone / all three launches on split-fp16 operands
+                blk.attn_kv16, blk.attn_qo16 = mode != "f32", mode == "kv16+qo16"
                 attn = torch.zeros((p.cap * nq + 1, 128), dtype=torch.float32, device=DEV)
                 fused._attention_call(blk, p, od, 128, nq, xhat, qbuf, attn)
-                rows[kv16] = attn
+                rows[mode] = attn
             nw = int(p.num_wins.item())
             valid = (q_ind[:nw] >= 0).reshape(-1)
-            a, b = rows[False][:nw * nq][valid], rows[True][:nw * nq][valid]
-            assert a.shape[0] > 1000 and not torch.equal(a, b)
-            assert torch.equal(rows[False][:nw * nq][~valid], rows[True][:nw * nq][~valid])
+            a = rows["f32"][:nw * nq][valid]
+            assert a.shape[0] > 1000
             tol = 1e-5 * float(a.abs().max()) + 1e-4 * a.abs()
-            assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
-            print("kv16 vs fp32 launches: max |diff| / max |ref| = %.2e" % (float((a - b).abs().max()) / float(a.abs().max())))
+            for mode in ("kv16", "kv16+qo16"):
+                b = rows[mode][:nw * nq][valid]
+                assert not torch.equal(a, b)
+                assert torch.equal(rows["f32"][:nw * nq][~valid], rows[mode][:nw * nq][~valid])
+                assert bool(((a - b).abs() <= tol).all()), (mode, float(((a - b).abs() / tol).max()))
+                print("%s vs fp32 launches: max |diff| / max |ref| = %.2e" % (mode, float((a - b).abs().max()) / float(a.abs().max())))
 
 
 def test_split_f16_window_launch_range_guard():

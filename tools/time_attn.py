@@ -29,14 +29,18 @@ with torch.no_grad():
         od = fused._work_order(blk, p, nq, feats.shape[0])
         qbuf = fused._query_scratch(p, od["row_cap"], blk.ms_attn, dev)
         outs = {}
-        for dt in ("f32", "kv16", "bf16"):
+        for dt in ("f32", "kv16", "kv16+qo16", "bf16"):
             blk.attn_dtype = "bf16" if dt == "bf16" else "f32"
-            blk.attn_kv16 = dt == "kv16"
+            blk.attn_kv16 = dt.startswith("kv16")
+            blk.attn_qo16 = dt == "kv16+qo16"
             attn = torch.zeros((p.cap * nq + 1, 128), dtype=torch.float32, device=dev)
             ms = bench.event_time_ms(lambda: fused._attention_call(blk, p, od, 128, nq, xhat, qbuf, attn), 20)
             outs[dt] = attn
             print("block %d (cbs_pattern %d, %d windows, %d query rows) %s: %.1f us" % (
                 bi, blk.cbs_pattern, int(p.num_wins.item()), int(od["n_rows"].item()), dt, ms * 1e3))
+        a, b = outs["f32"], outs["kv16+qo16"]
+        print("   kv16+qo16 vs f32: max err / max = %.3e, rms err / rms = %.3e" % (
+            float((a - b).abs().max() / a.abs().max()), float((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt())))
         a, b = outs["f32"], outs["kv16"]
         print("   kv16 vs f32: max err / max = %.3e, rms err / rms = %.3e" % (
             float((a - b).abs().max() / a.abs().max()), float((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt())))
