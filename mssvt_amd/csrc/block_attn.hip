@@ -421,13 +421,15 @@ __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_o(AttnPack p
 //   WkF [h][u][hi | lo][lane] x  8 B   A rows c = (16 * u + m), k slot (g, j) <-> o = 16 h + 4 g + j   (x scale)
 //   WvF [t][P][hi | lo][lane] x 16 B   A rows o = 16 t + m,        k slot (g, j) <-> the same channel of Xbar_t
 //   WoF [u][s][hi | lo][lane] x 16 B   A rows p = 16 u + m,        k slot (g, j) <-> o = 32 s + 16 (j / 4) + 4 g + j % 4
+//   WkF2 [p][u][hi | lo][lane] x 16 B  WkF of heads 2 p (j < 4) and 2 p + 1 (j >= 4) side by side: one K = 32 instruction
+//                                      per head PAIR in k_attn_kvh<.., QP> (its B operand is zero outside the column's head)
 #define ATTN_QO16_WAVES 8
 #define MFMA_H16(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x16f16((av), (bv), acc, 0, 0, 0)
 template <int CG>
 struct AttnBlob {
     static constexpr int NT = CG / 16, NP = CG / 32;
     static constexpr int WQ = 0, WK = WQ + NT * NP * 2 * 64 * 16, WV = WK + NT * NT * 2 * 64 * 8, WO = WV + NT * NP * 2 * 64 * 16,
-                         BYTES = WO + NT * NP * 2 * 64 * 16;
+                         WK2 = WO + NT * NP * 2 * 64 * 16, BYTES = WK2 + (NT / 2) * NT * 2 * 64 * 16;
 };
 
 template <int CG>
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(MSSVT_WAVE) k_attn_pack(const float *Wq, const
     using L = AttnBlob<CG>;
     constexpr int NT = L::NT, NP = L::NP;
     const int lane = lane_id(), m = lane & 15, g = lane >> 4, f = blockIdx.x;  // fragment index within its matrix
-    const int which = blockIdx.y;                                              // 0 Wq, 1 Wk, 2 Wv, 3 Wo
+    const int which = blockIdx.y;                                              // 0 Wq, 1 Wk, 2 Wv, 3 Wo, 4 Wk head pairs
     if (which == 1) {
         if (f >= NT * NT) return;
         const int h = f / NT, u = f % NT;
@@ -445,6 +447,22 @@ __global__ void __launch_bounds__(MSSVT_WAVE) k_attn_pack(const float *Wq, const
         h16x4 hi, lo;
         h16_split4(v, hi, lo);
         h16x4 *dst = reinterpret_cast<h16x4 *>(blob + L::WK) + (size_t)f * 2 * 64 + lane;
+        dst[0] = hi;
+        dst[64] = lo;
+        return;
+    }
+    if (which == 4) {
+        if (f >= (NT / 2) * NT) return;
+        const int pr = f / NT, u = f % NT;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = Wkv[(size_t)(16 * (2 * pr) + 4 * g + j) * CG + (16 * u + m)] * scale;
+            v1[j] = Wkv[(size_t)(16 * (2 * pr + 1) + 4 * g + j) * CG + (16 * u + m)] * scale;
+        }
+        h16x8 hi, lo;
+        h16_split8(v0, v1, hi, lo);
+        h16x8 *dst = reinterpret_cast<h16x8 *>(blob + L::WK2) + (size_t)f * 2 * 64 + lane;
         dst[0] = hi;
         dst[64] = lo;
         return;
@@ -479,9 +497,12 @@ __device__ __forceinline__ void attn_stage16(float4 *lds, const float4 *src) {
     }
 }
 
-// ---- A, kv16 form: rows -> Qt.  KV16OUT: Qt as (hi, lo) fragments for k_attn_kvh, else fp32 for k_attn_kv
+// ---- A, kv16 form: rows -> Qt.  OUT 0: Qt in fp32 for k_attn_kv; 1: Qt as (hi, lo) fragments for k_attn_kvh<.., false>;
+// 2: only Q' (scaled by the Wk fragments later) as (hi, lo) B fragments of the K = 16 product, [head][g][hi x 4 | lo x 4]
+// = 4 Cg bytes at the start of the row -- k_attn_kvh<.., true> multiplies by Wk_h itself: a quarter of the hand-off bytes
+// (this launch is bound by writing them: 67 MB for 33 k query rows) and of this launch's matrix work
 // (sched_barriers: without them the scheduler hoists the fragment reads of every step and spills ~100 registers)
-template <int CG, int HP, bool KV16OUT>
+template <int CG, int HP, int OUT>
 __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_q16(AttnPack pack) {
     const AttnArgs &a = pack.g[blockIdx.y];
     using L = AttnBlob<CG>;
@@ -489,7 +510,8 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_q16(Att
     extern __shared__ float4 lds4[];
     const h16x8 *WqF = reinterpret_cast<const h16x8 *>(lds4);
     const h16x4 *WkF = reinterpret_cast<const h16x4 *>(reinterpret_cast<const char *>(lds4) + L::WK);
-    float *bq_l = reinterpret_cast<float *>(reinterpret_cast<char *>(lds4) + L::WV);
+    constexpr int STAGED = OUT == 2 ? L::WK : L::WV;  // Wq fragments (+ Wk fragments)
+    float *bq_l = reinterpret_cast<float *>(reinterpret_cast<char *>(lds4) + STAGED);
     const int lane = lane_id(), r = lane & 15, g = lane >> 4;
     const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
     const int wv = threadIdx.x / MSSVT_WAVE;
@@ -497,7 +519,7 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_q16(Att
     int tile = wv * gridDim.x + blockIdx.x;
     float4 rm = a.qrow_meta[min(tile * 16 + r, rows - 1)];
     int2 src = a.qrow_src[min(tile * 16 + r, rows - 1)];
-    attn_stage16<L::WV / 16, ATTN_QO16_WAVES * MSSVT_WAVE>(lds4, reinterpret_cast<const float4 *>(a.packed));
+    attn_stage16<STAGED / 16, ATTN_QO16_WAVES * MSSVT_WAVE>(lds4, reinterpret_cast<const float4 *>(a.packed));
     if (threadIdx.x < CG) bq_l[threadIdx.x] = a.bq[threadIdx.x];
     // positional MLP as two K = 4 products (relative offset | 1, window centre): A row r of tile u <-> channel (16 * u + r)
     float wrel[NT], wctr[NT];
@@ -560,9 +582,16 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_q16(Att
                              __builtin_fmaf(cr[2], H16_INV, mm[2]), __builtin_fmaf(cr[3], H16_INV, mm[3])}, qh[t], ql[t]);
             if (t & 1) __builtin_amdgcn_sched_barrier(0);
         }
-        // GEMM2^T per head (= tile h): Qt_h^T[c][row] = sum_{o in head h} (scale Wk[o][c]) Q'[row][o]
         const bool row_ok = tile * 16 + r < rows;
         float *dst = a.qbuf + (size_t)(tile * 16 + r) * QROW;
+        if (OUT == 2) {  // lane (row, g) holds Q'[row][16 t + 4 g + i]: the B fragment of head t, lanes (., g)
+            h16x8 *dq = reinterpret_cast<h16x8 *>(dst);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (row_ok) dq[t * 4 + g] = h16_cat(qh[t], ql[t]);
+            continue;
+        }
+        // GEMM2^T per head (= tile h): Qt_h^T[c][row] = sum_{o in head h} (scale Wk[o][c]) Q'[row][o]
 #pragma unroll
         for (int h = 0; h < NT; ++h) {
 #pragma unroll
@@ -579,7 +608,7 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_q16(Att
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[e][i] = __builtin_fmaf(cr[i], H16_INV, mm[i]);
                 }
-                if (KV16OUT) {
+                if (OUT == 1) {
                     h16x8 *dsth = reinterpret_cast<h16x8 *>(dst + h * CG);
                     h16x8 hi, lo;
                     h16_split8(acc[0], acc[1], hi, lo);
@@ -607,7 +636,7 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_o16(Att
     extern __shared__ float4 lds4[];
     const h16x8 *WvF = reinterpret_cast<const h16x8 *>(lds4);
     const h16x8 *WoF = reinterpret_cast<const h16x8 *>(reinterpret_cast<const char *>(lds4) + (L::WO - L::WV));
-    float *bv_l = reinterpret_cast<float *>(reinterpret_cast<char *>(lds4) + (L::BYTES - L::WV)), *bo_l = bv_l + CG;
+    float *bv_l = reinterpret_cast<float *>(reinterpret_cast<char *>(lds4) + (L::WK2 - L::WV)), *bo_l = bv_l + CG;
     const int lane = lane_id(), r = lane & 15, g = lane >> 4;
     const int rows = *a.num_rows, tiles = (rows + 15) >> 4;
     const int wv = threadIdx.x / MSSVT_WAVE;
@@ -623,7 +652,7 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_o16(Att
         }                                                                                                 \
     }
     ATTN_O16_ROWS(x, min(tile * 16 + r, rows - 1), 0)
-    attn_stage16<(L::BYTES - L::WV) / 16, ATTN_QO16_WAVES * MSSVT_WAVE>(
+    attn_stage16<(L::WK2 - L::WV) / 16, ATTN_QO16_WAVES * MSSVT_WAVE>(
         lds4, reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.packed) + L::WV));
     if (threadIdx.x < CG) {
         bv_l[threadIdx.x] = a.bkv[CG + threadIdx.x];
@@ -984,8 +1013,24 @@ __device__ __forceinline__ h16x4 lds_read_tr16(const char *p) {
     return __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
         (__attribute__((address_space(3))) fp16v4 *)(p)));
 }
-template <int CG, int HD, int HP, int KT>
-__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k_attn_kvh(AttnPack pack) {
+// KVH_QT_AHEAD = 1: the first-pass Qt fragments of a window are requested one window ahead like its key rows (16 more
+// VGPRs: 3 waves / SIMD).  Measured on one box (tools/ab_kvh.sh): 94.2 / 46.9 us per Block attention against 91.6 / 45.5
+// without -- the window launch is not waiting for these loads, it is short of vector-memory issue slots (tools/ablate_kvh.sh:
+// dropping the 4 Qt loads of a pass -7.3 us, the 4 Xbar stores -5.9 us, serving the key rows from 8 hot rows -0.6 us).
+#ifndef KVH_QT_AHEAD
+#define KVH_QT_AHEAD 0
+#endif
+#ifdef KVH_ABLATE
+#define KVH_ABL(k_) (KVH_ABLATE == (k_))
+#else
+#define KVH_ABL(k_) false
+#endif
+// QP: the hand-off rows hold Q' fragments (k_attn_q16<.., 2>) and Qt_h = (scale Wk_h)^T q'_h is formed here, per pass, from the
+// Wk fragments of the pack blob staged into the LDS: one product per head with the columns of the other heads zeroed in
+// the B operand, all accumulated into one tile -- NH x NT x 3 K = 16 instructions for 1 instead of 4 row loads per lane
+template <int CG, int HD, int HP, int KT, bool QP>
+__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_AHEAD || QP ? 3 : 4) : 2) k_attn_kvh(AttnPack pack) {
+    static_assert(!QP || (HD == 16 && (CG / HD) % 2 == 0 && !KVH_QT_AHEAD), "Q' hand-off: head = one 16-row tile, heads in pairs");
     static_assert(CG % 32 == 0 && KT % 2 == 0, "32-channel and 32-key steps");
     const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int NT = CG / 16, NP = CG / 32, NS = KT / 2, NH = CG / HD, QROW = HP * CG, QPP = 16 / HP;
@@ -993,7 +1038,14 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
     extern __shared__ float4 lds4[];
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = threadIdx.x / MSSVT_WAVE;
-    char *Ti = reinterpret_cast<char *>(lds4) + (size_t)wv * 2 * IMG;
+    constexpr int WKB = QP ? AttnBlob<CG>::BYTES - AttnBlob<CG>::WK2 : 0;  // bytes of Wk pair fragments in front of the images
+    char *Ti = reinterpret_cast<char *>(lds4) + WKB + (size_t)wv * 2 * IMG;
+    const h16x8 *WkF2 = reinterpret_cast<const h16x8 *>(lds4);
+    if (QP) {  // before any wave can leave: every wave of the workgroup meets at the barrier
+        attn_stage16<(WKB > 0 ? WKB : 16) / 16, ATTN_ROW_WAVES * MSSVT_WAVE>(
+            lds4, reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.packed) + AttnBlob<CG>::WK2));
+        __syncthreads();
+    }
     // positional MLP operand of this lane: A row la of tile u <-> channel (16 * u + la), input g: the weight of the
     // relative offset (g < 3) | bias + window-centre part (g = 3: summed over the three lanes that hold its weights)
     float wrel[NT], wctr[NT];
@@ -1043,7 +1095,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
             vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
             used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
             rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
-            const unsigned ro_ = (unsigned)__umul24((unsigned)(ok_ ? r_ : 0), row_bytes) + lane_off; \
+            const unsigned ro_ = (unsigned)__umul24((unsigned)(KVH_ABL(1) ? (r_ & 7) : ok_ ? r_ : 0), row_bytes) + lane_off; \
             _Pragma("unroll") for (int S = 0; S < NT; ++S) T1n[t][S] = KVH_ROW4(ro_, S);   \
         }                                                                                  \
     }
@@ -1051,13 +1103,30 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
     w_p = a.perm[wi];
     KVH_LOAD_META()
     w_p = a.perm[min(wi + wstep, w_last)];
+    const int hh = la % HP;
+    const bool head_ok = hh < NH;
+    // first-pass Qt fragments of a window travel one window ahead as well (stage R): issued before the previous window's
+    // Xbar stores, so that waiting for them never waits for those stores (vmcnt retires in order)
+    h16x8 qh_r[NP], ql_r[NP];
+    (void)qh_r; (void)ql_r;
+#define KVH_ISSUE_QT()                                                                     \
+    {                                                                                      \
+        const int nq_ = qbase_r + nqv_r <= a.row_capacity ? nqv_r : 0;                     \
+        const h16x8 *qr_ = reinterpret_cast<const h16x8 *>(                                \
+            a.qbuf + ((size_t)qbase_r + max(min(la / HP, nq_ - 1), 0)) * QROW + (head_ok ? hh : 0) * CG); \
+        _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                   \
+            qh_r[P] = qr_[(P * 4 + g) * 2];                                                \
+            ql_r[P] = qr_[(P * 4 + g) * 2 + 1];                                            \
+        }                                                                                  \
+    }
     KVH_ISSUE_ROWS()
+#if KVH_QT_AHEAD
+    KVH_ISSUE_QT()
+#endif
     KVH_LOAD_META()
     w_p = a.perm[min(wi + 2 * wstep, w_last)];
     // transposed reads: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of its 4 x 16 block
     const char *tr_base = Ti + (4 * g + (la >> 2)) * RS + 8 * (la & 3);
-    const int hh = la % HP;
-    const bool head_ok = hh < NH;
     for (; wi < n_act; wi += wstep) {
         const float4 wc = wc_r;
         const int nqv = qbase_r + nqv_r <= a.row_capacity ? nqv_r : 0;
@@ -1071,7 +1140,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
 #pragma unroll
             for (int P = 0; P < NP; ++P) {
                 h16x8 th = h16x8{0, 0, 0, 0, 0, 0, 0, 0}, tl = th;
-                if (used >> t & 1) {
+                if (KVH_ABL(6)) { th = __builtin_bit_cast(h16x8, T1n[t][2 * P]); tl = __builtin_bit_cast(h16x8, T1n[t][2 * P + 1]); }
+                else if (used >> t & 1) {
                     f32x4 tk[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -1092,15 +1162,30 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
                 *reinterpret_cast<h16x8 *>(dst + IMG) = tl;
             }
         }
-        // first query pass: its Qt fragments travel while the image is written
-        const h16x8 *qrow = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + min(la / HP, nqv - 1)) * QROW + (head_ok ? hh : 0) * CG);
         h16x8 qh[NP], ql[NP];
+#if KVH_QT_AHEAD
 #pragma unroll
         for (int P = 0; P < NP; ++P) {
-            qh[P] = qrow[(P * 4 + g) * 2];
-            ql[P] = qrow[(P * 4 + g) * 2 + 1];
+            qh[P] = qh_r[P];
+            ql[P] = ql_r[P];
         }
+#else
+        h16x8 qp8 = h16x8{0, 0, 0, 0, 0, 0, 0, 0};  // Q' mode: (hi x 4 | lo x 4) of this lane's column
+        if (QP) {
+            qp8 = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + max(min(la / HP, nqv - 1), 0)) * QROW)[(head_ok ? hh : 0) * 4 + g];
+        } else {
+            const h16x8 *qr_ = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + max(min(la / HP, nqv - 1), 0)) * QROW + (head_ok ? hh : 0) * CG);
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                qh[P] = qr_[(P * 4 + g) * 2];
+                ql[P] = qr_[(P * 4 + g) * 2 + 1];
+            }
+        }
+#endif
         KVH_ISSUE_ROWS()
+#if KVH_QT_AHEAD
+        KVH_ISSUE_QT()
+#endif
         KVH_LOAD_META()
         w_p = a.perm[min(wi + 3 * wstep, w_last)];
         wave_lds_sync();
@@ -1109,11 +1194,44 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
             const bool q_ok = q < nqv && head_ok;
             float *xrow = a.qbuf + (qbase + min(q, nqv - 1)) * QROW + (head_ok ? hh : 0) * CG;
             if (q0 > 0) {
-                qrow = reinterpret_cast<const h16x8 *>(xrow);
+                if (QP) {
+                    qp8 = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + min(q, nqv - 1)) * QROW)[(head_ok ? hh : 0) * 4 + g];
+                } else {
+                    const h16x8 *qrow = reinterpret_cast<const h16x8 *>(xrow);
+#pragma unroll
+                    for (int P = 0; P < NP; ++P) {
+                        if (KVH_ABL(3)) continue;
+                        qh[P] = qrow[(P * 4 + g) * 2];
+                        ql[P] = qrow[(P * 4 + g) * 2 + 1];
+                    }
+                }
+            }
+            if (QP) {
+                // Qt^T[c][col] = sum_h sum_{k < 16} (scale Wk)[16 h + k][c] Q'[q(col)][16 h + k] [h == head(col)]
+                const h16x4 z4 = h16x4{0, 0, 0, 0};
+                const h16x4 bh = h16x4{qp8[0], qp8[1], qp8[2], qp8[3]}, bl = h16x4{qp8[4], qp8[5], qp8[6], qp8[7]};
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist all 32 fragment reads: 70 spilled registers)
 #pragma unroll
                 for (int P = 0; P < NP; ++P) {
-                    qh[P] = qrow[(P * 4 + g) * 2];
-                    ql[P] = qrow[(P * 4 + g) * 2 + 1];
+                    f32x4 qt[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int u = 2 * P + e;
+                        f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
+#pragma unroll
+                        for (int pr = 0; pr < NH / 2; ++pr) {  // heads 2 pr | 2 pr + 1 in the two halves of the k slots
+                            const h16x8 wh = WkF2[((pr * NT + u) * 2) * 64 + lane], wl = WkF2[((pr * NT + u) * 2 + 1) * 64 + lane];
+                            const h16x8 sh = h16_cat(hh == 2 * pr ? bh : z4, hh == 2 * pr + 1 ? bh : z4),
+                                        sl = h16_cat(hh == 2 * pr ? bl : z4, hh == 2 * pr + 1 ? bl : z4);
+                            MFMA_H(mm, wh, sh);
+                            MFMA_H(cr, wh, sl);
+                            MFMA_H(cr, wl, sh);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) qt[e][i] = __builtin_fmaf(cr[i], H16_INV, mm[i]);
+                    }
+                    h16_split8(qt[0], qt[1], qh[P], ql[P]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // scores S[key][col] = sum_c T[key][c] Qt[col][c]
@@ -1125,6 +1243,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
                 f32x4 mm = sc[t], cr = sc[t];
 #pragma unroll
                 for (int P = 0; P < NP; ++P) {
+                    if (KVH_ABL(5)) { mm[0] += (float)qh[P][t]; continue; }
                     const char *src = Ti + (16 * t + la) * RS + 64 * P + 16 * g;
                     const h16x8 th = *reinterpret_cast<const h16x8 *>(src), tl = *reinterpret_cast<const h16x8 *>(src + IMG);
                     MFMA_H(mm, th, qh[P]);
@@ -1162,6 +1281,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
                 f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
+                    if (KVH_ABL(4)) { mm[0] += (float)ph[s][u]; continue; }
                     const char *blk = tr_base + 32 * s * RS + 32 * u;
                     const h16x8 ah = h16_cat(lds_read_tr16(blk), lds_read_tr16(blk + 16 * RS));
                     const h16x8 al = h16_cat(lds_read_tr16(blk + IMG), lds_read_tr16(blk + IMG + 16 * RS));
@@ -1169,7 +1289,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
                     MFMA_H(cr, ah, pl[s]);
                     MFMA_H(cr, al, ph[s]);
                 }
-                if (q_ok)  // xbar replaces qt in place (this lane's own bytes of the row)
+                if (q_ok && !(KVH_ABL(2) && mm[0] != 12345.f))  // xbar replaces qt in place (this lane's own bytes of the row)
                     // image column 16 u + 4 g + i is k slot (2 (u % 2) + g / 2, 4 (g % 2) + i) of step u / 2 (see above)
                     store_handoff(xrow + 32 * (u >> 1) + 16 * (g & 1) + 8 * (u & 1) + 4 * (g >> 1), f32x4{__builtin_fmaf(cr[0], H16_INV, mm[0]), __builtin_fmaf(cr[1], H16_INV, mm[1]),
                                                                __builtin_fmaf(cr[2], H16_INV, mm[2]), __builtin_fmaf(cr[3], H16_INV, mm[3])});
@@ -1178,6 +1298,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? 4 : 2) k
         wave_lds_sync();  // the next window rewrites the image
     }
 #undef KVH_LOAD_META
+#undef KVH_ISSUE_QT
 #undef KVH_ISSUE_ROWS
 #undef KVH_ROW4
 }
@@ -1201,33 +1322,42 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, boo
         if (kv16 && K > 16 && K <= 64) {  // split-fp16 operands in launch B (k_attn_kvh); A writes Qt pre-split
             constexpr int RS = KVH_RS(CG);
             static const int kvh_wgs = getenv("MSSVT_ATTN_KVH_WGS") ? atoi(getenv("MSSVT_ATTN_KVH_WGS")) : 0;
-            const int wgs = kvh_wgs > 0 ? kvh_wgs : (K <= 32 ? 4 : 2);  // resident workgroups per CU
+            const int wgs = kvh_wgs > 0 ? kvh_wgs : (K <= 32 ? (KVH_QT_AHEAD ? 3 : 4) : 2);  // resident workgroups per CU
             const dim3 kv_grid(cus * wgs / ng > 0 ? cus * wgs / ng : 1, ng);
             const size_t img = (size_t)ATTN_ROW_WAVES * 2 * 16 * RS;  // per key tile of 16 slots, all waves, hi + lo
-            bool packed = HD == 16;
+            bool packed = HD == 16 && !KVH_QT_AHEAD;
             for (int g = 0; g < ng; ++g) packed = packed && pack.g[g].packed != nullptr;
             int grid16 = tiles_cap;  // 8-wave workgroups, two per CU
             if (grid16 > cus * 2 / ng) grid16 = cus * 2 / ng;
             if (grid16 < 1) grid16 = 1;
-            static const int qo16 = getenv("MSSVT_ATTN_QO16_MASK") ? atoi(getenv("MSSVT_ATTN_QO16_MASK")) : 3;  // 1: A, 2: C
-            const bool q16 = packed && (qo16 & 1), o16 = packed && (qo16 & 2);
+            static const int qo16 = getenv("MSSVT_ATTN_QO16_MASK") ? atoi(getenv("MSSVT_ATTN_QO16_MASK")) : 7;  // 1: A, 2: C, 4: Q' hand-off
+            const bool q16 = packed && (qo16 & 1), o16 = packed && (qo16 & 2), qp = q16 && (qo16 & 4) && K <= 32;
+            if constexpr (HD == 16 && !KVH_QT_AHEAD) {
+                if (qp) {
+                    using L = AttnBlob<CG>;
+                    const dim3 qp_grid(cus * 3 / ng > 0 ? cus * 3 / ng : 1, ng);
+                    k_attn_q16<CG, HP, 2><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, L::WK + CG * 4, stream>>>(pack);
+                    k_attn_kvh<CG, HD, HP, 2, true><<<qp_grid, ATTN_ROW_WAVES * MSSVT_WAVE, (L::BYTES - L::WK2) + 2 * img, stream>>>(pack);
+                }
+            }
             if constexpr (HD == 16) {
-                if (q16)
-                    k_attn_q16<CG, HP, true><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, AttnBlob<CG>::WV + CG * 4, stream>>>(pack);
+                if (q16 && !qp)
+                    k_attn_q16<CG, HP, 1><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, AttnBlob<CG>::WV + CG * 4, stream>>>(pack);
             }
             if (!q16)
                 k_attn_q<CG, HD, HP, true><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_q, stream>>>(pack);
-            if (K <= 32)
-                k_attn_kvh<CG, HD, HP, 2><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 2 * img, stream>>>(pack);
+            if (qp) {
+            } else if (K <= 32)
+                k_attn_kvh<CG, HD, HP, 2, false><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 2 * img, stream>>>(pack);
             else {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_kvh<CG, HD, HP, 4>),
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_kvh<CG, HD, HP, 4, false>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * img));
                 if (e != hipSuccess) return (int)e;
-                k_attn_kvh<CG, HD, HP, 4><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 4 * img, stream>>>(pack);
+                k_attn_kvh<CG, HD, HP, 4, false><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 4 * img, stream>>>(pack);
             }
             if constexpr (HD == 16) {
                 if (o16)
-                    k_attn_o16<CG, HP><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, AttnBlob<CG>::BYTES - AttnBlob<CG>::WV + 2 * CG * 4, stream>>>(pack);
+                    k_attn_o16<CG, HP><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, AttnBlob<CG>::WK2 - AttnBlob<CG>::WV + 2 * CG * 4, stream>>>(pack);
             }
             if (!o16)
                 k_attn_o<CG, HD, HP><<<dim3(row_grid, ng), ATTN_QO_WAVES * MSSVT_WAVE, lds_o, stream>>>(pack);
@@ -1374,8 +1504,245 @@ extern "C" int mssvt_attn_pack_weights(int Cg, int head_dim, float scale, const 
     if (!Wq || !Wkv || !Wo || !packed) return MSSVT_E_BADARG;
     if (head_dim != 16) return MSSVT_E_TOOLARGE;
     hipStream_t st = (hipStream_t)stream;
-    if (Cg == 64) k_attn_pack<64><<<dim3(16, 4), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
-    else if (Cg == 32) k_attn_pack<32><<<dim3(4, 4), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
+    if (Cg == 64) k_attn_pack<64><<<dim3(16, 5), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
+    else if (Cg == 32) k_attn_pack<32><<<dim3(4, 5), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
     else return MSSVT_E_TOOLARGE;
     return mssvt_launch_status();
+}
+
+// cell centre in metres, one rounding per op like the reference's torch expression
+// (ref: with_coords, mssvt_backbone.py:132-137)
+__device__ __forceinline__ float centre_of(int idx, float cell, float lo) {
+    return __fadd_rn(__fmul_rn(__fadd_rn((float)idx, 0.5f), cell), lo);
+}
+
+// ---------------------------------------------------------------------------------
+// interpolation (3-NN, inverse distance) + scatter + first residual
+// ---------------------------------------------------------------------------------
+struct ScatterArgs {
+    int C, nq, n1, interp;
+    const float *attn, *x_in;
+    float *x_new;
+    const int *indices, *win_ind, *num_wins, *win_vstart, *q_ind, *upd_ind, *owner;
+    float vsx, vsy, vsz, minx, miny, minz;
+    // table mode (tab_row != null): nothing is gathered; per owned voxel the three attention
+    // rows and weights are recorded so that a consumer (the fused FFN) can apply them
+    int4 *tab_row;
+    float4 *tab_w;
+    int zero_row;  // row of `attn` that holds zeros: target of empty slots / zero weights
+};
+
+#define SC_WPB 4
+#define SC_MAXQ 256
+#define SC_MAX_SETS 4
+struct ScatterPack {
+    ScatterArgs s[SC_MAX_SETS];
+};
+
+// blockIdx.y = set: the interpolation tables of all (cbs_pattern, interp) variants of a plan in one launch
+__global__ void __launch_bounds__(SC_WPB *MSSVT_WAVE) k_block_scatter(ScatterPack pack) {
+    const ScatterArgs &a = pack.s[blockIdx.y];
+    __shared__ float kx[SC_WPB][SC_MAXQ], ky[SC_WPB][SC_MAXQ], kz[SC_WPB][SC_MAXQ];
+    __shared__ int kvalid[SC_WPB][SC_MAXQ];
+    const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    const int nw = *a.num_wins;
+    for (int w = blockIdx.x * SC_WPB + wv; w < nw; w += gridDim.x * SC_WPB) {
+        const int vstart = a.win_vstart[w];
+        if (!a.interp) {  // ref mssvt_backbone.py:327-330: only the query voxels are updated
+            for (int i = 0; i < a.nq; ++i) {
+                const int v = a.q_ind[(size_t)w * a.nq + i];
+                if (v < 0 || a.owner[vstart + v] != w * a.nq + i) continue;
+                if (a.tab_row) {
+                    if (lane == 0) {
+                        a.tab_row[vstart + v] = make_int4(w * a.nq + i, a.zero_row, a.zero_row, 0);
+                        a.tab_w[vstart + v] = make_float4(1.f, 0.f, 0.f, 0.f);
+                    }
+                    continue;
+                }
+                const float *src = a.attn + ((size_t)w * a.nq + i) * a.C;
+                const size_t row = (size_t)(vstart + v) * a.C;
+                for (int c = lane; c < a.C; c += MSSVT_WAVE) a.x_new[row + c] = src[c] + a.x_in[row + c];
+            }
+            continue;
+        }
+        // known points = ALL nq query slots; empty slots sit at the world origin with zero
+        // features (ref :302 gathers coordinates with -1 -> 0 fill) -- kept as is
+        // Candidate list for the 3-NN search, in slot order: every valid slot, and of the EMPTY slots only the
+        // first three -- all empty slots are the same point (the origin), the search keeps the first seen on
+        // ties (strict <), so a fourth one can never enter the best three.  ~5 candidates instead of nq.
+        int ncand = 0, nempty = 0;
+        for (int i0 = 0; i0 < a.nq; i0 += MSSVT_WAVE) {
+            const int i = i0 + lane;
+            int v = -1;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (i < a.nq) {
+                v = a.q_ind[(size_t)w * a.nq + i];
+                if (v >= 0) {
+                    const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + v];
+                    x = centre_of(vi.w, a.vsx, a.minx);
+                    y = centre_of(vi.z, a.vsy, a.miny);
+                    z = centre_of(vi.y, a.vsz, a.minz);
+                }
+            }
+            const bool empty = i < a.nq && v < 0;
+            const unsigned long long me = __ballot(empty);
+            const bool keep = i < a.nq && (v >= 0 || nempty + __popcll(me & ((1ull << lane) - 1ull)) < 3);
+            const unsigned long long mk = __ballot(keep);
+            if (keep) {
+                const int p = ncand + __popcll(mk & ((1ull << lane) - 1ull));
+                kx[wv][p] = x; ky[wv][p] = y; kz[wv][p] = z;
+                kvalid[wv][p] = (i << 1) | (v >= 0 ? 1 : 0);  // original slot, valid bit
+            }
+            ncand += __popcll(mk);
+            nempty += __popcll(me);
+        }
+        wave_lds_sync();
+        for (int s0 = 0; s0 < a.n1; s0 += MSSVT_WAVE) {
+            const int s = s0 + lane;
+            int v = -1;
+            if (s < a.n1) {
+                v = a.upd_ind[(size_t)w * a.n1 + s];
+                if (v >= 0 && a.owner[vstart + v] != w * a.n1 + s) v = -1;  // another slot owns this voxel
+            }
+            int i1 = 0, i2 = 0, i3 = 0;
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+            if (v >= 0) {  // K9 (ref interpolate_gpu.cu:16-59) + weights (ref mssvt_backbone.py:305-307)
+                const int4 vi = reinterpret_cast<const int4 *>(a.indices)[vstart + v];
+                const float ux = centre_of(vi.w, a.vsx, a.minx), uy = centre_of(vi.z, a.vsy, a.miny),
+                            uz = centre_of(vi.y, a.vsz, a.minz);
+                // the reference keeps the running bests in double (initial 1e40) and compares float distances
+                // against them: the same order as float compares against +inf
+                float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+                int c1 = -1, c2 = -1, c3 = -1;  // candidate positions
+                for (int k = 0; k < ncand; ++k) {
+                    const float dx = ux - kx[wv][k], dy = uy - ky[wv][k], dz = uz - kz[wv][k];
+                    const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    if (d < b1) { b3 = b2; c3 = c2; b2 = b1; c2 = c1; b1 = d; c1 = k; }
+                    else if (d < b2) { b3 = b2; c3 = c2; b2 = d; c2 = k; }
+                    else if (d < b3) { b3 = d; c3 = k; }
+                }
+                // fewer than three candidates (nq < 3): the reference leaves index 0 / distance 1e40 -> weight ~0
+                const int m1 = c1 >= 0 ? kvalid[wv][c1] : 0, m2 = c2 >= 0 ? kvalid[wv][c2] : 0,
+                          m3 = c3 >= 0 ? kvalid[wv][c3] : 0;
+                i1 = m1 >> 1; i2 = m2 >> 1; i3 = m3 >> 1;
+                const float d1 = fmaxf(c1 >= 0 ? sqrtf(b1) : INFINITY, 1e-10f), d2 = fmaxf(c2 >= 0 ? sqrtf(b2) : INFINITY, 1e-10f),
+                            d3 = fmaxf(c3 >= 0 ? sqrtf(b3) : INFINITY, 1e-10f);
+                w1 = 1.0f / d1; w2 = 1.0f / d2; w3 = 1.0f / d3;
+                const float norm = (w1 + w2) + w3;
+                w1 /= norm; w2 /= norm; w3 /= norm;
+                if (!(m1 & 1) || c1 < 0) w1 = 0.f;  // empty slots carry zero features
+                if (!(m2 & 1) || c2 < 0) w2 = 0.f;
+                if (!(m3 & 1) || c3 < 0) w3 = 0.f;
+            }
+            if (a.tab_row) {
+                if (v >= 0) {
+                    a.tab_row[vstart + v] = make_int4(w1 != 0.f ? w * a.nq + i1 : a.zero_row,
+                                                      w2 != 0.f ? w * a.nq + i2 : a.zero_row,
+                                                      w3 != 0.f ? w * a.nq + i3 : a.zero_row, 0);
+                    a.tab_w[vstart + v] = make_float4(w1, w2, w3, 0.f);
+                }
+                continue;
+            }
+            unsigned long long todo = __ballot(v >= 0);
+            while (todo) {  // one covered voxel at a time, lanes sweep its channels
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int vv = __shfl(v, src);
+                const int j1 = __shfl(i1, src), j2 = __shfl(i2, src), j3 = __shfl(i3, src);
+                const float f1 = __shfl(w1, src), f2 = __shfl(w2, src), f3 = __shfl(w3, src);
+                const float *r1 = a.attn + ((size_t)w * a.nq + j1) * a.C;
+                const float *r2 = a.attn + ((size_t)w * a.nq + j2) * a.C;
+                const float *r3 = a.attn + ((size_t)w * a.nq + j3) * a.C;
+                const size_t row = (size_t)(vstart + vv) * a.C;
+                for (int c = lane; c < a.C; c += MSSVT_WAVE) {
+                    float acc = 0.f;  // a zero weight never touches the (unwritten) row of an empty slot
+                    if (f1 != 0.f) acc = r1[c] * f1;
+                    if (f2 != 0.f) acc += r2[c] * f2;
+                    if (f3 != 0.f) acc += r3[c] * f3;
+                    a.x_new[row + c] = acc + a.x_in[row + c];
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+extern "C" int mssvt_block_interp_scatter(int C, int nq, int n_upd, int use_interpolation,
+                                          const float *attn, const float *x_in, float *x_new,
+                                          const int *indices, const int *win_ind,
+                                          const int *num_wins_dev, int win_capacity,
+                                          const int *win_vstart, const int *q_ind,
+                                          const int *upd_ind, const int *owner,
+                                          const float *host_voxel_size3,
+                                          const float *host_range_min3, void *stream) {
+    if (!attn || !x_in || !x_new || !indices || !win_ind || !num_wins_dev || !win_vstart || !q_ind ||
+        !owner || !host_voxel_size3 || !host_range_min3 || C <= 0 || nq <= 0)
+        return MSSVT_E_BADARG;
+    if (use_interpolation && (!upd_ind || n_upd <= 0)) return MSSVT_E_BADARG;
+    if (nq > SC_MAXQ) return MSSVT_E_TOOLARGE;
+    if (win_capacity <= 0) return MSSVT_OK;
+    ScatterArgs a;
+    a.C = C; a.nq = nq; a.n1 = n_upd; a.interp = use_interpolation;
+    a.attn = attn; a.x_in = x_in; a.x_new = x_new;
+    a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev; a.win_vstart = win_vstart;
+    a.q_ind = q_ind; a.upd_ind = upd_ind; a.owner = owner;
+    a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
+    a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
+    a.tab_row = nullptr; a.tab_w = nullptr; a.zero_row = 0;
+    int grid = divup(win_capacity, SC_WPB);
+    if (grid > 4096) grid = 4096;  // grid-stride over the windows actually present
+    ScatterPack pack;
+    for (int i = 0; i < SC_MAX_SETS; ++i) pack.s[i] = a;
+    k_block_scatter<<<grid, SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(pack);
+    return mssvt_launch_status();
+}
+
+// Table form of mssvt_block_interp_scatter: records, per voxel owned by a list slot, the
+// (up to) three attention rows and inverse-distance weights instead of applying them.
+extern "C" int mssvt_block_interp_table_multi(int num_sets, const int *host_nq, const int *host_n_upd,
+                                              const int *host_interp, const int *indices, const int *win_ind,
+                                              const int *num_wins_dev, int win_capacity, const int *win_vstart,
+                                              const int *const *host_q_ind, const int *const *host_upd_ind,
+                                              const int *const *host_owner, const float *host_voxel_size3,
+                                              const float *host_range_min3, const int *host_zero_row,
+                                              int *const *host_tab_row, float *const *host_tab_w, void *stream) {
+    if (num_sets <= 0 || num_sets > SC_MAX_SETS) return num_sets <= 0 ? MSSVT_E_BADARG : MSSVT_E_TOOLARGE;
+    if (!host_nq || !host_n_upd || !host_interp || !indices || !win_ind || !num_wins_dev || !win_vstart ||
+        !host_q_ind || !host_upd_ind || !host_owner || !host_voxel_size3 || !host_range_min3 || !host_zero_row ||
+        !host_tab_row || !host_tab_w)
+        return MSSVT_E_BADARG;
+    if (win_capacity <= 0) return MSSVT_OK;
+    ScatterPack pack;
+    for (int i = 0; i < SC_MAX_SETS; ++i) {
+        const int k = i < num_sets ? i : 0;
+        if (!host_q_ind[k] || !host_owner[k] || !host_tab_row[k] || !host_tab_w[k] || host_nq[k] <= 0)
+            return MSSVT_E_BADARG;
+        if (host_interp[k] && (!host_upd_ind[k] || host_n_upd[k] <= 0)) return MSSVT_E_BADARG;
+        if (host_nq[k] > SC_MAXQ) return MSSVT_E_TOOLARGE;
+        ScatterArgs &a = pack.s[i];
+        a.C = 0; a.nq = host_nq[k]; a.n1 = host_n_upd[k]; a.interp = host_interp[k];
+        a.attn = nullptr; a.x_in = nullptr; a.x_new = nullptr;
+        a.indices = indices; a.win_ind = win_ind; a.num_wins = num_wins_dev; a.win_vstart = win_vstart;
+        a.q_ind = host_q_ind[k]; a.upd_ind = host_upd_ind[k]; a.owner = host_owner[k];
+        a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
+        a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
+        a.tab_row = reinterpret_cast<int4 *>(host_tab_row[k]);
+        a.tab_w = reinterpret_cast<float4 *>(host_tab_w[k]);
+        a.zero_row = host_zero_row[k];
+    }
+    int grid = divup(win_capacity, SC_WPB);
+    if (grid > 16384 / num_sets) grid = 16384 / num_sets;  // ~1 window per wave: the per-window chain is 3 dependent round trips
+    k_block_scatter<<<dim3(grid, num_sets), SC_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(pack);
+    return mssvt_launch_status();
+}
+
+extern "C" int mssvt_block_interp_table(int nq, int n_upd, int use_interpolation, const int *indices,
+                                        const int *win_ind, const int *num_wins_dev, int win_capacity,
+                                        const int *win_vstart, const int *q_ind, const int *upd_ind,
+                                        const int *owner, const float *host_voxel_size3,
+                                        const float *host_range_min3, int zero_row, int *tab_row,
+                                        float *tab_w, void *stream) {
+    return mssvt_block_interp_table_multi(1, &nq, &n_upd, &use_interpolation, indices, win_ind, num_wins_dev,
+                                          win_capacity, win_vstart, &q_ind, &upd_ind, &owner, host_voxel_size3,
+                                          host_range_min3, &zero_row, &tab_row, &tab_w, stream);
 }

@@ -479,7 +479,9 @@ class MixedScaleSparseTransformer(nn.Module):
         try:
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 if fused_path:
-                    arena = mssvt_ops.FillArena(getattr(self, '_fill_demand', 0), feats.device)
+                    # (+3 %: the demand follows the voxel count, which drifts from frame to frame -- a request that does not fit
+                    # costs its own fill launch)
+                    arena = mssvt_ops.FillArena(getattr(self, '_fill_demand', 0) * 33 // 32 + 4096, feats.device)
                 mssvt_ops.FillArena.current = arena
                 kw = dict(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
                           voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
