@@ -828,6 +828,54 @@ def side_stream(dev):
     return s
 
 
+# A lighter form of the same idea: only the two launches of a frame that neither need nor feed the index
+# chain -- the first Block's LayerNorm (HBM bound, 16 us) and the CompressBlock's pillar plan (one lane per window, 10 us
+# + its prefill) -- go to the side stream, under the Blocks' plan kernel (VALU / latency bound, 70 us).  Two events, no
+# record_stream walk: the side stream starts every frame behind everything queued on the caller's stream
+# (wait_stream), so memory it allocates is never rewritten before its readers are done.
+# Measured (bench.py, one box each): one scene 0.73 -> 0.80 ms with it (the cross-stream waits and the two stream switches
+# cost more than the 26 us they hide), batch 8 / bf16 4.15 -> 4.09 ms.  "auto": on from SIDE_OVERLAP_MIN_VOXELS up.
+SIDE_OVERLAP = os.environ.get("MSSVT_SIDE_OVERLAP", "auto")
+SIDE_OVERLAP_MIN_VOXELS = 200000
+
+
+def side_overlap_on(sp):
+    return SIDE_OVERLAP == "1" or (SIDE_OVERLAP == "auto" and sp.features.shape[0] >= SIDE_OVERLAP_MIN_VOXELS)
+
+
+@torch.no_grad()
+def overlap_front(schedule, sp):
+    """Issue norm1 of the first Block and the plan of the level's CompressBlock on the side stream; the consumers wait
+    for `sp._xhat_event` / `sp._cmp_plan_event` on their own stream (block_forward, _compress_forward_fused)."""
+    from .mssvt_backbone import MixedScaleSparseTransformerCompressBlock as Compress
+    blk, _nxt, _group, cmp_blk = schedule[0]
+    if isinstance(blk, Compress) or getattr(blk, "impl", None) != "fused" or not supported(blk, sp) or \
+            sp.features.shape[1] not in LN_WIDTHS or getattr(sp, "_xhat", None) is not None:
+        return
+    main = torch.cuda.current_stream(sp.features.device)
+    s2 = side_stream(sp.features.device)
+    s2.wait_stream(main)
+    with torch.cuda.stream(s2):
+        xhat = layer_norm(sp.features, blk.norm1)
+        ev = torch.cuda.Event()
+        ev.record(s2)
+        sp._xhat, sp._xhat_event = (xhat, blk.norm1, sp.features), ev
+        C = sp.features.shape[1]
+        if cmp_blk is not None and getattr(cmp_blk, "impl", None) == "fused" and getattr(sp, "_level", None) is not None and \
+                sp._level.get("sorted") and compress_supported(cmp_blk, sp) and CMP_FUSED and \
+                cmp_blk.linear1.in_features == C and _compress_fused_ok(cmp_blk, sp, C):
+            sp._cmp_plan = (cmp_blk, one_scale_plan(cmp_blk, sp, sync=False))
+            ev2 = torch.cuda.Event()
+            ev2.record(s2)
+            sp._cmp_plan_event = ev2
+
+
+def _wait_side(sp, name):
+    ev = sp.__dict__.pop(name, None)
+    if ev is not None:
+        torch.cuda.current_stream(sp.features.device).wait_event(ev)
+
+
 @torch.no_grad()
 def prefetch_level(schedule, sp):
     """All index work of the input level, on the CURRENT stream: the plans of its Blocks (with their work orders and
@@ -895,6 +943,7 @@ def block_forward(block, sp):
     ma = block.ms_attn
     qbuf = _query_scratch(p, od["row_cap"], ma, x_in.device)
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
+    _wait_side(sp, "_xhat_event")  # xhat of the frame's first Block comes from the side stream (overlap_front)
     _attention_call(block, p, od, C, nq, xhat, qbuf, attn)
     interp = 1 if block.use_feature_interpolation else 0
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
@@ -1194,7 +1243,8 @@ def _compress_forward_fused(block, sp, xhat, x_in):
     (the output shape)."""
     C = x_in.shape[1]
     dev = x_in.device
-    pre = sp.__dict__.pop("_cmp_plan", None)  # built ahead on the index stream (prefetch_level)
+    pre = sp.__dict__.pop("_cmp_plan", None)  # built ahead on the index stream (prefetch_level / overlap_front)
+    _wait_side(sp, "_cmp_plan_event")
     p = pre[1] if pre is not None and pre[0] is block else one_scale_plan(block, sp, sync=False)
     if not p.disjoint or p.with_pad:
         return None, p

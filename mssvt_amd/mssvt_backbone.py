@@ -501,6 +501,8 @@ class MixedScaleSparseTransformer(nn.Module):
             if side is not None:
                 main.wait_event(done)
                 fused.record_streams([sp, arena], main)
+            elif fused_path and not torch.is_grad_enabled() and getattr(sp, "_level", None) is not None and fused.side_overlap_on(sp):
+                fused.overlap_front(self._block_schedule(), sp)
             for i, (blk, nxt_norm, group, nxt_cmp) in enumerate(self._block_schedule()):
                 # lets a fused FFN epilogue also emit the next block's norm1 (mssvt_amd/fused.py)
                 sp._next_norm1 = nxt_norm
