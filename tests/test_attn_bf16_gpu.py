@@ -70,6 +70,30 @@ def test_bf16_backbone_small_scene_vs_oracle():
     assert not torch.equal(f32.features, sp.features)
 
 
+def test_bf16_batch8_vs_oracle():
+    """configs[2]'s batch shape against the fp32 CPU ORACLE itself (not the fp32 fused path): 8 scenes of 20k points in one
+    batch -- the size the oracle finishes in seconds -- with the bf16 tolerance above; indices bit-exact."""
+    from mssvt_amd import config, fused
+    B = 8
+    pts = synthetic.make_batch_points(20000, B, 800)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(8)).numpy()
+    torch.manual_seed(0)
+    cfg = config.load_yaml(config.DEFAULT_CFG)
+    net = config.build_backbone_from_cfg(cfg).eval()
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    want = block_ref.backbone_forward(sd, [dict(p) for p in cfg.MODEL.BACKBONE_3D.PARAMS], feats, vc, B,
+                                      synthetic.GRID_SIZE, synthetic.VOXEL_SIZE, synthetic.POINT_CLOUD_RANGE, 400000)
+    net = net.to(DEV).set_attn_dtype("bf16")
+    assert fused.attn_uses_bf16(net.backbone[0])
+    with torch.no_grad():
+        sp = net(dict(voxel_features=torch.from_numpy(feats).to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV),
+                      batch_size=B))["encoded_spconv_tensor"]
+    np.testing.assert_array_equal(sp.indices.cpu().numpy(), want.indices)
+    assert sp.v_bs_cnt.tolist() == [int((want.indices[:, 0] == b).sum()) for b in range(B)]
+    bf16_close(sp.features.cpu().numpy(), want.features, "backbone 20k x 8 vs oracle")
+
+
 def test_bf16_batch8_full_size_vs_fp32_fused():
     """BASELINE configs[2] at full size: 8 x 160k-point scenes in one batch, bf16-operand attention against the fp32
     fused path on the same frame (itself pinned to the oracle at full size in tests/test_module_gpu.py)."""
