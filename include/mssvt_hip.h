@@ -455,18 +455,17 @@ int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, c
  * :383-387): x = owner && owner[v] < 0 ? 2*x_in[v] : x_new[v];
  * y = x + linear2(relu(linear1(norm(x)))); optionally y_norm = next_norm(y) (the next block's
  * norm1).  x_new/x_in/y/y_norm (N,C) f32; W1 (FF,C), W2 (C,FF) as in nn.Linear.
- * hidden != NULL: scratch of n_rows x FF floats -> two launches with LDS-resident weights
- * (GEMM1 | GEMM2, the hidden activations make one round trip through `hidden`); NULL: one
- * launch that streams the weights through LDS.  num_rows_dev (optional, needs hidden): the
- * row count is read on the device and n_rows is only the capacity.  phases: 3 = the whole
- * tail; with hidden != NULL 1 = only the first launch (LayerNorm + GEMM1 + ReLU -> hidden,
- * x parked in y), 2 = only the second (GEMM2 + residual + next norm) -- for measurement.
+ * phases 3 (fp32 matrix instruction): hidden = scratch of n_rows x FF floats, two launches with LDS-resident
+ * weights (GEMM1 | GEMM2, the hidden activations make one round trip through `hidden`; hidden NULL ->
+ * MSSVT_E_BADARG).  num_rows_dev (optional): the row count is read on the device and n_rows is only the
+ * capacity.  phases 1 = only the first launch (LayerNorm + GEMM1 + ReLU -> hidden, x parked in y), 2 = only
+ * the second (GEMM2 + residual + next norm) -- for measurement.
  * phases 4 (num_rows_dev allowed; hidden = NULL, or the fragments written by
  * mssvt_ffn_pack_weights for these W1 / W2: saves the in-kernel split): ONE launch with register-stationary weights
  * and every fp32 operand split into two fp16 halves (22 of 24 mantissa bits) (3 x v_mfma_f32_16x16x32_f16 per
  * product sum, fp32 accumulation: the fp32 kernels' error against float64 at 3/16 of the matrix
  * cycles; no hidden round trip).  The CALLER guarantees the fp16 range: sqrt(C) max|norm_w| +
- * max|norm_b| and max_h(|W1_h|_1 * that + |b1_h|) below 3e4 (mssvt_amd/fused.py checks the
+ * max|norm_b| and max_h(|W1_h|_1 * that + |b1_h|) below 6e4 (fused.FFN_F16_LIMIT; mssvt_amd/fused.py checks the
  * parameters once per version and keeps phases 3 otherwise).
  * Instantiated for (C,FF) in {(128,256),(64,128),(32,64)}; MSSVT_E_TOOLARGE otherwise.   */
 int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *x_in, const int *owner,

@@ -1,7 +1,7 @@
 // ffn.hip -- fused per-voxel feed-forward tail of an MsSVT block on the matrix cores.
 //
-// Three generations live here, newest last (each section explains why it replaced the one before):
-//   k_ffn          one launch, weights streamed through LDS in chunks, fp32 MFMA            (kept for A/B)
+// Two generations live here (the first one -- one launch, both weight matrices streamed through the LDS in chunks of 32
+// hidden units, fp32 MFMA, ~40 % of the fp32 matrix peak -- was deleted in round 3; DESIGN.md section 5.1 keeps its numbers):
 //   k_ffn_up/down  two launches, whole weight matrix resident in LDS, fp32 MFMA             (ffn_arith = "f32", and
 //                                                                      parameters outside the fp16 range)
 //   k_ffn_ws       one launch, weights stationary in registers, fp32 operands split into two fp16 halves
@@ -12,35 +12,14 @@
 //     h   = norm2(x)                                LayerNorm kernel
 //     u   = relu(linear1(h))                        GEMM (N x C x FF) + bias + ReLU kernels
 //     y   = x + linear2(u)                          GEMM (N x FF x C) + bias + add kernels
-// and the NEXT block's norm1(y), with ONE kernel that builds x while loading it, and writes
-// y (and optionally norm1_next(y)) once; the N x FF hidden activations never leave registers.
+// and the NEXT block's norm1(y): x is built while it is loaded, y (and optionally norm1_next(y)) written once.
 //
-// MFMA mapping (v_mfma_f32_16x16x4_f32, exact fp32; one wavefront = 16 voxel rows):
-//   GEMM1 is computed TRANSPOSED:  D1[hidden][row] = sum_c W1[hidden][c] * h[row][c]
-//     A = W1 tile from LDS, B = the normalised rows held in registers (lane (row, kk)
-//     owns channels [kk*C/4, (kk+1)*C/4) of its row);
-//   its accumulator (lane = row, registers = 4 hidden units 4g..4g+3 of the 16-tile)
-//   IS the A operand of GEMM2 step by step -- no shuffle, no LDS round trip:
-//     D2[row][out] += sum_reg u[row][4g+reg] * W2[out][4g+reg],  B = one ds_read_b128 of W2.
-//   Independent accumulator chains are interleaved (32-cycle issue, 40-cycle dependent latency).
-// Weights (2 * C * FF floats = 256 KB at C=128, FF=256) do not fit the 160 KB LDS: they
-// stream through it in chunks of 32 hidden units (W1 rows + W2 columns of the chunk, 37 KB),
-// double buffered, loaded global->registers during the previous chunk's MFMAs.  Two 4-wave
-// workgroups per CU: one's loads / LayerNorm / epilogue overlap with the other's MFMA phase.
-// LDS row strides (C+2 for the b64 reads of W1, 40 for the b128 reads of W2) make the operand
-// reads bank-conflict free (enumerated; SQ_LDS_BANK_CONFLICT = 0).
-//
-// HBM access is fully coalesced although the MFMA operand layouts are not: rows are loaded and
-// stored as whole rows (float4 per lane, 2 rows of 512 B per wave instruction) and re-laid out
-// through a 16 x (C+4) LDS tile per wave, which lives in the weight buffer that is idle at the
-// batch boundary.  (First version: operand-shaped global loads, 64 different lines per
-// instruction -> every line missed the 32-KiB L1 eight times: 54k cycles per 16 rows.)
+// HBM access is fully coalesced although the MFMA operand layouts are not: rows are loaded and stored as whole rows
+// (float4 per lane) and re-laid out on chip.
 #include "common.hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define FFN_CH 32  // hidden units per LDS chunk
-#define FFN_NW 4   // waves per workgroup
 
 struct FfnArgs {
     int n_rows;
@@ -61,287 +40,13 @@ struct FfnArgs {
     float *y_norm;
 };
 
-template <int C, int FF>
-__global__ void __launch_bounds__(FFN_NW *MSSVT_WAVE, 2) k_ffn(FfnArgs a) {
-    constexpr int NW = FFN_NW;
-    constexpr int KS = C / 4;        // channels per lane slot (= GEMM1 k-steps)
-    constexpr int CH = FFN_CH;       // hidden units per chunk
-    constexpr int NCH = FF / CH;
-    constexpr int HT = CH / 16;
-    constexpr int RS1 = C + 2;       // W1 chunk row stride (floats)
-    constexpr int RS2 = CH + 8;      // W2 chunk row stride
-    constexpr int BUF = CH * RS1 + C * RS2;  // floats per chunk buffer
-    constexpr int V1 = CH * C / 2 / (NW * MSSVT_WAVE);  // float2 of W1 per thread per chunk
-    constexpr int V2 = C * CH / 4 / (NW * MSSVT_WAVE);  // float4 of W2 per thread per chunk
-    constexpr int TS = C + 4;        // row stride of the per-wave 16-row I/O tile
-    constexpr int LPR = C / 4;       // lanes per row in the coalesced layout (float4 per lane)
-    constexpr int RPI = MSSVT_WAVE / LPR;  // rows per wave instruction
-    constexpr int NI = 16 / RPI;     // instructions per 16-row tile
-    static_assert(NCH >= 2 && V1 >= 1 && V2 >= 1, "shape not supported by the staging pattern");
-    static_assert(NW * 16 * TS <= BUF, "I/O tiles must fit into one weight buffer");
-    extern __shared__ float4 lds4[];
-    float *lds = reinterpret_cast<float *>(lds4);
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;  // MFMA view: (row | out | hidden-in-tile, k slot)
-    const int crow = lane / LPR, ccol = (lane % LPR) * 4;  // coalesced view: row in instruction, first channel
-    const int nbatch = (a.n_rows + NW * 16 - 1) / (NW * 16);
-
-    // staging registers; STAGE_LOAD / STAGE_STORE are macros on purpose: handing the arrays to a
-    // lambda takes their address and hipcc then keeps them in scratch memory
-    float2 st1[V1];
-    float4 st2[V2];
-#define STAGE_LOAD(ch_)                                                                                    \
-    {                                                                                                      \
-        _Pragma("unroll") for (int v = 0; v < V1; ++v) { /* W1 rows [ch*CH, +CH), all C columns */        \
-            const int e = (v * NW * MSSVT_WAVE + tid) * 2;                                                 \
-            st1[v] = *reinterpret_cast<const float2 *>(a.W1 + (size_t)((ch_) * CH + e / C) * C + e % C);   \
-        }                                                                                                  \
-        _Pragma("unroll") for (int v = 0; v < V2; ++v) { /* W2 all C rows, columns [ch*CH, +CH) */        \
-            const int e = (v * NW * MSSVT_WAVE + tid) * 4;                                                 \
-            st2[v] = *reinterpret_cast<const float4 *>(a.W2 + (size_t)(e / CH) * FF + (ch_) * CH + e % CH); \
-        }                                                                                                  \
-    }
-#define STAGE_STORE(buf_)                                                                                  \
-    {                                                                                                      \
-        _Pragma("unroll") for (int v = 0; v < V1; ++v) {                                                  \
-            const int e = (v * NW * MSSVT_WAVE + tid) * 2;                                                 \
-            *reinterpret_cast<float2 *>((buf_) + (e / C) * RS1 + e % C) = st1[v];                          \
-        }                                                                                                  \
-        _Pragma("unroll") for (int v = 0; v < V2; ++v) {                                                  \
-            const int e = (v * NW * MSSVT_WAVE + tid) * 4;                                                 \
-            *reinterpret_cast<float4 *>((buf_) + CH * RS1 + (e / CH) * RS2 + e % CH) = st2[v];             \
-        }                                                                                                  \
-    }
-
-    STAGE_LOAD(0)
-    STAGE_STORE(lds)
-    __syncthreads();
-    int cur = 0;  // buffer holding the chunk about to be consumed; the other one is free at batch boundaries
-
-    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-        const int r0 = batch * (NW * 16) + wv * 16;
-        float *tile = lds + (cur ^ 1) * BUF + wv * 16 * TS;  // this wave's 16 x TS I/O tile
-        // ---- input: whole rows, coalesced; x is built on the fly, parked in y, and laid out for the MFMA.
-        // The 16 rows' table entries go through LDS first so that all row gathers of a half-tile are
-        // in flight together (a lane serves NI different rows; chasing table -> rows per row would be
-        // NI dependent round trips).
-        float *tabs = lds + 2 * BUF + wv * 128;  // 16 x (int4 | float4), behind the two weight buffers
-        if (a.tab_row && lane < 16) {
-            const int row = min(r0 + lane, a.n_rows - 1);
-            *reinterpret_cast<int4 *>(tabs + lane * 8) = a.tab_row[row];
-            *reinterpret_cast<float4 *>(tabs + lane * 8 + 4) = a.tab_w[row];
-        }
-        wave_lds_sync();
-        constexpr int HALF = NI > 1 ? NI / 2 : 1;  // rows gathered together: (4 streams x HALF) float4 in flight
-#pragma unroll
-        for (int h0 = 0; h0 < NI; h0 += HALF) {
-            float4 vx[HALF], v1[HALF], v2[HALF], v3[HALF];
-            float w1[HALF], w2[HALF], w3[HALF], wx[HALF];
-#pragma unroll
-            for (int u = 0; u < HALF; ++u) {
-                const int rr = (h0 + u) * RPI + crow;
-                const int row = min(r0 + rr, a.n_rows - 1);
-                if (a.tab_row) {
-                    const int4 tr = *reinterpret_cast<const int4 *>(tabs + rr * 8);
-                    const float4 tw = *reinterpret_cast<const float4 *>(tabs + rr * 8 + 4);
-                    const bool unowned = tr.x < 0;
-                    // an unowned voxel re-reads its own (finite) x_in row with weight 0: attention rows of
-                    // never-written slots may hold NaNs, and 0 * NaN is NaN
-                    const float *px = a.x_in + (size_t)row * C + ccol;
-                    vx[u] = *reinterpret_cast<const float4 *>(px);
-                    v1[u] = *reinterpret_cast<const float4 *>(unowned ? px : a.attn + (size_t)tr.x * C + ccol);
-                    v2[u] = *reinterpret_cast<const float4 *>(unowned ? px : a.attn + (size_t)tr.y * C + ccol);
-                    v3[u] = *reinterpret_cast<const float4 *>(unowned ? px : a.attn + (size_t)tr.z * C + ccol);
-                    w1[u] = unowned ? 0.f : tw.x;
-                    w2[u] = unowned ? 0.f : tw.y;
-                    w3[u] = unowned ? 0.f : tw.z;
-                    wx[u] = unowned ? 2.0f : 1.0f;  // untouched voxel: features + shortcut = 2 * x_in
-                } else {
-                    const bool dbl = a.owner != nullptr && a.owner[row] < 0;  // untouched voxel (ref quirk R12)
-                    vx[u] = *reinterpret_cast<const float4 *>((dbl ? a.x_in : a.x_new) + (size_t)row * C + ccol);
-                    v1[u] = v2[u] = v3[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    w1[u] = w2[u] = w3[u] = 0.f;
-                    wx[u] = dbl ? 2.0f : 1.0f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < HALF; ++u) {
-                const int rr = (h0 + u) * RPI + crow;
-                float4 o;
-                o.x = ((v1[u].x * w1[u] + v2[u].x * w2[u]) + v3[u].x * w3[u]) + vx[u].x * wx[u];
-                o.y = ((v1[u].y * w1[u] + v2[u].y * w2[u]) + v3[u].y * w3[u]) + vx[u].y * wx[u];
-                o.z = ((v1[u].z * w1[u] + v2[u].z * w2[u]) + v3[u].z * w3[u]) + vx[u].z * wx[u];
-                o.w = ((v1[u].w * w1[u] + v2[u].w * w2[u]) + v3[u].w * w3[u]) + vx[u].w * wx[u];
-                if (r0 + rr < a.n_rows) *reinterpret_cast<float4 *>(a.y + (size_t)(r0 + rr) * C + ccol) = o;  // park x
-                *reinterpret_cast<float4 *>(tile + rr * TS + ccol) = o;
-            }
-        }
-        wave_lds_sync();
-        float xn[KS];
-        {
-            const float *src = tile + li * TS + lg * KS;
-#pragma unroll
-            for (int s = 0; s < KS; s += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(src + s);
-                xn[s] = v.x; xn[s + 1] = v.y; xn[s + 2] = v.z; xn[s + 3] = v.w;
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) sum += xn[s];
-            sum += lane_xor16(sum);
-            sum += lane_xor32(sum);
-            const float mean = sum * (1.0f / C);
-            float var = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const float d = xn[s] - mean;
-                var = __builtin_fmaf(d, d, var);
-            }
-            var += lane_xor16(var);
-            var += lane_xor32(var);
-            const float rstd = rsqrtf(var * (1.0f / C) + a.eps);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int c = lg * KS + s;
-                xn[s] = (xn[s] - mean) * rstd * a.ln_w[c] + a.ln_b[c];
-            }
-        }
-        f32x4 acc2[C / 16];
-#pragma unroll
-        for (int ot = 0; ot < C / 16; ++ot) acc2[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        __syncthreads();  // every wave is done with its I/O tile: the buffer may be refilled with weights
-
-        // ---- hidden dimension in chunks; the next chunk's weights are in flight meanwhile ----------
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int nxt = ch + 1 < NCH ? ch + 1 : 0;
-            const bool more = ch + 1 < NCH || batch + (int)gridDim.x < nbatch;
-            const float *W1c = lds + cur * BUF;
-            const float *W2c = W1c + CH * RS1;
-            if (more) STAGE_LOAD(nxt)
-            // GEMM1 (transposed): HT tiles of 16 hidden units x 16 rows, K = C; chains interleaved
-            f32x4 d[HT];
-#pragma unroll
-            for (int ht = 0; ht < HT; ++ht) d[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < KS / 2; ++s2) {
-                float2 w[HT];
-#pragma unroll
-                for (int ht = 0; ht < HT; ++ht)
-                    w[ht] = *reinterpret_cast<const float2 *>(W1c + (ht * 16 + li) * RS1 + lg * KS + 2 * s2);
-#pragma unroll
-                for (int ht = 0; ht < HT; ++ht) d[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ht].x, xn[2 * s2], d[ht], 0, 0, 0);
-#pragma unroll
-                for (int ht = 0; ht < HT; ++ht) d[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ht].y, xn[2 * s2 + 1], d[ht], 0, 0, 0);
-            }
-#pragma unroll
-            for (int ht = 0; ht < HT; ++ht) {
-                // bias + ReLU on this lane's 4 hidden units (4g .. 4g+3 of the tile)
-                const float4 bb = *reinterpret_cast<const float4 *>(a.b1 + ch * CH + ht * 16 + 4 * lg);
-                d[ht][0] = fmaxf(d[ht][0] + bb.x, 0.f);
-                d[ht][1] = fmaxf(d[ht][1] + bb.y, 0.f);
-                d[ht][2] = fmaxf(d[ht][2] + bb.z, 0.f);
-                d[ht][3] = fmaxf(d[ht][3] + bb.w, 0.f);
-            }
-            // GEMM2: the GEMM1 accumulator is the A operand, one k-step per register; the C/16 output
-            // tiles are independent chains and are walked innermost
-#pragma unroll
-            for (int ht = 0; ht < HT; ++ht) {
-                constexpr int OG = C / 16;  // output tiles per group (all: 8 independent chains)
-#pragma unroll
-                for (int o0 = 0; o0 < C / 16; o0 += OG) {
-                    float4 w2[OG];
-#pragma unroll
-                    for (int ot = 0; ot < OG; ++ot)
-                        w2[ot] = *reinterpret_cast<const float4 *>(W2c + ((o0 + ot) * 16 + li) * RS2 + ht * 16 + 4 * lg);
-#pragma unroll
-                    for (int ot = 0; ot < OG; ++ot) acc2[o0 + ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[ht][0], w2[ot].x, acc2[o0 + ot], 0, 0, 0);
-#pragma unroll
-                    for (int ot = 0; ot < OG; ++ot) acc2[o0 + ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[ht][1], w2[ot].y, acc2[o0 + ot], 0, 0, 0);
-#pragma unroll
-                    for (int ot = 0; ot < OG; ++ot) acc2[o0 + ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[ht][2], w2[ot].z, acc2[o0 + ot], 0, 0, 0);
-#pragma unroll
-                    for (int ot = 0; ot < OG; ++ot) acc2[o0 + ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[ht][3], w2[ot].w, acc2[o0 + ot], 0, 0, 0);
-                }
-            }
-            if (more) STAGE_STORE(lds + (cur ^ 1) * BUF)
-            __syncthreads();  // everyone is done with `cur`, and the other buffer is complete
-            cur ^= 1;
-        }
-        // ---- epilogue: y = x + W2 u + b2.  The accumulators (lane = output channel li of each 16-tile,
-        // rows 4*lg+reg) go through this wave's I/O tile in the buffer that just became free, come back
-        // as whole rows, and leave as coalesced float4 stores.
-        tile = lds + (cur ^ 1) * BUF + wv * 16 * TS;
-#pragma unroll
-        for (int ot = 0; ot < C / 16; ++ot) {
-            const float bb = a.b2[ot * 16 + li];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) tile[(4 * lg + reg) * TS + ot * 16 + li] = acc2[ot][reg] + bb;
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int t = 0; t < NI; ++t) {
-            const int rr = t * RPI + crow;
-            const int row = min(r0 + rr, a.n_rows - 1);
-            // x was parked in y by this very lane (same coalesced layout): a plain reload
-            const float4 xv = *reinterpret_cast<const float4 *>(a.y + (size_t)row * C + ccol);
-            const float4 hv = *reinterpret_cast<const float4 *>(tile + rr * TS + ccol);
-            const float4 yv = make_float4(xv.x + hv.x, xv.y + hv.y, xv.z + hv.z, xv.w + hv.w);
-            const bool live = r0 + rr < a.n_rows;
-            if (live) *reinterpret_cast<float4 *>(a.y + (size_t)row * C + ccol) = yv;
-            if (a.y_norm) {  // LayerNorm of y for the next block: a row = LPR consecutive lanes
-                float s = (yv.x + yv.y) + (yv.z + yv.w);
-#pragma unroll
-                for (int off = LPR / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-                const float m = s * (1.0f / C);
-                const float dx = yv.x - m, dy = yv.y - m, dz = yv.z - m, dw = yv.w - m;
-                float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-#pragma unroll
-                for (int off = LPR / 2; off >= 1; off >>= 1) q += __shfl_xor(q, off);
-                const float rs = rsqrtf(q * (1.0f / C) + a.eps2);
-                const float4 g4 = *reinterpret_cast<const float4 *>(a.ln2_w + ccol);
-                const float4 b4 = *reinterpret_cast<const float4 *>(a.ln2_b + ccol);
-                if (live)
-                    *reinterpret_cast<float4 *>(a.y_norm + (size_t)row * C + ccol) =
-                        make_float4(dx * rs * g4.x + b4.x, dy * rs * g4.y + b4.y, dz * rs * g4.z + b4.z,
-                                    dw * rs * g4.w + b4.w);
-            }
-        }
-        wave_lds_sync();  // the next batch's input stage rewrites this tile
-    }
-}
-
-template <int C, int FF>
-static int launch_ffn(const FfnArgs &a, hipStream_t stream) {
-    constexpr int BUF = FFN_CH * (C + 2) + C * (FFN_CH + 8);
-    const size_t lds_bytes = ((size_t)BUF * 2 + FFN_NW * 128) * 4;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ffn<C, FF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        cus = 256;
-    const int nbatch = (a.n_rows + FFN_NW * 16 - 1) / (FFN_NW * 16);
-    int per_cu = (int)((160 * 1024) / lds_bytes);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
-    int grid = cus * per_cu;
-    if (grid > nbatch) grid = nbatch;
-    if (grid < 1) return MSSVT_OK;
-    k_ffn<C, FF><<<grid, FFN_NW * MSSVT_WAVE, lds_bytes, stream>>>(a);
-    return mssvt_launch_status();
-}
-
 // ---------------------------------------------------------------------------------------------
 // Split form: two launches with the WHOLE weight matrix of each GEMM resident in LDS
 // (W1: FF x (C+4) floats = 132 KiB at C=128, FF=256; W2: C x (FF+4) = 130 KiB), one 16-wave
 // workgroup per CU, 16 rows per wavefront, NO barrier after the weights are staged: waves run
 // independently, so one wave's row gathers / LayerNorm / stores overlap with the MFMAs of the
-// other three on its SIMD.  The fused kernel above streams both matrices through LDS for every
-// 64 rows (8 barriers per batch) and reaches ~40 % of the fp32 MFMA peak; the price of the split
+// other three on its SIMD.  (The deleted single-launch form streamed both matrices through LDS for every
+// 64 rows, 8 barriers per batch, ~40 % of the fp32 MFMA peak.)  The price of the split
 // is one (N, FF) round trip of the hidden activations (4*FF bytes per row written + read).
 // Both GEMMs are computed transposed (D^T[out][row]), see block_attn.hip: A = weight rows (one
 // ds_read_b128 per 4 k-steps, conflict free with the +4 padding), B = the activations held as
@@ -1202,12 +907,7 @@ static int dispatch_ffn(int C, int FF, const FfnArgs &a, float *hidden, int phas
         if (C == 32 && FF == 64) return launch_ffn_split<32, 64>(a, hidden, phases, st);
         return MSSVT_E_TOOLARGE;
     }
-    if (phases != 3) return MSSVT_E_BADARG;
-    if (a.n_rows_dev) return MSSVT_E_BADARG;  // the single-launch form sizes its grid on the host
-    if (C == 128 && FF == 256) return launch_ffn<128, 256>(a, st);
-    if (C == 64 && FF == 128) return launch_ffn<64, 128>(a, st);
-    if (C == 32 && FF == 64) return launch_ffn<32, 64>(a, st);
-    return MSSVT_E_TOOLARGE;  // shape not instantiated: callers use library GEMMs instead
+    return MSSVT_E_BADARG;  // the fp32 form needs the (n_rows, FF) scratch
 }
 
 extern "C" int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *x_in,

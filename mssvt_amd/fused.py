@@ -656,7 +656,6 @@ def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
 
 
 FFN_SHAPES = {(128, 256), (64, 128), (32, 64)}  # instantiated in csrc/ffn.hip
-FFN_SPLIT = os.environ.get("MSSVT_FFN_SPLIT", "1") != "0"
 CMP_FUSED = os.environ.get("MSSVT_CMP_FUSED", "1") != "0"
 FFN_TIMER = None  # bench.py sets this to a list to time k_ffn_up live (see _ffn_tail)
 # arithmetic of the FFN's matrix products: "f16x3" = every fp32 operand split into two fp16 halves (hi + 2^-11 lo: 22 of 24 mantissa bits), three
@@ -743,7 +742,7 @@ def _ffn_tail(block, sp, x_new, x_in=None, owner=None, table=None, n_rows_dev=No
             if packed is not None:
                 phases = 4  # one launch, split fp16 operands, no hidden scratch
         # fp32 MFMA: two launches with LDS-resident weights; the hidden activations go through this scratch
-        split = phases != 4 and (FFN_SPLIT or n_rows_dev is not None)  # a device-side row count needs the two-launch form
+        split = phases != 4
         hidden = torch.empty((n, FF), dtype=torch.float32, device=x_new.device) if split else packed
         tail = (_P(fr["lnw"]), _P(fr["lnb"]), _f(fr["eps"]), _P(fr["W1"]), _P(fr["b1"]), _P(fr["W2"]), _P(fr["b2"]), _P(y),
                 _P(nxt.weight if y_norm is not None else None),

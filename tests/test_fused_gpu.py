@@ -73,10 +73,9 @@ def test_window_plan_matches_oracle(ws, m1, m2, K, B, pts, occ, monkeypatch):
     np.testing.assert_array_equal(p.owner_win1.cpu().numpy(), own)
 
 
-@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("C,FF,n", [(128, 256, 5000), (64, 128, 1000), (32, 64, 129), (128, 256, 7)])
-def test_fused_ffn_kernel_matches_torch(C, FF, n, split):
-    """LN2 + linear1 + ReLU + linear2 + residual (+ next block's norm1) on the fp32 matrix cores."""
+def test_fused_ffn_kernel_matches_torch(C, FF, n):
+    """LN2 + linear1 + ReLU + linear2 + residual (+ next block's norm1) on the fp32 matrix cores (k_ffn_up / k_ffn_down)."""
     import ctypes
     from mssvt_amd import _lib
     torch.manual_seed(C + n)
@@ -94,7 +93,7 @@ def test_fused_ffn_kernel_matches_torch(C, FF, n, split):
         want = x + l2(torch.relu(l1(ln(x))))
         want_n = ln2(want)
     y, yn = torch.empty_like(x_new), torch.empty_like(x_new)
-    hidden = torch.empty((n, FF), device=DEV) if split else None  # split: two launches, LDS-resident weights
+    hidden = torch.empty((n, FF), device=DEV)  # two launches, LDS-resident weights
     i, f = ctypes.c_int, ctypes.c_float
     _lib.call("mssvt_ffn_fused", i(n), i(C), i(FF), _lib.ptr(x_new), _lib.ptr(x_in), _lib.ptr(owner),
               _lib.ptr(ln.weight), _lib.ptr(ln.bias), f(ln.eps), _lib.ptr(l1.weight), _lib.ptr(l1.bias),
