@@ -1398,20 +1398,24 @@ def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
         kg = (p.k_mask[g][:nw] == 0).sum(1).double()
         flop += float((4.0 * nqv * cg * cg + 4.0 * kg * cg * cg + 4.0 * nqv * kg * cg).sum()) + 12.0 * cg * float((nqv + kg).sum())
     bf16 = getattr(blk, "attn_dtype", "f32") == "bf16" and _attn_refs(blk, None)["bf16_ok"]
-    names = ["k_attn_bf16"] if bf16 else ["k_attn_q", "k_attn_kv", "k_attn_o"]
+    kv16 = not bf16 and getattr(blk, "attn_kv16", ATTN_KV16) and _attn_kv16_ok(blk, _attn_refs(blk, None), p)
+    names = ["k_attn_bf16"] if bf16 else ["k_attn_q", "k_attn_kv", "k_attn_o"]  # prefixes: k_attn_q16 / k_attn_kvh / k_attn_o16 too
     peak_tf = MFMA_F16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
     gbs = alg / (ms * 1e-3) / 1e9
     counters = {k: {kk: v.get(kk) for kk in ("hbm_bytes_per_launch", "mfma_busy_frac", "valu_issue_frac", "cycles_per_launch")}
                 for k, v in (pmc or {}).items() if isinstance(v, dict) and any(k.startswith(n) for n in names)}
     return {"bound": "hbm", "cbs_pattern": int(blk.cbs_pattern),
             "kernel": ("mssvt_block_attention_bf16 (k_attn_bf16: one launch, keys projected in the kernel, bf16 operands)" if bf16
+                       else "mssvt_block_attention_kv16, both head groups (k_attn_q16 + k_attn_kvh + k_attn_o16, grid.y = group: "
+                            "split-fp16 operands, fp32 accumulation, Q' hand-off)" if kv16
                        else "mssvt_block_attention, both head groups (k_attn_q + k_attn_kv + k_attn_o, grid.y = group)"),
             "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs, "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": ms * 1e3, "units_per_launch": {"windows": nw, "valid_key_rows": sum(keys), "valid_query_rows": n_q},
             "matrix": {"algorithmic_flop_per_launch": flop, "tflops": flop / (ms * 1e-3) / 1e12, "peak_tflops": peak_tf,
-                       "frac": flop / (ms * 1e-3) / 1e12 / peak_tf, "operands": "bf16" if bf16 else "f32"},
+                       "frac": flop / (ms * 1e-3) / 1e12 / peak_tf,
+                       "operands": "bf16" if bf16 else "f32 as hi + 2^-11 lo fp16 halves, 3 x v_mfma_f32_16x16x32_f16 (priced against the fp32 matrix peak)" if kv16 else "f32"},
             "pmc": counters or None,
-            "note": "algorithmic bytes exclude the Q~ / Xbar hand-off between the fp32 launches; pmc = per-launch means of "
+            "note": "algorithmic bytes exclude the Q' / Xbar hand-off between the launches; pmc = per-launch means of "
                     "profiles/pmc_frame.json (HBM bytes = 2 FETCH + WRITE, MFMA-pipe and VALU-issue busy fractions)"}
 
 
