@@ -203,6 +203,20 @@ def ffn_arith_name(net):
     return "v_mfma_f32_16x16x4_f32"
 
 
+def attn_arith_name(net, attn_dtype):
+    """How the window attention's matrix products are computed (mssvt_amd/fused.py ATTN_KV16 / attn_dtype)."""
+    from mssvt_amd import fused
+    blk = net.backbone[0]
+    if getattr(blk, "impl", None) != "fused":
+        return "operator path (fp32)"
+    if attn_dtype == "bf16" and fused.attn_uses_bf16(blk):
+        return "bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16), one launch"
+    if getattr(blk, "attn_kv16", fused.ATTN_KV16):
+        return ("fp32 operands as two fp16 halves (as ffn_arith) in all three launches when the parameters keep them inside "
+                "the fp16 range (checked per parameter version), else v_mfma_f32_16x16x4_f32")
+    return "v_mfma_f32_16x16x4_f32"
+
+
 def workload_name(args, cfg_given):
     if cfg_given:
         return "%s: %d-point scene x batch %d per GPU" % (os.path.basename(args.cfg), args.points, args.batch)
@@ -317,7 +331,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.attn_dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": workload_name(args, bool(args.cfg)),
-                       "impl": impl, "attn_dtype": args.attn_dtype, "ffn_arith": ffn_arith_name(net),
+                       "impl": impl, "attn_dtype": args.attn_dtype, "attn_arith": attn_arith_name(net, args.attn_dtype),
+                       "ffn_arith": ffn_arith_name(net),
                        "voxels_per_gpu": int(vc.shape[0]),
                        "frames_rotated": len(frames), "voxels_per_frame": [int(f[2].shape[0]) for f in frames],
                        "output_voxels": int(sp_out.features.shape[0]),

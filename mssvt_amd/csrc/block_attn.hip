@@ -92,14 +92,18 @@ struct AttnPack {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __fp16 fp16v4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define MFMA_H(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16((av), (bv), acc, 0, 0, 0)
 #define H16_SCALE 2048.0f
 #define H16_INV (1.0f / 2048.0f)
 __device__ __forceinline__ void h16_split4(const f32x4 v, h16x4 &hi, h16x4 &lo) {
     const fp16x2 a = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), b = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)a[0]) * H16_SCALE, (v[1] - (float)a[1]) * H16_SCALE),
-                 d = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)b[0]) * H16_SCALE, (v[3] - (float)b[1]) * H16_SCALE);
+    // (v - hi) 2^11 as fma(hi, -2^11, v 2^11): every step is exact, so the bits are those of the subtraction form, and
+    // the fp16 -> fp32 conversion of hi rides inside the instruction (v_fma_mix_f32): 3 instead of 4 VALU per value
+    const f32x2 s01 = f32x2{v[0], v[1]} * f32x2{H16_SCALE, H16_SCALE}, s23 = f32x2{v[2], v[3]} * f32x2{H16_SCALE, H16_SCALE};  // v_pk_mul_f32
+    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)a[0], -H16_SCALE, s01[0]), __builtin_fmaf((float)a[1], -H16_SCALE, s01[1])),
+                 d = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)b[0], -H16_SCALE, s23[0]), __builtin_fmaf((float)b[1], -H16_SCALE, s23[1]));
     hi = h16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
     lo = h16x4{(_Float16)c[0], (_Float16)c[1], (_Float16)d[0], (_Float16)d[1]};
 }
@@ -421,7 +425,7 @@ __global__ void __launch_bounds__(ATTN_QO_WAVES *MSSVT_WAVE) k_attn_o(AttnPack p
 //   WkF [h][u][hi | lo][lane] x  8 B   A rows c = (16 * u + m), k slot (g, j) <-> o = 16 h + 4 g + j   (x scale)
 //   WvF [t][P][hi | lo][lane] x 16 B   A rows o = 16 t + m,        k slot (g, j) <-> the same channel of Xbar_t
 //   WoF [u][s][hi | lo][lane] x 16 B   A rows p = 16 u + m,        k slot (g, j) <-> o = 32 s + 16 (j / 4) + 4 g + j % 4
-//   WkF2 [p][u][hi | lo][lane] x 16 B  WkF of heads 2 p (j < 4) and 2 p + 1 (j >= 4) side by side: one K = 32 instruction
+//   WkF2 [p][u][hi | lo][lane] x 16 B  WkF (x log2 e) of heads 2 p (j < 4) and 2 p + 1 (j >= 4) side by side: one K = 32 instruction
 //                                      per head PAIR in k_attn_kvh<.., QP> (its B operand is zero outside the column's head)
 #define ATTN_QO16_WAVES 8
 #define MFMA_H16(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x16f16((av), (bv), acc, 0, 0, 0)
@@ -457,8 +461,9 @@ __global__ void __launch_bounds__(MSSVT_WAVE) k_attn_pack(const float *Wq, const
         f32x4 v0, v1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v0[j] = Wkv[(size_t)(16 * (2 * pr) + 4 * g + j) * CG + (16 * u + m)] * scale;
-            v1[j] = Wkv[(size_t)(16 * (2 * pr + 1) + 4 * g + j) * CG + (16 * u + m)] * scale;
+            // (x log2 e: k_attn_kvh<.., QP> takes its softmax in base 2)
+            v0[j] = Wkv[(size_t)(16 * (2 * pr) + 4 * g + j) * CG + (16 * u + m)] * (scale * 1.4426950408889634f);
+            v1[j] = Wkv[(size_t)(16 * (2 * pr + 1) + 4 * g + j) * CG + (16 * u + m)] * (scale * 1.4426950408889634f);
         }
         h16x8 hi, lo;
         h16_split8(v0, v1, hi, lo);
@@ -1253,11 +1258,16 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[t][i] = __builtin_fmaf(cr[i], H16_INV, mm[i]);
             }
+            // softmax over the unmasked keys in base 2 (QP: log2 e is folded into the Wk fragments): masked slots score -inf
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, (vmask >> (4 * t + i) & 1) ? sc[t][i] : -INFINITY);
+                for (int i = 0; i < 4; ++i) {
+                    const float sv = QP ? sc[t][i] : sc[t][i] * 1.4426950408889634f;
+                    sc[t][i] = (vmask >> (4 * t + i) & 1) ? sv : -INFINITY;
+                    mx = fmaxf(mx, sc[t][i]);
+                }
             mx = fmaxf(mx, lane_xor16(mx));
             mx = fmaxf(mx, lane_xor32(mx));
             float sum = 0.f;
@@ -1265,7 +1275,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float e = (vmask >> (4 * t + i) & 1) ? __expf(sc[t][i] - mx) : 0.0f;
+                    const float e = __builtin_amdgcn_exp2f(sc[t][i] - mx);  // slot 0 of a list is never masked: mx is finite
                     sc[t][i] = e;
                     sum += e;
                 }

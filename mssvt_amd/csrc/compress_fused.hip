@@ -109,8 +109,9 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void cf_split4(const float v0, const float v1, const float v2, const float v3, h16x4 &hi, h16x4 &lo) {
     const fp16x2 a = __builtin_amdgcn_cvt_pkrtz(v0, v1), b = __builtin_amdgcn_cvt_pkrtz(v2, v3);
-    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz((v0 - (float)a[0]) * CF_SCALE, (v1 - (float)a[1]) * CF_SCALE);
-    const fp16x2 d = __builtin_amdgcn_cvt_pkrtz((v2 - (float)b[0]) * CF_SCALE, (v3 - (float)b[1]) * CF_SCALE);
+    // (v - hi) 2^11 as fma(hi, -2^11, v 2^11): exact steps, same bits, hi converted inside v_fma_mix_f32
+    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)a[0], -CF_SCALE, v0 * CF_SCALE), __builtin_fmaf((float)a[1], -CF_SCALE, v1 * CF_SCALE));
+    const fp16x2 d = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)b[0], -CF_SCALE, v2 * CF_SCALE), __builtin_fmaf((float)b[1], -CF_SCALE, v3 * CF_SCALE));
     hi = h16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
     lo = h16x4{(_Float16)c[0], (_Float16)c[1], (_Float16)d[0], (_Float16)d[1]};
 }

@@ -492,8 +492,11 @@ __device__ __forceinline__ f32x2 ffw_relu2(f32x2 v) { return f32x2{fmaxf(v[0], 0
 // v -> (hi, lo) halves of 4 floats
 __device__ __forceinline__ void ffw_split4(const f32x2 v01, const f32x2 v23, h16x4 &hi, h16x4 &lo) {
     const fp16x2 a = __builtin_amdgcn_cvt_pkrtz(v01[0], v01[1]), b = __builtin_amdgcn_cvt_pkrtz(v23[0], v23[1]);
-    const f32x2 r01 = (v01 - pk2((float)a[0], (float)a[1])) * pk1(FFW_SCALE), r23 = (v23 - pk2((float)b[0], (float)b[1])) * pk1(FFW_SCALE);
-    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz(r01[0], r01[1]), d = __builtin_amdgcn_cvt_pkrtz(r23[0], r23[1]);
+    // (v - hi) 2^11 as fma(hi, -2^11, v 2^11): exact steps, the bits of the subtraction form; the fp16 -> fp32 conversion
+    // of hi rides inside v_fma_mix_f32 (one packed multiply + two mixed fmas per pair instead of two conversions + two packed ops)
+    const f32x2 s01 = v01 * pk1(FFW_SCALE), s23 = v23 * pk1(FFW_SCALE);
+    const fp16x2 c = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)a[0], -FFW_SCALE, s01[0]), __builtin_fmaf((float)a[1], -FFW_SCALE, s01[1])),
+                 d = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)b[0], -FFW_SCALE, s23[0]), __builtin_fmaf((float)b[1], -FFW_SCALE, s23[1]));
     hi = h16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
     lo = h16x4{(_Float16)c[0], (_Float16)c[1], (_Float16)d[0], (_Float16)d[1]};
 }

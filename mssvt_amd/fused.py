@@ -615,9 +615,10 @@ def _attn_kv16_ok(block, r, p):
             cg = Wq.shape[0]
             Wq, bq, Wkv, bkv, Wo = [t.detach().float() for t in (Wq, bq, Wkv, bkv, Wo)]
             qmax = Wq.abs().sum(1) * tmax + bq.abs()  # (cg) bound of |q'_o|
-            worst += [qmax.max(), (Wkv[:cg].abs() * qmax[:, None]).sum(0).max() * abs(r["scale"]),
+            # (x log2 e: the Q' hand-off form folds it into the Wk fragments)
+            worst += [qmax.max(), (Wkv[:cg].abs() * qmax[:, None]).sum(0).max() * abs(r["scale"]) * 1.4426950408889634,
                       (Wkv[cg:].abs().sum(1) * tmax + bkv[cg:].abs()).max(), Wq.abs().max(),
-                      Wkv.abs().max() * max(1.0, abs(r["scale"])), Wo.abs().max()]
+                      Wkv.abs().max() * max(1.0, abs(r["scale"]) * 1.4426950408889634), Wo.abs().max()]
         worst = torch.stack([w.float() for w in worst]).max()
         r["kv16_ok"] = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
         r["kv16_packed"] = None
