@@ -554,8 +554,8 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_q16(Att
             wc = a.wcentre[src.x];
             ATTN_Q16_ROWS()
         }
-        const float relb = g == 0 ? rm.x : (g == 1 ? rm.y : (g == 2 ? rm.z : 1.0f));
-        const float ctrb = g == 0 ? wc.x : (g == 1 ? wc.y : (g == 2 ? wc.z : 0.0f));
+        const float relb = lane_pick4(g, rm.x, rm.y, rm.z, 1.0f);
+        const float ctrb = lane_pick4(g, wc.x, wc.y, wc.z, 0.0f);
         h16x8 xh[NP], xl[NP];
 #pragma unroll
         for (int P = 0; P < NP; ++P) {
@@ -812,7 +812,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
             const unsigned long long bal_ = __ballot(ok_);  /* bits 0..15: keys 16 t + 0..15 */ \
             vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
             used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
-            rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
+            rel_r[t] = lane_pick4(g, km_m[t].x, km_m[t].y, km_m[t].z, 1.0f); \
             const unsigned ro_ = (unsigned)__umul24((unsigned)(ok_ ? r_ : 0), row_bytes) + lane_off; \
             _Pragma("unroll") for (int S = 0; S < NT; ++S)                                 \
                 T1n[t][S] = (CGP == CG || 16 * S + 4 * g < CG) ? KV_ROW4(ro_, S) : f32x4{0.f, 0.f, 0.f, 0.f}; \
@@ -1099,7 +1099,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
             const unsigned long long bal_ = __ballot(ok_);                                 \
             vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
             used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
-            rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
+            rel_r[t] = lane_pick4(g, km_m[t].x, km_m[t].y, km_m[t].z, 1.0f); \
             const unsigned ro_ = (unsigned)__umul24((unsigned)(KVH_ABL(1) ? (r_ & 7) : ok_ ? r_ : 0), row_bytes) + lane_off; \
             _Pragma("unroll") for (int S = 0; S < NT; ++S) T1n[t][S] = KVH_ROW4(ro_, S);   \
         }                                                                                  \
@@ -1137,7 +1137,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         const int nqv = qbase_r + nqv_r <= a.row_capacity ? nqv_r : 0;
         const size_t qbase = (size_t)qbase_r;
         const unsigned vmask = vmask_r, used = used_r;
-        const float ctrb = g == 0 ? wc.x : (g == 1 ? wc.y : wc.z);  // wctr is 0 for g = 3
+        const float ctrb = lane_pick4(g, wc.x, wc.y, wc.z, wc.z);  // wctr is 0 for g = 3
         // key tokens = row + relu(positional MLP), split once, straight into the image (both products read it: the score
         // product row-wise, the second one transposed -- no token registers live across the passes: 4 waves / SIMD)
 #pragma unroll

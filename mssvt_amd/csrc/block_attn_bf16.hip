@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
             const unsigned long long bal_ = __ballot(ok_);                                 \
             vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
             used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
-            rel_r[t] = g == 0 ? km_m[t].x : (g == 1 ? km_m[t].y : (g == 2 ? km_m[t].z : 1.0f)); \
+            rel_r[t] = lane_pick4(g, km_m[t].x, km_m[t].y, km_m[t].z, 1.0f); \
             /* rows of empty slots / unused tiles read row 0 (never used; a guarded load would cost the pipeline) */ \
             const unsigned ro_ = (unsigned)__umul24((unsigned)(ok_ ? r_ : 0), row_bytes) + lane_off; \
             _Pragma("unroll") for (int S = 0; S < NT; ++S)                                 \
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(BA_WAVES *MSSVT_WAVE, KT >= 4 ? 1 : 2) k_attn_
 #pragma unroll
             for (int s = 0; s < NS; ++s) wq[s] = Wf[((0 * NT + 0) * NS + s) * 64 + lane];
             // query tokens: + relu(positional MLP) -> B operand of Q'^T = Wq Xq^T
-            const float qrel = g == 0 ? qm.x : (g == 1 ? qm.y : (g == 2 ? qm.z : 1.0f));
+            const float qrel = lane_pick4(g, qm.x, qm.y, qm.z, 1.0f);
             bf16x8 Xb[NS];
             {
                 f32x4 tk[2 * NS];

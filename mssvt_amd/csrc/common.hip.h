@@ -84,6 +84,15 @@ __device__ __forceinline__ float wave_max_uniform(float v) {
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+// component g (0..3) of (x, y, z, w), lane by lane, as three v_cndmask (the nested `g == 0 ? x : (g == 1 ? ...` form is
+// compiled into exec-masked branches: ~30 instructions and 6 branches per use inside the attention kernels' window loops)
+__device__ __forceinline__ float lane_pick4(int g, float x, float y, float z, float w) {
+    float r = w;
+    r = g == 2 ? z : r;
+    r = g == 1 ? y : r;
+    r = g == 0 ? x : r;
+    return r;
+}
 #define DPP_MOV_U(v, ctrl) (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true)
 __device__ __forceinline__ unsigned int wave_min_u32_uniform(unsigned int v) {
     unsigned int o;

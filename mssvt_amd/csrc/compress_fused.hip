@@ -292,7 +292,7 @@ __device__ __forceinline__ void cmp_keys_body(const CmpArgs &a, int block_id, in
     for (int t = 0; t < NT; ++t) {
         const float *wr = a.Wp1 + (size_t)(16 * t + la) * 6;
         w1a[t][0] = wr[g];
-        w1a[t][1] = g == 0 ? wr[4] : (g == 1 ? wr[5] : (g == 2 ? a.bp1[16 * t + la] : 0.f));
+        w1a[t][1] = lane_pick4(g, wr[4], wr[5], a.bp1[16 * t + la], 0.f);
     }
     __syncthreads();
     const int n = a.num_voxels, tiles = (n + 15) >> 4;
@@ -308,8 +308,8 @@ __device__ __forceinline__ void cmp_keys_body(const CmpArgs &a, int block_id, in
                     czm = cf_centre(wi.y, a.wsz, a.minz);
         const float rx = cf_centre(vi.w, a.vsx, a.minx) - cxm, ry = cf_centre(vi.z, a.vsy, a.miny) - cym,
                     rz = cf_centre(vi.y, a.vsz, a.minz) - czm;  // NOT masked in the CompressBlock (ref :372)
-        const float in0 = g == 0 ? rx : (g == 1 ? ry : (g == 2 ? rz : cxm));
-        const float in1 = g == 0 ? cym : (g == 1 ? czm : (g == 2 ? 1.0f : 0.0f));
+        const float in0 = lane_pick4(g, rx, ry, rz, cxm);
+        const float in1 = lane_pick4(g, cym, czm, 1.0f, 0.0f);
         const float *xr = a.xhat + (size_t)v * C + 4 * g;
         float4 xv[NT];
 #pragma unroll
