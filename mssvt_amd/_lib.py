@@ -35,10 +35,42 @@ def lib():
         _lib.mssvt_ffn_packed_bytes.restype = ctypes.c_longlong
         _lib.mssvt_level_sorted_scratch_ints.restype = ctypes.c_longlong
         _lib.mssvt_attn_packed_bytes.restype = ctypes.c_longlong
+        global TYPED
+        TYPED = _declare(_lib)
     return _lib
 
 
 _NULL = ctypes.c_void_p(0)
+TYPED = False  # argtypes of every entry point set from include/mssvt_hip.h: callers may pass plain ints / floats / addresses
+
+
+def _declare(lib_):
+    """argtypes / restype of every `mssvt_*` function from the declarations of include/mssvt_hip.h (int, float,
+    long long, pointers).  With them ctypes converts plain Python ints and floats in C: the fused forward passes ~600
+    scalar / pointer arguments per frame, and a ctypes.c_int / c_void_p object per argument cost ~0.1 ms of host time per
+    frame.  Without the header (a stripped install) nothing is declared and the callers keep wrapping."""
+    import re
+    path = os.path.join(os.path.dirname(_HERE), "include", "mssvt_hip.h")
+    if not os.path.exists(path):
+        return False
+    with open(path) as f:
+        txt = f.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    kinds = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong}
+    rets = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "const char *": ctypes.c_char_p}
+    for ret, name, params in re.findall(r"\b(int|long long|const char \*)\s*(mssvt_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        fn = getattr(lib_, name, None)
+        if fn is None:
+            continue
+        params = params.replace("\n", " ").strip()
+        args = []
+        for q in ([] if params in ("", "void") else params.split(",")):
+            q = q.strip()
+            args.append(ctypes.c_void_p if "*" in q else kinds[" ".join(q.split()[:-1])])
+        fn.argtypes = args
+        fn.restype = rets[ret]
+    return True
 
 
 def check(status, what):
@@ -60,6 +92,11 @@ def ptr_fast(t):
     """`ptr` without the device / contiguity checks: for buffers the fused path allocated itself and for module
     parameters (the frame's front is launch bound: ~200 pointer conversions per frame)."""
     return _NULL if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_raw(t):
+    """Address of a device buffer as a plain int (None -> NULL): for entry points with declared argtypes."""
+    return None if t is None else t.data_ptr()
 
 
 def stream():

@@ -28,8 +28,25 @@ import torch.nn.functional as F
 from . import _lib, mssvt_ops
 from .mssvt_utils import batch_counts
 
-_i, _f = ctypes.c_int, ctypes.c_float
-_P = _lib.ptr_fast  # every tensor handed over here is a contiguous device buffer (allocated below, or a parameter)
+try:
+    _lib.lib()
+except _lib.MssvtHipError:  # library not built: the first entry-point call raises (there is no CPU fallback)
+    pass
+# scalars and addresses go to the C entry points as plain Python values when their argtypes are declared (_lib.TYPED)
+_i, _f = (int, float) if _lib.TYPED else (ctypes.c_int, ctypes.c_float)
+def _no_grad(fn):
+    """torch.no_grad() as a decorator without its per-call cost when autograd is already off (the inference path enters ~30
+    decorated functions per frame; each torch.no_grad() entry clones the context object and flips the grad mode twice)."""
+    def wrapper(*args, **kwargs):
+        if torch.is_grad_enabled():
+            with torch.no_grad():
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+    return wrapper
+
+
+_P = _lib.ptr_raw if _lib.TYPED else _lib.ptr_fast  # every tensor handed over here is a contiguous device buffer (allocated below, or a parameter)
 
 
 def _f3(xs):
@@ -52,12 +69,8 @@ def _needs_grad(block, sp):
     return torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters()))
 
 
-def supported(block, sp):
-    """Shapes the v1 fused kernels cover; anything else runs the operator-level path."""
-    if torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters())):
-        return False  # forward-only kernels: training goes through the differentiable ops path
-    if sp.features.dtype != torch.float32 or not sp.features.is_cuda:
-        return False
+def _supported_static(block):
+    """The constructor-time half of `supported` (window sizes, list lengths, head shapes): evaluated once per block."""
     attn = block.ms_attn
     if any((cg, attn.per_head_dim) not in ATTN_SHAPES for cg in attn.scale_dims) or block.key_num_sample > 64:
         return False
@@ -70,7 +83,21 @@ def supported(block, sp):
     return nq <= 256 and max(block.win1_size) <= 60
 
 
-@torch.no_grad()
+def supported(block, sp):
+    """Shapes the v1 fused kernels cover; anything else runs the operator-level path."""
+    if torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters())):
+        return False  # forward-only kernels: training goes through the differentiable ops path
+    f = sp.features
+    if f.dtype != torch.float32 or not f.is_cuda:
+        return False
+    key = (block.cbs_pattern, block.key_num_sample, block.max_num_win1, block.max_num_win2)
+    ok = block.__dict__.get("_fused_static_ok")
+    if ok is None or ok[0] != key:
+        ok = block.__dict__["_fused_static_ok"] = (key, _supported_static(block))
+    return ok[1]
+
+
+@_no_grad
 def level_state(sp, blocks=()):
     """Per voxel-set (resolution level) device state shared by all plans on it.  A level the backbone did not set up
     (a Block called on its own SparseTensor) tries the sorted set-up first and reads its verdict with one host sync;
@@ -117,7 +144,7 @@ def _level_partitions(blocks):
     return todo
 
 
-@torch.no_grad()
+@_no_grad
 def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     """Level state from `mssvt_level_setup_sorted` (counts, occupancy columns, column bases, window partitions of
     `blocks`), or None when not applicable.  The caller checks st["level_status"] for ST_UNSORTED."""
@@ -216,7 +243,7 @@ def window_partition(block, sp, st, need_table=False):
 LEVEL_SETUP = True  # counts + voxel table + occupancy columns + window partitions of the input level in one call
 
 
-@torch.no_grad()
+@_no_grad
 def setup_input_level(blocks, sp_kwargs, assume_sorted=True):
     """SparseTensor of the backbone input with everything its first resolution level needs (`mssvt_level_setup`:
     per-sample counts, voxel hash table, occupancy columns, the window partitions of the Blocks up to and
@@ -356,7 +383,7 @@ def _table_footprint(block, t):
     return fp[1], fp[2]
 
 
-@torch.no_grad()
+@_no_grad
 def two_scale_plan(block, sp, all_lists=False):
     st = level_state(sp, [block] + ([sp._next_compress] if getattr(sp, "_next_compress", None) is not None else []))
     key = block.plan_key()
@@ -491,7 +518,7 @@ def _row_capacity(block, p, nq, num_voxels):
     return max(min(int(num_voxels) * overlap, int(p.cap) * int(nq)), 1)
 
 
-@torch.no_grad()
+@_no_grad
 def _work_order(block, p, nq, num_voxels):
     """Work order + compact query rows of this cbs_pattern's query list (mssvt_plan_order): dict of
     perm, n_act, q_off, nq_valid, row_meta, row_src, n_rows, row_cap."""
@@ -562,7 +589,7 @@ def _attn_refs(block, groups):
 ATTN_ARITH = os.environ.get("MSSVT_ATTN_ARITH", "f32")
 
 
-@torch.no_grad()
+@_no_grad
 def _attn_f16_ok(block, r, p):
     """True when tokens and projections of the window attention stay inside the fp16 range whatever the input is:
     |xhat| <= sqrt(C) max|w| + max|b|, the positional term <= |Wp_c|_1 max|coordinate| + |bp_c| (relative offsets and
@@ -595,7 +622,7 @@ ATTN_KV16 = os.environ.get("MSSVT_ATTN_KV16", "1") != "0"
 ATTN_QO16 = os.environ.get("MSSVT_ATTN_QO16", "1") != "0"
 
 
-@torch.no_grad()
+@_no_grad
 def _attn_kv16_ok(block, r, p):
     """True when the matrix operands of the split-fp16 attention launches stay inside the fp16 range whatever the input
     is: key / query tokens |xhat| + positional term (as _attn_f16_ok), Q' by |Wq_o|_1 tmax + |bq_o|, Qt = scale Wk_h^T q'_h
@@ -690,7 +717,7 @@ def _content_key(ts):
     return tuple(float(t.detach().double().sum().item()) + float(t.detach().double().abs().sum().item()) * 1e-3 for t in ts)
 
 
-@torch.no_grad()
+@_no_grad
 def _ffn_f16_weights(fr):
     """The split-fp16 fragments of W1 / W2 (mssvt_ffn_pack_weights) when the operands of the split-fp16 FFN stay inside
     the fp16 range whatever the input rows are, else None: a LayerNorm output is bounded by sqrt(C) max|w| + max|b|, a
@@ -843,7 +870,7 @@ def side_overlap_on(sp):
     return SIDE_OVERLAP == "1" or (SIDE_OVERLAP == "auto" and sp.features.shape[0] >= SIDE_OVERLAP_MIN_VOXELS)
 
 
-@torch.no_grad()
+@_no_grad
 def overlap_front(schedule, sp):
     """Issue norm1 of the first Block and the plan of the level's CompressBlock on the side stream; the consumers wait
     for `sp._xhat_event` / `sp._cmp_plan_event` on their own stream (block_forward, _compress_forward_fused)."""
@@ -876,7 +903,7 @@ def _wait_side(sp, name):
         torch.cuda.current_stream(sp.features.device).wait_event(ev)
 
 
-@torch.no_grad()
+@_no_grad
 def prefetch_level(schedule, sp):
     """All index work of the input level, on the CURRENT stream: the plans of its Blocks (with their work orders and
     interpolation tables) and the plan of the CompressBlock that ends it.  The feature phase finds them cached."""
@@ -966,8 +993,7 @@ def block_forward(block, sp):
     return sp
 
 
-@torch.no_grad()
-@torch.no_grad()
+@_no_grad
 def prepare_group(blocks, sp, p):
     """Work orders + interpolation tables of ALL blocks that share plan `p`, one launch (pair) per kind
     instead of one per block: they depend on the plan only, and a single-workgroup ordering kernel per
@@ -1063,7 +1089,7 @@ def compress_supported(block, sp):
     return hd <= 64 and (hd & (hd - 1)) == 0 and max(block.ms_attn.scale_dims) <= 128
 
 
-@torch.no_grad()
+@_no_grad
 def one_scale_plan(block, sp, sync=True):
     """K2 + K4 + pair-row allocation for a CompressBlock; sync=True: one host sync here (the ragged
     kernels size their buffers with the window count), sync=False: the caller reads p.ws later."""
@@ -1206,7 +1232,7 @@ def _compress_fused_ok(block, sp, C):
     return True
 
 
-@torch.no_grad()
+@_no_grad
 def _compress_f16_ok(block, sp):
     """True when every matrix operand of the CompressBlock attention stays inside the fp16 range whatever the input is
     (the split-fp16 products of csrc/compress_fused.hip): |xhat| <= sqrt(C) max|w1| + max|b1|; the positional hidden
@@ -1237,7 +1263,7 @@ def _compress_f16_ok(block, sp):
     return cache["ok"]
 
 
-@torch.no_grad()
+@_no_grad
 def _compress_forward_fused(block, sp, xhat, x_in):
     """Four MFMA launches + the two FFN launches, all counts on the device; ONE host sync at the end
     (the output shape)."""
