@@ -1140,6 +1140,14 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         const float ctrb = lane_pick4(g, wc.x, wc.y, wc.z, wc.z);  // wctr is 0 for g = 3
         // key tokens = row + relu(positional MLP), split once, straight into the image (both products read it: the score
         // product row-wise, the second one transposed -- no token registers live across the passes: 4 waves / SIMD)
+        float wu[NT];  // A operand of the positional product: once per window (the window centre), not once per key tile
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            float cs = wctr[u] * ctrb;
+            cs += lane_xor16(cs);
+            cs += lane_xor32(cs);
+            wu[u] = g == 3 ? wrel[u] + cs : wrel[u];
+        }
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
 #pragma unroll
@@ -1151,12 +1159,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int u = 2 * P + h;
-                        float cs = wctr[u] * ctrb;
-                        cs += lane_xor16(cs);
-                        cs += lane_xor32(cs);
-                        const float wu = g == 3 ? wrel[u] + cs : wrel[u];
                         f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        MFMA4(p1, wu, rel_r[t]);
+                        MFMA4(p1, wu[u], rel_r[t]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) tk[h][i] = T1n[t][u][i] + fmaxf(p1[i], 0.0f);
                     }
