@@ -663,6 +663,17 @@ def _attn_kv16_ok(block, r, p):
     return r["kv16_ok"]
 
 
+def _attn_weight_args(r, pa):
+    """The eight weight arguments of an attention entry point (six pointer arrays + the positional layer): built once per
+    parameter set -- the tensors of `r` are replaced together with `r` itself (_attn_refs, refresh_weights)."""
+    w = r.get("warg")
+    ptrs = tuple(t.data_ptr() for t in r["Wq"]) + (r["Wp"].data_ptr(),)
+    if w is None or w[0] != ptrs:
+        w = r["warg"] = (ptrs, (pa(r["Wq"]), pa(r["bq"]), pa(r["Wkv"]), pa(r["bkv"]), pa(r["Wo"]), pa(r["bo"]),
+                                _P(r["Wp"]), _P(r["bp"])))
+    return w[1]
+
+
 def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
     """mssvt_block_attention (or its bf16-operand form) for the given head groups (default: all)."""
     r = _attn_refs(block, groups)
@@ -670,8 +681,8 @@ def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
     pa = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
     head = (_i(C), _i(n), r["c0"], r["cg"], r["heads"], _i(r["hd"]), _f(r["scale"]), _i(nq), _i(r["K"]), _P(xhat),
             _P(od["n_act"]), _P(od["perm"]), _P(od["q_off"]), _P(od["nq_valid"]), _P(od["n_rows"]), _i(od["row_cap"]),
-            _P(od["row_meta"]), _P(od["row_src"]), pa([p.kmeta[g] for g in r["gs"]]), _P(p.wcentre), pa(r["Wq"]),
-            pa(r["bq"]), pa(r["Wkv"]), pa(r["bkv"]), pa(r["Wo"]), pa(r["bo"]), _P(r["Wp"]), _P(r["bp"]))
+            _P(od["row_meta"]), _P(od["row_src"]), pa([p.kmeta[g] for g in r["gs"]]), _P(p.wcentre),
+            *_attn_weight_args(r, pa))
     if getattr(block, "attn_dtype", "f32") == "bf16" and r["bf16_ok"]:
         _lib.call("mssvt_block_attention_bf16", *head, _P(attn), _lib.stream())
     elif r["bf16_ok"] and getattr(block, "attn_arith", ATTN_ARITH) == "f16x3" and _attn_f16_ok(block, r, p):
