@@ -263,3 +263,46 @@ def test_split_f16_window_launch_range_guard():
     with torch.no_grad():
         blk.ms_attn.to_qs[0].weight.mul_(3.0e4)
     assert not fused._attn_kv16_ok(blk, fused._attn_refs(blk, None), P)
+
+
+def test_split_f16_attention_with_64_keys_matches_fp32_kernels():
+    """key_num_sample = 64 at the benchmark's head shape (Cg 64, head dim 16): the window launch's four-tile
+    instantiation, fed with Qt fragments by launch A (the Q' hand-off is the K <= 32 form) -- against the fp32-instruction
+    launches, fp32 tolerance."""
+    from mssvt_amd import config, fused
+    from mssvt_amd.mssvt_utils import SparseTensor
+    cfg = config.load_yaml(config.DEFAULT_CFG)
+    params = [dict(p) for p in cfg.MODEL.BACKBONE_3D.PARAMS]
+    for p_ in params:
+        p_["key_num_sample"] = 64
+    cfg.MODEL.BACKBONE_3D.PARAMS = params
+    pts = synthetic.make_batch_points(60000, 1, 21)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    torch.manual_seed(0)
+    net = config.build_backbone_from_cfg(cfg).to(DEV).eval()
+    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        sp = SparseTensor(features=feats, indices=torch.from_numpy(vc).to(DEV).int().contiguous(),
+                          spatial_shape=net.grid_size, voxel_size=net.voxel_size,
+                          point_cloud_range=net.point_cloud_range, batch_size=1, hash_size=net.hash_size)
+        blk = net.backbone[0]
+        assert blk.key_num_sample == 64
+        p = fused.two_scale_plan(blk, sp)
+        xhat = fused.layer_norm(feats, blk.norm1)
+        q_ind, nq, _ = fused._query(blk, p)
+        od = fused._work_order(blk, p, nq, feats.shape[0])
+        qbuf = fused._query_scratch(p, od["row_cap"], blk.ms_attn, feats.device)
+        assert fused._attn_kv16_ok(blk, fused._attn_refs(blk, None), p)
+        rows = {}
+        for mode in ("f32", "kv16+qo16"):
+            blk.attn_kv16 = blk.attn_qo16 = mode != "f32"
+            attn = torch.zeros((p.cap * nq + 1, 128), dtype=torch.float32, device=DEV)
+            fused._attention_call(blk, p, od, 128, nq, xhat, qbuf, attn)
+            rows[mode] = attn
+        nw = int(p.num_wins.item())
+        valid = (q_ind[:nw] >= 0).reshape(-1)
+        a, b = rows["f32"][:nw * nq][valid], rows["kv16+qo16"][:nw * nq][valid]
+        assert a.shape[0] > 1000 and not torch.equal(a, b)
+        assert int((p.k_mask[1][:nw] == 0).sum(1).max()) > 32  # windows that really use more than two key tiles
+        tol = 1e-5 * float(a.abs().max()) + 1e-4 * a.abs()
+        assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
