@@ -471,6 +471,38 @@ def test_even_window_sizes_overlapping_lists_match_oracle(impl, m1, pattern, int
     assert_feat_close(sp.features.cpu().numpy(), want.features)
 
 
+@pytest.mark.parametrize("K", [32, 64])
+def test_half_width_backbone_matches_oracle(K):
+    """C = 64 with heads [2, 2]: head groups of 32 channels at head dim 16 -- the Cg = 32 instantiations of the split-fp16
+    attention launches (k_attn_q16 / k_attn_kvh / k_attn_o16, one head pair per group) and the (64, 128) FFN -- against the
+    oracle, both window-launch forms (K <= 32: Q' hand-off; K = 64: Qt fragments)."""
+    from mssvt_amd import fused
+    from mssvt_amd.mssvt_backbone import MixedScaleSparseTransformer
+    C, B, H = 64, 2, 100003
+    blk = lambda pat: dict(name="MixedScaleSparseTransformerBlock", channels=[C, 2 * C, C], num_heads=[2, 2],  # noqa: E731
+                           window_size=[[3, 3, 5], [7, 7, 7]], max_num_win1=45, max_num_win2=343, cbs_mode="odd_even",
+                           cbs_pattern=pat, key_num_sample=K, use_feature_interpolation=True)
+    params = [blk(1), blk(0), dict(name="MixedScaleSparseTransformerCompressBlock", channels=[C, 2 * C, C], num_heads=[4],
+                                   window_size=[[1, 1, 32]], max_num_win1=32)]
+    pts = synthetic.make_batch_points(12000, B, 77)
+    vc, _, _ = synthetic.voxelize_numpy(pts)
+    feats = torch.randn(vc.shape[0], C, generator=torch.Generator().manual_seed(4)).numpy()
+    torch.manual_seed(2)
+    net = MixedScaleSparseTransformer(_cfg(params, H, C), C, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
+                                      synthetic.POINT_CLOUD_RANGE).eval()
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    want = block_ref.backbone_forward(sd, params, feats, vc, B, synthetic.GRID_SIZE, synthetic.VOXEL_SIZE,
+                                      synthetic.POINT_CLOUD_RANGE, H)
+    net = net.to(DEV).set_impl("fused")
+    with torch.no_grad():
+        sp = net(dict(voxel_features=torch.from_numpy(feats).to(DEV), voxel_coords=torch.from_numpy(vc).to(DEV),
+                      batch_size=B))["encoded_spconv_tensor"]
+    r = fused._attn_refs(net.backbone[0], None)
+    assert r.get("kv16_ok") and r.get("kv16_packed") is not None, "the split-fp16 launches must have run"
+    np.testing.assert_array_equal(sp.indices.cpu().numpy(), want.indices)
+    assert_feat_close(sp.features.cpu().numpy(), want.features)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 5, 6, 7, 12, 13, 17, 1001, 1002, 1005, 1010, 1020])
 def test_random_configurations_fused_matches_operator_path(seed):
     """Random small backbones (window sizes incl. even ones, truncated lists, all cbs patterns, K, batch)."""
