@@ -308,7 +308,9 @@ int mssvt_block_attention(
  * (hi, lo = 2^11 (v - hi)) fp16 halves with fp32 accumulation -- the fp32 instruction's error at ~1/4 of its cycles.
  * The per-window launch (k_attn_kvh: scores, weighted key sum; Qt crosses qbuf pre-split, same bytes) always; the
  * two row-tiled launches (k_attn_q16 / k_attn_o16) when host_packed gives one mssvt_attn_pack_weights blob per head
- * group (head_dim 16), else they keep the fp32 instruction (host_packed may be NULL).  Same arguments and results (to
+ * group (head_dim 16), else they keep the fp32 instruction (host_packed may be NULL).  With the blobs and
+ * key_num_sample <= 32 only Q' crosses qbuf (a quarter of the bytes) and the window launch forms Qt = (scale Wk_h)^T q'_h
+ * itself from the blob's head-pair fragments, its softmax in base 2 (log2 e folded into them).  Same arguments and results (to
  * the fp32 tolerance) as mssvt_block_attention; shapes outside Cg % 32 == 0, 16 < key_num_sample <= 64 run the fp32
  * form.  The CALLER guarantees the fp16 range of key tokens, Q', Qt, Xbar, V (mssvt_amd/fused.py, _attn_kv16_ok). */
 int mssvt_block_attention_kv16(
@@ -321,8 +323,8 @@ int mssvt_block_attention_kv16(
     const void *const *host_packed, void *stream);
 
 /* Split-fp16 fragments of one head group's projections for mssvt_block_attention_kv16, in MFMA operand order: Wq
- * (Cg,Cg), Wkv (2Cg,Cg: K rows then V rows, the softmax scale folded into K), Wo (Cg,Cg) -- nn.Linear layouts of
- * ref mssvt_utils.py:92-103.  Once per parameter version.  mssvt_attn_packed_bytes: size of `packed`, 0 = shape not
+ * (Cg,Cg), Wkv (2Cg,Cg: K rows then V rows; the softmax scale folded into the K fragments, scale x log2 e into their
+ * head-pair copy), Wo (Cg,Cg) -- nn.Linear layouts of ref mssvt_utils.py:92-103.  Once per parameter version.  mssvt_attn_packed_bytes: size of `packed`, 0 = shape not
  * instantiated (head_dim 16, Cg 32 / 64).                                                                          */
 long long mssvt_attn_packed_bytes(int Cg, int head_dim);
 int mssvt_attn_pack_weights(int Cg, int head_dim, float scale, const float *Wq, const float *Wkv, const float *Wo,
