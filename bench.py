@@ -28,6 +28,8 @@ import json
 import os
 import subprocess
 import sys
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # see mssvt_amd/__init__.py (must precede the first GPU call)
 import time
 
 import torch
