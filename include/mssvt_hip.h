@@ -204,8 +204,12 @@ int mssvt_level_setup(int num_voxels, int batch_size, int x_max, int y_max, int 
  * level_status[0] gets ST_UNSORTED (8) when the list is not strictly ascending in (b,x,y,z) or holds an out-of-grid
  * voxel; every partition then reports 0 windows and the caller must use mssvt_level_setup (any order).
  * zero_region / zero_bytes: one caller allocation cleared by this call that contains sample_start, occ_columns,
- * level_status and the ws headers.  scratch: mssvt_level_sorted_scratch_ints(B, X, Y) ints.                     */
+ * level_status and the ws headers (zero_bytes < 0: |zero_bytes| bytes the caller has cleared itself, e.g. with
+ * mssvt_fill_two -- no clear here).  scratch: mssvt_level_sorted_scratch_ints(B, X, Y) ints.                     */
 long long mssvt_level_sorted_scratch_ints(int batch_size, int x_max, int y_max);
+/* a[0..n_a) = value_a and b[0..n_b) = value_b (int32, both 16-byte aligned) in ONE launch: the -1 prefill of a frame's
+ * tables / owner arrays (ref: torch.full(-1) per table, mssvt_utils.py:39, mssvt_ops.py:47) and its zeroed words.    */
+int mssvt_fill_two(int *a, long long n_a, int value_a, int *b, long long n_b, int value_b, void *stream);
 int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_max, int z_max, int hash_size,
                              const int *v_indices, void *zero_region, long long zero_bytes, int *v_bs_cnt,
                              int *sample_start, unsigned long long *occ_columns, int *column_vbase, int *level_status,

@@ -253,6 +253,8 @@ extern "C" int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_ma
                                         const int *host_win_size3, const int *host_max_num_wins, int *const *host_win_ind,
                                         int *const *host_tables, int *const *host_vcount, int *const *host_ws,
                                         int *scratch, void *stream_) {
+    const bool precleared = zero_bytes < 0;  // the caller cleared the region itself (mssvt_fill_two, with its other fills)
+    if (precleared) zero_bytes = -zero_bytes;
     if (!zero_region || zero_bytes <= 0 || !v_bs_cnt || !sample_start || !occ_columns || !column_vbase || !level_status ||
         !scratch || batch_size <= 0 || hash_size <= 0 || num_voxels < 0 || (!v_indices && num_voxels > 0) || x_max <= 0 ||
         y_max <= 0 || z_max <= 0 || num_sets < 0 || num_sets > LS_MAX_PARTS ||
@@ -293,11 +295,39 @@ extern "C" int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_ma
     }
     if (!ok) return MSSVT_E_BADARG;
     hipStream_t stream = (hipStream_t)stream_;
-    hipError_t e = hipMemsetAsync(zero_region, 0, (size_t)zero_bytes, stream);
-    if (e != hipSuccess) return (int)e;
+    if (!precleared) {
+        hipError_t e = hipMemsetAsync(zero_region, 0, (size_t)zero_bytes, stream);
+        if (e != hipSuccess) return (int)e;
+    }
     if (num_voxels > 0) k_level_mark<<<divup(num_voxels, 256), 256, 0, stream>>>(a);
     const dim3 grid(a.nblk, batch_size);
     k_col_sums<<<grid, LS_COLS, 0, stream>>>(a);
     k_col_emit<<<grid, LS_COLS, 0, stream>>>(a);
+    return mssvt_launch_status();
+}
+
+// ---- two constant fills in one launch: the frame's -1 arena (tables, owner arrays, list prefills) and its zero region
+// (status words, window headers, sample starts, occupancy words) were two framework / runtime fill launches
+__global__ void __launch_bounds__(256) k_fill_two(int *a, long long n_a, int value_a, int *b, long long n_b, int value_b) {
+    const long long q_a = n_a >> 2, q_b = n_b >> 2, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < q_a + q_b; i += stride) {
+        if (i < q_a) reinterpret_cast<int4 *>(a)[i] = make_int4(value_a, value_a, value_a, value_a);
+        else reinterpret_cast<int4 *>(b)[i - q_a] = make_int4(value_b, value_b, value_b, value_b);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) {  // the (at most 3 + 3) ints behind the last full quad of each region
+        const int t = threadIdx.x & 3;
+        if (threadIdx.x < 4) { if ((q_a << 2) + t < n_a) a[(q_a << 2) + t] = value_a; }
+        else if ((q_b << 2) + t < n_b) b[(q_b << 2) + t] = value_b;
+    }
+}
+
+extern "C" int mssvt_fill_two(int *a, long long n_a, int value_a, int *b, long long n_b, int value_b, void *stream) {
+    if (n_a < 0 || n_b < 0 || (n_a > 0 && !a) || (n_b > 0 && !b)) return MSSVT_E_BADARG;
+    if ((n_a > 0 && ((uintptr_t)a & 15)) || (n_b > 0 && ((uintptr_t)b & 15))) return MSSVT_E_BADARG;  // 16-byte stores
+    if (n_a + n_b == 0) return MSSVT_OK;
+    long long quads = (n_a >> 2) + (n_b >> 2);
+    int grid = (int)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
+    if (grid < 1) grid = 1;
+    k_fill_two<<<grid, 256, 0, (hipStream_t)stream>>>(a, n_a, value_a, b, n_b, value_b);
     return mssvt_launch_status();
 }

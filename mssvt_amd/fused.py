@@ -161,7 +161,12 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     al = lambda v: (int(v) + 63) // 64 * 64  # noqa: E731  (256-byte aligned pieces)
     sizes = [64, 64 * max(k, 1), al(B + 1), 2 * B * X * Y]
     offs = [sum(sizes[:i]) for i in range(len(sizes))]
-    zero = torch.empty(sum(sizes), dtype=torch.int32, device=dev)  # cleared by the call itself
+    # zeroed together with the frame's -1 arena when there is one (FillArena.take_zero), else cleared by the call itself
+    arena = mssvt_ops.FillArena.current
+    zero = arena.take_zero(sum(sizes)) if arena is not None and arena.buf.device == dev else None
+    precleared = zero is not None
+    if zero is None:
+        zero = torch.empty(sum(sizes), dtype=torch.int32, device=dev)
     status = zero[0:1]
     hdrs = [zero[offs[1] + 64 * i: offs[1] + 64 * (i + 1)] for i in range(k)]
     start = zero[offs[2]:offs[2] + B + 1]
@@ -177,8 +182,8 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     ints = lambda rows: (ctypes.c_int * max(3 * k, 1))(*[int(v) for r in rows for v in r])  # noqa: E731
     ptrs = lambda ts: (ctypes.c_void_p * max(k, 1))(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
     _lib.call("mssvt_level_setup_sorted", _i(n), _i(B), _i(X), _i(Y), _i(Z), _i(H), _P(indices), _P(zero),
-              ctypes.c_longlong(zero.numel() * 4), _P(cnt), _P(start), _P(occ), _P(vbase), _P(status), _i(k),
-              ints(shapes), ints([b.win1_size for b in todo]),
+              ctypes.c_longlong(-zero.numel() * 4 if precleared else zero.numel() * 4), _P(cnt), _P(start), _P(occ), _P(vbase),
+              _P(status), _i(k), ints(shapes), ints([b.win1_size for b in todo]),
               (ctypes.c_int * max(k, 1))(*[int(b.max_num_wins) for b in todo]), ptrs(wins), ptrs(tables),
               ptrs([vcounts[i] for i in range(k)]), ptrs(hdrs), _P(scratch), _lib.stream())
     st = {"indices": indices, "v_bs_cnt": cnt, "plans": {}, "occ": occ, "vbase": vbase, "level_status": status,

@@ -481,7 +481,8 @@ class MixedScaleSparseTransformer(nn.Module):
                 if fused_path:
                     # (+3 %: the demand follows the voxel count, which drifts from frame to frame -- a request that does not fit
                     # costs its own fill launch)
-                    arena = mssvt_ops.FillArena(getattr(self, '_fill_demand', 0) * 33 // 32 + 4096, feats.device)
+                    arena = mssvt_ops.FillArena(getattr(self, '_fill_demand', 0) * 33 // 32 + 4096, feats.device,
+                                                getattr(self, '_fill_zero_demand', 0))
                 mssvt_ops.FillArena.current = arena
                 kw = dict(features=feats, indices=coords.int().contiguous(), spatial_shape=self.grid_size,
                           voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range,
@@ -517,6 +518,6 @@ class MixedScaleSparseTransformer(nn.Module):
         finally:
             mssvt_ops.FillArena.current = None
             if arena is not None:
-                self._fill_demand = arena.demand
+                self._fill_demand, self._fill_zero_demand = arena.demand, arena.zero_demand
         batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
         return batch_dict

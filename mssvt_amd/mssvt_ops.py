@@ -36,14 +36,25 @@ def _ints(xs):
 
 class FillArena(object):
     """One -1-filled int32 buffer per forward, carved into the tables / owner arrays / list prefills the
-    path needs (each would otherwise be its own fill launch, ~4 us of GPU time and a framework call).
+    path needs (each would otherwise be its own fill launch, ~4 us of GPU time and a framework call), with a
+    ZEROED tail for the level's status words / occupancy bitmap: one launch (mssvt_fill_two) for both.
     Sized from the previous forward's demand; a request that does not fit falls back to its own fill."""
     current = None  # set by MixedScaleSparseTransformer.forward around the fused path
 
-    def __init__(self, numel, device):
-        self.buf = torch.full((max(int(numel), 1),), -1, dtype=torch.int32, device=device)
-        self.used = 0
-        self.demand = 0
+    def __init__(self, numel, device, zero_numel=0):
+        numel = (max(int(numel), 1) + 63) // 64 * 64
+        zero_numel = (max(int(zero_numel), 0) + 63) // 64 * 64
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            whole = torch.empty(numel + zero_numel, dtype=torch.int32, device=dev)
+            _lib.call("mssvt_fill_two", _lib.ptr_fast(whole), ctypes.c_longlong(numel), _i(-1),
+                      ctypes.c_void_p(whole.data_ptr() + 4 * numel), ctypes.c_longlong(zero_numel), _i(0), _lib.stream())
+            self.buf, self.zeros = whole[:numel], whole[numel:]
+        else:
+            self.buf = torch.full((numel,), -1, dtype=torch.int32, device=dev)
+            self.zeros = torch.zeros((zero_numel,), dtype=torch.int32, device=dev)
+        self.used = self.zero_used = 0
+        self.demand = self.zero_demand = 0
 
     def take(self, shape):
         n = 1
@@ -55,6 +66,16 @@ class FillArena(object):
             return None
         out = self.buf[self.used:self.used + n].view(*shape)
         self.used += n_al
+        return out
+
+    def take_zero(self, n):
+        """n zeroed ints (256-byte aligned) or None when the zero tail is exhausted."""
+        n_al = (int(n) + 63) // 64 * 64
+        self.zero_demand += n_al
+        if self.zero_used + n_al > self.zeros.numel():
+            return None
+        out = self.zeros[self.zero_used:self.zero_used + int(n)]
+        self.zero_used += n_al
         return out
 
 
