@@ -31,6 +31,25 @@ def test_library_builds_and_exports_declared_abi():
     assert lib.mssvt_hash_workspace_ints(1000, 2) >= 1000
 
 
+def test_every_declared_entry_point_gets_its_argument_types():
+    """mssvt_amd._lib declares argtypes / restype of every entry point from the header (the fused path then hands plain
+    ints and addresses to ctypes): every declared symbol must be covered, with one ctypes type per parameter."""
+    from mssvt_amd import _lib
+    lib = _lib.lib()
+    assert _lib.TYPED
+    src = open(os.path.join(ROOT, "include", "mssvt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name in declared_symbols():
+        fn = getattr(lib, name)
+        assert fn.argtypes is not None, name
+        m = re.search(r"\b%s\s*\(([^;{]*?)\)\s*;" % name, src, flags=re.S)
+        params = m.group(1).strip()
+        want = 0 if params in ("", "void") else params.count(",") + 1
+        assert len(fn.argtypes) == want, (name, len(fn.argtypes), want)
+    assert lib.mssvt_ffn_packed_bytes(128, 256) == 2 * 2 * 128 * 256 * 2  # plain ints in, long long out
+    assert lib.mssvt_hip_status_string(0) == b"ok"
+
+
 def test_argument_errors_are_status_codes_not_exits():
     from mssvt_amd import build
     lib = ctypes.CDLL(build.build())
