@@ -144,6 +144,9 @@ def _level_partitions(blocks):
     return todo
 
 
+_sorted_static = {}
+
+
 @_no_grad
 def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     """Level state from `mssvt_level_setup_sorted` (counts, occupancy columns, column bases, window partitions of
@@ -156,11 +159,24 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
         return None
     dev = indices.device
     B, H = int(B), int(H)
-    todo = _level_partitions(blocks)
-    k = len(todo)
-    al = lambda v: (int(v) + 63) // 64 * 64  # noqa: E731  (256-byte aligned pieces)
-    sizes = [64, 64 * max(k, 1), al(B + 1), 2 * B * X * Y]
-    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    # everything that only depends on the blocks and the grid: built once (the frame's front is host bound)
+    skey = (tuple((id(b), b.max_num_wins, b.win1_size[0], b.win1_size[1], b.win1_size[2]) for b in blocks), B, X, Y, Z)
+    static = _sorted_static.get(skey)
+    if static is None or any(a is not b for a, b in zip(static["blocks"], blocks)):
+        todo = _level_partitions(blocks)
+        k = len(todo)
+        al = lambda v: (int(v) + 63) // 64 * 64  # noqa: E731  (256-byte aligned pieces)
+        sizes = [64, 64 * max(k, 1), al(B + 1), 2 * B * X * Y]
+        ints_ = lambda rows: (ctypes.c_int * max(3 * k, 1))(*[int(v) for r in rows for v in r])  # noqa: E731
+        if len(_sorted_static) > 16:
+            _sorted_static.clear()
+        static = _sorted_static[skey] = dict(
+            blocks=list(blocks), todo=todo, k=k, sizes=sizes, offs=[sum(sizes[:i]) for i in range(len(sizes))],
+            shapes=ints_([[[X, Y, Z][i] // b.win1_size[i] for i in range(3)] for b in todo]),
+            wsizes=ints_([b.win1_size for b in todo]),
+            maxw=(ctypes.c_int * max(k, 1))(*[int(b.max_num_wins) for b in todo]),
+            scratch=int(_lib.lib().mssvt_level_sorted_scratch_ints(_i(B), _i(X), _i(Y))))
+    todo, k, sizes, offs = static["todo"], static["k"], static["sizes"], static["offs"]
     # zeroed together with the frame's -1 arena when there is one (FillArena.take_zero), else cleared by the call itself
     arena = mssvt_ops.FillArena.current
     zero = arena.take_zero(sum(sizes)) if arena is not None and arena.buf.device == dev else None
@@ -173,18 +189,15 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     occ = zero[offs[3]:offs[3] + 2 * B * X * Y].view(torch.int64)
     cnt = torch.empty(B, dtype=torch.int32, device=dev)
     vbase = torch.empty(B * X * Y, dtype=torch.int32, device=dev)
-    scratch = torch.empty(int(_lib.lib().mssvt_level_sorted_scratch_ints(_i(B), _i(X), _i(Y))), dtype=torch.int32, device=dev)
+    scratch = torch.empty(static["scratch"], dtype=torch.int32, device=dev)
     # only a CompressBlock's window table is ever read (it becomes the map_table of the block's output)
     tables = [mssvt_ops.full_neg1((B, H, 2), dev) if isinstance(b, Compress) else None for b in todo]
     wins = [torch.empty((n, 4), dtype=torch.int32, device=dev) for _ in range(k)]
     vcounts = torch.empty((max(k, 1), B), dtype=torch.int32, device=dev)
-    shapes = [[[X, Y, Z][i] // b.win1_size[i] for i in range(3)] for b in todo]
-    ints = lambda rows: (ctypes.c_int * max(3 * k, 1))(*[int(v) for r in rows for v in r])  # noqa: E731
     ptrs = lambda ts: (ctypes.c_void_p * max(k, 1))(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
     _lib.call("mssvt_level_setup_sorted", _i(n), _i(B), _i(X), _i(Y), _i(Z), _i(H), _P(indices), _P(zero),
               ctypes.c_longlong(-zero.numel() * 4 if precleared else zero.numel() * 4), _P(cnt), _P(start), _P(occ), _P(vbase),
-              _P(status), _i(k), ints(shapes), ints([b.win1_size for b in todo]),
-              (ctypes.c_int * max(k, 1))(*[int(b.max_num_wins) for b in todo]), ptrs(wins), ptrs(tables),
+              _P(status), _i(k), static["shapes"], static["wsizes"], static["maxw"], ptrs(wins), ptrs(tables),
               ptrs([vcounts[i] for i in range(k)]), ptrs(hdrs), _P(scratch), _lib.stream())
     st = {"indices": indices, "v_bs_cnt": cnt, "plans": {}, "occ": occ, "vbase": vbase, "level_status": status,
           "sorted": True, "status_words": [status], "_zero": zero,
