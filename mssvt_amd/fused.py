@@ -890,9 +890,9 @@ def side_stream(dev):
 # record_stream walk: the side stream starts every frame behind everything queued on the caller's stream
 # (wait_stream), so memory it allocates is never rewritten before its readers are done.
 # Measured (bench.py, one box each): one scene 0.73 -> 0.80 ms with it (the cross-stream waits and the two stream switches
-# cost more than the 26 us they hide), batch 8 / bf16 4.15 -> 4.09 ms.  "auto": on from SIDE_OVERLAP_MIN_VOXELS up.
+# cost more than the 26 us they hide), batch 4 (297k voxels) 2.407 -> 2.420 ms, batch 8 (594k) / bf16 4.15 -> 4.09 ms.  "auto": on from SIDE_OVERLAP_MIN_VOXELS up.
 SIDE_OVERLAP = os.environ.get("MSSVT_SIDE_OVERLAP", "auto")
-SIDE_OVERLAP_MIN_VOXELS = 200000
+SIDE_OVERLAP_MIN_VOXELS = 400000
 
 
 def side_overlap_on(sp):
