@@ -473,6 +473,26 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
 // interval has one MFMA phase and one row-wise phase: two barriers per tile.  (First version: split-K over
 // the hidden units in GEMM2 with the FF/32 partial tiles summed through LDS -- 128 more VALU instructions per wave
 // and tile for the partial epilogues than the third barrier costs; the phases are VALU-issue bound, not MFMA bound.)
+#ifndef FFW_MASKS
+#define FFW_MASKS 1   // gather-source selection with bit masks (no branch inside the barrier interval)
+#endif
+#ifndef FFW_SGB
+#define FFW_SGB 0     // sched_group_barrier pattern inside the two barrier intervals (MFMA : LDS read : VALU : gather)
+#endif
+#ifndef FFW_SGB_VALU
+#define FFW_SGB_VALU 4
+#endif
+#define FFW_SGB_STEP(id_, ds_, vm_)                                   \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, id_);              \
+    if (ds_) __builtin_amdgcn_sched_group_barrier(0x100, 1, id_);     \
+    __builtin_amdgcn_sched_group_barrier(0x002, FFW_SGB_VALU, id_);   \
+    if (vm_) __builtin_amdgcn_sched_group_barrier(0x020, 1, id_);
+#ifndef FFW_MANUAL
+#define FFW_MANUAL 1  // hand-placed chunks (sched_barrier fences) in the two barrier intervals of k_ffn_ws
+#endif
+#ifndef FFW_LN_LDS
+#define FFW_LN_LDS 1  // LayerNorm parameters read from LDS per tile instead of 16 resident VGPRs
+#endif
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
@@ -572,6 +592,11 @@ __device__ unsigned long long g_ws_stamps[4 * 8 * 16];  // [block < 4][wave][pha
 extern "C" int mssvt_debug_read_ffn_ws_stamps(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws_stamps), sizeof(g_ws_stamps));
 }
+// start / end of every workgroup on the 100 MHz wall clock (comparable across CUs): launch skew and tail of the grid
+__device__ unsigned long long g_ws_span[1024 * 2];
+extern "C" int mssvt_debug_read_ffn_ws_spans(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws_span), sizeof(g_ws_span));
+}
 #define WSTAMP(k_) { const unsigned long long t_ = __builtin_readcyclecounter(); ws_acc[k_] += t_ - ws_t; ws_t = t_; }
 #else
 #define WSTAMP(k_)
@@ -582,6 +607,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
 #ifdef MSSVT_STAMPS
     unsigned long long ws_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ws_t = __builtin_readcyclecounter();
     int ws_tiles = 0;
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_ws_span[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int NW = FF / 32, NP = C / 32, LPR = C / 4, RPW = MSSVT_WAVE / LPR, PS = C + 4;
     static_assert(FF == 2 * C && NW * RPW == 16 && NW * 16 == C && (LPR == 8 || LPR == 16 || LPR == 32),
@@ -590,6 +616,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     h16x8 *bfrag = reinterpret_cast<h16x8 *>(lds4);  // [NP][hi | lo][64 slots]   B operands of GEMM1
     h16x8 *ufrag = bfrag + NP * 2 * 64;              // [NW][hi | lo][64 lanes]   B operands of GEMM2, one k-slice per wave
     float *ytile = reinterpret_cast<float *>(ufrag + NW * 2 * 64);  // [16 rows][PS]
+    float *lnp = ytile + 16 * PS;                                   // [norm2 w | norm2 b | next norm w | next norm b][C]
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / MSSVT_WAVE);
     const int r = wv * RPW + lane / LPR, q = lane % LPR;  // row-wise view: row of the tile, channels [4 q, 4 q + 4)
@@ -612,17 +639,41 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     }
     float4 rx, r1, r2, r3;
     float w1 = 0.f, w2 = 0.f, w3 = 0.f, wx = 1.f;
-#define FFW_ISSUE(tile_, tr_, tw_, own_)                                                                    \
-    {                                                                                                       \
-        const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
-        if (TABBED) {                                                                                       \
+#if FFW_MASKS
+#define FFW_SELECT(tr_, tw_, row_)                                                                          \
+            /* unowned voxel (tr.x < 0): 2 x_in; it re-reads its own finite row with weight 0.  The selection is   \
+               written with MASKS, not ?: -- the compiler turns a group of selects on one condition into a BRANCH,   \
+               i.e. a basic-block boundary inside the barrier interval (MFMA and VALU interleave only within a      \
+               block), and with ?: on the pointers it even replaced one gather by "copy rx", which waits for the    \
+               row load issued a few instructions earlier */                                                        \
+            const int m_ = ~(tr_.x >> 31); /* owned: ~0, unowned: 0 */                                              \
+            const long long dm_ = ((const char *)a.x_in - (const char *)a.attn) & (long long)~m_;                   \
+            const char *b_ = (const char *)a.attn + dm_ + 16 * q;                                                   \
+            const float *px_ = a.x_in + (size_t)row_ * C + 4 * q;                                                   \
+            const int un_row_ = row_ & ~m_;                                                                         \
+            rx = *reinterpret_cast<const float4 *>(px_);                                                            \
+            r1 = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr_.x & m_) | un_row_) * (C * 4));               \
+            r2 = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr_.y & m_) | un_row_) * (C * 4));               \
+            r3 = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr_.z & m_) | un_row_) * (C * 4));               \
+            w1 = __builtin_bit_cast(float, __builtin_bit_cast(int, tw_.x) & m_);                                    \
+            w2 = __builtin_bit_cast(float, __builtin_bit_cast(int, tw_.y) & m_);                                    \
+            w3 = __builtin_bit_cast(float, __builtin_bit_cast(int, tw_.z) & m_);                                    \
+            wx = __builtin_bit_cast(float, 0x3F800000 + (~m_ & 0x00800000)); /* 1.0f, or 2.0f when unowned */
+#else
+#define FFW_SELECT(tr_, tw_, row_)                                                                          \
             const bool un_ = tr_.x < 0; /* unowned voxel: 2 x_in; re-reads its own finite row with weight 0 */ \
             const float *px_ = a.x_in + (size_t)row_ * C + 4 * q;                                           \
             rx = *reinterpret_cast<const float4 *>(px_);                                                    \
             r1 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.x * C + 4 * q);        \
             r2 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.y * C + 4 * q);        \
             r3 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.z * C + 4 * q);        \
-            w1 = un_ ? 0.f : tw_.x; w2 = un_ ? 0.f : tw_.y; w3 = un_ ? 0.f : tw_.z; wx = un_ ? 2.0f : 1.0f; \
+            w1 = un_ ? 0.f : tw_.x; w2 = un_ ? 0.f : tw_.y; w3 = un_ ? 0.f : tw_.z; wx = un_ ? 2.0f : 1.0f;
+#endif
+#define FFW_ISSUE(tile_, tr_, tw_, own_)                                                                    \
+    {                                                                                                       \
+        const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
+        if (TABBED) {                                                                                       \
+            FFW_SELECT(tr_, tw_, row_)                                                                      \
         } else {                                                                                            \
             const bool dbl_ = a.owner != nullptr && own_ < 0;                                               \
             rx = *reinterpret_cast<const float4 *>((dbl_ ? a.x_in : a.x_new) + (size_t)row_ * C + 4 * q);   \
@@ -650,6 +701,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
             __builtin_fmaf(d23_[1], d23_[1], __builtin_fmaf(d23_[0], d23_[0], __builtin_fmaf(d01_[1], d01_[1], d01_[0] * d01_[0])))); \
         const float rstd_ = rsqrtf(var_ * (1.0f / C) + a.eps);                                              \
         h16x4 hi_, lo_;                                                                                     \
+        const float4 lnw = FFW_LNW, lnb = FFW_LNB;                                                          \
         ffw_split4(d01_ * pk1(rstd_) * pk2(lnw.x, lnw.y) + pk2(lnb.x, lnb.y),                               \
                    d23_ * pk1(rstd_) * pk2(lnw.z, lnw.w) + pk2(lnb.z, lnb.w), hi_, lo_);                     \
         const int P_ = q >> 3, gq_ = (q >> 1) & 3, j0_ = (q & 1) * 4;                                       \
@@ -657,6 +709,27 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         dst_[0] = hi_;                                                                                      \
         dst_[64 * 2] = lo_; /* the lo fragment follows the hi fragment: 64 slots x 2 h16x4 */               \
     }
+#ifndef FFW_T_OUTER
+#define FFW_T_OUTER 0
+#endif
+#if FFW_T_OUTER
+    /* hidden tile T = 0 completely, then T = 1: the split of tile 0 can run under the products of tile 1 */
+#define FFW_GEMM1_PRODUCTS()                                                                                \
+        _Pragma("unroll") for (int T = 0; T < 2; ++T) {                                                    \
+            _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                               \
+                MFMA_H(um_[T], W1h[T][P], bh_[P]);                                                          \
+                MFMA_H(ul_[T], W1h[T][P], bl_[P]);                                                          \
+                MFMA_H(uk_[T], W1l[T][P], bh_[P]);                                                          \
+            }                                                                                               \
+        }
+#else
+#define FFW_GEMM1_PRODUCTS()                                                                                \
+        _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                                   \
+            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(um_[T], W1h[T][P], bh_[P]);               \
+            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(ul_[T], W1h[T][P], bl_[P]);               \
+            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(uk_[T], W1l[T][P], bh_[P]);               \
+        }
+#endif
     // u^T = relu(W1 xn + b1) for this wave's 32 hidden units -> its k-slice of GEMM2's B operand
 #define FFW_GEMM1()                                                                                         \
     {                                                                                                       \
@@ -672,11 +745,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
             ul_[T] = f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
             uk_[T] = f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
         }                                                                                                   \
-        _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                                   \
-            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(um_[T], W1h[T][P], bh_[P]);               \
-            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(ul_[T], W1h[T][P], bl_[P]);               \
-            _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(uk_[T], W1l[T][P], bh_[P]);               \
-        }                                                                                                   \
+        FFW_GEMM1_PRODUCTS()                                                                                \
         h16x4 h0_, l0_, h1_, l1_;                                                                           \
         ffw_split4(FFW_U2(0, 0), FFW_U2(0, 2), h0_, l0_);                                                   \
         ffw_split4(FFW_U2(1, 0), FFW_U2(1, 2), h1_, l1_);                                                   \
@@ -722,12 +791,36 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         for (int i = 0; i < 4; ++i) bias1[T][i] = a.b1[32 * wv + 16 * T + 4 * g + i];
     const float4 bias2 = *reinterpret_cast<const float4 *>(a.b2 + 16 * wv + 4 * g);  // MFMA view: channels 16 wv + 4 g + i
     // row-wise constants of this lane's 4 channels
-    const float4 lnw = *reinterpret_cast<const float4 *>(a.ln_w + 4 * q), lnb = *reinterpret_cast<const float4 *>(a.ln_b + 4 * q);
-    float4 ln2w = make_float4(0.f, 0.f, 0.f, 0.f), ln2b = ln2w;
-    if (NORM2) {
-        ln2w = *reinterpret_cast<const float4 *>(a.ln2_w + 4 * q);
-        ln2b = *reinterpret_cast<const float4 *>(a.ln2_b + 4 * q);
+    // (kept in LDS, not in 16 VGPRs: with the weights in 128 registers the loop sits at the 256-register limit, and every
+    // register less is a spill or a v_mov less; four ds_read_b128 per tile)
+#if FFW_LN_LDS
+    if (threadIdx.x < C / 4) {
+        const int c4 = threadIdx.x * 4;
+        *reinterpret_cast<float4 *>(lnp + c4) = *reinterpret_cast<const float4 *>(a.ln_w + c4);
+        *reinterpret_cast<float4 *>(lnp + C + c4) = *reinterpret_cast<const float4 *>(a.ln_b + c4);
+        if (NORM2) {
+            *reinterpret_cast<float4 *>(lnp + 2 * C + c4) = *reinterpret_cast<const float4 *>(a.ln2_w + c4);
+            *reinterpret_cast<float4 *>(lnp + 3 * C + c4) = *reinterpret_cast<const float4 *>(a.ln2_b + c4);
+        }
     }
+    __syncthreads();
+#define FFW_LNW *reinterpret_cast<const float4 *>(lnp + 4 * q)
+#define FFW_LNB *reinterpret_cast<const float4 *>(lnp + C + 4 * q)
+#define FFW_LN2W *reinterpret_cast<const float4 *>(lnp + 2 * C + 4 * q)
+#define FFW_LN2B *reinterpret_cast<const float4 *>(lnp + 3 * C + 4 * q)
+#else
+    const float4 lnw_r = *reinterpret_cast<const float4 *>(a.ln_w + 4 * q), lnb_r = *reinterpret_cast<const float4 *>(a.ln_b + 4 * q);
+    float4 ln2w_r = make_float4(0.f, 0.f, 0.f, 0.f), ln2b_r = ln2w_r;
+    if (NORM2) {
+        ln2w_r = *reinterpret_cast<const float4 *>(a.ln2_w + 4 * q);
+        ln2b_r = *reinterpret_cast<const float4 *>(a.ln2_b + 4 * q);
+    }
+    (void)lnp;
+#define FFW_LNW lnw_r
+#define FFW_LNB lnb_r
+#define FFW_LN2W ln2w_r
+#define FFW_LN2B ln2b_r
+#endif
 
     // Software pipeline over the tiles, two barrier intervals per tile, each holding one MFMA phase and one row-wise
     // (VALU / memory) phase of a DIFFERENT tile so that the matrix pipe and the vector ALU overlap:
@@ -748,6 +841,149 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     FFW_GEMM1()
     WSTAMP(0)
     __syncthreads();
+#if FFW_MANUAL
+    // The two intervals are written as CHUNKS fenced by sched_barrier(0): a chunk = the three products of one k-step (one
+    // hi hi, one hi lo, one lo hi MFMA: independent accumulators) + the LDS reads of the next step + one PIECE of the
+    // row-wise work of the other tile.  Left to itself the scheduler either serialises the two phases (every MFMA, then
+    // every vector instruction: both waves of a SIMD then want the same pipe at the same time) or hoists every LDS read to
+    // the top (spills at 256 registers); sched_group_barrier patterns were tried and are not stable from build to build.
+    for (;;) {
+        const int tile_next = tile + gridDim.x;
+        const bool has_next = tile_next < tiles;
+        const int t1 = has_next ? tile_next : tile;  // the tile whose A / GEMM1 run in this iteration
+        WSTAMP(1)
+        // ---- I2: GEMM2(t): this wave's 16 output channels over all k-slices | A(t1) ------------------------------
+        float4 xn;
+        {
+            constexpr int NPC2 = 6, PPS2 = (NPC2 + NW - 1) / NW;  // pieces of A, pieces per k-step
+            f32x4 m = f32x4{bias2.x, bias2.y, bias2.z, bias2.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
+            h16x8 uh = ufrag[lane], ulo = ufrag[64 + lane];
+            f32x2 d01_ = pk1(0.f), d23_ = pk1(0.f), n01_ = pk1(0.f), n23_ = pk1(0.f);
+            float mean_ = 0.f, var_ = 0.f;
+            (void)mean_;
+#pragma unroll
+            for (int ks = 0; ks < NW; ++ks) {
+                h16x8 uhn = uh, ulon = ulo;
+                if (ks + 1 < NW) {
+                    uhn = ufrag[((ks + 1) * 2) * 64 + lane];
+                    ulon = ufrag[((ks + 1) * 2 + 1) * 64 + lane];
+                }
+                MFMA_H(m, W2h[ks], uh);
+                MFMA_H(l, W2h[ks], ulo);
+                MFMA_H(k, W2l[ks], uh);
+#pragma unroll
+                for (int pc = ks * PPS2; pc < (ks + 1) * PPS2 && pc < NPC2; ++pc) {
+                    if (pc == 0) {
+                        FFW_COMBINE(xn)
+                    } else if (pc == 1) {
+                        const int t2 = min(t1 + (int)gridDim.x, tiles - 1);
+                        FFW_ISSUE(t2, trn, twn, ownn)
+                        FFW_TAB(min(t2 + (int)gridDim.x, tiles - 1), trn, twn, ownn)
+                    } else if (pc == 2) {
+                        mean_ = ffw_row_sum<LPR>((xn.x + xn.y) + (xn.z + xn.w)) * (1.0f / C);
+                        d01_ = pk2(xn.x, xn.y) - pk1(mean_);
+                        d23_ = pk2(xn.z, xn.w) - pk1(mean_);
+                    } else if (pc == 3) {
+                        var_ = ffw_row_sum<LPR>(__builtin_fmaf(
+                            d23_[1], d23_[1], __builtin_fmaf(d23_[0], d23_[0], __builtin_fmaf(d01_[1], d01_[1], d01_[0] * d01_[0]))));
+                    } else if (pc == 4) {
+                        const float rstd_ = rsqrtf(var_ * (1.0f / C) + a.eps);
+                        const float4 lnw = FFW_LNW, lnb = FFW_LNB;
+                        n01_ = d01_ * pk1(rstd_) * pk2(lnw.x, lnw.y) + pk2(lnb.x, lnb.y);
+                        n23_ = d23_ * pk1(rstd_) * pk2(lnw.z, lnw.w) + pk2(lnb.z, lnb.w);
+                    } else {
+                        h16x4 hi_, lo_;
+                        ffw_split4(n01_, n23_, hi_, lo_);
+                        const int P_ = q >> 3, gq_ = (q >> 1) & 3, j0_ = (q & 1) * 4;
+                        h16x4 *dst_ = reinterpret_cast<h16x4 *>(bfrag + (P_ * 2) * 64 + 16 * gq_ + ((r + 4 * gq_ + P_) & 15)) + (j0_ >> 2);
+                        dst_[0] = hi_;
+                        dst_[64 * 2] = lo_;
+                    }
+                }
+                uh = uhn;
+                ulo = ulon;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                const f32x2 y01 = pk_fma(pk2(l[0], l[1]) + pk2(k[0], k[1]), pk1(FFW_INV), pk2(m[0], m[1])),
+                            y23 = pk_fma(pk2(l[2], l[3]) + pk2(k[2], k[3]), pk1(FFW_INV), pk2(m[2], m[3]));
+                *reinterpret_cast<float4 *>(ytile + la * PS + 16 * wv + 4 * g) = make_float4(y01[0], y01[1], y23[0], y23[1]);
+            }
+        }
+        WSTAMP(2)
+        __syncthreads();
+        WSTAMP(3)
+        // ---- I1: D(t): y = x + (W2 u + b2), the next block's LayerNorm, whole rows out | GEMM1(t1) ------------------
+        {
+            constexpr int NS1 = 2 * NP, NPC1 = NORM2 ? 5 : 2;  // steps (T, P); pieces of D + the split of hidden tile 0
+            const size_t row = (size_t)min(tile * 16 + r, n - 1);
+            f32x4 um_[2], ul_[2], uk_[2];
+            h16x8 bh_[NP], bl_[NP];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                um_[T] = f32x4{bias1[T][0], bias1[T][1], bias1[T][2], bias1[T][3]};
+                ul_[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                uk_[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            bh_[0] = bfrag[16 * g + ((la + 4 * g) & 15)];
+            bl_[0] = bfrag[64 + 16 * g + ((la + 4 * g) & 15)];
+            const float4 yt = *reinterpret_cast<const float4 *>(ytile + r * PS + 4 * q);
+            f32x2 y01 = pk1(0.f), y23 = y01, d01 = y01, d23 = y01;
+            float var = 0.f;
+            h16x4 h0_, l0_, h1_, l1_;
+#pragma unroll
+            for (int st = 0; st < NS1; ++st) {
+                const int T = st / NP, P = st % NP;
+                if (T == 0 && P + 1 < NP) {
+                    const int slot_ = 16 * g + ((la + 4 * g + P + 1) & 15);
+                    bh_[P + 1] = bfrag[((P + 1) * 2) * 64 + slot_];
+                    bl_[P + 1] = bfrag[((P + 1) * 2 + 1) * 64 + slot_];
+                }
+                MFMA_H(um_[T], W1h[T][P], bh_[P]);
+                MFMA_H(ul_[T], W1h[T][P], bl_[P]);
+                MFMA_H(uk_[T], W1l[T][P], bh_[P]);
+                // pieces of D spread over the first NP steps; the split of hidden tile 0 one step after its last product
+                constexpr int PPS1 = (4 + NP - 1) / NP;
+#pragma unroll
+                for (int pc = st * PPS1; pc < (st + 1) * PPS1 && pc < 4 && st < NP; ++pc) {
+                    if (pc == 0) {
+                        y01 = pk2(yt.x, yt.y) + pk2(xc.x, xc.y);
+                        y23 = pk2(yt.z, yt.w) + pk2(xc.z, xc.w);
+                        *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = make_float4(y01[0], y01[1], y23[0], y23[1]);
+                    } else if (pc == 1 && NORM2) {
+                        const float mean = ffw_row_sum<LPR>((y01[0] + y01[1]) + (y23[0] + y23[1])) * (1.0f / C);
+                        d01 = y01 - pk1(mean);
+                        d23 = y23 - pk1(mean);
+                    } else if (pc == 2 && NORM2) {
+                        var = ffw_row_sum<LPR>(
+                            __builtin_fmaf(d23[1], d23[1], __builtin_fmaf(d23[0], d23[0], __builtin_fmaf(d01[1], d01[1], d01[0] * d01[0]))));
+                    } else if (pc == 3 && NORM2) {
+                        const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
+                        const float4 ln2w = FFW_LN2W, ln2b = FFW_LN2B;
+                        const f32x2 n01 = d01 * pk1(rstd) * pk2(ln2w.x, ln2w.y) + pk2(ln2b.x, ln2b.y),
+                                    n23 = d23 * pk1(rstd) * pk2(ln2w.z, ln2w.w) + pk2(ln2b.z, ln2b.w);
+                        *reinterpret_cast<float4 *>(a.y_norm + row * C + 4 * q) = make_float4(n01[0], n01[1], n23[0], n23[1]);
+                    }
+                }
+                if (st == (NP + 1 < NS1 ? NP + 1 : NS1 - 1)) ffw_split4(FFW_U2(0, 0), FFW_U2(0, 2), h0_, l0_);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            (void)NPC1;
+            ffw_split4(FFW_U2(1, 0), FFW_U2(1, 2), h1_, l1_);
+            ufrag[(wv * 2) * 64 + lane] = ffw_cat(h0_, h1_);
+            ufrag[(wv * 2 + 1) * 64 + lane] = ffw_cat(l0_, l1_);
+        }
+        WSTAMP(4)
+        __syncthreads();
+        WSTAMP(5)
+#ifdef MSSVT_STAMPS
+        ++ws_tiles;
+#endif
+        xc = xn;
+        if (!has_next) break;
+        tile = tile_next;
+    }
+#else
     for (;;) {
         const int tile_next = tile + gridDim.x;
         const bool has_next = tile_next < tiles;
@@ -777,8 +1013,18 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                 *reinterpret_cast<float4 *>(ytile + la * PS + 16 * wv + 4 * g) = make_float4(y01[0], y01[1], y23[0], y23[1]);
             }
         }
+#if FFW_SGB
+        // instruction order of the interval: one MFMA, (one LDS read,) a few vector instructions, (one row gather) -- 24 times
+        FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0)
+        FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 1)
+        FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0)
+        FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0)
+#endif
         WSTAMP(2)
         __syncthreads();
+#if FFW_SGB > 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         WSTAMP(3)
         // ---- I1: D(t): y = x + (W2 u + b2), the next block's LayerNorm, whole rows out | GEMM1(t1) ------------------
         {
@@ -792,14 +1038,24 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                 const float var = ffw_row_sum<LPR>(
                     __builtin_fmaf(d23[1], d23[1], __builtin_fmaf(d23[0], d23[0], __builtin_fmaf(d01[1], d01[1], d01[0] * d01[0]))));
                 const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
+                const float4 ln2w = FFW_LN2W, ln2b = FFW_LN2B;
                 const f32x2 n01 = d01 * pk1(rstd) * pk2(ln2w.x, ln2w.y) + pk2(ln2b.x, ln2b.y),
                             n23 = d23 * pk1(rstd) * pk2(ln2w.z, ln2w.w) + pk2(ln2b.z, ln2b.w);
                 *reinterpret_cast<float4 *>(a.y_norm + row * C + 4 * q) = make_float4(n01[0], n01[1], n23[0], n23[1]);
             }
             FFW_GEMM1()
         }
+#if FFW_SGB
+FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0)
+        FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0)
+        FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0)
+        FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0)
+#endif
         WSTAMP(4)
         __syncthreads();
+#if FFW_SGB > 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         WSTAMP(5)
 #ifdef MSSVT_STAMPS
         ++ws_tiles;
@@ -808,6 +1064,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         if (!has_next) break;
         tile = tile_next;
     }
+#endif
     WSTAMP(6)
 #undef FFW_COMBINE
 #undef FFW_NORM_TO_BFRAG
@@ -815,6 +1072,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
 #undef FFW_U
 #undef FFW_U2
 #ifdef MSSVT_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_ws_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     if (lane == 0 && blockIdx.x < 4) {
         for (int k = 0; k < 7; ++k) g_ws_stamps[(blockIdx.x * 8 + (wv & 7)) * 16 + k] = ws_acc[k];
         g_ws_stamps[(blockIdx.x * 8 + (wv & 7)) * 16 + 9] = ws_tiles;
@@ -827,7 +1085,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
 template <int C, int FF>
 static int launch_ffn_ws(const FfnArgs &a, const void *packed, hipStream_t stream) {
     constexpr int NW = FF / 32;
-    const size_t lds = (size_t)(C / 32 + NW) * 2 * 64 * 16 + (size_t)16 * (C + 4) * 4;
+    const size_t lds = (size_t)(C / 32 + NW) * 2 * 64 * 16 + (size_t)16 * (C + 4) * 4 + (size_t)4 * C * 4;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)

@@ -28,3 +28,30 @@ tot = s[:, :7].sum(1).mean()
 print("waves", s.shape[0], "tiles per wave", tiles, "cycles per wave", tot, "(100 MHz counter: x24 = shader clocks)")
 for k in range(7):
     print("   %-36s %9.0f   %5.1f%%   per tile %7.1f" % (names[k], s[:, k].mean(), 100 * s[:, k].mean() / tot, s[:, k].mean() / (tiles if 0 < k < 6 else 1)))
+
+# ---- launch skew and tail of the grid: start / end of every workgroup on the 100 MHz wall clock (round 4)
+if hasattr(_lib.lib(), "mssvt_debug_read_ffn_ws_spans"):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        e0.record()
+        fused._ffn_tail(blk, SP(), x)
+        e1.record()
+    torch.cuda.synchronize()
+    sp = np.zeros(1024 * 2, dtype=np.uint64)
+    _lib.lib().mssvt_debug_read_ffn_ws_spans(sp.ctypes.data_as(ctypes.c_void_p))
+    grid = min(256, (n + 15) // 16)
+    sp = sp.reshape(1024, 2)[:grid].astype(np.float64) / 100.0  # us
+    t0 = sp[:, 0].min()
+    st, en = sp[:, 0] - t0, sp[:, 1] - t0
+    print("grid %d: event time of the launch %.1f us; first start -> last end %.1f us" % (grid, e0.elapsed_time(e1) * 1e3, en.max()))
+    pct = lambda v: " ".join("%.1f" % np.percentile(v, p) for p in (0, 10, 50, 90, 100))
+    print("   start offsets (us, p0 p10 p50 p90 p100): ", pct(st))
+    print("   end   offsets (us):                      ", pct(en))
+    print("   workgroup durations (us):                ", pct(en - st))
+    tiles = (n + 15) // 16
+    per = np.array([len(range(b, tiles, grid)) for b in range(grid)])
+    for k in sorted(set(per)):
+        sel = per == k
+        print("   workgroups with %d tiles: %d, mean duration %.1f us, %.3f us per tile" % (k, sel.sum(), (en - st)[sel].mean(), (en - st)[sel].mean() / k))
+    # by XCD (workgroup b runs on XCD b % 8)
+    print("   mean duration by XCD:", " ".join("%.1f" % (en - st)[x::8].mean() for x in range(8)))
