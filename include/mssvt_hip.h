@@ -348,20 +348,6 @@ int mssvt_block_attention_bf16(
     const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
     const float *const *host_bo, const float *Wpos, const float *bpos, float *attn, void *stream);
 
-/* The same single launch with fp32-accurate products: every MFMA operand split into two fp16 halves (hi + 2^-11 lo: 22 of 24 mantissa bits)
- * (hi + 2^-11 lo; 3 x v_mfma_f32_16x16x32_f16 per product sum, fp32 accumulation: the fp32 matrix instruction's error
- * against float64 at 3/16 of its cycles), keys projected in the kernel, no hand-off through HBM.  Arguments of
- * mssvt_block_attention minus qbuf.  The CALLER guarantees the fp16 range of tokens, Q' (scaled), K', V'
- * (mssvt_amd/fused.py bounds them from the parameters) and runs mssvt_block_attention otherwise.
- * MSSVT_E_TOOLARGE: shape not instantiated (use the fp32 entry point).                                    */
-int mssvt_block_attention_f16x3(
-    int C, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads, int head_dim, float scale,
-    int nq, int key_num_sample, const float *xhat, const int *num_active_dev, const int *perm, const int *q_off,
-    const int *nq_valid, const int *num_rows_dev, int row_capacity, const float *qrow_meta, const int *qrow_src,
-    const float *const *host_kmeta, const float *wcentre, const float *const *host_Wq, const float *const *host_bq,
-    const float *const *host_Wkv, const float *const *host_bkv, const float *const *host_Wo,
-    const float *const *host_bo, const float *Wpos, const float *bpos, float *attn, void *stream);
-
 /* 3-NN inverse-distance interpolation of the attention rows onto the win1 voxels (K9,
  * K10, ref mssvt_backbone.py:298-311) + scatter + first residual (ref :313-338):
  * x_new[v] = interp(v) + x_in[v] for every voxel v owned by a list slot; rows of other
@@ -615,6 +601,74 @@ int mssvt_pair_attention_bwd(int nw, int cg, int heads, int hd, const int *q_off
 long long mssvt_csr_transpose_workspace_bytes(int nnz, int n_src);
 int mssvt_csr_transpose(int nnz, int n_dst, int n_src, const int *off, const int *idx, const float *w, int drop_src,
                         int long_list, int *t_off, int *t_idx, float *t_w, int *max_count, void *workspace, void *stream);
+
+/* ======================================================================== *
+ * Part 5 -- a whole backbone forward behind ONE call (round 4).
+ *
+ * ref: MixedScaleSparseTransformer.forward, pcdet/models/backbones_3d/mssvt_backbone.py:450-472, which drives its blocks
+ * from Python (>= 5B + L(5B+2) host syncs, ~100 launches per Block).  A frame object describes one resolution level
+ * of the network -- L two-scale Blocks that share one window configuration, closed by a CompressBlock over pillar
+ * windows [1,1,z] -- and mssvt_frame_forward enqueues the entry points of part 2 for it in the order the Python
+ * module path (mssvt_amd/fused.py) issues them, out of ONE caller-owned workspace: same kernels, same arguments,
+ * bit-identical results, no allocation and no host synchronisation inside the call.  The object holds parameter
+ * POINTERS (device memory owned by the caller: rebuild it when a parameter moves), one pinned 4-KiB host buffer and
+ * one event for the frame's single device-to-host hand-over.  add_* return MSSVT_E_TOOLARGE for shapes this path
+ * does not cover; the caller keeps its own path for those.
+ * Input: a voxel list sorted by (b,x,y,z) (what DynamicVFE emits); any other order is reported in the status
+ * word (MSSVT_ST_UNSORTED) and the outputs are then empty.
+ * ======================================================================== */
+#define MSSVT_ST_UNSORTED 8 /* level status: the voxel list is not strictly ascending in (b,x,y,z) */
+
+int mssvt_frame_create(void **frame_out);
+int mssvt_frame_destroy(void *frame);
+/* Level geometry (ref mssvt_backbone.py:436-448): grid [x,y,z] (z <= 64), voxel size, point cloud range
+ * [x0,y0,z0,x1,y1,z1] (HOST arrays), channel width C of every block and FF of every feed-forward layer ((C,FF)
+ * instantiated in csrc/ffn.hip).  Clears the block list.                                                        */
+int mssvt_frame_set_level(void *frame, int batch_size, int x_max, int y_max, int z_max, int hash_size,
+                          const float *host_voxel_size3, const float *host_range6, int C, int FF);
+/* One MixedScaleSparseTransformerBlock (ref mssvt_backbone.py:11-347): window configuration (arguments of
+ * mssvt_window_plan_two: win1 size, list capacities, the four offset tables on the device, their footprint and packed
+ * form, key_num_sample, max_num_wins -- identical for every Block of the level), cbs_pattern (0 even / 1 odd / 2 win1
+ * queries), use_feature_interpolation, norm1, the attention parameters (arguments of mssvt_block_attention; two head
+ * groups), attn_mode 0 = mssvt_block_attention, 1 = mssvt_block_attention_kv16 (host_packed: its blobs or NULL),
+ * 2 = mssvt_block_attention_bf16; norm2 + linear1 / linear2 and the fragments of mssvt_ffn_pack_weights.           */
+int mssvt_frame_add_block(
+    void *frame, const int *host_win1_size3, int max_num_odd, int max_num_even, int max_num_win1, int max_num_win2,
+    int num_odd, int num_even, int num_win1, int num_win2, const int *vox_query_odd, const int *vox_query_even,
+    const int *vox_query_win1, const int *vox_query_win2, const int *host_footprint4, const int *packed_offsets,
+    int key_num_sample, int max_num_wins, int cbs_pattern, int use_interpolation, const float *norm1_w,
+    const float *norm1_b, float norm1_eps, int num_groups, const int *host_c0, const int *host_cg, const int *host_heads,
+    int head_dim, float scale, const float *const *host_Wq, const float *const *host_bq, const float *const *host_Wkv,
+    const float *const *host_bkv, const float *const *host_Wo, const float *const *host_bo,
+    const void *const *host_packed, const float *Wpos, const float *bpos, int attn_mode, const float *norm2_w,
+    const float *norm2_b, float norm2_eps, const float *W1, const float *b1, const float *W2, const float *b2,
+    const void *ffn_packed);
+/* The MixedScaleSparseTransformerCompressBlock that ends the level (ref mssvt_backbone.py:349-398): pillar windows
+ * [1,1,z] whose offset table stays inside the window (one lane per window in the plan kernel), one head group;
+ * arguments of mssvt_window_plan_one / mssvt_compress_fused / mssvt_ffn_fused.                                   */
+int mssvt_frame_add_compress(
+    void *frame, const int *host_win_size3, int max_num_win1, int num_win1, const int *vox_query_win1, int max_num_wins,
+    const float *norm1_w, const float *norm1_b, float norm1_eps, const float *Wpos1, const float *bpos1, const float *Wpos2,
+    const float *bpos2, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
+    int head_dim, float scale, int split_f16, const float *norm2_w, const float *norm2_b, float norm2_eps, const float *W1,
+    const float *b1, const float *W2, const float *b2, const void *ffn_packed);
+/* on != 0: the first norm1 and the CompressBlock's pillar plan run on a stream of the frame object, under the Blocks'
+ * plan kernel (two event edges per frame; results unchanged).                                                     */
+int mssvt_frame_set_overlap(void *frame, int on);
+/* Bytes of workspace a forward over num_voxels voxels needs (0: frame incomplete). */
+long long mssvt_frame_workspace_bytes(void *frame, int num_voxels);
+/* Enqueue the forward on `stream`.  features (N,C) f32, indices (N,4) int32 [b,z,y,x]; workspace: 256-byte aligned,
+ * contents irrelevant (reusable by the next frame on the same stream).  Outputs, capacity-sized and caller-owned:
+ * out_features (N,C) / out_indices (N,4): the first `rows` rows are the output voxel set (window order);
+ * out_table (B,H,2): its hash table (filled here, -1 prefill included); out_counts (B) rows per sample.
+ * `rows` and the status words travel to the host through the frame's pinned buffer: mssvt_frame_wait_words blocks
+ * until they have landed (long before the frame's kernels end) and copies words [0, num_words) out:
+ * [0] level status (MSSVT_ST_UNSORTED), [64] status / [65] window count of the Blocks' partition,
+ * [128] status / [129] window count of the CompressBlock's partition = rows.                                     */
+int mssvt_frame_forward(void *frame, int num_voxels, const float *features, const int *indices, void *workspace,
+                        long long workspace_bytes, float *out_features, int *out_indices, int *out_table,
+                        int *out_counts, void *stream);
+int mssvt_frame_wait_words(void *frame, int *host_out, int num_words);
 
 #ifdef __cplusplus
 }

@@ -26,17 +26,15 @@ def lib():
             raise MssvtHipError(
                 "libmssvt_hip.so not built (%s). Run `python -m mssvt_amd.build`; there is no "
                 "CPU fallback for the MsSVT hot path." % LIB_PATH)
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.mssvt_hip_status_string.restype = ctypes.c_char_p
-        _lib.mssvt_hash_workspace_ints.restype = ctypes.c_longlong
-        _lib.mssvt_nms_workspace_bytes.restype = ctypes.c_longlong
-        _lib.mssvt_linear_wgrad_workspace_floats.restype = ctypes.c_longlong
-        _lib.mssvt_csr_transpose_workspace_bytes.restype = ctypes.c_longlong
-        _lib.mssvt_ffn_packed_bytes.restype = ctypes.c_longlong
-        _lib.mssvt_level_sorted_scratch_ints.restype = ctypes.c_longlong
-        _lib.mssvt_attn_packed_bytes.restype = ctypes.c_longlong
+        lib_ = ctypes.CDLL(LIB_PATH)
+        lib_.mssvt_hip_status_string.restype = ctypes.c_char_p
+        for name in ("mssvt_hash_workspace_ints", "mssvt_nms_workspace_bytes", "mssvt_linear_wgrad_workspace_floats",
+                     "mssvt_csr_transpose_workspace_bytes", "mssvt_ffn_packed_bytes", "mssvt_level_sorted_scratch_ints",
+                     "mssvt_attn_packed_bytes", "mssvt_frame_workspace_bytes"):
+            getattr(lib_, name).restype = ctypes.c_longlong
         global TYPED
-        TYPED = _declare(_lib)
+        TYPED = _declare(lib_)
+        _lib = lib_  # only a fully declared library is cached
     return _lib
 
 
@@ -67,7 +65,9 @@ def _declare(lib_):
         args = []
         for q in ([] if params in ("", "void") else params.split(",")):
             q = q.strip()
-            args.append(ctypes.c_void_p if "*" in q else kinds[" ".join(q.split()[:-1])])
+            args.append(ctypes.c_void_p if "*" in q else kinds.get(" ".join(q.split()[:-1])))
+        if None in args:
+            continue  # a parameter type this parser does not know: leave the function undeclared (callers wrap)
         fn.argtypes = args
         fn.restype = rets[ret]
     return True

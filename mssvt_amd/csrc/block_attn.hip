@@ -1000,7 +1000,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
 // them per window, pass and head group at K = 32 -- ~2.3 k of the ~3.2 k cycles a window keeps its SIMD busy).  Here every
 // product sum is three v_mfma_f32_16x16x32_f16 on (hi, lo) halves (see h16_split4; fp32 accumulation, the error of the fp32
 // instruction as in csrc/ffn.hip): 12 + 12 sixteen-cycle instructions per window and pass instead of 32 + 32 thirty-two-cycle
-// ones.  What makes it cheaper here than in the single-launch k_attn_f16x3 (which split ~20 fragments per window): the
+// ones.  What makes it cheaper here than in a single-launch form that projects the keys (round 2: ~20 fragment splits per window, slower): the
 // key tokens are the only operand split in this kernel, ONCE per window (Qt arrives split from k_attn_q<KV16>, P is 8
 // values per lane and pass), and the transposed operand of the second product comes out of the LDS image by
 // ds_read_b64_tr_b16 instead of 32 scalar column reads.

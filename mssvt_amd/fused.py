@@ -166,7 +166,9 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
         todo = _level_partitions(blocks)
         k = len(todo)
         al = lambda v: (int(v) + 63) // 64 * 64  # noqa: E731  (256-byte aligned pieces)
-        sizes = [64, 64 * max(k, 1), al(B + 1), 2 * B * X * Y]
+        # (sample counts and windows-per-sample live in the zeroed block too: the set-up kernels leave them untouched on a
+        # list that is not sorted, and a rejected level must read as EMPTY, not as garbage, until the frame is redone)
+        sizes = [64, 64 * max(k, 1), al(B + 1), al(2 * B * X * Y), al(B), al(max(k, 1) * B)]
         ints_ = lambda rows: (ctypes.c_int * max(3 * k, 1))(*[int(v) for r in rows for v in r])  # noqa: E731
         if len(_sorted_static) > 16:
             _sorted_static.clear()
@@ -187,13 +189,13 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     hdrs = [zero[offs[1] + 64 * i: offs[1] + 64 * (i + 1)] for i in range(k)]
     start = zero[offs[2]:offs[2] + B + 1]
     occ = zero[offs[3]:offs[3] + 2 * B * X * Y].view(torch.int64)
-    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    cnt = zero[offs[4]:offs[4] + B]
     vbase = torch.empty(B * X * Y, dtype=torch.int32, device=dev)
     scratch = torch.empty(static["scratch"], dtype=torch.int32, device=dev)
     # only a CompressBlock's window table is ever read (it becomes the map_table of the block's output)
     tables = [mssvt_ops.full_neg1((B, H, 2), dev) if isinstance(b, Compress) else None for b in todo]
     wins = [torch.empty((n, 4), dtype=torch.int32, device=dev) for _ in range(k)]
-    vcounts = torch.empty((max(k, 1), B), dtype=torch.int32, device=dev)
+    vcounts = zero[offs[5]:offs[5] + max(k, 1) * B].view(max(k, 1), B)
     ptrs = lambda ts: (ctypes.c_void_p * max(k, 1))(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
     _lib.call("mssvt_level_setup_sorted", _i(n), _i(B), _i(X), _i(Y), _i(Z), _i(H), _P(indices), _P(zero),
               ctypes.c_longlong(-zero.numel() * 4 if precleared else zero.numel() * 4), _P(cnt), _P(start), _P(occ), _P(vbase),
@@ -382,6 +384,7 @@ def _voxel_table(sp, st, occ):
     level is only built when somebody asks for `sp.map_table`."""
     if st.get("sorted") and occ is not None and st.get("vbase") is not None:
         return sp._map_table  # whatever exists; never forces the build
+    _speculative_verdict(sp)
     return sp.map_table
 
 
@@ -601,37 +604,6 @@ def _attn_refs(block, groups):
     return r
 
 
-# arithmetic of the fp32 attention: "f16x3" = ONE launch, keys projected in the kernel, every MFMA operand split
-# into two fp16 halves (22 of 24 mantissa bits kept) (csrc/block_attn_f16x3.hip: the fp32 instruction's error, no hand-off through HBM); "f32" = the
-# three fp32-MFMA launches of csrc/block_attn.hip.  Operands outside the fp16 range always take "f32".
-ATTN_ARITH = os.environ.get("MSSVT_ATTN_ARITH", "f32")
-
-
-@_no_grad
-def _attn_f16_ok(block, r, p):
-    """True when tokens and projections of the window attention stay inside the fp16 range whatever the input is:
-    |xhat| <= sqrt(C) max|w| + max|b|, the positional term <= |Wp_c|_1 max|coordinate| + |bp_c| (relative offsets and
-    window centres are metres inside the point cloud range), Q' / K' / V' by |W_row|_1 times the token bound (+ bias),
-    O <= the V' bound.  Once per parameter version (one small host sync)."""
-    ts = [block.norm1.weight, block.norm1.bias, r["Wp"], r["bp"]] + list(r["Wq"]) + list(r["bq"]) + list(r["Wkv"]) + \
-        list(r["bkv"]) + list(r["Wo"])
-    ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + (float(p.coord_bound),) + _content_key(ts)
-    if r.get("f16_ver") != ver:
-        g1, b1, Wp, bp = [t.detach().float() for t in ts[:4]]
-        C = g1.numel()
-        xmax = (C ** 0.5) * g1.abs().max() + b1.abs().max()
-        tmax = xmax + (Wp.reshape(C, -1).abs().sum(1) * p.coord_bound + bp.abs()).max()
-        worst = [tmax]
-        for Wq, bq, Wkv, bkv, Wo in zip(r["Wq"], r["bq"], r["Wkv"], r["bkv"], r["Wo"]):
-            worst.append((Wq.detach().abs().sum(1) * tmax + bq.detach().abs()).max() * abs(r["scale"]) * 1.4426950408889634)
-            worst.append((Wkv.detach().abs().sum(1) * tmax + bkv.detach().abs()).max())
-            worst += [Wq.detach().abs().max(), Wkv.detach().abs().max(), Wo.detach().abs().max()]
-        worst = torch.stack([w.float() for w in worst]).max()
-        r["f16_ok"] = bool(torch.isfinite(worst).item() and float(worst) < FFN_F16_LIMIT)
-        r["f16_ver"] = ver
-    return r["f16_ok"]
-
-
 # launch B of the fp32 attention (scores, softmax, weighted key sum per window) with split-fp16 matrix operands
 # (csrc/block_attn.hip, k_attn_kvh: hi + 2^-11 lo halves, 3 x v_mfma_f32_16x16x32_f16 per product sum, fp32 accumulation --
 # the FFN's arithmetic); "0" keeps the fp32 matrix instruction.  Operands outside the fp16 range always take the fp32 form.
@@ -643,7 +615,7 @@ ATTN_QO16 = os.environ.get("MSSVT_ATTN_QO16", "1") != "0"
 @_no_grad
 def _attn_kv16_ok(block, r, p):
     """True when the matrix operands of the split-fp16 attention launches stay inside the fp16 range whatever the input
-    is: key / query tokens |xhat| + positional term (as _attn_f16_ok), Q' by |Wq_o|_1 tmax + |bq_o|, Qt = scale Wk_h^T q'_h
+    is: key / query tokens |xhat| + positional term (|xhat| <= sqrt(C) max|w| + max|b|; positional term <= |Wp_c|_1 max|coordinate| + |bp_c|), Q' by |Wq_o|_1 tmax + |bq_o|, Qt = scale Wk_h^T q'_h
     by scale sum_o |Wk_oc| |q'_o|, Xbar (a convex combination of key tokens) by tmax, V by |Wv_o|_1 tmax + |bv_o|, and the
     weights themselves.  Once per parameter version (one small host sync); the same pass packs the projections into
     MFMA fragments (mssvt_attn_pack_weights -> r["kv16_packed"], a ctypes pointer array, or None: shape not instantiated)."""
@@ -685,7 +657,7 @@ def _attn_weight_args(r, pa):
     """The eight weight arguments of an attention entry point (six pointer arrays + the positional layer): built once per
     parameter set -- the tensors of `r` are replaced together with `r` itself (_attn_refs, refresh_weights)."""
     w = r.get("warg")
-    ptrs = tuple(t.data_ptr() for t in r["Wq"]) + (r["Wp"].data_ptr(),)
+    ptrs = tuple(t.data_ptr() for k in ("Wq", "bq", "Wkv", "bkv", "Wo", "bo") for t in r[k]) + (r["Wp"].data_ptr(), r["bp"].data_ptr())
     if w is None or w[0] != ptrs:
         w = r["warg"] = (ptrs, (pa(r["Wq"]), pa(r["bq"]), pa(r["Wkv"]), pa(r["bkv"]), pa(r["Wo"]), pa(r["bo"]),
                                 _P(r["Wp"]), _P(r["bp"])))
@@ -703,8 +675,6 @@ def _attention_call(block, p, od, C, nq, xhat, qbuf, attn, groups=None):
             *_attn_weight_args(r, pa))
     if getattr(block, "attn_dtype", "f32") == "bf16" and r["bf16_ok"]:
         _lib.call("mssvt_block_attention_bf16", *head, _P(attn), _lib.stream())
-    elif r["bf16_ok"] and getattr(block, "attn_arith", ATTN_ARITH) == "f16x3" and _attn_f16_ok(block, r, p):
-        _lib.call("mssvt_block_attention_f16x3", *head, _P(attn), _lib.stream())
     elif getattr(block, "attn_kv16", ATTN_KV16) and _attn_kv16_ok(block, r, p):
         _lib.call("mssvt_block_attention_kv16", *head, _P(qbuf), _P(attn),
                   r["kv16_packed"] if getattr(block, "attn_qo16", ATTN_QO16) else None, _lib.stream())
@@ -984,6 +954,7 @@ def block_forward(block, sp):
         if _needs_grad(block, sp) and TRAIN_COMPACT:
             from . import train_path  # differentiable compact path (deterministic segmented-sum backward)
             return train_path.block_forward(block, sp)
+        _speculative_verdict(sp)
         return block.forward_ops(sp)
     xhat = _norm1(block, sp, sp.features)
     x_in = sp.features.contiguous()
@@ -1230,6 +1201,15 @@ def check_level_status(sp, max_num_wins=None):
         raise _lib.MssvtHipError("a sample has more windows than max_num_wins")
     if status & mssvt_ops.ST_TABLE_OVERFLOW:
         raise _lib.MssvtHipError("hash table overflow (hash_size=%d)" % sp.hash_size)
+
+
+def _speculative_verdict(sp):
+    """Before anything outside the fused kernels (operator path, lazily built hash table) reads a level that was set
+    up speculatively as sorted: fetch its status (one host sync, once per level) and raise UnsortedVoxels first."""
+    st = getattr(sp, "_level", None)
+    if st is not None and st.get("speculative") and not st.get("verdict_read"):
+        st["verdict_read"] = True
+        _raise_if_unsorted(st, [int(st["level_status"].item())])
 
 
 def _raise_if_unsorted(st, words):

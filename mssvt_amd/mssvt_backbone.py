@@ -129,7 +129,7 @@ class MixedScaleSparseTransformerBlock(nn.Module):
 
     # -- derived-weight caches of the fused path ---------------------------------------------------------------
     # The fused kernels keep, per parameter VERSION, the split-fp16 fragments of linear1 / linear2 and the fp16 range
-    # verdicts of the attention / CompressBlock weights (mssvt_amd/fused.py: _ffn_f16_weights, _attn_f16_ok,
+    # verdicts of the attention / CompressBlock weights (mssvt_amd/fused.py: _ffn_f16_weights, _attn_kv16_ok,
     # _compress_f16_ok), keyed on `tensor._version` + `data_ptr()`.  Every update that goes through autograd-visible
     # in-place ops, `load_state_dict`, `.to()` / `.half()` / `.cuda()` is seen (the last three through the hooks below).
     # An in-place write through `.data` (`p.data.copy_(ema)`, weight clipping, hand-written optimizers) is NOT: it does
@@ -424,6 +424,7 @@ class MixedScaleSparseTransformer(nn.Module):
         after parameters were overwritten through `.data`."""
         for blk in self.backbone:
             blk.refresh_weights()
+        self.__dict__.pop("_frame_state", None)
         return self
 
     def set_impl(self, impl):
@@ -465,6 +466,13 @@ class MixedScaleSparseTransformer(nn.Module):
         from . import fused
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         fused_path = feats.is_cuda and any(getattr(b, 'impl', None) == 'fused' for b in self.backbone)
+        if fused_path and assume_sorted:
+            # the whole frame behind one C call (mssvt_amd/frame.py) when the network shape is the common one
+            from . import frame
+            sp = frame.forward(self, feats, coords, batch_dict['batch_size'])
+            if sp is not None:
+                batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
+                return batch_dict
         # index work of the frame on a side stream (mssvt_amd/fused.py, "Index work of a frame on a second HIP stream")
         side = main = None
         if fused_path and self.async_index and not torch.is_grad_enabled():

@@ -168,44 +168,6 @@ def test_bf16_attention_rows_vs_fp32_kernels():
     assert err <= 5e-2 and rms <= 1e-2
 
 
-def test_split_f16_single_launch_attention_rows_vs_fp32_kernels():
-    """csrc/block_attn_f16x3.hip (opt-in, MSSVT_ATTN_ARITH=f16x3 / block.attn_arith): ONE launch, keys projected in the
-    kernel, every MFMA operand split exactly into two fp16 halves.  Same plan, against the three fp32 launches, with the
-    fp32 parity path's own tolerance |diff| <= 1e-5 max|ref| + 1e-4 |ref| (it is an fp32-accurate form, unlike bf16)."""
-    from mssvt_amd import config, fused
-    from mssvt_amd.mssvt_utils import SparseTensor
-    pts = synthetic.make_batch_points(40000, 1, 9)
-    vc, _, _ = synthetic.voxelize_numpy(pts)
-    torch.manual_seed(0)
-    net = config.build_backbone_from_cfg().to(DEV).eval()
-    feats = torch.randn(vc.shape[0], 128, generator=torch.Generator().manual_seed(2)).to(DEV)
-    with torch.no_grad():
-        sp = SparseTensor(features=feats, indices=torch.from_numpy(vc).to(DEV).int().contiguous(),
-                          spatial_shape=net.grid_size, voxel_size=net.voxel_size,
-                          point_cloud_range=net.point_cloud_range, batch_size=1, hash_size=net.hash_size)
-        for blk in (net.backbone[0], net.backbone[1]):
-            p = fused.two_scale_plan(blk, sp)
-            xhat = fused.layer_norm(feats, blk.norm1)
-            q_ind, nq, _ = fused._query(blk, p)
-            od = fused._work_order(blk, p, nq, feats.shape[0])
-            qbuf = fused._query_scratch(p, od["row_cap"], blk.ms_attn, feats.device)
-            assert fused._attn_f16_ok(blk, fused._attn_refs(blk, None), p)
-            rows = {}
-            blk.attn_kv16 = False  # "f32" = the fp32 matrix instruction in all three launches
-            for arith in ("f32", "f16x3"):
-                blk.attn_arith = arith
-                attn = torch.zeros((p.cap * nq + 1, 128), dtype=torch.float32, device=DEV)
-                fused._attention_call(blk, p, od, 128, nq, xhat, qbuf, attn)
-                rows[arith] = attn
-            nw = int(p.num_wins.item())
-            valid = (q_ind[:nw] >= 0).reshape(-1)
-            a, b = rows["f32"][:nw * nq][valid], rows["f16x3"][:nw * nq][valid]
-            assert a.shape[0] > 1000 and not torch.equal(a, b)
-            assert torch.equal(rows["f32"][:nw * nq][~valid], rows["f16x3"][:nw * nq][~valid])
-            tol = 1e-5 * float(a.abs().max()) + 1e-4 * a.abs()
-            assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
-
-
 @pytest.mark.parametrize("seed,points,batch", [(9, 40000, 1), (4, 30000, 2)])
 def test_split_f16_window_launch_attention_rows_vs_fp32_kernels(seed, points, batch):
     """mssvt_block_attention_kv16 (the default of the fp32 path): launch B with split-fp16 matrix operands (k_attn_kvh),
