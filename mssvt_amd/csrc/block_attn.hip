@@ -804,7 +804,9 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
     f32x4 T1n[KT][NT];
 #define KV_ISSUE_ROWS()                                                                    \
     {                                                                                      \
-        wc_r = wc_m; nqv_r = nqv_m; qbase_r = qbase_m;                                     \
+        wc_r = wc_m;                                                                       \
+        nqv_r = __builtin_amdgcn_readfirstlane(nqv_m);                                     \
+        qbase_r = __builtin_amdgcn_readfirstlane(qbase_m);                                 \
         vmask_r = 0; used_r = 0;                                                           \
         _Pragma("unroll") for (int t = 0; t < KT; ++t) {                                   \
             const int r_ = __builtin_bit_cast(int, km_m[t].w);                             \
@@ -1072,17 +1074,37 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     // piece S of a row: channels 16 S + 4 g + i (dense: the four g lanes of a key read 64 contiguous bytes)
 #define KVH_ROW4(off_, S_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_rs, (off_) + 64u * (S_), 0, 0))
     // the software pipeline of k_attn_kv: window ids three steps ahead, metadata two, raw rows one; every load unconditional
-    int w_p;
+    // The per-window words (query count, first query row, the window id three steps ahead) stay in VECTOR registers until
+    // the iteration that uses them: loaded through an index the compiler cannot prove uniform.  With a uniform index it
+    // emits global_load + s_waitcnt + v_readfirstlane right behind the load -- a full memory round trip on every window's
+    // critical path, with the next window's row gathers (issued just before) drained along the way.
+    int w_p, w_p_v;
     float4 wc_m, km_m[KT];
     int nqv_m, qbase_m;
+#ifndef KVH_LAZY
+#define KVH_LAZY 1  // 0: the round-3 form (uniform loads + immediate readfirstlane, Q' loaded in the window that uses it) -- A/B only
+#endif
+#if KVH_LAZY
+#define KVH_OPAQUE(i_) asm volatile("" : "+v"(i_))
+#else
+#define KVH_OPAQUE(i_)
+#endif
 #define KVH_LOAD_META()                                                                    \
     {                                                                                      \
-        wc_m = a.wcentre[w_p];                                                             \
-        nqv_m = a.nq_valid[w_p];                                                           \
-        qbase_m = a.q_off[w_p];                                                            \
+        int wv_ = w_p;                                                                     \
+        KVH_OPAQUE(wv_);                                                                   \
+        wc_m = a.wcentre[wv_];                                                             \
+        nqv_m = a.nq_valid[wv_];                                                           \
+        qbase_m = a.q_off[wv_];                                                            \
         _Pragma("unroll") for (int t = 0; t < KT; ++t)                                     \
             km_m[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(    \
                 km_rs, ((unsigned)w_p * (unsigned)K + (unsigned)min(16 * t + la, K - 1)) * 16u, 0, 0)); \
+    }
+#define KVH_LOAD_PERM(i_)                                                                  \
+    {                                                                                      \
+        int pi_ = (i_);                                                                    \
+        KVH_OPAQUE(pi_);                                                                   \
+        w_p_v = a.perm[pi_];                                                               \
     }
     float4 wc_r;
     int nqv_r, qbase_r;
@@ -1091,7 +1113,9 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     f32x4 T1n[KT][NT];
 #define KVH_ISSUE_ROWS()                                                                   \
     {                                                                                      \
-        wc_r = wc_m; nqv_r = nqv_m; qbase_r = qbase_m;                                     \
+        wc_r = wc_m;                                                                       \
+        nqv_r = __builtin_amdgcn_readfirstlane(nqv_m);                                     \
+        qbase_r = __builtin_amdgcn_readfirstlane(qbase_m);                                 \
         vmask_r = 0; used_r = 0;                                                           \
         _Pragma("unroll") for (int t = 0; t < KT; ++t) {                                   \
             const int r_ = __builtin_bit_cast(int, km_m[t].w);                             \
@@ -1108,6 +1132,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     w_p = a.perm[wi];
     KVH_LOAD_META()
     w_p = a.perm[min(wi + wstep, w_last)];
+    KVH_LOAD_PERM(min(wi + 2 * wstep, w_last))
     const int hh = la % HP;
     const bool head_ok = hh < NH;
     // first-pass Qt fragments of a window travel one window ahead as well (stage R): issued before the previous window's
@@ -1124,12 +1149,21 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
             ql_r[P] = qr_[(P * 4 + g) * 2 + 1];                                            \
         }                                                                                  \
     }
+    // Q' mode: the first pass's Q' fragment of a window (8 halves per lane) travels one window ahead like its key rows
+    h16x8 qp8_n = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#define KVH_ISSUE_QP()                                                                     \
+    if (QP && KVH_LAZY) {                                                                              \
+        const int nq_ = qbase_r + nqv_r <= a.row_capacity ? nqv_r : 0;                     \
+        qp8_n = reinterpret_cast<const h16x8 *>(a.qbuf + ((size_t)qbase_r + max(min(la / HP, nq_ - 1), 0)) * QROW)[(head_ok ? hh : 0) * 4 + g]; \
+    }
     KVH_ISSUE_ROWS()
+    KVH_ISSUE_QP()
 #if KVH_QT_AHEAD
     KVH_ISSUE_QT()
 #endif
     KVH_LOAD_META()
-    w_p = a.perm[min(wi + 2 * wstep, w_last)];
+    w_p = __builtin_amdgcn_readfirstlane(w_p_v);
+    KVH_LOAD_PERM(min(wi + 3 * wstep, w_last))
     // transposed reads: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of its 4 x 16 block
     const char *tr_base = Ti + (4 * g + (la >> 2)) * RS + 8 * (la & 3);
     for (; wi < n_act; wi += wstep) {
@@ -1180,8 +1214,11 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         }
 #else
         h16x8 qp8 = h16x8{0, 0, 0, 0, 0, 0, 0, 0};  // Q' mode: (hi x 4 | lo x 4) of this lane's column
-        if (QP) {
+        if (QP && !KVH_LAZY) {
             qp8 = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + max(min(la / HP, nqv - 1), 0)) * QROW)[(head_ok ? hh : 0) * 4 + g];
+        } else if (QP) {
+            qp8 = qp8_n;  // requested one window ago (a load issued here was sunk behind the next window's gathers by the
+                          // scheduler and then waited for with vmcnt(0): everything just issued, on every window)
         } else {
             const h16x8 *qr_ = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + max(min(la / HP, nqv - 1), 0)) * QROW + (head_ok ? hh : 0) * CG);
 #pragma unroll
@@ -1192,11 +1229,13 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         }
 #endif
         KVH_ISSUE_ROWS()
+        KVH_ISSUE_QP()
 #if KVH_QT_AHEAD
         KVH_ISSUE_QT()
 #endif
         KVH_LOAD_META()
-        w_p = a.perm[min(wi + 3 * wstep, w_last)];
+        w_p = __builtin_amdgcn_readfirstlane(w_p_v);  // loaded one window ago
+        KVH_LOAD_PERM(min(wi + 4 * wstep, w_last))
         wave_lds_sync();
         for (int q0 = 0; q0 < nqv; q0 += QPP) {
             const int q = q0 + la / HP;
@@ -1312,6 +1351,9 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         wave_lds_sync();  // the next window rewrites the image
     }
 #undef KVH_LOAD_META
+#undef KVH_LOAD_PERM
+#undef KVH_ISSUE_QP
+#undef KVH_OPAQUE
 #undef KVH_ISSUE_QT
 #undef KVH_ISSUE_ROWS
 #undef KVH_ROW4

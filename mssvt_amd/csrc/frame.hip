@@ -353,9 +353,11 @@ extern "C" int mssvt_frame_add_block(
         // every Block of the level shares ONE window plan (the reference recomputes it per block, mssvt_backbone.py:139-199)
         const FrPlanCfg &q = f->plan;
         bool same = p.n_o == q.n_o && p.n_e == q.n_e && p.n1 == q.n1 && p.n2 == q.n2 && p.num_o == q.num_o && p.num_e == q.num_e &&
-                    p.num_1 == q.num_1 && p.num_2 == q.num_2 && p.K == q.K && p.max_wins == q.max_wins && p.t_o == q.t_o &&
-                    p.t_e == q.t_e && p.t_1 == q.t_1 && p.t_2 == q.t_2 && p.packed_offsets == q.packed_offsets;
+                    p.num_1 == q.num_1 && p.num_2 == q.num_2 && p.K == q.K && p.max_wins == q.max_wins;
         for (int i = 0; i < 3; ++i) same = same && p.ws[i] == q.ws[i];
+        for (int i = 0; i < 4; ++i) same = same && p.fp4[i] == q.fp4[i];
+        // (the offset tables are per-block copies of the same contents -- the caller compares them, fused.plan_key --
+        // the first Block's are used)
         if (!same) return MSSVT_E_TOOLARGE;
     }
     FrBlock k;

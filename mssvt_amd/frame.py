@@ -181,7 +181,12 @@ def _state(net, feats, batch_size):
                   b.vox_query_table['win1'].data_ptr()) for b in net.backbone)) + fused._content_key(ps)
     if st["key"] != key:
         with torch.no_grad():
-            st["frame"] = _build(net, feats.device, batch_size)
+            try:
+                st["frame"] = _build(net, feats.device, batch_size)
+            except _lib.MssvtHipError as e:
+                if "status -2" not in str(e):  # MSSVT_E_TOOLARGE: a shape the frame call does not cover -> Python path
+                    raise
+                st["frame"] = None
         st["key"] = key
     return st["frame"]
 

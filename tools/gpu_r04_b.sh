@@ -18,3 +18,4 @@ done
 ROWS=50 bash tools/prof.sh r04b_b1 --steps 20 > $out/prof_b1.txt; cat $out/prof_b1.txt | cut -d, -f1-4 | cut -c1-120
 MSSVT_FRAME_OVERLAP=1 ROWS=50 bash tools/prof.sh r04b_b1_overlap --steps 20 > $out/prof_b1_overlap.txt; head -4 $out/prof_b1_overlap.txt | cut -c1-100
 timeout 900 python -m pytest tests -m gpu -x -q > $out/pytest.txt 2>&1; echo "pytest rc $?"; tail -3 $out/pytest.txt
+bash tools/ab_flags.sh "k_attn_kvh|k_attn_q16|k_attn_o16" "-DKVH_LAZY=1" "-DKVH_LAZY=0" "-DKVH_LAZY=1" "-DKVH_LAZY=0" > $out/ab_kvh.txt 2>&1; cat $out/ab_kvh.txt
