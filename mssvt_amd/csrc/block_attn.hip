@@ -804,9 +804,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
     f32x4 T1n[KT][NT];
 #define KV_ISSUE_ROWS()                                                                    \
     {                                                                                      \
-        wc_r = wc_m;                                                                       \
-        nqv_r = __builtin_amdgcn_readfirstlane(nqv_m);                                     \
-        qbase_r = __builtin_amdgcn_readfirstlane(qbase_m);                                 \
+        wc_r = wc_m; nqv_r = nqv_m; qbase_r = qbase_m;                                     \
         vmask_r = 0; used_r = 0;                                                           \
         _Pragma("unroll") for (int t = 0; t < KT; ++t) {                                   \
             const int r_ = __builtin_bit_cast(int, km_m[t].w);                             \
@@ -1022,15 +1020,10 @@ __device__ __forceinline__ h16x4 lds_read_tr16(const char *p) {
 }
 // KVH_QT_AHEAD = 1: the first-pass Qt fragments of a window are requested one window ahead like its key rows (16 more
 // VGPRs: 3 waves / SIMD).  Measured on one box (tools/ab_kvh.sh): 94.2 / 46.9 us per Block attention against 91.6 / 45.5
-// without -- the window launch is not waiting for these loads, it is short of vector-memory issue slots (tools/ablate_kvh.sh:
+// without -- the window launch is not waiting for these loads, it is short of vector-memory issue slots (round-3 timing-only ablation builds, DESIGN.md section 4:
 // dropping the 4 Qt loads of a pass -7.3 us, the 4 Xbar stores -5.9 us, serving the key rows from 8 hot rows -0.6 us).
 #ifndef KVH_QT_AHEAD
 #define KVH_QT_AHEAD 0
-#endif
-#ifdef KVH_ABLATE
-#define KVH_ABL(k_) (KVH_ABLATE == (k_))
-#else
-#define KVH_ABL(k_) false
 #endif
 // QP: the hand-off rows hold Q' fragments (k_attn_q16<.., 2>) and Qt_h = (scale Wk_h)^T q'_h is formed here, per pass, from the
 // Wk fragments of the pack blob staged into the LDS: one product per head with the columns of the other heads zeroed in
@@ -1074,37 +1067,17 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     // piece S of a row: channels 16 S + 4 g + i (dense: the four g lanes of a key read 64 contiguous bytes)
 #define KVH_ROW4(off_, S_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_rs, (off_) + 64u * (S_), 0, 0))
     // the software pipeline of k_attn_kv: window ids three steps ahead, metadata two, raw rows one; every load unconditional
-    // The per-window words (query count, first query row, the window id three steps ahead) stay in VECTOR registers until
-    // the iteration that uses them: loaded through an index the compiler cannot prove uniform.  With a uniform index it
-    // emits global_load + s_waitcnt + v_readfirstlane right behind the load -- a full memory round trip on every window's
-    // critical path, with the next window's row gathers (issued just before) drained along the way.
-    int w_p, w_p_v;
+    int w_p;
     float4 wc_m, km_m[KT];
     int nqv_m, qbase_m;
-#ifndef KVH_LAZY
-#define KVH_LAZY 1  // 0: the round-3 form (uniform loads + immediate readfirstlane, Q' loaded in the window that uses it) -- A/B only
-#endif
-#if KVH_LAZY
-#define KVH_OPAQUE(i_) asm volatile("" : "+v"(i_))
-#else
-#define KVH_OPAQUE(i_)
-#endif
 #define KVH_LOAD_META()                                                                    \
     {                                                                                      \
-        int wv_ = w_p;                                                                     \
-        KVH_OPAQUE(wv_);                                                                   \
-        wc_m = a.wcentre[wv_];                                                             \
-        nqv_m = a.nq_valid[wv_];                                                           \
-        qbase_m = a.q_off[wv_];                                                            \
+        wc_m = a.wcentre[w_p];                                                             \
+        nqv_m = a.nq_valid[w_p];                                                           \
+        qbase_m = a.q_off[w_p];                                                            \
         _Pragma("unroll") for (int t = 0; t < KT; ++t)                                     \
             km_m[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(    \
                 km_rs, ((unsigned)w_p * (unsigned)K + (unsigned)min(16 * t + la, K - 1)) * 16u, 0, 0)); \
-    }
-#define KVH_LOAD_PERM(i_)                                                                  \
-    {                                                                                      \
-        int pi_ = (i_);                                                                    \
-        KVH_OPAQUE(pi_);                                                                   \
-        w_p_v = a.perm[pi_];                                                               \
     }
     float4 wc_r;
     int nqv_r, qbase_r;
@@ -1113,9 +1086,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     f32x4 T1n[KT][NT];
 #define KVH_ISSUE_ROWS()                                                                   \
     {                                                                                      \
-        wc_r = wc_m;                                                                       \
-        nqv_r = __builtin_amdgcn_readfirstlane(nqv_m);                                     \
-        qbase_r = __builtin_amdgcn_readfirstlane(qbase_m);                                 \
+        wc_r = wc_m; nqv_r = nqv_m; qbase_r = qbase_m;                                     \
         vmask_r = 0; used_r = 0;                                                           \
         _Pragma("unroll") for (int t = 0; t < KT; ++t) {                                   \
             const int r_ = __builtin_bit_cast(int, km_m[t].w);                             \
@@ -1124,7 +1095,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
             vmask_r |= (unsigned)((bal_ >> (4 * g)) & 15ull) << (4 * t);                   \
             used_r |= (t == 0 || (bal_ & 0xFFFFull) != 0ull) ? 1u << t : 0u;               \
             rel_r[t] = lane_pick4(g, km_m[t].x, km_m[t].y, km_m[t].z, 1.0f); \
-            const unsigned ro_ = (unsigned)__umul24((unsigned)(KVH_ABL(1) ? (r_ & 7) : ok_ ? r_ : 0), row_bytes) + lane_off; \
+            const unsigned ro_ = (unsigned)__umul24((unsigned)(ok_ ? r_ : 0), row_bytes) + lane_off; \
             _Pragma("unroll") for (int S = 0; S < NT; ++S) T1n[t][S] = KVH_ROW4(ro_, S);   \
         }                                                                                  \
     }
@@ -1132,7 +1103,6 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     w_p = a.perm[wi];
     KVH_LOAD_META()
     w_p = a.perm[min(wi + wstep, w_last)];
-    KVH_LOAD_PERM(min(wi + 2 * wstep, w_last))
     const int hh = la % HP;
     const bool head_ok = hh < NH;
     // first-pass Qt fragments of a window travel one window ahead as well (stage R): issued before the previous window's
@@ -1149,21 +1119,12 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
             ql_r[P] = qr_[(P * 4 + g) * 2 + 1];                                            \
         }                                                                                  \
     }
-    // Q' mode: the first pass's Q' fragment of a window (8 halves per lane) travels one window ahead like its key rows
-    h16x8 qp8_n = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#define KVH_ISSUE_QP()                                                                     \
-    if (QP && KVH_LAZY) {                                                                              \
-        const int nq_ = qbase_r + nqv_r <= a.row_capacity ? nqv_r : 0;                     \
-        qp8_n = reinterpret_cast<const h16x8 *>(a.qbuf + ((size_t)qbase_r + max(min(la / HP, nq_ - 1), 0)) * QROW)[(head_ok ? hh : 0) * 4 + g]; \
-    }
     KVH_ISSUE_ROWS()
-    KVH_ISSUE_QP()
 #if KVH_QT_AHEAD
     KVH_ISSUE_QT()
 #endif
     KVH_LOAD_META()
-    w_p = __builtin_amdgcn_readfirstlane(w_p_v);
-    KVH_LOAD_PERM(min(wi + 3 * wstep, w_last))
+    w_p = a.perm[min(wi + 2 * wstep, w_last)];
     // transposed reads: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of its 4 x 16 block
     const char *tr_base = Ti + (4 * g + (la >> 2)) * RS + 8 * (la & 3);
     for (; wi < n_act; wi += wstep) {
@@ -1187,8 +1148,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
 #pragma unroll
             for (int P = 0; P < NP; ++P) {
                 h16x8 th = h16x8{0, 0, 0, 0, 0, 0, 0, 0}, tl = th;
-                if (KVH_ABL(6)) { th = __builtin_bit_cast(h16x8, T1n[t][2 * P]); tl = __builtin_bit_cast(h16x8, T1n[t][2 * P + 1]); }
-                else if (used >> t & 1) {
+                if (used >> t & 1) {
                     f32x4 tk[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -1214,11 +1174,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         }
 #else
         h16x8 qp8 = h16x8{0, 0, 0, 0, 0, 0, 0, 0};  // Q' mode: (hi x 4 | lo x 4) of this lane's column
-        if (QP && !KVH_LAZY) {
+        if (QP) {
             qp8 = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + max(min(la / HP, nqv - 1), 0)) * QROW)[(head_ok ? hh : 0) * 4 + g];
-        } else if (QP) {
-            qp8 = qp8_n;  // requested one window ago (a load issued here was sunk behind the next window's gathers by the
-                          // scheduler and then waited for with vmcnt(0): everything just issued, on every window)
         } else {
             const h16x8 *qr_ = reinterpret_cast<const h16x8 *>(a.qbuf + (qbase + max(min(la / HP, nqv - 1), 0)) * QROW + (head_ok ? hh : 0) * CG);
 #pragma unroll
@@ -1229,13 +1186,11 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         }
 #endif
         KVH_ISSUE_ROWS()
-        KVH_ISSUE_QP()
 #if KVH_QT_AHEAD
         KVH_ISSUE_QT()
 #endif
         KVH_LOAD_META()
-        w_p = __builtin_amdgcn_readfirstlane(w_p_v);  // loaded one window ago
-        KVH_LOAD_PERM(min(wi + 4 * wstep, w_last))
+        w_p = a.perm[min(wi + 3 * wstep, w_last)];
         wave_lds_sync();
         for (int q0 = 0; q0 < nqv; q0 += QPP) {
             const int q = q0 + la / HP;
@@ -1248,7 +1203,6 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
                     const h16x8 *qrow = reinterpret_cast<const h16x8 *>(xrow);
 #pragma unroll
                     for (int P = 0; P < NP; ++P) {
-                        if (KVH_ABL(3)) continue;
                         qh[P] = qrow[(P * 4 + g) * 2];
                         ql[P] = qrow[(P * 4 + g) * 2 + 1];
                     }
@@ -1291,7 +1245,6 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
                 f32x4 mm = sc[t], cr = sc[t];
 #pragma unroll
                 for (int P = 0; P < NP; ++P) {
-                    if (KVH_ABL(5)) { mm[0] += (float)qh[P][t]; continue; }
                     const char *src = Ti + (16 * t + la) * RS + 64 * P + 16 * g;
                     const h16x8 th = *reinterpret_cast<const h16x8 *>(src), tl = *reinterpret_cast<const h16x8 *>(src + IMG);
                     MFMA_H(mm, th, qh[P]);
@@ -1334,7 +1287,6 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
                 f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    if (KVH_ABL(4)) { mm[0] += (float)ph[s][u]; continue; }
                     const char *blk = tr_base + 32 * s * RS + 32 * u;
                     const h16x8 ah = h16_cat(lds_read_tr16(blk), lds_read_tr16(blk + 16 * RS));
                     const h16x8 al = h16_cat(lds_read_tr16(blk + IMG), lds_read_tr16(blk + IMG + 16 * RS));
@@ -1342,7 +1294,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
                     MFMA_H(cr, ah, pl[s]);
                     MFMA_H(cr, al, ph[s]);
                 }
-                if (q_ok && !(KVH_ABL(2) && mm[0] != 12345.f))  // xbar replaces qt in place (this lane's own bytes of the row)
+                if (q_ok)  // xbar replaces qt in place (this lane's own bytes of the row)
                     // image column 16 u + 4 g + i is k slot (2 (u % 2) + g / 2, 4 (g % 2) + i) of step u / 2 (see above)
                     store_handoff(xrow + 32 * (u >> 1) + 16 * (g & 1) + 8 * (u & 1) + 4 * (g >> 1), f32x4{__builtin_fmaf(cr[0], H16_INV, mm[0]), __builtin_fmaf(cr[1], H16_INV, mm[1]),
                                                                __builtin_fmaf(cr[2], H16_INV, mm[2]), __builtin_fmaf(cr[3], H16_INV, mm[3])});
@@ -1351,9 +1303,6 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         wave_lds_sync();  // the next window rewrites the image
     }
 #undef KVH_LOAD_META
-#undef KVH_LOAD_PERM
-#undef KVH_ISSUE_QP
-#undef KVH_OPAQUE
 #undef KVH_ISSUE_QT
 #undef KVH_ISSUE_ROWS
 #undef KVH_ROW4

@@ -284,9 +284,7 @@ __device__ __forceinline__ void plan_emit_list(int w, int lane, int maxn, int nv
             qmeta[(size_t)w * maxn + k] = make_float4(valid ? m.x : 0.f, valid ? m.y : 0.f, valid ? m.z : 0.f,
                                                        valid ? m.w : __builtin_bit_cast(float, -1));
         }
-#if !(defined(PLAN_ABLATE) && PLAN_ABLATE == 5)  // (timing-only build 5: no owner atomics)
         if (valid) atomicMax(owner + vstart + sv, w * maxn + k);
-#endif
     }
 }
 
@@ -376,10 +374,6 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
     const float4 m0 = make_float4(plan_centre(v0.w, a.vsx, a.minx) - wcx, plan_centre(v0.z, a.vsy, a.miny) - wcy,
                                   plan_centre(v0.y, a.vsz, a.minz) - wcz, __builtin_bit_cast(float, vstart));
     PSTAMP()
-#if defined(PLAN_ABLATE) && PLAN_ABLATE == 2  // timing-only build: stop after the column loads
-    if (colw[lane % max(ncols, 1)] == 0x1234567ull) a.win_vstart[w] = 1;
-    return;
-#endif
     // ---- K3: the hit sequence ---------------------------------------------------------------------------
     // hits of the first 1 / 2 / 3 / 4 tables; a count is fixed in the step that holds its table's end (-1: not reached,
     // every hit so far belongs to it)
@@ -484,10 +478,6 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     PSTAMP()
-#if defined(PLAN_ABLATE) && PLAN_ABLATE == 3  // timing-only build: stop after K3 + indices
-    if (hsv[lane] == 0x12345678) a.win_vstart[w] = 1;
-    return;
-#endif
     plan_emit_list(w, lane, a.max_odd, nO, 0, hsv, hmeta, a.ind_odd, a.kmeta1 ? a.qmeta_odd : nullptr, a.owner_odd, vstart);
     plan_emit_list(w, lane, a.max_even, nE, cnt_odd, hsv, hmeta, a.ind_even, a.kmeta1 ? a.qmeta_even : nullptr, a.owner_even, vstart);
     plan_emit_list(w, lane, a.max_win1, n1, 0, hsv, hmeta, a.ind_win1, a.kmeta1 ? a.qmeta_win1 : nullptr, a.owner_win1, vstart);
@@ -594,12 +584,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
         const int n = scale ? a.max_win2 : a.max_win1;
         const int bs = scale ? a.bs2 : a.bs1;
         const int nv = scale ? n2 : n1;
-#if defined(PLAN_ABLATE) && PLAN_ABLATE == 1  // timing-only build: no sampling
-        if (lane < K) fps_out[lane] = 0;
-        if (false) {
-#else
         if (nv <= MSSVT_WAVE && nv <= bs && bs >= 2) {
-#endif
             const int pk0 = lane < nv ? hpk[lane] : PACK0;
             if (K > MSSVT_WAVE)
                 fps_on_list_fast<false, 4>(pk0, n, nv, K, bs, fps_out, lane);
@@ -649,11 +634,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
                         }
                     }
                 }
-#if !(defined(PLAN_ABLATE) && PLAN_ABLATE == 6)  // (timing-only build 6: no key metadata stores)
                 (scale ? a.kmeta2 : a.kmeta1)[(size_t)w * K + j] = m;
-#else
-                if (m.x == 123.f) a.win_vstart[w] = 1;
-#endif
             }
         }
         wave_lds_sync();
