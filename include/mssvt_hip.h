@@ -459,9 +459,6 @@ int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, c
  * cycles; no hidden round trip).  The CALLER guarantees the fp16 range: sqrt(C) max|norm_w| +
  * max|norm_b| and max_h(|W1_h|_1 * that + |b1_h|) below 6e4 (fused.FFN_F16_LIMIT; mssvt_amd/fused.py checks the
  * parameters once per version and keeps phases 3 otherwise).
- * phases 5 / 6: as 4 with the kernel form pinned -- 5 = every wave of the workgroup in the same phase (k_ffn_ws), 6 =
- * producer / consumer waves (k_ffn_wsp: one half of the waves owns linear1 and the rows in, the other half linear2 and
- * the rows out; the default of phases 4 unless MSSVT_FFN_PC=0); the two forms give bit-identical results.
  * Instantiated for (C,FF) in {(128,256),(64,128),(32,64)}; MSSVT_E_TOOLARGE otherwise.   */
 int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, const float *x_in, const int *owner,
                     const float *norm_w, const float *norm_b, float eps, const float *W1,

@@ -7,6 +7,7 @@ under that attribute name, so state-dict keys read ``vfe.*``, ``backbone_3d.back
 eval mode, and the checkpoint loaders ``load_params_from_file`` / ``_load_state_dict`` (:330-372: update by key where
 the shapes agree, report what stayed).  Training losses, the dataset classes, recall bookkeeping and the spconv weight
 layout adaptation (no spconv module exists here) are out of scope."""
+import contextlib
 import os
 from types import SimpleNamespace
 
@@ -133,10 +134,21 @@ class CenterPoint(nn.Module):
         if not os.path.isfile(filename):
             raise FileNotFoundError(filename)
         loc = torch.device("cpu") if to_cpu else None
+        import pickle
         try:
-            # tensors / plain containers only: loading a checkpoint cannot run code
-            ckpt = torch.load(filename, map_location=loc, weights_only=True)
-        except Exception as err:  # noqa: BLE001  (pickled objects beyond tensors: OpenPCDet stores e.g. numpy scalars)
+            # tensors / plain containers only: loading a checkpoint cannot run code.  The numpy scalar types OpenPCDet
+            # stores beside the weights (epoch, it, version strings) are plain data: allowed explicitly.
+            safe = []
+            try:
+                import numpy as np
+                core = getattr(np, "_core", None) or getattr(np, "core")
+                safe = [core.multiarray.scalar, np.dtype]
+            except Exception:  # noqa: BLE001
+                safe = []
+            with (torch.serialization.safe_globals(safe) if safe and hasattr(torch.serialization, "safe_globals")
+                  else contextlib.nullcontext()):
+                ckpt = torch.load(filename, map_location=loc, weights_only=True)
+        except pickle.UnpicklingError as err:  # a global weights_only does not allow; corrupt files / I/O errors propagate as they are
             if os.environ.get("MSSVT_TRUST_CHECKPOINTS", "0") != "1":
                 raise RuntimeError(
                     "%s holds pickled objects beyond tensors (%s); unpickling them can execute arbitrary code. Set "

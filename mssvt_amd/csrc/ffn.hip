@@ -16,7 +16,6 @@
 //
 // HBM access is fully coalesced although the MFMA operand layouts are not: rows are loaded and stored as whole rows
 // (float4 per lane) and re-laid out on chip.
-#include <stdlib.h>
 #include "common.hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -474,26 +473,6 @@ __global__ void __launch_bounds__(FFS_NW *MSSVT_WAVE) k_ffn_down(FfnArgs a, cons
 // interval has one MFMA phase and one row-wise phase: two barriers per tile.  (First version: split-K over
 // the hidden units in GEMM2 with the FF/32 partial tiles summed through LDS -- 128 more VALU instructions per wave
 // and tile for the partial epilogues than the third barrier costs; the phases are VALU-issue bound, not MFMA bound.)
-#ifndef FFW_MASKS
-#define FFW_MASKS 1   // gather-source selection with bit masks (no branch inside the barrier interval)
-#endif
-#ifndef FFW_SGB
-#define FFW_SGB 0     // sched_group_barrier pattern inside the two barrier intervals (MFMA : LDS read : VALU : gather)
-#endif
-#ifndef FFW_SGB_VALU
-#define FFW_SGB_VALU 4
-#endif
-#define FFW_SGB_STEP(id_, ds_, vm_)                                   \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, id_);              \
-    if (ds_) __builtin_amdgcn_sched_group_barrier(0x100, 1, id_);     \
-    __builtin_amdgcn_sched_group_barrier(0x002, FFW_SGB_VALU, id_);   \
-    if (vm_) __builtin_amdgcn_sched_group_barrier(0x020, 1, id_);
-#ifndef FFW_MANUAL
-#define FFW_MANUAL 1  // hand-placed chunks (sched_barrier fences) in the two barrier intervals of k_ffn_ws
-#endif
-#ifndef FFW_LN_LDS
-#define FFW_LN_LDS 1  // LayerNorm parameters read from LDS per tile instead of 16 resident VGPRs
-#endif
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
@@ -640,7 +619,6 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     }
     float4 rx, r1, r2, r3;
     float w1 = 0.f, w2 = 0.f, w3 = 0.f, wx = 1.f;
-#if FFW_MASKS
 #define FFW_SELECT(tr_, tw_, row_)                                                                          \
             /* unowned voxel (tr.x < 0): 2 x_in; it re-reads its own finite row with weight 0.  The selection is   \
                written with MASKS, not ?: -- the compiler turns a group of selects on one condition into a BRANCH,   \
@@ -660,16 +638,6 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
             w2 = __builtin_bit_cast(float, __builtin_bit_cast(int, tw_.y) & m_);                                    \
             w3 = __builtin_bit_cast(float, __builtin_bit_cast(int, tw_.z) & m_);                                    \
             wx = __builtin_bit_cast(float, 0x3F800000 + (~m_ & 0x00800000)); /* 1.0f, or 2.0f when unowned */
-#else
-#define FFW_SELECT(tr_, tw_, row_)                                                                          \
-            const bool un_ = tr_.x < 0; /* unowned voxel: 2 x_in; re-reads its own finite row with weight 0 */ \
-            const float *px_ = a.x_in + (size_t)row_ * C + 4 * q;                                           \
-            rx = *reinterpret_cast<const float4 *>(px_);                                                    \
-            r1 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.x * C + 4 * q);        \
-            r2 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.y * C + 4 * q);        \
-            r3 = *reinterpret_cast<const float4 *>(un_ ? px_ : a.attn + (size_t)tr_.z * C + 4 * q);        \
-            w1 = un_ ? 0.f : tw_.x; w2 = un_ ? 0.f : tw_.y; w3 = un_ ? 0.f : tw_.z; wx = un_ ? 2.0f : 1.0f;
-#endif
 #define FFW_ISSUE(tile_, tr_, tw_, own_)                                                                    \
     {                                                                                                       \
         const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
@@ -710,27 +678,12 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         dst_[0] = hi_;                                                                                      \
         dst_[64 * 2] = lo_; /* the lo fragment follows the hi fragment: 64 slots x 2 h16x4 */               \
     }
-#ifndef FFW_T_OUTER
-#define FFW_T_OUTER 0
-#endif
-#if FFW_T_OUTER
-    /* hidden tile T = 0 completely, then T = 1: the split of tile 0 can run under the products of tile 1 */
-#define FFW_GEMM1_PRODUCTS()                                                                                \
-        _Pragma("unroll") for (int T = 0; T < 2; ++T) {                                                    \
-            _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                               \
-                MFMA_H(um_[T], W1h[T][P], bh_[P]);                                                          \
-                MFMA_H(ul_[T], W1h[T][P], bl_[P]);                                                          \
-                MFMA_H(uk_[T], W1l[T][P], bh_[P]);                                                          \
-            }                                                                                               \
-        }
-#else
 #define FFW_GEMM1_PRODUCTS()                                                                                \
         _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                                   \
             _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(um_[T], W1h[T][P], bh_[P]);               \
             _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(ul_[T], W1h[T][P], bl_[P]);               \
             _Pragma("unroll") for (int T = 0; T < 2; ++T) MFMA_H(uk_[T], W1l[T][P], bh_[P]);               \
         }
-#endif
     // u^T = relu(W1 xn + b1) for this wave's 32 hidden units -> its k-slice of GEMM2's B operand
 #define FFW_GEMM1()                                                                                         \
     {                                                                                                       \
@@ -794,7 +747,6 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     // row-wise constants of this lane's 4 channels
     // (kept in LDS, not in 16 VGPRs: with the weights in 128 registers the loop sits at the 256-register limit, and every
     // register less is a spill or a v_mov less; four ds_read_b128 per tile)
-#if FFW_LN_LDS
     if (threadIdx.x < C / 4) {
         const int c4 = threadIdx.x * 4;
         *reinterpret_cast<float4 *>(lnp + c4) = *reinterpret_cast<const float4 *>(a.ln_w + c4);
@@ -809,19 +761,6 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
 #define FFW_LNB *reinterpret_cast<const float4 *>(lnp + C + 4 * q)
 #define FFW_LN2W *reinterpret_cast<const float4 *>(lnp + 2 * C + 4 * q)
 #define FFW_LN2B *reinterpret_cast<const float4 *>(lnp + 3 * C + 4 * q)
-#else
-    const float4 lnw_r = *reinterpret_cast<const float4 *>(a.ln_w + 4 * q), lnb_r = *reinterpret_cast<const float4 *>(a.ln_b + 4 * q);
-    float4 ln2w_r = make_float4(0.f, 0.f, 0.f, 0.f), ln2b_r = ln2w_r;
-    if (NORM2) {
-        ln2w_r = *reinterpret_cast<const float4 *>(a.ln2_w + 4 * q);
-        ln2b_r = *reinterpret_cast<const float4 *>(a.ln2_b + 4 * q);
-    }
-    (void)lnp;
-#define FFW_LNW lnw_r
-#define FFW_LNB lnb_r
-#define FFW_LN2W ln2w_r
-#define FFW_LN2B ln2b_r
-#endif
 
     // Software pipeline over the tiles, two barrier intervals per tile, each holding one MFMA phase and one row-wise
     // (VALU / memory) phase of a DIFFERENT tile so that the matrix pipe and the vector ALU overlap:
@@ -842,7 +781,6 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     FFW_GEMM1()
     WSTAMP(0)
     __syncthreads();
-#if FFW_MANUAL
     // The two intervals are written as CHUNKS fenced by sched_barrier(0): a chunk = the three products of one k-step (one
     // hi hi, one hi lo, one lo hi MFMA: independent accumulators) + the LDS reads of the next step + one PIECE of the
     // row-wise work of the other tile.  Left to itself the scheduler either serialises the two phases (every MFMA, then
@@ -984,88 +922,6 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         if (!has_next) break;
         tile = tile_next;
     }
-#else
-    for (;;) {
-        const int tile_next = tile + gridDim.x;
-        const bool has_next = tile_next < tiles;
-        const int t1 = has_next ? tile_next : tile;  // the tile whose A / GEMM1 run in this iteration
-        WSTAMP(1)
-        // ---- I2: GEMM2(t): this wave's 16 output channels over all k-slices | A(t1) ------------------------------
-        float4 xn;
-        {
-            f32x4 m = f32x4{bias2.x, bias2.y, bias2.z, bias2.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
-#pragma unroll
-            for (int ks = 0; ks < NW; ++ks) {
-                const h16x8 uh = ufrag[(ks * 2) * 64 + lane], ulo = ufrag[(ks * 2 + 1) * 64 + lane];
-                MFMA_H(m, W2h[ks], uh);
-                MFMA_H(l, W2h[ks], ulo);
-                MFMA_H(k, W2l[ks], uh);
-            }
-            FFW_COMBINE(xn)
-            {
-                const int t2 = min(t1 + (int)gridDim.x, tiles - 1);
-                FFW_ISSUE(t2, trn, twn, ownn)
-                FFW_TAB(min(t2 + (int)gridDim.x, tiles - 1), trn, twn, ownn)
-            }
-            FFW_NORM_TO_BFRAG(xn)
-            {
-                const f32x2 y01 = pk_fma(pk2(l[0], l[1]) + pk2(k[0], k[1]), pk1(FFW_INV), pk2(m[0], m[1])),
-                            y23 = pk_fma(pk2(l[2], l[3]) + pk2(k[2], k[3]), pk1(FFW_INV), pk2(m[2], m[3]));
-                *reinterpret_cast<float4 *>(ytile + la * PS + 16 * wv + 4 * g) = make_float4(y01[0], y01[1], y23[0], y23[1]);
-            }
-        }
-#if FFW_SGB
-        // instruction order of the interval: one MFMA, (one LDS read,) a few vector instructions, (one row gather) -- 24 times
-        FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0)
-        FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 1)
-        FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 1) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0)
-        FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0)
-#endif
-        WSTAMP(2)
-        __syncthreads();
-#if FFW_SGB > 1
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        WSTAMP(3)
-        // ---- I1: D(t): y = x + (W2 u + b2), the next block's LayerNorm, whole rows out | GEMM1(t1) ------------------
-        {
-            const size_t row = (size_t)min(tile * 16 + r, n - 1);
-            const float4 yt = *reinterpret_cast<const float4 *>(ytile + r * PS + 4 * q);
-            const f32x2 y01 = pk2(yt.x, yt.y) + pk2(xc.x, xc.y), y23 = pk2(yt.z, yt.w) + pk2(xc.z, xc.w);
-            *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = make_float4(y01[0], y01[1], y23[0], y23[1]);
-            if (NORM2) {
-                const float mean = ffw_row_sum<LPR>((y01[0] + y01[1]) + (y23[0] + y23[1])) * (1.0f / C);
-                const f32x2 d01 = y01 - pk1(mean), d23 = y23 - pk1(mean);
-                const float var = ffw_row_sum<LPR>(
-                    __builtin_fmaf(d23[1], d23[1], __builtin_fmaf(d23[0], d23[0], __builtin_fmaf(d01[1], d01[1], d01[0] * d01[0]))));
-                const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
-                const float4 ln2w = FFW_LN2W, ln2b = FFW_LN2B;
-                const f32x2 n01 = d01 * pk1(rstd) * pk2(ln2w.x, ln2w.y) + pk2(ln2b.x, ln2b.y),
-                            n23 = d23 * pk1(rstd) * pk2(ln2w.z, ln2w.w) + pk2(ln2b.z, ln2b.w);
-                *reinterpret_cast<float4 *>(a.y_norm + row * C + 4 * q) = make_float4(n01[0], n01[1], n23[0], n23[1]);
-            }
-            FFW_GEMM1()
-        }
-#if FFW_SGB
-FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0)
-        FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0)
-        FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0)
-        FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0) FFW_SGB_STEP(0, 0, 0)
-#endif
-        WSTAMP(4)
-        __syncthreads();
-#if FFW_SGB > 1
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        WSTAMP(5)
-#ifdef MSSVT_STAMPS
-        ++ws_tiles;
-#endif
-        xc = xn;
-        if (!has_next) break;
-        tile = tile_next;
-    }
-#endif
     WSTAMP(6)
 #undef FFW_COMBINE
 #undef FFW_NORM_TO_BFRAG
@@ -1084,304 +940,8 @@ FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0, 1, 0) FFW_SGB_STEP(0
 }
 
 
-// =====================================================================================================
-// k_ffn_wsp: the same tail with PRODUCER and CONSUMER waves (round 4)
-// =====================================================================================================
-// In k_ffn_ws all waves of the workgroup run the same phase at the same time: the two waves of a SIMD want the matrix
-// pipe together (GEMM phases) and the vector issue port together (row-wise phases), and a 16-row tile costs ~3 500
-// clocks against 1 536 clocks of matrix-pipe work per SIMD (stamps: tools/stamps_ffn_ws.py).  Here the weights are
-// split by ROLE instead of by slice of both products:
-//   A waves (FF / 64 of them): rows in (residual input from x_in + 3 attention rows, LayerNorm, split -> B fragments of
-//            GEMM1 + the fp32 x tile in LDS), GEMM1 with ALL of W1 (64 hidden units per wave, 128 VGPRs), ReLU, split
-//            -> k-slices of u in LDS;
-//   B waves (C / 32 of them):  GEMM2 with ALL of W2 (32 output channels per wave, 128 VGPRs) -> y tile in LDS, then the
-//            row-wise epilogue (y + x, stores, the next block's LayerNorm).
-// A SIMD hosts one wave of each kind, and the schedule makes their phases complementary -- per tile two barrier
-// intervals:
-//        interval alpha(i):   A: GEMM1(i) + split of u          (matrix pipe)   |   B: epilogue of tile i - 1      (vector)
-//        interval beta(i):    A: rows of tile i + 1 in          (vector, loads) |   B: GEMM2(i)                    (matrix pipe)
-// Same arithmetic, same operand order per output element as k_ffn_ws (the split products accumulate hi hi | hi lo | lo hi
-// over the same k order): results are bit-identical to it.  LDS reads per tile halve (each fragment set is read by 4
-// waves instead of 8).
-template <int C, int FF, bool TABBED, bool NORM2>
-__global__ void __launch_bounds__((FF / 64 + C / 32) * MSSVT_WAVE, 1) k_ffn_wsp(FfnArgs a, const h16x8 *packed) {
-    constexpr int NW = FF / 32, NP = C / 32, LPR = C / 4, PS = C + 4, NA = FF / 64, NB = C / 32;
-    constexpr int RPW = MSSVT_WAVE / LPR;  // rows per wave and pass of the row-wise phases
-    static_assert(FF == 2 * C && NA == NB && NA * RPW == 8 && (LPR == 8 || LPR == 16 || LPR == 32),
-                  "two passes of 8 rows per group and tile");
-    extern __shared__ float4 lds4[];
-    h16x8 *bfrag = reinterpret_cast<h16x8 *>(lds4);                  // [NP][hi | lo][64 slots]  B operands of GEMM1
-    h16x8 *ufrag = bfrag + NP * 2 * 64;                              // [NW][hi | lo][64 lanes]  B operands of GEMM2
-    float *ytile = reinterpret_cast<float *>(ufrag + NW * 2 * 64);   // [16 rows][PS]            W2 u + b2
-    float *xbuf = ytile + 16 * PS;                                   // [2][16 rows][C]          residual input x of tile i, i + 1
-    float *lnp = xbuf + 2 * 16 * C;                                  // [norm2 w | norm2 b | next norm w | next norm b | b1 (FF)]
-    const int lane = lane_id(), la = lane & 15, g = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / MSSVT_WAVE);
-    const bool isA = wv < NA;
-    const int gw = isA ? wv : wv - NA;                               // index inside the group
-    const int rsub = gw * RPW + lane / LPR, q = lane % LPR;          // row-wise view: row 8 pass + rsub, channels [4 q, 4 q + 4)
-    const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
-    const int tiles = (n + 15) >> 4, G = gridDim.x;
-    if (n <= 0 || (int)blockIdx.x >= tiles) return;
-    const int nt = (tiles - (int)blockIdx.x + G - 1) / G;            // tiles of this workgroup
-    // LayerNorm parameters and b1 live in LDS (registers hold 128 weight VGPRs per wave)
-    for (int c4 = threadIdx.x * 4; c4 < C; c4 += blockDim.x * 4) {
-        *reinterpret_cast<float4 *>(lnp + c4) = *reinterpret_cast<const float4 *>(a.ln_w + c4);
-        *reinterpret_cast<float4 *>(lnp + C + c4) = *reinterpret_cast<const float4 *>(a.ln_b + c4);
-        if (NORM2) {
-            *reinterpret_cast<float4 *>(lnp + 2 * C + c4) = *reinterpret_cast<const float4 *>(a.ln2_w + c4);
-            *reinterpret_cast<float4 *>(lnp + 3 * C + c4) = *reinterpret_cast<const float4 *>(a.ln2_b + c4);
-        }
-    }
-    for (int c4 = threadIdx.x * 4; c4 < FF; c4 += blockDim.x * 4)
-        *reinterpret_cast<float4 *>(lnp + 4 * C + c4) = *reinterpret_cast<const float4 *>(a.b1 + c4);
-    // tile k of this workgroup (clamped past the end: redundant work on the last tile instead of branches)
-#define FWP_TILE(k_) min((int)blockIdx.x + (k_) * G, tiles - 1)
-
-    if (isA) {
-        // ================================ A: rows in, GEMM1 ================================
-        // W1 rows 64 gw + 16 T + la (T = 0 .. 3), k slot (g, j) <-> channel 32 P + 8 g + j: fragments of k_ffn_pack's waves
-        // 2 gw and 2 gw + 1
-        h16x8 W1h[4][NP], W1l[4][NP];
-        if (packed) {
-#pragma unroll
-            for (int T = 0; T < 4; ++T) {
-                const h16x8 *src = packed + (size_t)(2 * gw + T / 2) * (4 * NP + 2 * NW) * 64 + lane;
-#pragma unroll
-                for (int P = 0; P < NP; ++P) {
-                    W1h[T][P] = src[(((T & 1) * NP + P) * 2) * 64];
-                    W1l[T][P] = src[(((T & 1) * NP + P) * 2 + 1) * 64];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int T = 0; T < 4; ++T)
-#pragma unroll
-                for (int P = 0; P < NP; ++P) {
-                    const float *src = a.W1 + (size_t)(64 * gw + 16 * T + la) * C + 32 * P + 8 * g;
-                    ffw_split8(src, src + 4, W1h[T][P], W1l[T][P]);
-                }
-        }
-        // row gathers of the two passes of a tile, one tile ahead; table entries two tiles ahead
-        float4 rx[2], r1[2], r2[2], r3[2];
-        float w1[2] = {0.f, 0.f}, w2[2] = {0.f, 0.f}, w3[2] = {0.f, 0.f}, wx[2] = {1.f, 1.f};
-        int4 tr[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
-        float4 tw[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-        int own[2] = {0, 0};
-#define FWP_TAB(tile_)                                                                                      \
-    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                     \
-        const int row_ = min((tile_) * 16 + 8 * p_ + rsub, n - 1);                                          \
-        if (TABBED) { tr[p_] = a.tab_row[row_]; tw[p_] = a.tab_w[row_]; }                                   \
-        else if (a.owner) own[p_] = a.owner[row_];                                                          \
-    }
-        // (selection with masks, not ?: -- see k_ffn_ws: a group of selects on one condition becomes a branch)
-#define FWP_ISSUE(tile_)                                                                                    \
-    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                     \
-        const int row_ = min((tile_) * 16 + 8 * p_ + rsub, n - 1);                                          \
-        if (TABBED) {                                                                                       \
-            const int m_ = ~(tr[p_].x >> 31); /* owned: ~0, unowned (2 x_in): 0 */                          \
-            const long long dm_ = ((const char *)a.x_in - (const char *)a.attn) & (long long)~m_;           \
-            const char *b_ = (const char *)a.attn + dm_ + 16 * q;                                           \
-            const int un_row_ = row_ & ~m_;                                                                 \
-            rx[p_] = *reinterpret_cast<const float4 *>(a.x_in + (size_t)row_ * C + 4 * q);                  \
-            r1[p_] = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr[p_].x & m_) | un_row_) * (C * 4)); \
-            r2[p_] = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr[p_].y & m_) | un_row_) * (C * 4)); \
-            r3[p_] = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr[p_].z & m_) | un_row_) * (C * 4)); \
-            w1[p_] = __builtin_bit_cast(float, __builtin_bit_cast(int, tw[p_].x) & m_);                     \
-            w2[p_] = __builtin_bit_cast(float, __builtin_bit_cast(int, tw[p_].y) & m_);                     \
-            w3[p_] = __builtin_bit_cast(float, __builtin_bit_cast(int, tw[p_].z) & m_);                     \
-            wx[p_] = __builtin_bit_cast(float, 0x3F800000 + (~m_ & 0x00800000));                            \
-        } else {                                                                                            \
-            const bool dbl_ = a.owner != nullptr && own[p_] < 0;                                            \
-            rx[p_] = *reinterpret_cast<const float4 *>((dbl_ ? a.x_in : a.x_new) + (size_t)row_ * C + 4 * q); \
-            wx[p_] = dbl_ ? 2.0f : 1.0f;                                                                    \
-        }                                                                                                   \
-    }
-        // rows of a tile: residual input x -> xbuf (fp32, for the epilogue), LayerNorm (norm2), split -> bfrag
-#define FWP_ROWS_IN(slot_)                                                                                  \
-    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                     \
-        float4 x_;                                                                                          \
-        if (TABBED) {                                                                                       \
-            const f32x2 a_ = ((pk2(r1[p_].x, r1[p_].y) * pk1(w1[p_]) + pk2(r2[p_].x, r2[p_].y) * pk1(w2[p_])) + pk2(r3[p_].x, r3[p_].y) * pk1(w3[p_])) + pk2(rx[p_].x, rx[p_].y) * pk1(wx[p_]); \
-            const f32x2 b_ = ((pk2(r1[p_].z, r1[p_].w) * pk1(w1[p_]) + pk2(r2[p_].z, r2[p_].w) * pk1(w2[p_])) + pk2(r3[p_].z, r3[p_].w) * pk1(w3[p_])) + pk2(rx[p_].z, rx[p_].w) * pk1(wx[p_]); \
-            x_ = make_float4(a_[0], a_[1], b_[0], b_[1]);                                                   \
-        } else {                                                                                            \
-            const f32x2 a_ = pk2(rx[p_].x, rx[p_].y) * pk1(wx[p_]), b_ = pk2(rx[p_].z, rx[p_].w) * pk1(wx[p_]); \
-            x_ = make_float4(a_[0], a_[1], b_[0], b_[1]);                                                   \
-        }                                                                                                   \
-        const int r_ = 8 * p_ + rsub;                                                                       \
-        *reinterpret_cast<float4 *>(xbuf + ((slot_) * 16 + r_) * C + 4 * q) = x_;                           \
-        const float mean_ = ffw_row_sum<LPR>((x_.x + x_.y) + (x_.z + x_.w)) * (1.0f / C);                   \
-        const f32x2 d01_ = pk2(x_.x, x_.y) - pk1(mean_), d23_ = pk2(x_.z, x_.w) - pk1(mean_);               \
-        const float var_ = ffw_row_sum<LPR>(                                                                \
-            __builtin_fmaf(d23_[1], d23_[1], __builtin_fmaf(d23_[0], d23_[0], __builtin_fmaf(d01_[1], d01_[1], d01_[0] * d01_[0])))); \
-        const float rstd_ = rsqrtf(var_ * (1.0f / C) + a.eps);                                              \
-        const float4 lnw_ = *reinterpret_cast<const float4 *>(lnp + 4 * q), lnb_ = *reinterpret_cast<const float4 *>(lnp + C + 4 * q); \
-        h16x4 hi_, lo_;                                                                                     \
-        ffw_split4(d01_ * pk1(rstd_) * pk2(lnw_.x, lnw_.y) + pk2(lnb_.x, lnb_.y),                           \
-                   d23_ * pk1(rstd_) * pk2(lnw_.z, lnw_.w) + pk2(lnb_.z, lnb_.w), hi_, lo_);                 \
-        const int P_ = q >> 3, gq_ = (q >> 1) & 3, j0_ = (q & 1) * 4;                                       \
-        h16x4 *dst_ = reinterpret_cast<h16x4 *>(bfrag + (P_ * 2) * 64 + 16 * gq_ + ((r_ + 4 * gq_ + P_) & 15)) + (j0_ >> 2); \
-        dst_[0] = hi_;                                                                                      \
-        dst_[64 * 2] = lo_;                                                                                 \
-    }
-        FWP_TAB(FWP_TILE(0))
-        FWP_ISSUE(FWP_TILE(0))
-        FWP_TAB(FWP_TILE(1))
-        __syncthreads();  // [0] LayerNorm parameters / b1 are in LDS
-        FWP_ROWS_IN(0)
-        FWP_ISSUE(FWP_TILE(1))
-        FWP_TAB(FWP_TILE(2))
-        __syncthreads();  // [1] bfrag(0), xbuf[0] complete
-        for (int i = 0; i < nt; ++i) {
-            // ---- alpha(i): u^T = relu(W1 xn + b1) for this wave's 64 hidden units -> two k-slices of GEMM2's B operand
-            {
-                h16x8 bh[NP], bl[NP];
-#pragma unroll
-                for (int P = 0; P < NP; ++P) {
-                    const int slot = 16 * g + ((la + 4 * g + P) & 15);
-                    bh[P] = bfrag[(P * 2) * 64 + slot];
-                    bl[P] = bfrag[(P * 2 + 1) * 64 + slot];
-                }
-                h16x4 uh[4], ulo[4];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    f32x4 um[2], ul[2], uk[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const float4 b1v = *reinterpret_cast<const float4 *>(lnp + 4 * C + 64 * gw + 16 * (2 * half + t) + 4 * g);
-                        um[t] = f32x4{b1v.x, b1v.y, b1v.z, b1v.w};
-                        ul[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        uk[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    // (P outer, the two hidden tiles inner: the order of k_ffn_ws -- bit-identical sums)
-#pragma unroll
-                    for (int P = 0; P < NP; ++P) {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) MFMA_H(um[t], W1h[2 * half + t][P], bh[P]);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) MFMA_H(ul[t], W1h[2 * half + t][P], bl[P]);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) MFMA_H(uk[t], W1l[2 * half + t][P], bh[P]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const f32x2 u01 = ffw_relu2(pk_fma(pk2(ul[t][0], ul[t][1]) + pk2(uk[t][0], uk[t][1]), pk1(FFW_INV), pk2(um[t][0], um[t][1]))),
-                                    u23 = ffw_relu2(pk_fma(pk2(ul[t][2], ul[t][3]) + pk2(uk[t][2], uk[t][3]), pk1(FFW_INV), pk2(um[t][2], um[t][3])));
-                        ffw_split4(u01, u23, uh[2 * half + t], ulo[2 * half + t]);
-                    }
-                    // k-slice 2 gw + half = hidden [64 gw + 32 half, + 32): k slot (g, j) <-> hidden 16 (j / 4) + 4 g + j % 4
-                    ufrag[((2 * gw + half) * 2) * 64 + lane] = ffw_cat(uh[2 * half], uh[2 * half + 1]);
-                    ufrag[((2 * gw + half) * 2 + 1) * 64 + lane] = ffw_cat(ulo[2 * half], ulo[2 * half + 1]);
-                }
-            }
-            __syncthreads();
-            // ---- beta(i): rows of tile i + 1 in (their gathers left one interval ago), gathers of tile i + 2 out
-            FWP_ROWS_IN((i + 1) & 1)
-            FWP_ISSUE(FWP_TILE(i + 2))
-            FWP_TAB(FWP_TILE(i + 3))
-            __syncthreads();
-        }
-#undef FWP_TAB
-#undef FWP_ISSUE
-#undef FWP_ROWS_IN
-    } else {
-        // ================================ B: GEMM2, epilogue ================================
-        // W2 rows 32 gw + 16 U + la (U = 0, 1), k slice ks: fragments of k_ffn_pack's waves 2 gw + U
-        h16x8 W2h[2][NW], W2l[2][NW];
-        if (packed) {
-#pragma unroll
-            for (int U = 0; U < 2; ++U) {
-                const h16x8 *src = packed + (size_t)(2 * gw + U) * (4 * NP + 2 * NW) * 64 + lane;
-#pragma unroll
-                for (int ks = 0; ks < NW; ++ks) {
-                    W2h[U][ks] = src[(4 * NP + 2 * ks) * 64];
-                    W2l[U][ks] = src[(4 * NP + 2 * ks + 1) * 64];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int U = 0; U < 2; ++U)
-#pragma unroll
-                for (int ks = 0; ks < NW; ++ks) {
-                    const float *src = a.W2 + (size_t)(32 * gw + 16 * U + la) * FF + 32 * ks + 4 * g;
-                    ffw_split8(src, src + 16, W2h[U][ks], W2l[U][ks]);
-                }
-        }
-        float4 bias2[2];
-#pragma unroll
-        for (int U = 0; U < 2; ++U) bias2[U] = *reinterpret_cast<const float4 *>(a.b2 + 32 * gw + 16 * U + 4 * g);
-        // epilogue of a tile: y = x + (W2 u + b2), the next block's LayerNorm, whole rows out
-#define FWP_EPILOGUE(tile_, slot_)                                                                          \
-    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                     \
-        const int r_ = 8 * p_ + rsub;                                                                       \
-        const size_t row_ = (size_t)min((tile_) * 16 + r_, n - 1);                                          \
-        const float4 yt_ = *reinterpret_cast<const float4 *>(ytile + r_ * PS + 4 * q);                      \
-        const float4 xv_ = *reinterpret_cast<const float4 *>(xbuf + ((slot_) * 16 + r_) * C + 4 * q);      \
-        const f32x2 y01_ = pk2(yt_.x, yt_.y) + pk2(xv_.x, xv_.y), y23_ = pk2(yt_.z, yt_.w) + pk2(xv_.z, xv_.w); \
-        *reinterpret_cast<float4 *>(a.y + row_ * C + 4 * q) = make_float4(y01_[0], y01_[1], y23_[0], y23_[1]); \
-        if (NORM2) {                                                                                        \
-            const float mean_ = ffw_row_sum<LPR>((y01_[0] + y01_[1]) + (y23_[0] + y23_[1])) * (1.0f / C);   \
-            const f32x2 d01_ = y01_ - pk1(mean_), d23_ = y23_ - pk1(mean_);                                 \
-            const float var_ = ffw_row_sum<LPR>(                                                            \
-                __builtin_fmaf(d23_[1], d23_[1], __builtin_fmaf(d23_[0], d23_[0], __builtin_fmaf(d01_[1], d01_[1], d01_[0] * d01_[0])))); \
-            const float rstd_ = rsqrtf(var_ * (1.0f / C) + a.eps2);                                         \
-            const float4 w_ = *reinterpret_cast<const float4 *>(lnp + 2 * C + 4 * q), b_ = *reinterpret_cast<const float4 *>(lnp + 3 * C + 4 * q); \
-            const f32x2 n01_ = d01_ * pk1(rstd_) * pk2(w_.x, w_.y) + pk2(b_.x, b_.y),                       \
-                        n23_ = d23_ * pk1(rstd_) * pk2(w_.z, w_.w) + pk2(b_.z, b_.w);                       \
-            *reinterpret_cast<float4 *>(a.y_norm + row_ * C + 4 * q) = make_float4(n01_[0], n01_[1], n23_[0], n23_[1]); \
-        }                                                                                                   \
-    }
-        __syncthreads();  // [0]
-        __syncthreads();  // [1]
-        for (int i = 0; i < nt; ++i) {
-            // ---- alpha(i): epilogue of tile i - 1 (its y tile was finished in beta(i - 1))
-            if (i > 0) FWP_EPILOGUE((int)blockIdx.x + (i - 1) * G, (i - 1) & 1)
-            __syncthreads();
-            // ---- beta(i): y^T = W2 u + b2 for this wave's 32 output channels over all k-slices
-            {
-                f32x4 m[2], l[2], k[2];
-#pragma unroll
-                for (int U = 0; U < 2; ++U) {
-                    m[U] = f32x4{bias2[U].x, bias2[U].y, bias2[U].z, bias2[U].w};
-                    l[U] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    k[U] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                h16x8 uh = ufrag[lane], ulo = ufrag[64 + lane];
-#pragma unroll
-                for (int ks = 0; ks < NW; ++ks) {
-                    h16x8 uhn = uh, ulon = ulo;
-                    if (ks + 1 < NW) {
-                        uhn = ufrag[((ks + 1) * 2) * 64 + lane];
-                        ulon = ufrag[((ks + 1) * 2 + 1) * 64 + lane];
-                    }
-#pragma unroll
-                    for (int U = 0; U < 2; ++U) MFMA_H(m[U], W2h[U][ks], uh);
-#pragma unroll
-                    for (int U = 0; U < 2; ++U) MFMA_H(l[U], W2h[U][ks], ulo);
-#pragma unroll
-                    for (int U = 0; U < 2; ++U) MFMA_H(k[U], W2l[U][ks], uh);
-                    uh = uhn;
-                    ulo = ulon;
-                    __builtin_amdgcn_sched_barrier(0);  // (keeps the LDS reads of later steps where they are: registers)
-                }
-#pragma unroll
-                for (int U = 0; U < 2; ++U) {
-                    const f32x2 y01 = pk_fma(pk2(l[U][0], l[U][1]) + pk2(k[U][0], k[U][1]), pk1(FFW_INV), pk2(m[U][0], m[U][1])),
-                                y23 = pk_fma(pk2(l[U][2], l[U][3]) + pk2(k[U][2], k[U][3]), pk1(FFW_INV), pk2(m[U][2], m[U][3]));
-                    *reinterpret_cast<float4 *>(ytile + la * PS + 32 * gw + 16 * U + 4 * g) = make_float4(y01[0], y01[1], y23[0], y23[1]);
-                }
-            }
-            __syncthreads();
-        }
-        FWP_EPILOGUE((int)blockIdx.x + (nt - 1) * G, (nt - 1) & 1)
-#undef FWP_EPILOGUE
-    }
-#undef FWP_TILE
-}
-
 template <int C, int FF>
-static int launch_ffn_ws(const FfnArgs &a, const void *packed, hipStream_t stream, int form = 0) {
+static int launch_ffn_ws(const FfnArgs &a, const void *packed, hipStream_t stream) {
     constexpr int NW = FF / 32;
     const size_t lds = (size_t)(C / 32 + NW) * 2 * 64 * 16 + (size_t)16 * (C + 4) * 4 + (size_t)4 * C * 4;
     int dev = 0, cus = 256;
@@ -1394,20 +954,6 @@ static int launch_ffn_ws(const FfnArgs &a, const void *packed, hipStream_t strea
     if (grid < 1) return MSSVT_OK;
     const h16x8 *pk = reinterpret_cast<const h16x8 *>(packed);
     const dim3 block(NW * MSSVT_WAVE);
-    // producer / consumer waves (k_ffn_wsp) unless MSSVT_FFN_PC=0
-    static const int pc = getenv("MSSVT_FFN_PC") ? atoi(getenv("MSSVT_FFN_PC")) : 1;
-    if (form == 2 || (form == 0 && pc)) {
-        const size_t lds_pc = (size_t)(C / 32 + NW) * 2 * 64 * 16 + (size_t)16 * (C + 4) * 4 + (size_t)2 * 16 * C * 4 +
-                              (size_t)(4 * C + FF) * 4;
-        if (a.tab_row) {
-            if (a.y_norm) k_ffn_wsp<C, FF, true, true><<<grid, block, lds_pc, stream>>>(a, pk);
-            else k_ffn_wsp<C, FF, true, false><<<grid, block, lds_pc, stream>>>(a, pk);
-        } else {
-            if (a.y_norm) k_ffn_wsp<C, FF, false, true><<<grid, block, lds_pc, stream>>>(a, pk);
-            else k_ffn_wsp<C, FF, false, false><<<grid, block, lds_pc, stream>>>(a, pk);
-        }
-        return mssvt_launch_status();
-    }
     if (a.tab_row) {
         if (a.y_norm) k_ffn_ws<C, FF, true, true><<<grid, block, lds, stream>>>(a, pk);
         else k_ffn_ws<C, FF, true, false><<<grid, block, lds, stream>>>(a, pk);
@@ -1467,12 +1013,11 @@ static int launch_ffn_split(const FfnArgs &a, float *hidden, int phases, hipStre
 }
 
 static int dispatch_ffn(int C, int FF, const FfnArgs &a, float *hidden, int phases, hipStream_t st) {
-    if (phases >= 4 && phases <= 6) {  // single launch, split fp16 operands (the caller has checked their range); hidden =
-                                       // the fragments of mssvt_ffn_pack_weights, or NULL: split in the kernel's prologue
-        const int form = phases - 4;   // 0: default, 1: k_ffn_ws (all waves in step), 2: k_ffn_wsp (producer / consumer waves)
-        if (C == 128 && FF == 256) return launch_ffn_ws<128, 256>(a, hidden, st, form);
-        if (C == 64 && FF == 128) return launch_ffn_ws<64, 128>(a, hidden, st, form);
-        if (C == 32 && FF == 64) return launch_ffn_ws<32, 64>(a, hidden, st, form);
+    if (phases == 4) {  // single launch, split fp16 operands (the caller has checked their range); hidden = the
+                        // fragments of mssvt_ffn_pack_weights, or NULL: split in the kernel's prologue
+        if (C == 128 && FF == 256) return launch_ffn_ws<128, 256>(a, hidden, st);
+        if (C == 64 && FF == 128) return launch_ffn_ws<64, 128>(a, hidden, st);
+        if (C == 32 && FF == 64) return launch_ffn_ws<32, 64>(a, hidden, st);
         return MSSVT_E_TOOLARGE;
     }
     if (hidden) {

@@ -97,7 +97,7 @@ struct Bump {
     }
 };
 
-// a[0..n_a) = -1, b[0..n_b) = -1, c[0..n_c) = 0, d[0..n_d) = 0 (counts in ints, multiples of 4, 16-byte aligned)
+// a[0..n_a) = -1, b[0..n_b) = -1, c[0..n_c) = 0, d[0..n_d) = 0 (counts in ints; 16-byte aligned bases)
 __global__ void __launch_bounds__(256) k_frame_fill(int *a, long long n_a, int *b, long long n_b, int *c, long long n_c, int *d,
                                                    long long n_d) {
     const long long qa = n_a >> 2, qb = n_b >> 2, qc = n_c >> 2, qd = n_d >> 2, stride = (long long)gridDim.x * blockDim.x;
@@ -107,6 +107,12 @@ __global__ void __launch_bounds__(256) k_frame_fill(int *a, long long n_a, int *
         else if (i < qa + qb) reinterpret_cast<int4 *>(b)[i - qa] = neg;
         else if (i < qa + qb + qc) reinterpret_cast<int4 *>(c)[i - qa - qb] = zero;
         else reinterpret_cast<int4 *>(d)[i - qa - qb - qc] = zero;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16) {  // the (at most 3) ints behind the last full quad of each region
+        const int reg = threadIdx.x >> 2, t = threadIdx.x & 3;
+        int *base = reg == 0 ? a : reg == 1 ? b : reg == 2 ? c : d;
+        const long long nn = reg == 0 ? n_a : reg == 1 ? n_b : reg == 2 ? n_c : n_d, done = (nn >> 2) << 2;
+        if (done + t < nn) base[done + t] = reg < 2 ? -1 : 0;
     }
 }
 
@@ -454,7 +460,6 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
     // ---- one fill: -1 arena, the output level's hash table, zero region, the attention buffers' zero row
     {
         const long long n_tab = (long long)B * H * 2, n_zr = (C + 3) / 4 * 4;
-        if ((n_tab & 3) != 0) return MSSVT_E_BADARG;
         const long long quads = ((long long)L.neg_ints + n_tab + (long long)L.zero_ints + n_zr) >> 2;
         int grid = (int)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
         k_frame_fill<<<grid < 1 ? 1 : grid, 256, 0, stream>>>(L.neg0, (long long)L.neg_ints, out_table, n_tab, L.zero0,

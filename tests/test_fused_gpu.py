@@ -129,8 +129,7 @@ def test_ffn_single_launch_split_fp16_matches_float64(C, FF, n, packed):
         want_n = torch.nn.functional.layer_norm(want, (C,), d(ln2.weight), d(ln2.bias), ln2.eps)
     i, f = ctypes.c_int, ctypes.c_float
     res = {}
-    outs = {}
-    for phases in (3, 4, 5, 6):  # 3: fp32 instruction; 4: default; 5: k_ffn_ws (all waves in step); 6: k_ffn_wsp (producer / consumer)
+    for phases in (3, 4):
         y, yn = torch.empty_like(x_new), torch.empty_like(x_new)
         if phases == 3:
             ws = torch.empty((n, FF), device=DEV)
@@ -145,10 +144,6 @@ def test_ffn_single_launch_split_fp16_matches_float64(C, FF, n, packed):
                   _lib.ptr(l2.weight), _lib.ptr(l2.bias), _lib.ptr(y), _lib.ptr(ln2.weight), _lib.ptr(ln2.bias),
                   f(ln2.eps), _lib.ptr(yn), _lib.ptr(ws), None, i(phases), _lib.stream())
         res[phases] = (float((y.double() - want).abs().max()), float((yn.double() - want_n).abs().max()))
-        outs[phases] = (y, yn)
-    # the two single-launch forms compute every output element with the same operations in the same order
-    assert torch.equal(outs[5][0], outs[6][0]) and torch.equal(outs[5][1], outs[6][1])
-    assert torch.equal(outs[4][0], outs[6][0]) or torch.equal(outs[4][0], outs[5][0])
     scale = max(1.0, float(want.abs().max()))
     print("max err vs float64: fp32 MFMA %.2e / %.2e, split fp16 %.2e / %.2e (scale %.1f)" % (res[3] + res[4] + (scale,)))
     assert res[4][0] <= 4e-6 * scale and res[4][1] <= 2e-5
@@ -157,9 +152,9 @@ def test_ffn_single_launch_split_fp16_matches_float64(C, FF, n, packed):
 
 @pytest.mark.parametrize("C,FF,n,norm2", [(128, 256, 74270, True), (128, 256, 4097, False), (64, 128, 1000, True), (32, 64, 129, True),
                                          (128, 256, 5, True)])
-def test_ffn_table_fed_forms_are_bit_identical(C, FF, n, norm2):
-    """mssvt_ffn_fused_interp (x = x_in + 3 weighted attention rows, or 2 x_in for unowned voxels): k_ffn_wsp (phases 6,
-    producer / consumer waves) against k_ffn_ws (phases 5) -- bit-identical -- and against a float64 restatement."""
+def test_ffn_table_fed_matches_float64(C, FF, n, norm2):
+    """mssvt_ffn_fused_interp (x = x_in + 3 weighted attention rows, or 2 x_in for unowned voxels; the gather sources are
+    selected with bit masks in the kernel) against a float64 restatement, with and without the second LayerNorm."""
     import ctypes
     from mssvt_amd import _lib
     torch.manual_seed(3 * C + n)
@@ -176,14 +171,13 @@ def test_ffn_table_fed_forms_are_bit_identical(C, FF, n, norm2):
     ws = torch.empty((int(_lib.lib().mssvt_ffn_packed_bytes(i(C), i(FF))),), dtype=torch.uint8, device=DEV)
     _lib.call("mssvt_ffn_pack_weights", i(C), i(FF), _lib.ptr(l1.weight), _lib.ptr(l2.weight), _lib.ptr(ws), _lib.stream())
     outs = {}
-    for phases in (5, 6):
+    for phases in (4,):
         y, yn = torch.empty_like(x_in), torch.full_like(x_in, 7.0)
         _lib.call("mssvt_ffn_fused_interp", i(n), i(C), i(FF), _lib.ptr(x_in), _lib.ptr(tab_row), _lib.ptr(tab_w), _lib.ptr(attn),
                   _lib.ptr(ln.weight), _lib.ptr(ln.bias), f(ln.eps), _lib.ptr(l1.weight), _lib.ptr(l1.bias), _lib.ptr(l2.weight),
                   _lib.ptr(l2.bias), _lib.ptr(y), _lib.ptr(ln2.weight) if norm2 else None, _lib.ptr(ln2.bias) if norm2 else None,
                   f(ln2.eps), _lib.ptr(yn) if norm2 else None, _lib.ptr(ws), None, i(phases), _lib.stream())
         outs[phases] = (y, yn)
-    assert torch.equal(outs[5][0], outs[6][0]) and torch.equal(outs[5][1], outs[6][1])
     with torch.no_grad():
         d = lambda t: t.detach().double()  # noqa: E731
         own = (tab_row[:, 0] >= 0).unsqueeze(1)
@@ -193,10 +187,10 @@ def test_ffn_table_fed_forms_are_bit_identical(C, FF, n, norm2):
         h = torch.nn.functional.layer_norm(x, (C,), d(ln.weight), d(ln.bias), ln.eps)
         want = x + torch.relu(h @ d(l1.weight).t() + d(l1.bias)) @ d(l2.weight).t() + d(l2.bias)
     scale = max(1.0, float(want.abs().max()))
-    assert float((outs[6][0].double() - want).abs().max()) <= 6e-6 * scale
+    assert float((outs[4][0].double() - want).abs().max()) <= 6e-6 * scale
     if norm2:
         want_n = torch.nn.functional.layer_norm(want, (C,), d(ln2.weight), d(ln2.bias), ln2.eps)
-        assert float((outs[6][1].double() - want_n).abs().max()) <= 3e-5
+        assert float((outs[4][1].double() - want_n).abs().max()) <= 3e-5
 
 
 @pytest.mark.parametrize("pts,B", [(20000, 1), (160000, 2), (300000, 1), (50, 3)])
