@@ -21,8 +21,11 @@ from .mssvt_utils import SparseTensor
 
 ENABLED = os.environ.get("MSSVT_FRAME", "1") != "0"
 _WORDS = 192
-# the first norm1 and the CompressBlock's pillar plan on a second stream, under the Blocks' plan kernel
-OVERLAP = os.environ.get("MSSVT_FRAME_OVERLAP", "0") == "1"
+# the first norm1 and the CompressBlock's pillar plan on a second stream, under the Blocks' plan kernel: "auto" = from
+# OVERLAP_MIN_VOXELS up (measured with the frame call: one scene 1 432 -> 1 422 frames/s, batch 4 1 739 -> 1 782, batch 8
+# 1 828 -> 1 853: the plan kernel slows down when it shares the chip, large frames gain more than that costs)
+OVERLAP = os.environ.get("MSSVT_FRAME_OVERLAP", "auto")
+OVERLAP_MIN_VOXELS = 250000
 
 
 class _Stub(object):
@@ -159,7 +162,7 @@ def _build(net, dev, batch_size):
               P(ma.to_qs[0].weight), P(ma.to_qs[0].bias), P(ma.to_kvs[0].weight), P(ma.to_kvs[0].bias),
               P(ma.projs[0].weight), P(ma.projs[0].bias), int(ma.per_head_dim), float(ma.scale), split, P(ffr["lnw"]),
               P(ffr["lnb"]), float(ffr["eps"]), P(ffr["W1"]), P(ffr["b1"]), P(ffr["W2"]), P(ffr["b2"]), P(ffn_packed))
-    _lib.call("mssvt_frame_set_overlap", fr.handle, 1 if OVERLAP else 0)
+    fr.overlap = None
     return fr
 
 
@@ -222,6 +225,10 @@ def forward(net, feats, coords, batch_size):
         # persistent: the next frame reuses it (stream order keeps the frames apart); grown with 12 % of slack
         fr.workspace = ws = None
         ws = fr.workspace = torch.empty(need + need // 8, dtype=torch.uint8, device=dev)
+    overlap = OVERLAP == "1" or (OVERLAP == "auto" and n >= OVERLAP_MIN_VOXELS)
+    if fr.overlap != overlap:
+        _lib.call("mssvt_frame_set_overlap", fr.handle, 1 if overlap else 0)
+        fr.overlap = overlap
     out_f = torch.empty((n, C), dtype=torch.float32, device=dev)
     out_i = torch.empty((n, 4), dtype=torch.int32, device=dev)
     out_t = torch.empty((B, H, 2), dtype=torch.int32, device=dev)

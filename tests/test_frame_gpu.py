@@ -63,6 +63,23 @@ def test_frame_call_is_bit_identical_to_the_python_driven_path(points, B, monkey
         _same(got, want)
 
 
+def test_frame_call_with_the_side_stream_gives_the_same_frames(monkeypatch):
+    """MSSVT_FRAME_OVERLAP: first norm1 + pillar plan on the frame object's second stream (auto for large frames)."""
+    from mssvt_amd import frame
+    net = _net()
+    feats, vc = _scene(20000, 2, 21)
+    want, _ = _run(net, feats, vc, 2, False, monkeypatch)
+    monkeypatch.setattr(frame, "OVERLAP", "1")
+    for _ in range(3):
+        got, used = _run(net, feats, vc, 2, True, monkeypatch)
+        assert used
+        _same(got, want)
+    monkeypatch.setattr(frame, "OVERLAP", "0")
+    got, used = _run(net, feats, vc, 2, True, monkeypatch)
+    assert used
+    _same(got, want)
+
+
 def test_frame_call_bf16_attention_and_other_patterns(monkeypatch):
     net = _net().set_attn_dtype("bf16")
     feats, vc = _scene(20000, 2, 7)
