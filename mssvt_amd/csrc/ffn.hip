@@ -604,36 +604,22 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     const int tiles = (n + 15) >> 4;
     if (n <= 0 || (int)blockIdx.x >= tiles) return;
 
-    // The streams that walk the tile's own rows (x_in, the table, y, the next LayerNorm's output) go through BUFFER
-    // resources: scalar base + scalar tile offset + a per-lane constant -- no vector address arithmetic per tile (the
-    // kernel is bound by the number of vector instructions it issues: ~250 per wave and tile against 48 MFMAs); rows
-    // past the end read zeros and their stores are dropped by the bounds check.  The three attention rows of a voxel keep
-    // 64-bit addresses (rows of a buffer of unknown size; an unowned voxel re-reads its own x_in row there).  Nothing is
-    // predicated: no branches inside the barrier intervals (the scheduler interleaves MFMA and VALU only within a block).
-    typedef unsigned int u32x4 __attribute__((vector_size(16)));
-    constexpr unsigned ROWB = C * 4u;
-    const unsigned vo_row = (unsigned)r * ROWB + 16u * (unsigned)q, vo_tab = (unsigned)r * 16u;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(TABBED ? a.x_in : a.y), 0, (int)((unsigned)n * ROWB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int4 *>(TABBED ? a.tab_row : nullptr), 0, TABBED ? n * 16 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(TABBED ? a.tab_w : nullptr), 0, TABBED ? n * 16 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)n * ROWB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_yn = __builtin_amdgcn_make_buffer_rsrc(NORM2 ? a.y_norm : a.y, 0, (int)((unsigned)n * ROWB), 0x00020000);
+    // Rows past the end are CLAMPED to row n - 1 everywhere (table, gathers, stores): such lanes compute exactly what the
+    // lanes of row n - 1 compute and store the same values to the same place -- no predication, hence no branches
+    // inside the barrier intervals (the scheduler interleaves MFMA and VALU only within one basic block).
     int tile = blockIdx.x;
     int4 tr = make_int4(0, 0, 0, 0);
     float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
     int own = 0;
 #define FFW_TAB(tile_, tr_, tw_, own_)                                                                      \
     {                                                                                                       \
-        if (TABBED) {                                                                                       \
-            tr_ = __builtin_bit_cast(int4, __builtin_amdgcn_raw_buffer_load_b128(rs_tr, vo_tab, (tile_) * 256, 0)); \
-            tw_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_tw, vo_tab, (tile_) * 256, 0)); \
-        } else if (a.owner) {                                                                               \
-            own_ = a.owner[min((tile_) * 16 + r, n - 1)];                                                   \
-        }                                                                                                   \
+        const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
+        if (TABBED) { tr_ = a.tab_row[row_]; tw_ = a.tab_w[row_]; }                                         \
+        else if (a.owner) own_ = a.owner[row_];                                                             \
     }
     float4 rx, r1, r2, r3;
     float w1 = 0.f, w2 = 0.f, w3 = 0.f, wx = 1.f;
-#define FFW_SELECT(tile_, tr_, tw_, row_)                                                                         \
+#define FFW_SELECT(tr_, tw_, row_)                                                                          \
             /* unowned voxel (tr.x < 0): 2 x_in; it re-reads its own finite row with weight 0.  The selection is   \
                written with MASKS, not ?: -- the compiler turns a group of selects on one condition into a BRANCH,   \
                i.e. a basic-block boundary inside the barrier interval (MFMA and VALU interleave only within a      \
@@ -642,8 +628,9 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
             const int m_ = ~(tr_.x >> 31); /* owned: ~0, unowned: 0 */                                              \
             const long long dm_ = ((const char *)a.x_in - (const char *)a.attn) & (long long)~m_;                   \
             const char *b_ = (const char *)a.attn + dm_ + 16 * q;                                                   \
+            const float *px_ = a.x_in + (size_t)row_ * C + 4 * q;                                                   \
             const int un_row_ = row_ & ~m_;                                                                         \
-            rx = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo_row, (tile_) * (16 * (int)ROWB), 0)); \
+            rx = *reinterpret_cast<const float4 *>(px_);                                                            \
             r1 = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr_.x & m_) | un_row_) * (C * 4));               \
             r2 = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr_.y & m_) | un_row_) * (C * 4));               \
             r3 = *reinterpret_cast<const float4 *>(b_ + (size_t)((tr_.z & m_) | un_row_) * (C * 4));               \
@@ -655,7 +642,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     {                                                                                                       \
         const int row_ = min((tile_) * 16 + r, n - 1);                                                      \
         if (TABBED) {                                                                                       \
-            FFW_SELECT(tile_, tr_, tw_, row_)                                                                   \
+            FFW_SELECT(tr_, tw_, row_)                                                                      \
         } else {                                                                                            \
             const bool dbl_ = a.owner != nullptr && own_ < 0;                                               \
             rx = *reinterpret_cast<const float4 *>((dbl_ ? a.x_in : a.x_new) + (size_t)row_ * C + 4 * q);   \
@@ -681,7 +668,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         const f32x2 d01_ = pk2(x_.x, x_.y) - pk1(mean_), d23_ = pk2(x_.z, x_.w) - pk1(mean_);               \
         const float var_ = ffw_row_sum<LPR>(                                                                \
             __builtin_fmaf(d23_[1], d23_[1], __builtin_fmaf(d23_[0], d23_[0], __builtin_fmaf(d01_[1], d01_[1], d01_[0] * d01_[0])))); \
-        const float rstd_ = __builtin_amdgcn_rsqf(var_ * (1.0f / C) + a.eps);                                              \
+        const float rstd_ = rsqrtf(var_ * (1.0f / C) + a.eps);                                              \
         h16x4 hi_, lo_;                                                                                     \
         const float4 lnw = FFW_LNW, lnb = FFW_LNB;                                                          \
         ffw_split4(d01_ * pk1(rstd_) * pk2(lnw.x, lnw.y) + pk2(lnb.x, lnb.y),                               \
@@ -839,7 +826,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                         var_ = ffw_row_sum<LPR>(__builtin_fmaf(
                             d23_[1], d23_[1], __builtin_fmaf(d23_[0], d23_[0], __builtin_fmaf(d01_[1], d01_[1], d01_[0] * d01_[0]))));
                     } else if (pc == 4) {
-                        const float rstd_ = __builtin_amdgcn_rsqf(var_ * (1.0f / C) + a.eps);
+                        const float rstd_ = rsqrtf(var_ * (1.0f / C) + a.eps);
                         const float4 lnw = FFW_LNW, lnb = FFW_LNB;
                         n01_ = d01_ * pk1(rstd_) * pk2(lnw.x, lnw.y) + pk2(lnb.x, lnb.y);
                         n23_ = d23_ * pk1(rstd_) * pk2(lnw.z, lnw.w) + pk2(lnb.z, lnb.w);
@@ -868,6 +855,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         // ---- I1: D(t): y = x + (W2 u + b2), the next block's LayerNorm, whole rows out | GEMM1(t1) ------------------
         {
             constexpr int NS1 = 2 * NP, NPC1 = NORM2 ? 5 : 2;  // steps (T, P); pieces of D + the split of hidden tile 0
+            const size_t row = (size_t)min(tile * 16 + r, n - 1);
             f32x4 um_[2], ul_[2], uk_[2];
             h16x8 bh_[NP], bl_[NP];
 #pragma unroll
@@ -900,8 +888,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                     if (pc == 0) {
                         y01 = pk2(yt.x, yt.y) + pk2(xc.x, xc.y);
                         y23 = pk2(yt.z, yt.w) + pk2(xc.z, xc.w);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(y01[0], y01[1], y23[0], y23[1])), rs_y,
-                                                               vo_row, tile * (16 * (int)ROWB), 0);
+                        *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = make_float4(y01[0], y01[1], y23[0], y23[1]);
                     } else if (pc == 1 && NORM2) {
                         const float mean = ffw_row_sum<LPR>((y01[0] + y01[1]) + (y23[0] + y23[1])) * (1.0f / C);
                         d01 = y01 - pk1(mean);
@@ -910,12 +897,11 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                         var = ffw_row_sum<LPR>(
                             __builtin_fmaf(d23[1], d23[1], __builtin_fmaf(d23[0], d23[0], __builtin_fmaf(d01[1], d01[1], d01[0] * d01[0]))));
                     } else if (pc == 3 && NORM2) {
-                        const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / C) + a.eps2);
+                        const float rstd = rsqrtf(var * (1.0f / C) + a.eps2);
                         const float4 ln2w = FFW_LN2W, ln2b = FFW_LN2B;
                         const f32x2 n01 = d01 * pk1(rstd) * pk2(ln2w.x, ln2w.y) + pk2(ln2b.x, ln2b.y),
                                     n23 = d23 * pk1(rstd) * pk2(ln2w.z, ln2w.w) + pk2(ln2b.z, ln2b.w);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(n01[0], n01[1], n23[0], n23[1])), rs_yn,
-                                                               vo_row, tile * (16 * (int)ROWB), 0);
+                        *reinterpret_cast<float4 *>(a.y_norm + row * C + 4 * q) = make_float4(n01[0], n01[1], n23[0], n23[1]);
                     }
                 }
                 if (st == (NP + 1 < NS1 ? NP + 1 : NS1 - 1)) ffw_split4(FFW_U2(0, 0), FFW_U2(0, 2), h0_, l0_);
@@ -962,7 +948,6 @@ static int launch_ffn_ws(const FfnArgs &a, const void *packed, hipStream_t strea
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    if ((long long)a.n_rows * C * 4 >= (1LL << 31)) return MSSVT_E_TOOLARGE;  // buffer resources: 32-bit byte offsets
     const int tiles = (a.n_rows + 15) / 16;
     int grid = cus * (NW >= 8 ? 1 : 8 / NW);  // 8 waves per CU
     if (grid > tiles) grid = tiles;
