@@ -297,9 +297,23 @@ def main():
             with torch.no_grad():
                 return net(dict(voxel_features=feats_, voxel_coords=vc_, batch_size=args.batch))
     impl = net.backbone[0].impl
+    # which host path issued the timed frames: the whole-frame C call (mssvt_amd/frame.py) or the Python-driven path
+    from mssvt_amd import frame as _frame
+    host_calls = []
+    _real_frame_forward = _frame.forward
+
+    def _spy(*a, **k):
+        r = _real_frame_forward(*a, **k)
+        host_calls.append(r is not None)
+        return r
+    _frame.forward = _spy
 
     for _ in range(args.warmup):
         step()
+    if host_calls:
+        _frame.forward = _real_frame_forward  # (nothing extra inside the timed region; without warm-up steps the spy stays: ~1 us)
+    host_path = lambda: ("mssvt_frame_forward: one C call per frame, persistent workspace (mssvt_amd/frame.py)"  # noqa: E731
+                         if host_calls and all(host_calls) else "Python-driven entry points (mssvt_amd/fused.py)")
     elapsed, out = mdist.timed_steps(step, args.steps, dist, dev)
     # SURVEY 8(d) protocol beside the driver's K-step clock: every step between two HIP events
     # (a training step is collective -- every rank takes part; the forward is not, rank 0 measures alone)
@@ -334,7 +348,7 @@ def main():
             "dtype": "bf16" if args.attn_dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": workload_name(args, bool(args.cfg)),
                        "impl": impl, "attn_dtype": args.attn_dtype, "attn_arith": attn_arith_name(net, args.attn_dtype),
-                       "ffn_arith": ffn_arith_name(net),
+                       "ffn_arith": ffn_arith_name(net), "host_path": host_path(),
                        "voxels_per_gpu": int(vc.shape[0]),
                        "frames_rotated": len(frames), "voxels_per_frame": [int(f[2].shape[0]) for f in frames],
                        "output_voxels": int(sp_out.features.shape[0]),
