@@ -208,3 +208,30 @@ __device__ __forceinline__ int table_insert_min(int key, int value, int hash_siz
         if (++prob >= hash_size) return -1;
     }
 }
+
+// ---- LayerNorm over the last dimension of (n, C = 4 LPR) rows: workgroup `block` of 256 threads normalises 4 * (64 / LPR)
+// rows, LPR lanes (a float4 each) per row (k_layer_norm, rowops.hip; the fill launch of frame.hip)
+template <int LPR>
+__device__ __forceinline__ void layer_norm_rows(const float *x, int n, const float *w, const float *b, float eps, float *y,
+                                                unsigned int block) {
+    constexpr int C = LPR * 4, RPW = MSSVT_WAVE / LPR;
+    const int lane = lane_id();
+    const size_t row = ((size_t)block * 4 + threadIdx.x / MSSVT_WAVE) * RPW + lane / LPR;
+    const int col = (lane % LPR) * 4;
+    const bool live = row < (size_t)n;
+    const float4 v = live ? *reinterpret_cast<const float4 *>(x + row * C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float m = s * (1.0f / C);
+    const float dx = v.x - m, dy = v.y - m, dz = v.z - m, dw = v.w - m;
+    float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rs = rsqrtf(q * (1.0f / C) + eps);
+    const float4 g4 = *reinterpret_cast<const float4 *>(w + col);
+    const float4 b4 = *reinterpret_cast<const float4 *>(b + col);
+    if (live)
+        *reinterpret_cast<float4 *>(y + row * C + col) =
+            make_float4(dx * rs * g4.x + b4.x, dy * rs * g4.y + b4.y, dz * rs * g4.z + b4.z, dw * rs * g4.w + b4.w);
+}

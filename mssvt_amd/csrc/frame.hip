@@ -6,12 +6,11 @@
 // per frame -- as much as the kernels.  Here the same sequence of the SAME entry points (same arguments, same order:
 // results are bit-identical to the Python-driven fused path) is issued from C++ out of one caller-owned workspace:
 //
-//     fill (-1 arena, zero region, the output table)                                         mssvt_frame_fill
-//     level set-up of the (b,x,y,z)-sorted input list + early device-to-host copy            mssvt_level_setup_sorted
-//     first norm1                                                                            mssvt_layer_norm
+//     fill (-1 arena, zero region, the output table) + the first norm1 in the same launch    k_frame_fill_ln
+//     level set-up of the (b,x,y,z)-sorted input list + early device-to-host copy            mssvt_level_setup_sorted_pillars
 //     window plan of the two-scale Blocks (+ interpolation tables), work orders              mssvt_window_plan_two, mssvt_plan_order_multi
 //     per Block: window attention, FFN tail (emits the next block's norm1)                   mssvt_block_attention*, mssvt_ffn_fused_interp
-//     CompressBlock: pillar plan, attention, FFN tail                                        mssvt_window_plan_one, mssvt_compress_fused, mssvt_ffn_fused
+//     CompressBlock: attention (its pillar lists come out of the level set-up), FFN tail      mssvt_compress_fused, mssvt_ffn_fused
 //
 // A frame object (mssvt_frame_create) only holds the description of the network: window configuration, parameter
 // pointers (device memory owned by the caller), one pinned 4-KiB host buffer and one event for the frame's single
@@ -116,6 +115,33 @@ __global__ void __launch_bounds__(256) k_frame_fill(int *a, long long n_a, int *
     }
 }
 
+// The same fill with the frame's first LayerNorm riding along: workgroups [0, fill_blocks) fill, the others normalise 4 * (64 /
+// LPR) rows each -- two independent pieces of work at the very front of the frame in ONE launch (each launch of the frame
+// has a floor of ~4.5 us in the profiler's accounting; the fill alone is 5.6 us for 8.6 MB).
+template <int LPR>
+__global__ void __launch_bounds__(256) k_frame_fill_ln(int *a, long long n_a, int *b, long long n_b, int *c, long long n_c, int *d,
+                                                      long long n_d, int fill_blocks, const float *x, int n, const float *w,
+                                                      const float *bias, float eps, float *y) {
+    if ((int)blockIdx.x >= fill_blocks) {
+        layer_norm_rows<LPR>(x, n, w, bias, eps, y, blockIdx.x - fill_blocks);
+        return;
+    }
+    const long long qa = n_a >> 2, qb = n_b >> 2, qc = n_c >> 2, qd = n_d >> 2, stride = (long long)fill_blocks * blockDim.x;
+    const int4 neg = make_int4(-1, -1, -1, -1), zero = make_int4(0, 0, 0, 0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < qa + qb + qc + qd; i += stride) {
+        if (i < qa) reinterpret_cast<int4 *>(a)[i] = neg;
+        else if (i < qa + qb) reinterpret_cast<int4 *>(b)[i - qa] = neg;
+        else if (i < qa + qb + qc) reinterpret_cast<int4 *>(c)[i - qa - qb] = zero;
+        else reinterpret_cast<int4 *>(d)[i - qa - qb - qc] = zero;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16) {
+        const int reg = threadIdx.x >> 2, t = threadIdx.x & 3;
+        int *base = reg == 0 ? a : reg == 1 ? b : reg == 2 ? c : d;
+        const long long nn = reg == 0 ? n_a : reg == 1 ? n_b : reg == 2 ? n_c : n_d, done = (nn >> 2) << 2;
+        if (done + t < nn) base[done + t] = reg < 2 ? -1 : 0;
+    }
+}
+
 inline size_t ints_al(size_t n) { return (n + 63) / 64 * 64; }  // 256-byte pieces, multiples of 4 ints
 
 int q_slots(const FrPlanCfg &p, int pattern) { return pattern == 0 ? p.n_e : pattern == 1 ? p.n_o : p.n1; }
@@ -145,6 +171,8 @@ struct Layout {
     int *perm[3], *n_act[3], *q_off[3], *row_src[3], *n_rows[3];
     float *row_meta[3];
     long long row_cap;
+    int order_groups;
+    int *order_hist;
     float *qbuf, *attn[3];
     int attn_zero_row[3];
     float *x[2], *xh[2];
@@ -183,6 +211,16 @@ void make_layout(const Frame &f, int n, char *base, Layout &L) {
     L.pair_win = b.take<int>(ints_al(cap));
     b.off = al256(b.off);
     L.neg_ints = (size_t)(b.base + b.off - reinterpret_cast<char *>(L.neg0)) / 4;
+    // work orders (fused._work_order / prepare_group): row capacity = max over the patterns of min(N * overlap, cap * nq)
+    long long overlap = 1;
+    for (int i = 0; i < 3; ++i) overlap *= p.ws[i] % 2 == 0 ? 2 : 1;
+    L.row_cap = 1;
+    for (int i = 0; i < L.n_pat; ++i) {
+        long long rc = (long long)N * overlap, lim = (long long)cap * q_slots(p, L.pats[i]);
+        if (rc > lim) rc = lim;
+        if (rc > L.row_cap) L.row_cap = rc;
+    }
+    L.order_groups = mssvt_plan_order_groups((int)cap, (int)L.row_cap);
     // ---- zero region (the block of fused._sorted_level: status | partition headers | sample starts | occupancy words)
     L.zero0 = b.take<int>(0);
     L.status = b.take<int>(64);
@@ -190,6 +228,7 @@ void make_layout(const Frame &f, int n, char *base, Layout &L) {
     L.hdr[1] = b.take<int>(64);
     L.start = b.take<int>(ints_al(B + 1));
     L.occ = reinterpret_cast<unsigned long long *>(b.take<int>(ints_al((size_t)2 * B * f.X * f.Y)));
+    L.order_hist = b.take<int>(ints_al((size_t)3 * L.order_groups * 258));  // counted by the plan kernel
     b.off = al256(b.off);
     L.zero_ints = (size_t)(b.base + b.off - reinterpret_cast<char *>(L.zero0)) / 4;
     // ---- uninitialised
@@ -216,15 +255,6 @@ void make_layout(const Frame &f, int n, char *base, Layout &L) {
     L.wcentre = b.take<float>(cap * 4);
     L.nq_valid = b.take<int>(3 * cap);
     L.tab_w = b.take<float>((size_t)L.n_tabs * N * 4);
-    // work orders (fused._work_order / prepare_group): row capacity = max over the patterns of min(N * overlap, cap * nq)
-    long long overlap = 1;
-    for (int i = 0; i < 3; ++i) overlap *= p.ws[i] % 2 == 0 ? 2 : 1;
-    L.row_cap = 1;
-    for (int i = 0; i < L.n_pat; ++i) {
-        long long rc = (long long)N * overlap, lim = (long long)cap * q_slots(p, L.pats[i]);
-        if (rc > lim) rc = lim;
-        if (rc > L.row_cap) L.row_cap = rc;
-    }
     for (int i = 0; i < L.n_pat; ++i) {
         L.perm[i] = b.take<int>(cap);
         L.n_act[i] = b.take<int>(1);
@@ -458,12 +488,27 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
     const FrCompress &c = f->cmp;
 
     // ---- one fill: -1 arena, the output level's hash table, zero region, the attention buffers' zero row
+    bool ln_in_fill = false;
     {
         const long long n_tab = (long long)B * H * 2, n_zr = (C + 3) / 4 * 4;
         const long long quads = ((long long)L.neg_ints + n_tab + (long long)L.zero_ints + n_zr) >> 2;
         int grid = (int)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
-        k_frame_fill<<<grid < 1 ? 1 : grid, 256, 0, stream>>>(L.neg0, (long long)L.neg_ints, out_table, n_tab, L.zero0,
-                                                            (long long)L.zero_ints, reinterpret_cast<int *>(L.attn_zero), n_zr);
+        if (grid < 1) grid = 1;
+        // ... and the first norm1 in the same launch (it depends on nothing the fill writes) unless it goes to the side stream
+        const FrBlock &k0 = f->blocks[0];
+        const int lpr = C / 4, ln_blocks = (n + 4 * (MSSVT_WAVE / (lpr > 0 ? lpr : 1)) - 1) / (4 * (MSSVT_WAVE / (lpr > 0 ? lpr : 1)));
+        ln_in_fill = !f->overlap && (lpr == 8 || lpr == 16 || lpr == 32);
+#define FR_FILL_LN(LPR_)                                                                                                  \
+    k_frame_fill_ln<LPR_><<<grid + ln_blocks, 256, 0, stream>>>(L.neg0, (long long)L.neg_ints, out_table, n_tab, L.zero0, \
+                                                                (long long)L.zero_ints, reinterpret_cast<int *>(L.attn_zero), \
+                                                                n_zr, grid, features, n, k0.n1w, k0.n1b, k0.n1eps, L.xhat0)
+        if (ln_in_fill && lpr == 32) FR_FILL_LN(32);
+        else if (ln_in_fill && lpr == 16) FR_FILL_LN(16);
+        else if (ln_in_fill && lpr == 8) FR_FILL_LN(8);
+        else
+            k_frame_fill<<<grid, 256, 0, stream>>>(L.neg0, (long long)L.neg_ints, out_table, n_tab, L.zero0, (long long)L.zero_ints,
+                                                   reinterpret_cast<int *>(L.attn_zero), n_zr);
+#undef FR_FILL_LN
         FR_TRY(mssvt_launch_status());
     }
     // ---- level set-up (sorted list; the device verifies the order): partition 0 = the Blocks' windows, 1 = the pillars
@@ -472,8 +517,11 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
     const int maxw[2] = {p.max_wins, c.max_wins};
     int *wins[2] = {L.win_blk, out_indices}, *tables[2] = {nullptr, out_table}, *vcounts[2] = {L.vcount_blk, out_counts};
     int *hdrs[2] = {L.hdr[0], L.hdr[1]};
-    FR_TRY(mssvt_level_setup_sorted(n, B, X, Y, Z, H, indices, L.zero0, -(long long)L.zero_ints * 4, L.cnt, L.start, L.occ, L.vbase,
-                                    L.status, 2, grid3, wsize3, maxw, wins, tables, vcounts, hdrs, L.scratch, stream));
+    // (the CompressBlock's pillar lists fall out of the same launches: every pillar window is a slab of one column word)
+    FR_TRY(mssvt_level_setup_sorted_pillars(n, B, X, Y, Z, H, indices, L.zero0, -(long long)L.zero_ints * 4, L.cnt, L.start, L.occ,
+                                            L.vbase, L.status, 2, grid3, wsize3, maxw, wins, tables, vcounts, hdrs, L.scratch, 1,
+                                            c.ns, c.num_1, c.t_1, L.c_k_ind, L.c_win_vstart, L.c_win_cnt, L.c_pair_base, L.pair_win,
+                                            L.c_pair_vox, stream));
     // the words the host needs (level status | per partition: status, window count) are final here: copy them out now
     f->words = 64 * 3;
     {
@@ -489,11 +537,9 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
         if (e != hipSuccess) return (int)e;
         s2 = f->side;
     }
-    FR_TRY(mssvt_layer_norm(features, n, C, f->blocks[0].n1w, f->blocks[0].n1b, f->blocks[0].n1eps, L.xhat0, s2));
+    if (!ln_in_fill)
+        FR_TRY(mssvt_layer_norm(features, n, C, f->blocks[0].n1w, f->blocks[0].n1b, f->blocks[0].n1eps, L.xhat0, s2));
     if (f->overlap) {
-        FR_TRY(mssvt_window_plan_one(X, Y, Z, c.ws[0], c.ws[1], c.ws[2], c.ns, H, c.num_1, c.t_1, out_indices, L.hdr[1] + 1, cap,
-                                     nullptr, L.cnt, 0, 2, n, L.c_k_ind, L.c_win_vstart, L.c_win_cnt, L.c_pair_base, L.pair_win,
-                                     L.c_pair_vox, L.hdr[1] + 2, L.occ, L.vbase, L.status, s2));
         const hipError_t e = hipEventRecord(f->join, s2);
         if (e != hipSuccess) return (int)e;
     }
@@ -511,12 +557,13 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
             tab_row[t] = L.tab_rows + (size_t)t * n * 4;
             tab_w[t] = L.tab_w + (size_t)t * n * 4;
         }
-        FR_TRY(mssvt_window_plan_two(
+        FR_TRY(mssvt_window_plan_two_hist(
             X, Y, Z, p.ws[0], p.ws[1], p.ws[2], p.n_o, p.n_e, p.n1, p.n2, H, B, p.num_o, p.num_e, p.num_1, p.num_2, p.t_o, p.t_e,
             p.t_1, p.t_2, p.K, L.win_blk, L.hdr[0] + 1, cap, nullptr, L.cnt, L.ind_odd, L.ind_even, L.ind_win1, L.k_ind[0],
             L.k_ind[1], L.k_mask[0], L.k_mask[1], L.win_vstart, owner_win1, owner_odd, owner_even, indices, f->vs, mn3, wsm,
             L.qmeta[0], L.qmeta[1], L.qmeta[2], L.kmeta[0], L.kmeta[1], L.wcentre, L.nq_valid, L.occ, p.fp4, p.packed_offsets,
-            L.vbase, L.status, L.vcount_blk, L.n_tabs, tab_list, L.tab_interp, tab_zero, tab_row, tab_w, stream));
+            L.vbase, L.status, L.vcount_blk, L.n_tabs, tab_list, L.tab_interp, tab_zero, tab_row, tab_w, L.order_groups, L.order_hist,
+            stream));
     }
     // ---- work orders + compact query rows of every query pattern in one launch group
     {
@@ -529,8 +576,10 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
             nq[i] = q_slots(p, L.pats[i]);
             qm[i] = L.qmeta[l];
         }
-        FR_TRY(mssvt_plan_order_multi(L.n_pat, L.hdr[0] + 1, nqv, nq, qm, cap, (int)L.row_cap, L.perm, L.n_act, L.q_off, L.row_meta,
-                                      L.row_src, L.n_rows, stream));
+        const int *hist[3];
+        for (int i = 0; i < L.n_pat; ++i) hist[i] = L.order_hist + (size_t)q_list(L.pats[i]) * L.order_groups * 258;
+        FR_TRY(mssvt_plan_order_multi_hist(L.n_pat, L.hdr[0] + 1, nqv, nq, qm, cap, (int)L.row_cap, L.perm, L.n_act, L.q_off,
+                                           L.row_meta, L.row_src, L.n_rows, hist, stream));
     }
     if (f->overlap) {
         const hipError_t e = hipStreamWaitEvent(stream, f->join, 0);
@@ -571,10 +620,6 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
         xhat = yn;
     }
     // ---- CompressBlock: pillar plan, attention (three launches), FFN tail over the live windows
-    if (!f->overlap)
-        FR_TRY(mssvt_window_plan_one(X, Y, Z, c.ws[0], c.ws[1], c.ws[2], c.ns, H, c.num_1, c.t_1, out_indices, L.hdr[1] + 1, cap,
-                                     nullptr, L.cnt, 0, 2, n, L.c_k_ind, L.c_win_vstart, L.c_win_cnt, L.c_pair_base, L.pair_win,
-                                     L.c_pair_vox, L.hdr[1] + 2, L.occ, L.vbase, L.status, stream));
     const float cwsm[3] = {f->vs[0] * c.ws[0], f->vs[1] * c.ws[1], f->vs[2] * c.ws[2]};
     FR_TRY(mssvt_compress_fused(C, c.head_dim, c.scale, c.ns, n, L.hdr[1] + 1, cap, out_indices, indices, L.c_k_ind, L.c_win_vstart,
                                 L.c_win_cnt, L.pair_win, f->vs, mn3, cwsm, xhat, c.Wp1, c.bp1, c.Wp2, c.bp2, c.Wq, c.bq, c.Wkv, c.bkv,

@@ -43,6 +43,12 @@ struct LsArgs {
     int nparts, nblk;
     int *sums;  // (B, nblk, 1 + LS_MAX_PARTS)
     LsPart p[LS_MAX_PARTS];
+    // optional (pl_part >= 0): the K4 lists of partition pl_part's windows -- pillar windows [1,1,z]: each is a slab of this very
+    // column's occupancy word -- written while the window is emitted (what k_window_plan_pillars, compress.hip, computes
+    // in a launch of its own: ref gather_one_window_voxels, ms_sparse_attention_gpu.cu:383-433)
+    int pl_part, pl_max, pl_n;  // partition, max_num_win1, table entries
+    const int *pl_table;        // (pl_n, 3) offsets; x = y = 0 (the caller checked), z used
+    int *pl_k_ind, *pl_vstart, *pl_cnt, *pl_base, *pl_pair_win, *pl_pair_vox;
 };
 
 __global__ void __launch_bounds__(256) k_level_mark(LsArgs a) {
@@ -127,7 +133,9 @@ __global__ void __launch_bounds__(LS_COLS) k_col_emit(LsArgs a) {
     __shared__ int red[NW][2 * NQ];
     __shared__ int pre_own[NQ], pre_all[NQ];  // blocks before this one: of this sample / of the earlier samples
     __shared__ int wtot[NW][NQ];
+    __shared__ int pl_oz[MSSVT_WAVE];
     const int b = blockIdx.y, blk = blockIdx.x, ncol = a.X * a.Y, lane = lane_id(), wv = threadIdx.x / MSSVT_WAVE;
+    if (a.pl_part >= 0 && threadIdx.x < MSSVT_WAVE) pl_oz[threadIdx.x] = a.pl_table[min((int)threadIdx.x, a.pl_n - 1) * 3 + 2];
     // ---- prefixes over the workgroups' sums ----------------------------------------------------------------
     {
         int own[NQ] = {0, 0, 0, 0, 0}, all[NQ] = {0, 0, 0, 0, 0};
@@ -210,6 +218,28 @@ __global__ void __launch_bounds__(LS_COLS) k_col_emit(LsArgs a) {
                 const int wz = __ffsll((long long)f) - 1;
                 f &= f - 1ull;
                 reinterpret_cast<int4 *>(P.win_ind)[pre_all[1 + t] + rank] = make_int4(b, wz, wy, wx);
+                if (t == a.pl_part) {  // the window's K4 list: set bits of its slab in table order (offsets around the slab centre)
+                    const int W = pre_all[1 + t] + rank, vstart = a.start[b], cz = wz * P.wsz + P.wsz / 2;
+                    int *row = a.pl_k_ind + (size_t)W * a.pl_max;
+                    int cnt = 0;
+                    for (int q = 0; q < a.pl_n; ++q) {
+                        const int sz = cz + pl_oz[q];
+                        if ((unsigned int)sz < (unsigned int)a.Z && ((word >> sz) & 1ull)) {
+                            if (cnt < a.pl_max) {
+                                const int sv = ex[0] + __popcll(word & ((1ull << sz) - 1ull));
+                                row[cnt] = sv;
+                                a.pl_pair_win[vstart + sv] = W;
+                                a.pl_pair_vox[vstart + sv] = vstart + sv;
+                            }
+                            ++cnt;
+                        }
+                    }
+                    const int nk = cnt < a.pl_max ? cnt : a.pl_max;
+                    for (int k = nk; k < a.pl_max; ++k) row[k] = -1;
+                    a.pl_vstart[W] = vstart;
+                    a.pl_cnt[W] = nk;
+                    a.pl_base[W] = -1;
+                }
                 if (P.table && rank < P.max_wins) {  // ref :154-161: the reference writes out of bounds beyond max_wins
                     const int st = table_insert_ordered(wx * P.gy * P.gz + wy * P.gz + wz, rank, a.H, P.table + (size_t)b * a.H);
                     if (st & ST_TABLE_OVERFLOW) atomicOr(P.ws + WS_STATUS, ST_TABLE_OVERFLOW);
@@ -246,13 +276,19 @@ extern "C" long long mssvt_level_sorted_scratch_ints(int batch_size, int x_max, 
     return (long long)batch_size * nblk * (1 + LS_MAX_PARTS);
 }
 
-extern "C" int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_max, int z_max, int hash_size,
-                                        const int *v_indices, void *zero_region, long long zero_bytes, int *v_bs_cnt,
-                                        int *sample_start, unsigned long long *occ_columns, int *column_vbase,
-                                        int *level_status, int num_sets, const int *host_win_grid3,
-                                        const int *host_win_size3, const int *host_max_num_wins, int *const *host_win_ind,
-                                        int *const *host_tables, int *const *host_vcount, int *const *host_ws,
-                                        int *scratch, void *stream_) {
+struct LsPillars {
+    int part, max_win1, n_win1;
+    const int *table;
+    int *k_ind, *vstart, *cnt, *base, *pair_win, *pair_vox;
+};
+
+static int level_setup_sorted_impl(int num_voxels, int batch_size, int x_max, int y_max, int z_max, int hash_size,
+                                   const int *v_indices, void *zero_region, long long zero_bytes, int *v_bs_cnt,
+                                   int *sample_start, unsigned long long *occ_columns, int *column_vbase,
+                                   int *level_status, int num_sets, const int *host_win_grid3,
+                                   const int *host_win_size3, const int *host_max_num_wins, int *const *host_win_ind,
+                                   int *const *host_tables, int *const *host_vcount, int *const *host_ws,
+                                   int *scratch, const LsPillars *pl, void *stream_) {
     const bool precleared = zero_bytes < 0;  // the caller cleared the region itself (mssvt_fill_two, with its other fills)
     if (precleared) zero_bytes = -zero_bytes;
     if (!zero_region || zero_bytes <= 0 || !v_bs_cnt || !sample_start || !occ_columns || !column_vbase || !level_status ||
@@ -294,6 +330,19 @@ extern "C" int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_ma
         ok = ok && inside(P.ws, WS_HDR_INTS * sizeof(int));
     }
     if (!ok) return MSSVT_E_BADARG;
+    a.pl_part = -1;
+    a.pl_max = a.pl_n = 0;
+    a.pl_table = nullptr;
+    a.pl_k_ind = a.pl_vstart = a.pl_cnt = a.pl_base = a.pl_pair_win = a.pl_pair_vox = nullptr;
+    if (pl) {
+        if (pl->part < 0 || pl->part >= num_sets || pl->max_win1 <= 0 || pl->n_win1 < 1 || pl->n_win1 > MSSVT_WAVE || !pl->table ||
+            !pl->k_ind || !pl->vstart || !pl->cnt || !pl->base || !pl->pair_win || !pl->pair_vox)
+            return MSSVT_E_BADARG;
+        if (a.p[pl->part].wsx != 1 || a.p[pl->part].wsy != 1) return MSSVT_E_TOOLARGE;  // pillar windows only
+        a.pl_part = pl->part; a.pl_max = pl->max_win1; a.pl_n = pl->n_win1; a.pl_table = pl->table;
+        a.pl_k_ind = pl->k_ind; a.pl_vstart = pl->vstart; a.pl_cnt = pl->cnt; a.pl_base = pl->base;
+        a.pl_pair_win = pl->pair_win; a.pl_pair_vox = pl->pair_vox;
+    }
     hipStream_t stream = (hipStream_t)stream_;
     if (!precleared) {
         hipError_t e = hipMemsetAsync(zero_region, 0, (size_t)zero_bytes, stream);
@@ -304,6 +353,33 @@ extern "C" int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_ma
     k_col_sums<<<grid, LS_COLS, 0, stream>>>(a);
     k_col_emit<<<grid, LS_COLS, 0, stream>>>(a);
     return mssvt_launch_status();
+}
+
+extern "C" int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_max, int z_max, int hash_size,
+                                        const int *v_indices, void *zero_region, long long zero_bytes, int *v_bs_cnt,
+                                        int *sample_start, unsigned long long *occ_columns, int *column_vbase,
+                                        int *level_status, int num_sets, const int *host_win_grid3,
+                                        const int *host_win_size3, const int *host_max_num_wins, int *const *host_win_ind,
+                                        int *const *host_tables, int *const *host_vcount, int *const *host_ws,
+                                        int *scratch, void *stream) {
+    return level_setup_sorted_impl(num_voxels, batch_size, x_max, y_max, z_max, hash_size, v_indices, zero_region, zero_bytes,
+                                   v_bs_cnt, sample_start, occ_columns, column_vbase, level_status, num_sets, host_win_grid3,
+                                   host_win_size3, host_max_num_wins, host_win_ind, host_tables, host_vcount, host_ws, scratch,
+                                   nullptr, stream);
+}
+
+extern "C" int mssvt_level_setup_sorted_pillars(
+    int num_voxels, int batch_size, int x_max, int y_max, int z_max, int hash_size, const int *v_indices, void *zero_region,
+    long long zero_bytes, int *v_bs_cnt, int *sample_start, unsigned long long *occ_columns, int *column_vbase,
+    int *level_status, int num_sets, const int *host_win_grid3, const int *host_win_size3, const int *host_max_num_wins,
+    int *const *host_win_ind, int *const *host_tables, int *const *host_vcount, int *const *host_ws, int *scratch,
+    int pillar_set, int max_num_win1, int num_win1, const int *vox_query_win1, int *k_ind, int *win_vstart, int *win_cnt,
+    int *pair_base, int *pair_win, int *pair_vox, void *stream) {
+    const LsPillars pl = {pillar_set, max_num_win1, num_win1, vox_query_win1, k_ind, win_vstart, win_cnt, pair_base, pair_win, pair_vox};
+    return level_setup_sorted_impl(num_voxels, batch_size, x_max, y_max, z_max, hash_size, v_indices, zero_region, zero_bytes,
+                                   v_bs_cnt, sample_start, occ_columns, column_vbase, level_status, num_sets, host_win_grid3,
+                                   host_win_size3, host_max_num_wins, host_win_ind, host_tables, host_vcount, host_ws, scratch,
+                                   &pl, stream);
 }
 
 // ---- two constant fills in one launch: the frame's -1 arena (tables, owner arrays, list prefills) and its zero region

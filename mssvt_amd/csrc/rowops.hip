@@ -55,30 +55,12 @@ int mssvt_batch_counts_launch(const int *indices, int num_rows, int batch_size, 
     return mssvt_launch_status();
 }
 
-// LPR lanes (float4 each) per row, 64 / LPR rows per wavefront instruction
+// LPR lanes (float4 each) per row, 64 / LPR rows per wavefront instruction (the row body lives in common.hip.h: the frame
+// call runs it inside its fill launch)
 template <int LPR>
 __global__ void __launch_bounds__(256) k_layer_norm(const float *x, int n, const float *w, const float *b, float eps,
                                                     float *y) {
-    constexpr int C = LPR * 4, RPW = MSSVT_WAVE / LPR;
-    const int lane = lane_id();
-    const size_t row = ((size_t)blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE) * RPW + lane / LPR;
-    const int col = (lane % LPR) * 4;
-    const bool live = row < (size_t)n;
-    const float4 v = live ? *reinterpret_cast<const float4 *>(x + row * C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float s = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-    for (int off = LPR / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    const float m = s * (1.0f / C);
-    const float dx = v.x - m, dy = v.y - m, dz = v.z - m, dw = v.w - m;
-    float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-#pragma unroll
-    for (int off = LPR / 2; off >= 1; off >>= 1) q += __shfl_xor(q, off);
-    const float rs = rsqrtf(q * (1.0f / C) + eps);
-    const float4 g4 = *reinterpret_cast<const float4 *>(w + col);
-    const float4 b4 = *reinterpret_cast<const float4 *>(b + col);
-    if (live)
-        *reinterpret_cast<float4 *>(y + row * C + col) =
-            make_float4(dx * rs * g4.x + b4.x, dy * rs * g4.y + b4.y, dz * rs * g4.z + b4.z, dw * rs * g4.w + b4.w);
+    layer_norm_rows<LPR>(x, n, w, b, eps, y, blockIdx.x);
 }
 
 extern "C" int mssvt_layer_norm(const float *x, int num_rows, int C, const float *weight, const float *bias,
