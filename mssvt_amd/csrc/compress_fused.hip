@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // not fit beside the per-wave window lists), as many waves as the registers allow
 #define CFQ_NW 12  // k_cmp_query_keys (<= 168 VGPRs)
 #define CFK_NW 12  // k_cmp_kv
-#define CFO_NW 12  // k_cmp_out (<= 168 VGPRs: two list slots in flight)
+#define CFO_NW 16  // k_cmp_out (<= 128 VGPRs)
 #define MFMA4(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), acc, 0, 0, 0)
 
 struct CmpArgs {
@@ -473,36 +473,29 @@ __global__ void __launch_bounds__(CFO_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
             sum[S] = 0.f;
             o[S] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // two list slots per iteration: both slots' rows are in flight before the first is used (the walk is a chain of
-        // dependent round trips as long as the tile's longest list; the update order is the sequential one)
-        for (int s = 0; s < cmax; s += 2) {
-            float4 vv[2][NT];
-            float sc[2][NT];
+        for (int s = 0; s < cmax; ++s) {
+            const bool on = s < cnt;
+            const int vrow = list[s];
+            const float *sr = a.score + (size_t)vrow * NH;
+            const float *vr = a.vp + (size_t)vrow * C + 4 * g;
+            float4 vv[NT];
+            float sc[NT];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int vrow = list[min(s + h, a.ns - 1)];
-                const float *sr = a.score + (size_t)vrow * NH;
-                const float *vr = a.vp + (size_t)vrow * C + 4 * g;
+            for (int S = 0; S < NT; ++S) {
+                vv[S] = *reinterpret_cast<const float4 *>(vr + 16 * S);
+                sc[S] = sr[(16 * S + 4 * g) / HD];
+            }
+            if (on) {
 #pragma unroll
                 for (int S = 0; S < NT; ++S) {
-                    vv[h][S] = *reinterpret_cast<const float4 *>(vr + 16 * S);
-                    sc[h][S] = sr[(16 * S + 4 * g) / HD];
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (s + h < cnt) {
-#pragma unroll
-                    for (int S = 0; S < NT; ++S) {
-                        const float mn = fmaxf(mx[S], sc[h][S]);
-                        const float corr = __expf(mx[S] - mn), e = __expf(sc[h][S] - mn);  // first step: exp(-inf) = 0
-                        mx[S] = mn;
-                        sum[S] = sum[S] * corr + e;
-                        o[S][0] = __builtin_fmaf(e, vv[h][S].x, o[S][0] * corr);
-                        o[S][1] = __builtin_fmaf(e, vv[h][S].y, o[S][1] * corr);
-                        o[S][2] = __builtin_fmaf(e, vv[h][S].z, o[S][2] * corr);
-                        o[S][3] = __builtin_fmaf(e, vv[h][S].w, o[S][3] * corr);
-                    }
+                    const float mn = fmaxf(mx[S], sc[S]);
+                    const float corr = __expf(mx[S] - mn), e = __expf(sc[S] - mn);  // first step: exp(-inf) = 0
+                    mx[S] = mn;
+                    sum[S] = sum[S] * corr + e;
+                    o[S][0] = __builtin_fmaf(e, vv[S].x, o[S][0] * corr);
+                    o[S][1] = __builtin_fmaf(e, vv[S].y, o[S][1] * corr);
+                    o[S][2] = __builtin_fmaf(e, vv[S].z, o[S][2] * corr);
+                    o[S][3] = __builtin_fmaf(e, vv[S].w, o[S][3] * corr);
                 }
             }
         }
