@@ -220,7 +220,7 @@ int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_ma
 /* mssvt_level_setup_sorted that also writes the K4 lists of partition `pillar_set` -- pillar windows [1,1,z], offsets of
  * vox_query_win1 (num_win1 <= 64 rows) with x = y = 0 -- i.e. the outputs of mssvt_window_plan_one(disjoint_lists = 2,
  * with_pad = 0) for that partition (k_ind (cap,max_num_win1), win_vstart, win_cnt, pair_base (cap), pair_win / pair_vox (N);
- * pair_win pre-filled with -1): every such window is a slab of ONE column's occupancy word, so its list falls out where
+ * pair_win pre-filled with -1; pair_base / pair_vox may be NULL: mssvt_compress_fused reads neither): every such window is a slab of ONE column's occupancy word, so its list falls out where
  * the window is numbered, without a launch of its own (ref gather_one_window_voxels, ms_sparse_attention_gpu.cu:383-433).
  * MSSVT_E_TOOLARGE: the partition's windows are not pillars.                                                        */
 int mssvt_level_setup_sorted_pillars(
@@ -269,25 +269,6 @@ int mssvt_window_plan_two(
     const int *win_counts_dev, int num_tabs, const int *host_tab_list, const int *host_tab_interp,
     const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, void *stream);
 
-/* mssvt_window_plan_two that also counts the key histograms of mssvt_plan_order while it writes nq_valid (atomics on
- * order_hist: 3 lists x order_groups x 258 ints, zeroed by the caller; order_groups = mssvt_plan_order_groups(...) of the
- * mssvt_plan_order_multi_hist call that follows; <= 1: nothing is counted).  Same results; one launch less per plan.  */
-int mssvt_window_plan_two_hist(
-    int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
-    int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
-    int num_win1, int num_win2, const int *vox_query_odd, const int *vox_query_even,
-    const int *vox_query_win1, const int *vox_query_win2, int key_num_sample, const int *win_indices,
-    const int *num_wins_dev, int win_capacity, const int *xyz_to_vidx, const int *v_bs_cnt,
-    int *ind_odd, int *ind_even, int *ind_win1, int *k_ind1, int *k_ind2, unsigned char *k_mask1,
-    unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
-    const int *indices, const float *host_voxel_size3, const float *host_range_min3,
-    const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
-    float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
-    const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
-    const int *win_counts_dev, int num_tabs, const int *host_tab_list, const int *host_tab_interp,
-    const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, int order_groups,
-    int *order_hist, void *stream);
-
 /* Occupancy columns of a voxel set (z_max <= 64): columns (B*x_max*y_max) 64-bit words, bit z of
  * word (b*x_max + x)*y_max + y set when cell (b,x,y,z) holds a voxel.  Optional input of
  * mssvt_window_plan_two (together with host_footprint4 = {min x offset, min y offset, x extent,
@@ -320,16 +301,6 @@ int mssvt_plan_order_multi(int num_sets, const int *num_wins_dev, const int *con
                            int row_capacity, int *const *host_perm, int *const *host_num_active,
                            int *const *host_q_off, float *const *host_qrow_meta, int *const *host_qrow_src,
                            int *const *host_num_rows, void *stream);
-
-/* Workgroups per query list of mssvt_plan_order_multi for these capacities (= chunks of the histograms), and the form
- * that takes the histograms from mssvt_window_plan_two_hist: host_hist[s] = order_hist + list(s) * groups * 258 with
- * list 0 = odd, 1 = even, 2 = win1 (the list nq_valid[s] / qmeta[s] belong to).                                      */
-int mssvt_plan_order_groups(int win_capacity, int row_capacity);
-int mssvt_plan_order_multi_hist(int num_sets, const int *num_wins_dev, const int *const *host_nq_valid,
-                                const int *host_nq, const float *const *host_qmeta, int win_capacity,
-                                int row_capacity, int *const *host_perm, int *const *host_num_active,
-                                int *const *host_q_off, float *const *host_qrow_meta, int *const *host_qrow_src,
-                                int *const *host_num_rows, const int *const *host_hist, void *stream);
 
 /* Fused attention of a Block, all head groups (group g = channels [c0[g], c0[g]+Cg[g]),
  * Cg = heads[g]*head_dim <= 64, attends to key scale g): gathers + positional MLP +

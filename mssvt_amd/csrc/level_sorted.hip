@@ -221,24 +221,45 @@ __global__ void __launch_bounds__(LS_COLS) k_col_emit(LsArgs a) {
                 if (t == a.pl_part) {  // the window's K4 list: set bits of its slab in table order (offsets around the slab centre)
                     const int W = pre_all[1 + t] + rank, vstart = a.start[b], cz = wz * P.wsz + P.wsz / 2;
                     int *row = a.pl_k_ind + (size_t)W * a.pl_max;
+                    // the list goes out in 16-byte pieces (a thread owns the whole 4 pl_max byte row: dword stores from 64
+                    // columns at once are 64 different cache lines per instruction, 32 instructions in a row)
+                    const bool vec = (a.pl_max & 3) == 0;
+                    int4 piece = make_int4(-1, -1, -1, -1);
                     int cnt = 0;
                     for (int q = 0; q < a.pl_n; ++q) {
                         const int sz = cz + pl_oz[q];
                         if ((unsigned int)sz < (unsigned int)a.Z && ((word >> sz) & 1ull)) {
                             if (cnt < a.pl_max) {
                                 const int sv = ex[0] + __popcll(word & ((1ull << sz) - 1ull));
-                                row[cnt] = sv;
+                                if (vec) {
+                                    const int j = cnt & 3;
+                                    piece.x = j == 0 ? sv : piece.x; piece.y = j == 1 ? sv : piece.y;
+                                    piece.z = j == 2 ? sv : piece.z; piece.w = j == 3 ? sv : piece.w;
+                                    if (j == 3) {
+                                        reinterpret_cast<int4 *>(row)[cnt >> 2] = piece;
+                                        piece = make_int4(-1, -1, -1, -1);
+                                    }
+                                } else {
+                                    row[cnt] = sv;
+                                }
                                 a.pl_pair_win[vstart + sv] = W;
-                                a.pl_pair_vox[vstart + sv] = vstart + sv;
+                                if (a.pl_pair_vox) a.pl_pair_vox[vstart + sv] = vstart + sv;
                             }
                             ++cnt;
                         }
                     }
                     const int nk = cnt < a.pl_max ? cnt : a.pl_max;
-                    for (int k = nk; k < a.pl_max; ++k) row[k] = -1;
+                    if (vec) {
+                        for (int k4 = nk >> 2; k4 < a.pl_max >> 2; ++k4) {  // the partly filled piece, then -1 padding
+                            reinterpret_cast<int4 *>(row)[k4] = piece;
+                            piece = make_int4(-1, -1, -1, -1);
+                        }
+                    } else {
+                        for (int k = nk; k < a.pl_max; ++k) row[k] = -1;
+                    }
                     a.pl_vstart[W] = vstart;
                     a.pl_cnt[W] = nk;
-                    a.pl_base[W] = -1;
+                    if (a.pl_base) a.pl_base[W] = -1;
                 }
                 if (P.table && rank < P.max_wins) {  // ref :154-161: the reference writes out of bounds beyond max_wins
                     const int st = table_insert_ordered(wx * P.gy * P.gz + wy * P.gz + wz, rank, a.H, P.table + (size_t)b * a.H);
@@ -336,7 +357,7 @@ static int level_setup_sorted_impl(int num_voxels, int batch_size, int x_max, in
     a.pl_k_ind = a.pl_vstart = a.pl_cnt = a.pl_base = a.pl_pair_win = a.pl_pair_vox = nullptr;
     if (pl) {
         if (pl->part < 0 || pl->part >= num_sets || pl->max_win1 <= 0 || pl->n_win1 < 1 || pl->n_win1 > MSSVT_WAVE || !pl->table ||
-            !pl->k_ind || !pl->vstart || !pl->cnt || !pl->base || !pl->pair_win || !pl->pair_vox)
+            !pl->k_ind || !pl->vstart || !pl->cnt || !pl->pair_win)
             return MSSVT_E_BADARG;
         if (a.p[pl->part].wsx != 1 || a.p[pl->part].wsy != 1) return MSSVT_E_TOOLARGE;  // pillar windows only
         a.pl_part = pl->part; a.pl_max = pl->max_win1; a.pl_n = pl->n_win1; a.pl_table = pl->table;

@@ -22,7 +22,6 @@
 #include <stdlib.h>
 #include "common.hip.h"
 #define PLAN_MAX_WPB 4
-#define PO_KEYS 257  // mssvt_plan_order: query counts 0 .. 256 (larger ones share the last key)
 #ifndef PLAN_WAVES_PER_SIMD
 #define PLAN_WAVES_PER_SIMD 5  // register budget of the common instantiation (96 VGPRs; 8, 6 and 4 waves measured the same)
 #endif
@@ -67,10 +66,6 @@ struct PlanArgs {
     // stand-alone form): per voxel the three attention rows + weights its update comes from, for up to PLAN_MAX_TABS
     // (query list, interpolation) variants -- built here, where the window's lists sit in LDS, when the lists of
     // different windows cannot overlap (every voxel then has one owner: this window)
-    // optional: the key histograms of mssvt_plan_order (windows per query count and chunk of windows, row totals) counted
-    // here with atomics -- its first launch then falls away.  (3 lists, order_groups chunks, PO_KEYS + 1 ints each, zeroed.)
-    int *order_hist;
-    int order_groups;
     int n_tabs, tab_q;  // tab_q: candidate slots per wave (largest query list + 3)
     struct PlanTab {
         int list, maxn, interp, zero_row;  // list: 0 odd, 1 even, 2 win1 (the queries); zero_row: attention row of zeros
@@ -493,17 +488,6 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
             a.nq_valid[w] = nO;
             a.nq_valid[a.win_capacity + w] = nE;
             a.nq_valid[2 * a.win_capacity + w] = n1;
-            if (a.order_hist) {  // what k_plan_order<0> counts: (chunk of windows, query count) -> windows; chunk -> rows
-                const int G = a.order_groups, per = (*a.num_wins + G - 1) / G;
-                int *h = a.order_hist + (size_t)(w / per) * (PO_KEYS + 1);
-                const size_t ls = (size_t)G * (PO_KEYS + 1);
-                atomicAdd(h + min(nO, min(a.max_odd, 256)), 1);
-                atomicAdd(h + ls + min(nE, min(a.max_even, 256)), 1);
-                atomicAdd(h + 2 * ls + min(n1, min(a.max_win1, 256)), 1);
-                if (nO) atomicAdd(h + PO_KEYS, nO);
-                if (nE) atomicAdd(h + ls + PO_KEYS, nE);
-                if (n1) atomicAdd(h + 2 * ls + PO_KEYS, n1);
-            }
         }
     }
 
@@ -669,7 +653,7 @@ static inline int plan_opt_n_threads(int work_size) {  // ref cuda_utils.h:10-14
     return v;
 }
 
-static int window_plan_two_impl(
+extern "C" int mssvt_window_plan_two(
     int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
     int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
     int num_win1, int num_win2, const int *vox_query_odd, const int *vox_query_even,
@@ -682,7 +666,7 @@ static int window_plan_two_impl(
     float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
     const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
     const int *win_counts_dev, int num_tabs, const int *host_tab_list, const int *host_tab_interp,
-    const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, int order_groups, int *order_hist, void *stream) {
+    const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, void *stream) {
     if (!win_indices || !num_wins_dev || !v_bs_cnt || !ind_odd || !ind_even ||
         !ind_win1 || !k_ind1 || !k_ind2 || !k_mask1 || !k_mask2 || !win_vstart || !owner_win1 ||
         !owner_odd || !owner_even || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
@@ -743,8 +727,6 @@ static int window_plan_two_impl(
     a.win_counts = win_counts_dev;
     a.n_tabs = 0;
     a.tab_q = 0;
-    a.order_hist = order_groups > 1 ? order_hist : nullptr;
-    a.order_groups = order_groups;
     if (num_tabs < 0 || num_tabs > 4) return MSSVT_E_TOOLARGE;
     if (num_tabs > 0) {
         if (!kmeta1 || !host_tab_list || !host_tab_interp || !host_tab_zero_row || !host_tab_row || !host_tab_w) return MSSVT_E_BADARG;
@@ -813,40 +795,6 @@ static int window_plan_two_impl(
     return mssvt_launch_status();
 }
 
-extern "C" int mssvt_window_plan_two(
-    int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
-    int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
-    int num_win1, int num_win2, const int *vox_query_odd, const int *vox_query_even,
-    const int *vox_query_win1, const int *vox_query_win2, int key_num_sample, const int *win_indices,
-    const int *num_wins_dev, int win_capacity, const int *xyz_to_vidx, const int *v_bs_cnt,
-    int *ind_odd, int *ind_even, int *ind_win1, int *k_ind1, int *k_ind2, unsigned char *k_mask1,
-    unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
-    const int *indices, const float *host_voxel_size3, const float *host_range_min3,
-    const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
-    float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
-    const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
-    const int *win_counts_dev, int num_tabs, const int *host_tab_list, const int *host_tab_interp,
-    const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, void *stream) {
-    return window_plan_two_impl(x_max, y_max, z_max, x_ws, y_ws, z_ws, max_num_odd, max_num_even, max_num_win1, max_num_win2, hash_size, batch_size, num_odd, num_even, num_win1, num_win2, vox_query_odd, vox_query_even, vox_query_win1, vox_query_win2, key_num_sample, win_indices, num_wins_dev, win_capacity, xyz_to_vidx, v_bs_cnt, ind_odd, ind_even, ind_win1, k_ind1, k_ind2, k_mask1, k_mask2, win_vstart, owner_win1, owner_odd, owner_even, indices, host_voxel_size3, host_range_min3, host_win_size3, qmeta_odd, qmeta_even, qmeta_win1, kmeta1, kmeta2, wcentre, nq_valid, occ_columns, host_footprint4, packed_offsets, column_vbase, level_status_dev, win_counts_dev, num_tabs, host_tab_list, host_tab_interp, host_tab_zero_row, host_tab_row, host_tab_w, 0, nullptr, stream);
-}
-
-extern "C" int mssvt_window_plan_two_hist(
-    int x_max, int y_max, int z_max, int x_ws, int y_ws, int z_ws, int max_num_odd, int max_num_even,
-    int max_num_win1, int max_num_win2, int hash_size, int batch_size, int num_odd, int num_even,
-    int num_win1, int num_win2, const int *vox_query_odd, const int *vox_query_even,
-    const int *vox_query_win1, const int *vox_query_win2, int key_num_sample, const int *win_indices,
-    const int *num_wins_dev, int win_capacity, const int *xyz_to_vidx, const int *v_bs_cnt,
-    int *ind_odd, int *ind_even, int *ind_win1, int *k_ind1, int *k_ind2, unsigned char *k_mask1,
-    unsigned char *k_mask2, int *win_vstart, int *owner_win1, int *owner_odd, int *owner_even,
-    const int *indices, const float *host_voxel_size3, const float *host_range_min3,
-    const float *host_win_size3, float *qmeta_odd, float *qmeta_even, float *qmeta_win1, float *kmeta1,
-    float *kmeta2, float *wcentre, int *nq_valid, const unsigned long long *occ_columns,
-    const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
-    const int *win_counts_dev, int num_tabs, const int *host_tab_list, const int *host_tab_interp,
-    const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, int order_groups, int *order_hist, void *stream) {
-    return window_plan_two_impl(x_max, y_max, z_max, x_ws, y_ws, z_ws, max_num_odd, max_num_even, max_num_win1, max_num_win2, hash_size, batch_size, num_odd, num_even, num_win1, num_win2, vox_query_odd, vox_query_even, vox_query_win1, vox_query_win2, key_num_sample, win_indices, num_wins_dev, win_capacity, xyz_to_vidx, v_bs_cnt, ind_odd, ind_even, ind_win1, k_ind1, k_ind2, k_mask1, k_mask2, win_vstart, owner_win1, owner_odd, owner_even, indices, host_voxel_size3, host_range_min3, host_win_size3, qmeta_odd, qmeta_even, qmeta_win1, kmeta1, kmeta2, wcentre, nq_valid, occ_columns, host_footprint4, packed_offsets, column_vbase, level_status_dev, win_counts_dev, num_tabs, host_tab_list, host_tab_interp, host_tab_zero_row, host_tab_row, host_tab_w, order_groups, order_hist, stream);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Occupancy columns of a voxel set: one 64-bit word per (b, x, y), bit z = the cell holds a voxel
 // (z_max <= 64).  1.8 MB for a 470 x 470 grid: L2 resident.
@@ -889,6 +837,7 @@ int mssvt_occupancy_columns_launch(const int *indices, int num_voxels, int batch
 // arbitrary, which is harmless: every window writes only its own rows).
 // ---------------------------------------------------------------------------------------------
 #define PO_WAVES 16
+#define PO_KEYS 257
 #define PO_V 8  // window batches of 64 in flight per wave (one global-load latency per PO_V batches)
 #define PO_MAX_SETS 4
 struct PlanOrderSet {
@@ -898,7 +847,6 @@ struct PlanOrderSet {
     int *perm, *num_active, *q_off, *num_rows;
     float4 *rmeta;
     int2 *rsrc;
-    const int *hist;  // optional: the PHASE 0 histograms, counted by the plan kernel (mssvt_window_plan_two_hist)
 };
 struct PlanOrderPack {
     PlanOrderSet s[PO_MAX_SETS];
@@ -917,7 +865,6 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
     const int max_key = ps.max_key;
     const int G = gridDim.x, gidx = blockIdx.x;
     int *scratch = reinterpret_cast<int *>(ps.rsrc);
-    const int *hsrc = ps.hist ? ps.hist : scratch;
     int *perm = ps.perm, *num_active = ps.num_active, *q_off = ps.q_off, *num_rows = ps.num_rows;
     // per-wave histograms: copies sit PO_KEYS (odd) words apart -> different LDS banks, so the 16
     // waves' atomics on the few populated keys proceed in parallel
@@ -971,7 +918,7 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
     if (threadIdx.x <= max_key) {
         int run = 0, all = 0;
         for (int gg = 0; gg < G && G > 1; ++gg) {
-            const int c = hsrc[gg * (PO_KEYS + 1) + threadIdx.x];
+            const int c = scratch[gg * (PO_KEYS + 1) + threadIdx.x];
             run += gg < gidx ? c : 0;
             all += c;
         }
@@ -987,7 +934,7 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
     if (threadIdx.x == PO_WAVES * MSSVT_WAVE - 1) {
         int before = 0, all = 0;
         for (int gg = 0; gg < G && G > 1; ++gg) {
-            const int c = hsrc[gg * (PO_KEYS + 1) + PO_KEYS];
+            const int c = scratch[gg * (PO_KEYS + 1) + PO_KEYS];
             before += gg < gidx ? c : 0;
             all += c;
         }
@@ -1071,21 +1018,11 @@ __global__ void __launch_bounds__(256) k_query_rows(const int *num_wins, int row
     }
 }
 
-static int plan_order_groups(int win_capacity, int row_capacity) {
-    // workgroups per list: one per ~2k windows of capacity, as long as their histograms fit the head of the row array
-    int G = win_capacity / 2048;
-    if (G > 64) G = 64;
-    while (G > 1 && (long long)G * (PO_KEYS + 1) > 2LL * row_capacity) --G;
-    return G < 1 ? 1 : G;
-}
-
-extern "C" int mssvt_plan_order_groups(int win_capacity, int row_capacity) { return plan_order_groups(win_capacity, row_capacity); }
-
-static int plan_order_impl(int num_sets, const int *num_wins_dev, const int *const *host_nq_valid,
-                           const int *host_nq, const float *const *host_qmeta, int win_capacity,
-                           int row_capacity, int *const *host_perm, int *const *host_num_active,
-                           int *const *host_q_off, float *const *host_qrow_meta,
-                           int *const *host_qrow_src, int *const *host_num_rows, const int *const *host_hist, void *stream) {
+extern "C" int mssvt_plan_order_multi(int num_sets, const int *num_wins_dev, const int *const *host_nq_valid,
+                                      const int *host_nq, const float *const *host_qmeta, int win_capacity,
+                                      int row_capacity, int *const *host_perm, int *const *host_num_active,
+                                      int *const *host_q_off, float *const *host_qrow_meta,
+                                      int *const *host_qrow_src, int *const *host_num_rows, void *stream) {
     if (num_sets <= 0 || num_sets > PO_MAX_SETS) return num_sets <= 0 ? MSSVT_E_BADARG : MSSVT_E_TOOLARGE;
     if (!num_wins_dev || !host_nq_valid || !host_nq || !host_qmeta || !host_perm || !host_num_active || !host_q_off ||
         !host_qrow_meta || !host_qrow_src || !host_num_rows || win_capacity <= 0 || row_capacity <= 0)
@@ -1105,13 +1042,13 @@ static int plan_order_impl(int num_sets, const int *num_wins_dev, const int *con
         ps.num_rows = host_num_rows[k];
         ps.rmeta = reinterpret_cast<float4 *>(host_qrow_meta[k]);
         ps.rsrc = reinterpret_cast<int2 *>(host_qrow_src[k]);
-        ps.hist = host_hist ? host_hist[k] : nullptr;
-        if (host_hist && !host_hist[k]) return MSSVT_E_BADARG;
     }
-    const int G = plan_order_groups(win_capacity, row_capacity);
+    // workgroups per list: one per ~2k windows of capacity, as long as their histograms fit the head of the row array
+    int G = win_capacity / 2048;
+    if (G > 64) G = 64;
+    while (G > 1 && (long long)G * (PO_KEYS + 1) > 2LL * row_capacity) --G;
     if (G > 1) {
-        if (!host_hist)  // (else the plan kernel counted them: mssvt_window_plan_two_hist)
-            k_plan_order<0><<<dim3(G, num_sets), PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
+        k_plan_order<0><<<dim3(G, num_sets), PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
         k_plan_order<1><<<dim3(G, num_sets), PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
     } else {
         k_plan_order<1><<<dim3(1, num_sets), PO_WAVES * MSSVT_WAVE, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
@@ -1120,24 +1057,6 @@ static int plan_order_impl(int num_sets, const int *num_wins_dev, const int *con
     if (grid > 4096) grid = 4096;
     k_query_rows<<<dim3(grid, num_sets), 256, 0, (hipStream_t)stream>>>(num_wins_dev, row_capacity, pack);
     return mssvt_launch_status();
-}
-
-extern "C" int mssvt_plan_order_multi(int num_sets, const int *num_wins_dev, const int *const *host_nq_valid,
-                                      const int *host_nq, const float *const *host_qmeta, int win_capacity,
-                                      int row_capacity, int *const *host_perm, int *const *host_num_active,
-                                      int *const *host_q_off, float *const *host_qrow_meta,
-                                      int *const *host_qrow_src, int *const *host_num_rows, void *stream) {
-    return plan_order_impl(num_sets, num_wins_dev, host_nq_valid, host_nq, host_qmeta, win_capacity, row_capacity, host_perm,
-                           host_num_active, host_q_off, host_qrow_meta, host_qrow_src, host_num_rows, nullptr, stream);
-}
-
-extern "C" int mssvt_plan_order_multi_hist(int num_sets, const int *num_wins_dev, const int *const *host_nq_valid,
-                                           const int *host_nq, const float *const *host_qmeta, int win_capacity,
-                                           int row_capacity, int *const *host_perm, int *const *host_num_active,
-                                           int *const *host_q_off, float *const *host_qrow_meta, int *const *host_qrow_src,
-                                           int *const *host_num_rows, const int *const *host_hist, void *stream) {
-    return plan_order_impl(num_sets, num_wins_dev, host_nq_valid, host_nq, host_qmeta, win_capacity, row_capacity, host_perm,
-                           host_num_active, host_q_off, host_qrow_meta, host_qrow_src, host_num_rows, host_hist, stream);
 }
 
 extern "C" int mssvt_plan_order(const int *num_wins_dev, const int *nq_valid, int nq, const float *qmeta,
