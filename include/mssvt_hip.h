@@ -220,7 +220,8 @@ int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_ma
 /* mssvt_level_setup_sorted that also writes the K4 lists of partition `pillar_set` -- pillar windows [1,1,z], offsets of
  * vox_query_win1 (num_win1 <= 64 rows) with x = y = 0 -- i.e. the outputs of mssvt_window_plan_one(disjoint_lists = 2,
  * with_pad = 0) for that partition (k_ind (cap,max_num_win1), win_vstart, win_cnt, pair_base (cap), pair_win / pair_vox (N);
- * pair_win pre-filled with -1; pair_base / pair_vox may be NULL: mssvt_compress_fused reads neither): every such window is a slab of ONE column's occupancy word, so its list falls out where
+ * pair_win AND k_ind pre-filled with -1 -- only listed slots are written --; pair_base / pair_vox may be NULL:
+ * mssvt_compress_fused reads neither; table z offsets in [-32, 31]): every such window is a slab of ONE column's occupancy word, so its list falls out where
  * the window is numbered, without a launch of its own (ref gather_one_window_voxels, ms_sparse_attention_gpu.cu:383-433).
  * MSSVT_E_TOOLARGE: the partition's windows are not pillars.                                                        */
 int mssvt_level_setup_sorted_pillars(

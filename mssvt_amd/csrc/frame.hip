@@ -207,6 +207,7 @@ void make_layout(const Frame &f, int n, char *base, Layout &L) {
     L.owners = b.take<int>(ints_al(3 * cap));
     L.tab_rows = b.take<int>(ints_al((size_t)L.n_tabs * N * 4));
     L.pair_win = b.take<int>(ints_al(cap));
+    L.c_k_ind = b.take<int>(ints_al(cap * (size_t)(f.has_cmp ? f.cmp.ns : 1)));  // (the level set-up writes the listed slots only)
     b.off = al256(b.off);
     L.neg_ints = (size_t)(b.base + b.off - reinterpret_cast<char *>(L.neg0)) / 4;
     // work orders (fused._work_order / prepare_group): row capacity = max over the patterns of min(N * overlap, cap * nq)
@@ -281,7 +282,6 @@ void make_layout(const Frame &f, int n, char *base, Layout &L) {
         L.xh[i] = b.take<float>(N * C);
     }
     // CompressBlock
-    L.c_k_ind = b.take<int>(cap * (size_t)(f.has_cmp ? f.cmp.ns : 1));
     L.c_win_vstart = b.take<int>(cap);
     L.c_win_cnt = b.take<int>(cap);
     L.c_pair_base = b.take<int>(cap);

@@ -172,3 +172,62 @@ def test_frame_call_hash_overflow_is_loud(monkeypatch):
     with pytest.raises(MssvtHipError), torch.no_grad():
         net(dict(voxel_features=feats, voxel_coords=vc, batch_size=1))
     torch.cuda.synchronize()
+
+
+def test_pillar_lists_inside_the_level_setup_equal_the_plan_kernel():
+    """mssvt_level_setup_sorted_pillars (the CompressBlock's K4 lists written where k_col_emit numbers the window) against
+    mssvt_level_setup_sorted + mssvt_window_plan_one: k_ind / win_vstart / win_cnt / pair_win bit-identical."""
+    import ctypes
+    from mssvt_amd import _lib, fused, mssvt_ops
+    from mssvt_amd.mssvt_utils import SparseTensor
+    net = _net()
+    B = 3
+    feats, vc = _scene(30000, B, 31)
+    cmp_blk = net.backbone[-1]
+    with torch.no_grad():
+        # reference: the Python-driven path's level + one_scale_plan
+        sp = fused.setup_input_level(net.backbone, dict(features=feats, indices=vc.int().contiguous(), spatial_shape=net.grid_size,
+                                                        voxel_size=net.voxel_size, point_cloud_range=net.point_cloud_range,
+                                                        batch_size=B, hash_size=net.hash_size, gather_dict=None))
+        assert sp is not None and sp._level.get("sorted")
+        p = fused.one_scale_plan(cmp_blk, sp, sync=False)
+        p.host_ev.synchronize()
+        nw = p.host_words()[1]
+        assert p.disjoint == 2 and nw > 1000
+        # the merged form, fresh buffers
+        n = vc.shape[0]
+        X, Y, Z = (int(v) for v in net.grid_size)
+        H = int(net.hash_size)
+        dev = feats.device
+        blk = net.backbone[0]
+        al = lambda v: (int(v) + 63) // 64 * 64  # noqa: E731
+        sizes = [64, 128, al(B + 1), 2 * B * X * Y]
+        offs = [sum(sizes[:i]) for i in range(4)]
+        zero = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
+        i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)  # noqa: E731
+        cnt, vbase = i32(B), i32(B * X * Y)
+        scratch = i32(int(_lib.lib().mssvt_level_sorted_scratch_ints(B, X, Y)))
+        wins = [i32(n, 4), i32(n, 4)]
+        table = torch.full((B, H, 2), -1, dtype=torch.int32, device=dev)
+        vcounts = i32(2, B)
+        ns = cmp_blk.max_num_win1
+        k_ind, vstart, wcnt = torch.full((n, ns), -1, dtype=torch.int32, device=dev), i32(n), i32(n)
+        pair_win = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        t1 = cmp_blk._tables_on(dev)['win1']
+        ia = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])  # noqa: E731
+        pa = lambda ts: (ctypes.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
+        parts = [blk, cmp_blk]
+        _lib.call("mssvt_level_setup_sorted_pillars", n, B, X, Y, Z, H, vc.int().contiguous().data_ptr(), zero.data_ptr(),
+                  ctypes.c_longlong(-zero.numel() * 4), cnt.data_ptr(), zero[offs[2]:].data_ptr(), zero[offs[3]:].data_ptr(),
+                  vbase.data_ptr(), zero.data_ptr(), 2, ia([[X, Y, Z][i] // b.win1_size[i] for b in parts for i in range(3)]),
+                  ia([w for b in parts for w in b.win1_size]), ia([b.max_num_wins for b in parts]), pa(wins), pa([None, table]),
+                  pa([vcounts[0], vcounts[1]]), pa([zero[64:128], zero[128:192]]), scratch.data_ptr(), 1, ns, int(t1.shape[0]),
+                  t1.data_ptr(), k_ind.data_ptr(), vstart.data_ptr(), wcnt.data_ptr(), None, pair_win.data_ptr(), None,
+                  _lib.stream())
+        torch.cuda.synchronize()
+        assert int(zero[129]) == nw and int(zero[0]) == 0
+        assert torch.equal(wins[1][:nw], p.win_ind[:nw])
+        assert torch.equal(k_ind[:nw], p.k_ind[:nw])
+        assert torch.equal(vstart[:nw], p.win_vstart[:nw]) and torch.equal(wcnt[:nw], p.win_cnt[:nw])
+        assert torch.equal(pair_win, p.pair_win[:n])
+        assert torch.equal(table, p.win_table)
