@@ -443,6 +443,27 @@ int mssvt_compress_fused(
     const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
     float *qp, float *ktok, float *score, float *vp, float *out, int split_f16, void *stream);
 
+/* The same attention (same inputs, same `out`) in ONE launch and without any scratch, for the case the detector runs:
+ * a level set up as SORTED (mssvt_level_setup_sorted*: windows are numbered in row order), pillar windows x_ws = y_ws = 1
+ * (window cell = (x, y, z / z_ws): the window rows are not read) whose lists cannot be truncated (z_ws <= max_num_win1 <= 32),
+ * so that every window is one run of consecutive voxel rows and
+ * consecutive windows are consecutive runs; one head group, head_dim 16, C = 128; split-fp16 products (the caller
+ * guarantees the fp16 range exactly as for mssvt_compress_fused(split_f16 = 1)).  One workgroup per CU keeps pos_proj.2, Wk
+ * and Wv as MFMA fragments in registers (wave h = head h), Wq / Wo in LDS; the key tokens, K, V, the scores and the
+ * projected queries never leave the CU (csrc/compress_ws.hip).  packed: mssvt_compress_ws_packed_bytes(C) bytes written by
+ * mssvt_compress_ws_pack from pos_proj.2 (C,C), to_q (C,C), to_kv (2C,C), proj (C,C) -- once per parameter version.
+ * MSSVT_E_TOOLARGE: shape not covered (use mssvt_compress_fused).  Deterministic; differs from mssvt_compress_fused by the
+ * association of the softmax sums only.                                                                              */
+long long mssvt_compress_ws_packed_bytes(int C);
+int mssvt_compress_ws_pack(int C, const float *Wpos2, const float *Wq, const float *Wkv, const float *Wo, void *packed,
+                           void *stream);
+int mssvt_compress_ws(int C, int head_dim, float scale, int z_ws, int max_num_win1, int num_voxels, const int *num_wins_dev,
+                      int win_capacity, const int *indices, const int *k_ind, const int *win_vstart, const int *win_cnt,
+                      const int *pair_win, const float *host_voxel_size3, const float *host_range_min3,
+                      const float *host_win_size3, const float *xhat, const float *Wpos1, const float *bpos1,
+                      const float *bpos2, const float *bq, const float *bkv, const float *bo, const void *packed, float *out,
+                      void *stream);
+
 /* Backward of mssvt_layer_norm (training path; autograd's LayerNorm backward in the reference): dx (N,C), dweight (C),
  * dbias (C) from x, dy; mean / rstd are recomputed.  The column sums are per-workgroup partial rows in `workspace`
  * (512 * 2 * C floats) added in workgroup order: deterministic.  C in {16,32,64,128,256}.                      */
@@ -660,13 +681,15 @@ int mssvt_frame_add_block(
     const void *ffn_packed);
 /* The MixedScaleSparseTransformerCompressBlock that ends the level (ref mssvt_backbone.py:349-398): pillar windows
  * [1,1,z] whose offset table stays inside the window (one lane per window in the plan kernel), one head group;
- * arguments of mssvt_window_plan_one / mssvt_compress_fused / mssvt_ffn_fused.                                   */
+ * arguments of mssvt_window_plan_one / mssvt_compress_fused / mssvt_ffn_fused.  compress_ws_packed: the fragments of
+ * mssvt_compress_ws_pack when the caller has checked mssvt_compress_ws's preconditions (the table lists every cell of
+ * the slab, fp16 range) -- the attention is then that one launch -- or NULL.                                          */
 int mssvt_frame_add_compress(
     void *frame, const int *host_win_size3, int max_num_win1, int num_win1, const int *vox_query_win1, int max_num_wins,
     const float *norm1_w, const float *norm1_b, float norm1_eps, const float *Wpos1, const float *bpos1, const float *Wpos2,
     const float *bpos2, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
     int head_dim, float scale, int split_f16, const float *norm2_w, const float *norm2_b, float norm2_eps, const float *W1,
-    const float *b1, const float *W2, const float *b2, const void *ffn_packed);
+    const float *b1, const float *W2, const float *b2, const void *ffn_packed, const void *compress_ws_packed);
 /* on != 0: the first norm1 and the CompressBlock's pillar plan run on a stream of the frame object, under the Blocks'
  * plan kernel (two event edges per frame; results unchanged).                                                     */
 int mssvt_frame_set_overlap(void *frame, int on);

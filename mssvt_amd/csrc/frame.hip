@@ -61,6 +61,7 @@ struct FrCompress {
     float n2eps;
     const float *W1, *b1, *W2, *b2;
     const void *ffn_packed;
+    const void *ws_packed;  // fragments of mssvt_compress_ws_pack, or null: mssvt_compress_fused
 };
 
 struct Frame {
@@ -432,7 +433,7 @@ extern "C" int mssvt_frame_add_compress(
     const float *norm1_w, const float *norm1_b, float norm1_eps, const float *Wpos1, const float *bpos1, const float *Wpos2,
     const float *bpos2, const float *Wq, const float *bq, const float *Wkv, const float *bkv, const float *Wo, const float *bo,
     int head_dim, float scale, int split_f16, const float *norm2_w, const float *norm2_b, float norm2_eps, const float *W1,
-    const float *b1, const float *W2, const float *b2, const void *ffn_packed) {
+    const float *b1, const float *W2, const float *b2, const void *ffn_packed, const void *compress_ws_packed) {
     Frame *f = as_frame(frame);
     if (!f || !f->level_set || !host_win_size3 || !vox_query_win1 || !norm1_w || !norm1_b || !Wpos1 || !bpos1 || !Wpos2 ||
         !bpos2 || !Wq || !bq || !Wkv || !bkv || !Wo || !bo || !norm2_w || !norm2_b || !W1 || !b1 || !W2 || !b2 || !ffn_packed)
@@ -450,6 +451,10 @@ extern "C" int mssvt_frame_add_compress(
     c.head_dim = head_dim; c.scale = scale; c.split_f16 = split_f16;
     c.n2w = norm2_w; c.n2b = norm2_b; c.n2eps = norm2_eps;
     c.W1 = W1; c.b1 = b1; c.W2 = W2; c.b2 = b2; c.ffn_packed = ffn_packed;
+    // one launch instead of three when the caller prepared the fragments (it has checked: every cell of the slab listed, fp16
+    // range) and no list can be truncated -- a window is then one run of rows of the sorted level
+    c.ws_packed = compress_ws_packed && f->C == 128 && head_dim == 16 && host_win_size3[2] <= max_num_win1 && max_num_win1 <= 32
+                      ? compress_ws_packed : nullptr;
     f->has_cmp = true;
     return MSSVT_OK;
 }
@@ -616,9 +621,15 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
     }
     // ---- CompressBlock: pillar plan, attention (three launches), FFN tail over the live windows
     const float cwsm[3] = {f->vs[0] * c.ws[0], f->vs[1] * c.ws[1], f->vs[2] * c.ws[2]};
-    FR_TRY(mssvt_compress_fused(C, c.head_dim, c.scale, c.ns, n, L.hdr[1] + 1, cap, out_indices, indices, L.c_k_ind, L.c_win_vstart,
-                                L.c_win_cnt, L.pair_win, f->vs, mn3, cwsm, xhat, c.Wp1, c.bp1, c.Wp2, c.bp2, c.Wq, c.bq, c.Wkv, c.bkv,
-                                c.Wo, c.bo, L.c_qp, L.c_ktok, L.c_score, L.c_vp, L.c_new, c.split_f16, stream));
+    if (c.ws_packed) {
+        FR_TRY(mssvt_compress_ws(C, c.head_dim, c.scale, c.ws[2], c.ns, n, L.hdr[1] + 1, cap, indices, L.c_k_ind, L.c_win_vstart,
+                                 L.c_win_cnt, L.pair_win, f->vs, mn3, cwsm, xhat, c.Wp1, c.bp1, c.bp2, c.bq, c.bkv, c.bo, c.ws_packed,
+                                 L.c_new, stream));
+    } else {
+        FR_TRY(mssvt_compress_fused(C, c.head_dim, c.scale, c.ns, n, L.hdr[1] + 1, cap, out_indices, indices, L.c_k_ind, L.c_win_vstart,
+                                    L.c_win_cnt, L.pair_win, f->vs, mn3, cwsm, xhat, c.Wp1, c.bp1, c.Wp2, c.bp2, c.Wq, c.bq, c.Wkv,
+                                    c.bkv, c.Wo, c.bo, L.c_qp, L.c_ktok, L.c_score, L.c_vp, L.c_new, c.split_f16, stream));
+    }
     FR_TRY(mssvt_ffn_fused(cap, C, FF, L.c_new, nullptr, nullptr, c.n2w, c.n2b, c.n2eps, c.W1, c.b1, c.W2, c.b2, out_features, nullptr,
                            nullptr, 0.f, nullptr, const_cast<float *>(reinterpret_cast<const float *>(c.ffn_packed)), L.hdr[1] + 1, 4,
                            stream));

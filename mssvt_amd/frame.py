@@ -155,13 +155,19 @@ def _build(net, dev, batch_size):
         return None
     t = blk._tables_on(dev)
     split = 1 if fused._compress_f16_ok(blk, stub) else 0
-    fr.keep += [t, ffr, ffn_packed]
+    # the one-launch attention of a sorted pillar level (csrc/compress_ws.hip): the table must list every cell of the slab
+    tz = t['win1'].cpu()
+    full = bool((tz[:, :2] == 0).all()) and len(set(int(z) for z in tz[:, 2])) == int(blk.win1_size[2]) and \
+        int(blk.win1_size[2]) <= int(blk.max_num_win1) <= 32
+    ws_packed = fused._compress_ws_weights(blk, stub) if fused.CMP_WS and full else None
+    fr.keep += [t, ffr, ffn_packed, ws_packed]
     _lib.call("mssvt_frame_add_compress", fr.handle, i3(blk.win1_size), int(blk.max_num_win1), int(t['win1'].shape[0]),
               P(t['win1']), int(blk.max_num_wins), P(blk.norm1.weight), P(blk.norm1.bias), float(blk.norm1.eps),
               P(blk.pos_proj[0].weight), P(blk.pos_proj[0].bias), P(blk.pos_proj[2].weight), P(blk.pos_proj[2].bias),
               P(ma.to_qs[0].weight), P(ma.to_qs[0].bias), P(ma.to_kvs[0].weight), P(ma.to_kvs[0].bias),
               P(ma.projs[0].weight), P(ma.projs[0].bias), int(ma.per_head_dim), float(ma.scale), split, P(ffr["lnw"]),
-              P(ffr["lnb"]), float(ffr["eps"]), P(ffr["W1"]), P(ffr["b1"]), P(ffr["W2"]), P(ffr["b2"]), P(ffn_packed))
+              P(ffr["lnb"]), float(ffr["eps"]), P(ffr["W1"]), P(ffr["b1"]), P(ffr["W2"]), P(ffr["b2"]), P(ffn_packed),
+              P(ws_packed))
     fr.overlap = None
     return fr
 
@@ -177,7 +183,7 @@ def _state(net, feats, batch_size):
         return None
     ps = st["params"]
     key = (feats.device, int(batch_size), OVERLAP, int(net.hash_size), tuple(int(v) for v in net.grid_size),
-           tuple(float(v) for v in net.voxel_size), tuple(float(v) for v in net.point_cloud_range), fused.FFN_ARITH, fused.ATTN_KV16, fused.ATTN_QO16,
+           tuple(float(v) for v in net.voxel_size), tuple(float(v) for v in net.point_cloud_range), fused.FFN_ARITH, fused.ATTN_KV16, fused.ATTN_QO16, fused.CMP_WS,
            tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps),
            tuple((getattr(b, "impl", None), getattr(b, "attn_dtype", "f32"), getattr(b, "ffn_arith", None),
                   getattr(b, "attn_kv16", None), getattr(b, "attn_qo16", None), b._table_sig,

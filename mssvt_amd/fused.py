@@ -1115,10 +1115,15 @@ def one_scale_plan(block, sp, sync=True):
         hi = torch.tensor([w - w // 2 - 1 for w in block.win1_size])
         tcpu = tw.cpu()
         dis = 1 if bool(((tcpu >= lo) & (tcpu <= hi)).all()) else 0
+        full = False
         if dis and bool((tcpu[:, :2] == 0).all()):
             dis = 2  # ... and every offset stays in the window's own (x, y) column (pillar windows: a lane per window)
-        cached = block._disjoint_cache = (tw, dis)
+            # ... and the table lists EVERY cell of the slab: a window of a sorted level is then one run of voxel rows
+            full = block.win1_size[0] == 1 and block.win1_size[1] == 1 and \
+                len(set(int(z) for z in tcpu[:, 2])) == block.win1_size[2]
+        cached = block._disjoint_cache = (tw, dis, full)
     p.disjoint = cached[1]
+    p.runs = bool(cached[2]) and block.win1_size[2] <= ns <= 32 and bool(st.get("sorted"))
     overlap = 1 if p.disjoint else 8
     row_cap = cap * overlap + (cap if p.with_pad else 0)
     p.k_ind = torch.empty((cap, ns), dtype=torch.int32, device=dev)
@@ -1272,6 +1277,31 @@ def _compress_f16_ok(block, sp):
     return cache["ok"]
 
 
+CMP_WS = os.environ.get("MSSVT_CMP_WS", "1") != "0"  # csrc/compress_ws.hip (sorted pillar levels); 0: compress_fused.hip
+
+
+@_no_grad
+def _compress_ws_weights(block, sp):
+    """The split-fp16 fragments of pos_proj.2 / to_q / to_kv / proj for mssvt_compress_ws (once per parameter version), or
+    None: shape not covered (C = 128, one head group of 16-channel heads), fp32 arithmetic asked for, or operands that may
+    leave the fp16 range."""
+    ma = block.ms_attn
+    C = block.linear1.in_features
+    if C != 128 or ma.num_head_groups != 1 or ma.per_head_dim != 16 or getattr(block, "ffn_arith", FFN_ARITH) != "f16x3":
+        return None
+    if not _compress_f16_ok(block, sp):
+        return None
+    ts = (block.pos_proj[2].weight, ma.to_qs[0].weight, ma.to_kvs[0].weight, ma.projs[0].weight)
+    ver = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + _content_key(ts)
+    cache = block.__dict__.setdefault("_cmp_ws_cache", {})
+    if cache.get("ver") != ver:
+        nbytes = int(_lib.lib().mssvt_compress_ws_packed_bytes(_i(C)))
+        packed = torch.empty((nbytes,), dtype=torch.uint8, device=ts[0].device)
+        _lib.call("mssvt_compress_ws_pack", _i(C), *[_lib.ptr(t.detach().contiguous()) for t in ts], _lib.ptr(packed), _lib.stream())
+        cache["packed"], cache["ver"] = packed, ver
+    return cache["packed"]
+
+
 @_no_grad
 def _compress_forward_fused(block, sp, xhat, x_in):
     """Four MFMA launches + the two FFN launches, all counts on the device; ONE host sync at the end
@@ -1287,6 +1317,16 @@ def _compress_forward_fused(block, sp, xhat, x_in):
     ma = block.ms_attn
     vs3, mn3, ws3 = _f3(sp.voxel_size), _f3(sp.point_cloud_range[0:3]), _f3(p.win_size_m)
     f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    packed = _compress_ws_weights(block, sp) if CMP_WS and getattr(p, "runs", False) else None
+    if packed is not None:
+        # a sorted pillar level: every window is a run of consecutive rows -> ONE launch, nothing handed through memory
+        new = f32(cap_w, C)
+        _lib.call("mssvt_compress_ws", _i(C), _i(ma.per_head_dim), _f(ma.scale), _i(block.win1_size[2]), _i(ns), _i(N),
+                  _P(p.num_wins), _i(cap_w), _P(sp.indices), _P(p.k_ind), _P(p.win_vstart), _P(p.win_cnt), _P(p.pair_win),
+                  vs3, mn3, ws3, _P(xhat), _P(block.pos_proj[0].weight), _P(block.pos_proj[0].bias),
+                  _P(block.pos_proj[2].bias), _P(ma.to_qs[0].bias), _P(ma.to_kvs[0].bias), _P(ma.projs[0].bias),
+                  _P(packed), _P(new), _lib.stream())
+        return _compress_fused_tail(block, sp, p, new)
     qp, ktok, score, vp, new = f32(cap_w, C), f32(max(N, 1), C), f32(max(N, 1), C // ma.per_head_dim), \
         f32(max(N, 1), C), f32(cap_w, C)
     _lib.call("mssvt_compress_fused", _i(C), _i(ma.per_head_dim), _f(ma.scale), _i(ns), _i(N), _P(p.num_wins),
@@ -1298,6 +1338,11 @@ def _compress_forward_fused(block, sp, xhat, x_in):
               _P(ma.to_kvs[0].bias), _P(ma.projs[0].weight), _P(ma.projs[0].bias),
               _P(qp), _P(ktok), _P(score), _P(vp), _P(new),
               _i(1 if getattr(block, "ffn_arith", FFN_ARITH) == "f16x3" and _compress_f16_ok(block, sp) else 0), _lib.stream())
+    return _compress_fused_tail(block, sp, p, new)
+
+
+def _compress_fused_tail(block, sp, p, new):
+    """FFN tail over the live windows + the forward's single host wait (the output shape)."""
     y = _ffn_tail(block, sp, new, n_rows_dev=p.num_wins, apply_out=False)  # no residual to the block input (ref :383-385)
     p.host_ev.synchronize()  # the forward's single host wait: the output shape (copied out long ago)
     host = p.host_words()
