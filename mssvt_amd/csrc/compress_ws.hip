@@ -129,134 +129,25 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
 #ifdef CW_STAMPS
     unsigned long long cs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cs_t = __builtin_readcyclecounter();
 #endif
-    constexpr int NW = C / 16, NP = C / 32, LPR = C / 4, RPW = MSSVT_WAVE / LPR, FR = NP * 2 * 64;  // FR: h16x8 per fragment set
+    constexpr int NW = C / 16, NP = C / 32, LPR = C / 4, RPW = MSSVT_WAVE / LPR, FR = NP * 2 * 64, T = NW * MSSVT_WAVE;
     static_assert(NW * RPW == 16 && (LPR == 32 || LPR == 16 || LPR == 8), "16 rows per pass of the row-wise view");
     extern __shared__ float4 lds4[];
     h16x8 *wq_l = reinterpret_cast<h16x8 *>(lds4);  // [wave][P][hi | lo][lane]
     h16x8 *wo_l = wq_l + NW * FR;
     h16x8 *hfrag = wo_l + NW * FR;                  // B operands of the pos_proj.2 product
-    h16x8 *kfrag = hfrag + FR;                      // ... of the K / V products
+    h16x8 *kfrag = hfrag + FR;                      // ... of the K / V products (and of the Wq product at a group switch)
     h16x8 *ofrag = kfrag + FR;                      // ... of the Wo product
-    // keys of the channel-wise max of the NEXT tile's windows, [16 windows][C]; channel c of window w sits at
+    // keys of the channel-wise max of the NEXT group's windows, [16 windows][C]; channel c of window w sits at
     // w C + ((c + 4 w) mod C): the 16 windows of a fragment read start in different banks
     int *qmax = reinterpret_cast<int *>(ofrag + FR);
 #define CW_QSLOT(w_, c_) ((w_) * C + (((c_) + 4 * (w_)) & (C - 1)))
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / MSSVT_WAVE);
     const int r = wv * RPW + lane / LPR, q = lane % LPR;  // row-wise view: row of a 16-row pass, channels [4 q, 4 q + 4)
-    const int nw = *a.num_wins, tiles = (nw + 15) >> 4;
-    if (tiles <= 0) return;
-    // ---- this workgroup's tiles: a CONTIGUOUS range holding ~1 / gridDim of the COST.  16 rows of a run cost ~5000 clocks, the
-    // per-tile steps (Q, O, their barriers) ~2500 per 16 windows, and a tile holds 16 to 130 rows at 160k points (dealt
-    // round-robin the busiest CU carries 1.5 x the mean; split by rows alone, the CUs of the sparse far field get 18
-    // tiles instead of 8): cost before row r = 8 r + 5 pair_win[r] (windows are numbered in row order), range c starts
-    // at the first tile boundary at or after cost c total / gridDim.  Found by one probe per thread + one scan of the
-    // bracket: two dependent loads, no prefix sums.  (Any f(c) with f(0) = 0, f(grid) = tiles covers every tile.)
-    int tile, tile_end;
-    {
-        int *ps = qmax;  // [probes | 2 results | 2 brackets]
-        const int T = NW * MSSVT_WAVE, n = a.num_voxels;
-        const int ri = (int)((long long)threadIdx.x * n / T);
-        ps[threadIdx.x] = 8 * ri + 5 * max(a.pair_win[min(ri, n - 1)], 0);
-        if (threadIdx.x < 2) {
-            ps[T + threadIdx.x] = 0x7FFFFFFF;
-            ps[T + 2 + threadIdx.x] = -1;
-        }
-        __syncthreads();
-        const long long total = 8ll * n + 5ll * nw;
-        long long tgt[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            tgt[e] = total * ((int)blockIdx.x + e) / (int)gridDim.x;
-            if (ps[threadIdx.x] < tgt[e] && (threadIdx.x == T - 1 || ps[threadIdx.x + 1] >= tgt[e])) ps[T + 2 + e] = threadIdx.x;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int b = ps[T + 2 + e];
-            if (b < 0) continue;  // (target at or below the first probe: boundary 0)
-            const int lo = (int)((long long)b * n / T), hi = b + 1 < T ? (int)((long long)(b + 1) * n / T) + 1 : n;
-            for (int row = lo + threadIdx.x; row < min(hi, n); row += T) {
-                const int pw = a.pair_win[row];
-                if (pw >= 0 && 8ll * row + 5ll * pw >= tgt[e]) atomicMin(ps + T + e, pw);
-            }
-        }
-        __syncthreads();
-        int ends[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int cc = (int)blockIdx.x + e, w = ps[T + e];
-            ends[e] = cc <= 0 ? 0 : cc >= (int)gridDim.x ? tiles : ps[T + 2 + e] < 0 ? 0 : w == 0x7FFFFFFF ? tiles : min((w + 15) >> 4, tiles);
-        }
-        tile = ends[0];
-        tile_end = ends[1];
-        __syncthreads();  // (the scratch becomes the max tile)
-    }
-    if (tile >= tile_end) return;
+    const int nw = *a.num_wins, n = a.num_voxels;
+    if (nw <= 0) return;
 
-    // ---- the run of rows of a tile: [first row of its first window, last row of its last window] -----------------------
-    // lanes 0-31: the K4 list of the first window, lanes 32-63: of the last one (k_ind is -1 beyond the list): three
-    // independent loads, issued a tile ahead and reduced when needed
-    int run_v = 0, run_c = 0, run_s = 0;
-#define CW_RUN_ISSUE(tile_)                                                                                   \
-    {                                                                                                         \
-        const int t_ = min((tile_), tiles - 1), w0_ = t_ * 16;                                                \
-        const int w_ = lane < 32 ? w0_ : min(w0_ + 15, nw - 1);                                               \
-        run_c = a.win_cnt[w_];                                                                                \
-        run_s = a.win_vstart[w_];                                                                             \
-        run_v = (lane & 31) < a.ns ? a.k_ind[(size_t)w_ * a.ns + (lane & 31)] : -1;                           \
-    }
-#define CW_RUN_TAKE(r0_, r1_)                                                                                 \
-    {                                                                                                         \
-        int v_ = run_v < 0 ? 0x7FFFFFFF : run_v;                                                              \
-        _Pragma("unroll") for (int off_ = 1; off_ < 32; off_ <<= 1) v_ = min(v_, __shfl_xor(v_, off_));       \
-        r0_ = __builtin_amdgcn_readlane(run_s + v_, 0);                                                       \
-        r1_ = __builtin_amdgcn_readlane(run_s + v_ + run_c, 32);                                              \
-        if (r1_ < r0_ || r0_ < 0 || r1_ > a.num_voxels) r1_ = r0_ = 0; /* (only after a table overflow) */     \
-    }
-    // one pass of the channel-wise max: rows [rb_, rb_ + 32) of a run ending at re_ -> qmax (windows of the tile at w0_)
-#define CW_MAX_LOAD(rb_, re_)                                                                                 \
-    {                                                                                                         \
-        const int ra_ = (rb_) + r, rc_ = (rb_) + 16 + r;                                                      \
-        mxa = mxb = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
-        mpa = mpb = -1;                                                                                       \
-        if (ra_ < (re_)) {                                                                                    \
-            mxa = *reinterpret_cast<const float4 *>(a.xhat + (size_t)ra_ * C + 4 * q);                        \
-            mpa = a.pair_win[ra_];                                                                            \
-        }                                                                                                     \
-        if (rc_ < (re_)) {                                                                                    \
-            mxb = *reinterpret_cast<const float4 *>(a.xhat + (size_t)rc_ * C + 4 * q);                        \
-            mpb = a.pair_win[rc_];                                                                            \
-        }                                                                                                     \
-    }
-#define CW_MAX_PUT(w0_, nwt_)                                                                                 \
-    {                                                                                                         \
-        if ((unsigned int)(mpa - (w0_)) < (unsigned int)(nwt_)) {                                             \
-            const int w_ = mpa - (w0_);                                                                       \
-            atomicMax(qmax + CW_QSLOT(w_, 4 * q), cw_key(mxa.x)); atomicMax(qmax + CW_QSLOT(w_, 4 * q + 1), cw_key(mxa.y)); \
-            atomicMax(qmax + CW_QSLOT(w_, 4 * q + 2), cw_key(mxa.z)); atomicMax(qmax + CW_QSLOT(w_, 4 * q + 3), cw_key(mxa.w)); \
-        }                                                                                                     \
-        if ((unsigned int)(mpb - (w0_)) < (unsigned int)(nwt_)) {                                             \
-            const int w_ = mpb - (w0_);                                                                       \
-            atomicMax(qmax + CW_QSLOT(w_, 4 * q), cw_key(mxb.x)); atomicMax(qmax + CW_QSLOT(w_, 4 * q + 1), cw_key(mxb.y)); \
-            atomicMax(qmax + CW_QSLOT(w_, 4 * q + 2), cw_key(mxb.z)); atomicMax(qmax + CW_QSLOT(w_, 4 * q + 3), cw_key(mxb.w)); \
-        }                                                                                                     \
-    }
-    // initial keys of a tile's windows: 0 (= key(0.0f): the zero padding takes part, ref :370) unless the list is full
-#define CW_MAX_INIT(w0_, nwt_)                                                                                \
-    {                                                                                                         \
-        const int w_ = threadIdx.x / LPR; /* NW * 64 / LPR = 16 windows */                                    \
-        const int cnt_ = a.win_cnt[min((w0_) + w_, nw - 1)];                                                  \
-        const int init_ = w_ < (nwt_) && cnt_ >= a.ns ? cw_key(-INFINITY) : 0;                                \
-        *reinterpret_cast<int4 *>(qmax + w_ * C + 4 * q) = make_int4(init_, init_, init_, init_);             \
-    }
-    float4 mxa, mxb;
-    int mpa, mpb;
-
-    int r0, r1, nr0 = 0, nr1 = 0;
-    CW_RUN_ISSUE(tile)
-    CW_MAX_INIT(tile * 16, min(16, nw - tile * 16))
-    // ---- weights ---------------------------------------------------------------------------------------------------
+    // ---- weights (requested first: they travel under the search below) ---------------------------------------------------
     h16x8 Wph[NP], Wpl[NP], Wkh[NP], Wkl[NP], Wvh[NP], Wvl[NP];
     {
         const h16x8 *src = packed + (size_t)wv * FR + lane;
@@ -269,23 +160,85 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
             Wvh[P] = src[(size_t)2 * NW * FR + (P * 2) * 64];
             Wvl[P] = src[(size_t)2 * NW * FR + (P * 2 + 1) * 64];
         }
-        // Wq | Wo fragments of every wave -> LDS, lane-linear (2 NW FR x 16 bytes)
-        const h16x8 *s2 = packed + (size_t)3 * NW * FR;
-        constexpr int UN = 8;
-        for (int e0 = threadIdx.x; e0 < 2 * NW * FR; e0 += NW * MSSVT_WAVE * UN) {
-            h16x8 v[UN];
+    }
+    // Wq | Wo fragments of every wave -> LDS, lane-linear (2 NW FR x 16 bytes): all 16 requests of a thread in flight at once,
+    // written to LDS after the search's first exchange (its latency covers theirs)
+    constexpr int WCP = 2 * NW * FR / T;  // 16
+    h16x8 wcp[WCP];
+    {
+        const h16x8 *s2 = packed + (size_t)3 * NW * FR + threadIdx.x;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int e = e0 + u * NW * MSSVT_WAVE;
-                v[u] = s2[e < 2 * NW * FR ? e : 0];
-            }
+        for (int u = 0; u < WCP; ++u) wcp[u] = s2[u * T];
+    }
+    // ---- this workgroup's CHUNK: consecutive windows [Wa, Wb) = consecutive rows [Ra, Rb) holding 1 / gridDim of the cost
+    // (cost before row r = 8 r + 5 pair_win[r]: 16 rows cost ~5000 clocks, the per-group steps ~2500 per 16 windows; windows are
+    // numbered in row order).  4096 probes -> the first probe at or above c total / gridDim -> the next window START at or
+    // after it.  Every workgroup evaluates both of its ends with the same function: the chunks tile the level.
+    int Wa, Wb, Ra, Rb;
+    {
+        constexpr int NPB = 8, NPROBE = NPB * T;
+        int *ps = reinterpret_cast<int *>(hfrag);  // [probes] (16 KB: hfrag | kfrag), results behind the max tile's start
+        static_assert(NPROBE * 4 <= 2 * FR * 16, "probes fit the two fragment sets");
+        int *res = qmax;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int e = e0 + u * NW * MSSVT_WAVE;
-                if (e < 2 * NW * FR) wq_l[e] = v[u];
+        for (int k = 0; k < NPB; ++k) {
+            const int idx = threadIdx.x + k * T, row = (int)((long long)idx * n / NPROBE);
+            ps[idx] = 8 * row + 5 * max(a.pair_win[row], 0);
+        }
+        if (threadIdx.x < 2) res[threadIdx.x] = NPROBE;
+#pragma unroll
+        for (int u = 0; u < WCP; ++u) wq_l[threadIdx.x + u * T] = wcp[u];
+        __syncthreads();
+        const long long total = 8ll * n + 5ll * nw;
+        int ends_w[2], ends_r[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const long long tgt = total * ((int)blockIdx.x + e) / (int)gridDim.x;
+#pragma unroll
+            for (int k = 0; k < NPB; ++k) {
+                const int idx = threadIdx.x + k * T;
+                if (ps[idx] >= tgt && (idx == 0 || ps[idx - 1] < tgt)) atomicMin(res + e, idx);
             }
         }
+        __syncthreads();
+        // the next window START at or after each end's probe row: the first listed row whose window differs from the row before
+        // it.  Both ends' requests leave together (one round trip); 64 rows at a time
+        int r0[2], prev[2], pwl[2];
+        bool search[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int cc = (int)blockIdx.x + e, idx = res[e];
+            search[e] = cc > 0 && cc < (int)gridDim.x && idx < NPROBE;
+            ends_w[e] = cc <= 0 ? 0 : nw;
+            ends_r[e] = cc <= 0 ? 0 : n;
+            r0[e] = search[e] ? (int)((long long)idx * n / NPROBE) : 0;
+            prev[e] = r0[e] > 0 ? a.pair_win[r0[e] - 1] : -1;
+            pwl[e] = r0[e] + lane < n ? a.pair_win[r0[e] + lane] : -1;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!search[e]) continue;
+            int pv = prev[e], pw = pwl[e];
+            for (int rr = r0[e];;) {
+                const unsigned long long hit = __ballot(pw >= 0 && pw != pv);
+                if (hit) {
+                    const int l = __ffsll((long long)hit) - 1;
+                    ends_w[e] = __builtin_amdgcn_readlane(pw, l);
+                    ends_r[e] = rr + l;
+                    break;
+                }
+                // (64 rows of one window / of no window: carry the last listed window on)
+                const unsigned long long any = __ballot(pw >= 0);
+                if (any) pv = __builtin_amdgcn_readlane(pw, 63 - __clzll((long long)any));
+                rr += MSSVT_WAVE;
+                if (rr >= n) break;
+                pw = rr + lane < n ? a.pair_win[rr + lane] : -1;
+            }
+        }
+        Wa = ends_w[0]; Wb = ends_w[1]; Ra = ends_r[0]; Rb = ends_r[1];
     }
+    if (Wa >= Wb || Ra >= Rb) return;  // (wave-uniform, the same in every wave)
+
     const int ch = 16 * wv + 4 * g;  // MFMA view: this lane's 4 output channels
     const float4 bp2 = *reinterpret_cast<const float4 *>(a.bp2 + ch), bq = *reinterpret_cast<const float4 *>(a.bq + ch),
                  bk = *reinterpret_cast<const float4 *>(a.bkv + ch), bv = *reinterpret_cast<const float4 *>(a.bkv + C + ch),
@@ -304,162 +257,233 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
                 g_cw0 = lane_pick4(g, a.wsx, a.wsy, a.wsz, a.wsx), g_cw1 = lane_pick4(g, a.wsy, a.wsz, 0.f, 0.f),
                 g_lo1 = lane_pick4(g, a.miny, a.minz, 0.f, 0.f);
 
-    // ---- the first tile's channel-wise max (every later tile's is taken under the tile before it) -----------------------
-    CW_RUN_TAKE(r0, r1)
-    CW_RUN_ISSUE(tile + 1)
-    __syncthreads();
-    CSTAMP(0)  // weights, partition, first run
-    for (int rb = r0; rb < r1; rb += 32) {
-        CW_MAX_LOAD(rb, r1)
-        CW_MAX_PUT(tile * 16, min(16, nw - tile * 16))
+    // ---- the channel-wise max of a GROUP of 16 windows (the query tokens, ref :370), one group ahead of the rows ------------
+    // One pass = 32 rows from `mp` in the row-wise view (coalesced) -> integer atomics on the keys.  Every wave also looks at
+    // the windows of the 32 rows itself: the pass that meets the first row of the next group ends the group (mdone) and
+    // leaves mp there -- wave-uniform without an exchange.
+    float4 mxa, mxb;
+    int mpa, mpb, pwp;
+    int mp = Ra;
+    bool mdone = false;
+#define CW_MAX_LOAD()                                                                                         \
+    {                                                                                                         \
+        const int ra_ = mp + r, rc_ = mp + 16 + r, rp_ = mp + (lane & 31);                                    \
+        pwp = rp_ < Rb ? a.pair_win[rp_] : 0x7FFFFFFF;                                                        \
+        mxa = mxb = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+        mpa = mpb = -1;                                                                                       \
+        if (ra_ < Rb) {                                                                                       \
+            mxa = *reinterpret_cast<const float4 *>(a.xhat + (size_t)ra_ * C + 4 * q);                        \
+            mpa = a.pair_win[ra_];                                                                            \
+        }                                                                                                     \
+        if (rc_ < Rb) {                                                                                       \
+            mxb = *reinterpret_cast<const float4 *>(a.xhat + (size_t)rc_ * C + 4 * q);                        \
+            mpb = a.pair_win[rc_];                                                                            \
+        }                                                                                                     \
     }
-    __syncthreads();
-    CSTAMP(1)  // first tile's max
+#define CW_MAX_PUT(w0_, w1_)                                                                                  \
+    {                                                                                                         \
+        if (mpa >= (w0_) && mpa < (w1_)) {                                                                    \
+            const int w_ = mpa - (w0_);                                                                       \
+            atomicMax(qmax + CW_QSLOT(w_, 4 * q), cw_key(mxa.x)); atomicMax(qmax + CW_QSLOT(w_, 4 * q + 1), cw_key(mxa.y)); \
+            atomicMax(qmax + CW_QSLOT(w_, 4 * q + 2), cw_key(mxa.z)); atomicMax(qmax + CW_QSLOT(w_, 4 * q + 3), cw_key(mxa.w)); \
+        }                                                                                                     \
+        if (mpb >= (w0_) && mpb < (w1_)) {                                                                    \
+            const int w_ = mpb - (w0_);                                                                       \
+            atomicMax(qmax + CW_QSLOT(w_, 4 * q), cw_key(mxb.x)); atomicMax(qmax + CW_QSLOT(w_, 4 * q + 1), cw_key(mxb.y)); \
+            atomicMax(qmax + CW_QSLOT(w_, 4 * q + 2), cw_key(mxb.z)); atomicMax(qmax + CW_QSLOT(w_, 4 * q + 3), cw_key(mxb.w)); \
+        }                                                                                                     \
+        const unsigned long long past_ = __ballot(pwp >= (w1_)); /* (rows in no window: -1, never past) */    \
+        if (past_) {                                                                                          \
+            mp += __ffsll((long long)past_) - 1; /* lanes 0-31 hold the 32 rows in order */                   \
+            mdone = true;                                                                                     \
+        } else {                                                                                              \
+            mp += 32;                                                                                         \
+        }                                                                                                     \
+    }
+    // initial keys of a group's windows: 0 (= key(0.0f): the zero padding takes part, ref :370) unless the list is full;
+    // cnt_: win_cnt of window w0_ + threadIdx / LPR, requested a group earlier
+#define CW_CNT_LOAD(w0_) a.win_cnt[min((w0_) + (int)threadIdx.x / LPR, nw - 1)]
+#define CW_MAX_INIT(w0_, cnt_)                                                                                \
+    {                                                                                                         \
+        const int w_ = threadIdx.x / LPR; /* T / LPR = 16 windows */                                          \
+        const int init_ = (w0_) + w_ < Wb && (cnt_) >= a.ns ? cw_key(-INFINITY) : 0;                          \
+        *reinterpret_cast<int4 *>(qmax + w_ * C + 4 * q) = make_int4(init_, init_, init_, init_);             \
+    }
+    int cnt_pre = CW_CNT_LOAD(Wa);
+    __syncthreads();  // (the search's scratch is dead)
+    CW_MAX_INIT(Wa, cnt_pre)
+    cnt_pre = CW_CNT_LOAD(Wa + 16);
+    CSTAMP(0)  // weights, chunk search
 
     // rows of the MFMA view, requested 16 rows ahead: window, next row's window, cell, this wave's 16 channels of xhat
 #define CW_ROW_LOAD(rb_, pw_, pn_, vi_, xs_)                                                                  \
     {                                                                                                         \
-        const int row_ = max(min((rb_) + la, r1 - 1), 0);                                                     \
+        const int row_ = min((rb_) + la, Rb - 1);                                                             \
         pw_ = a.pair_win[row_];                                                                               \
-        pn_ = a.pair_win[min(row_ + 1, a.num_voxels - 1)];                                                    \
+        pn_ = a.pair_win[min(row_ + 1, n - 1)];                                                               \
         vi_ = reinterpret_cast<const int4 *>(a.indices)[row_];                                                \
         xs_ = *reinterpret_cast<const float4 *>(a.xhat + (size_t)row_ * C + ch);                              \
     }
-    for (;;) {
-        const int w0 = tile * 16, nwt = min(16, nw - w0);
-        const int tile_n = tile + 1;
-        const bool has_n = tile_n < tile_end;
-        const int w0n = min(tile_n, tiles - 1) * 16, nwtn = has_n ? min(16, nw - w0n) : 0;
-        // ---- Q: q' = scale log2(e) (Wq q_tok + bq): head w of the 16 queries, lane (la = window, g): channels 16 w + 4 g + i
-        f32x4 qp;
-        {
-            f32x4 m = f32x4{bq.x, bq.y, bq.z, bq.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
-            const h16x8 *wf = wq_l + (size_t)wv * FR + lane;
-#pragma unroll
-            for (int P = 0; P < NP; ++P) {
-                const int4 k0 = *reinterpret_cast<const int4 *>(qmax + CW_QSLOT(la, 32 * P + 4 * g)),
-                           k1 = *reinterpret_cast<const int4 *>(qmax + CW_QSLOT(la, 32 * P + 16 + 4 * g));
-                h16x4 h0, l0, h1, l1;
-                cw_split4(cw_unkey(k0.x), cw_unkey(k0.y), cw_unkey(k0.z), cw_unkey(k0.w), h0, l0);
-                cw_split4(cw_unkey(k1.x), cw_unkey(k1.y), cw_unkey(k1.z), cw_unkey(k1.w), h1, l1);
-                const h16x8 bh = cw_cat(h0, h1), bl = cw_cat(l0, l1);
-                const h16x8 ah = wf[(P * 2) * 64], al = wf[(P * 2 + 1) * 64];
-                MFMA_H(m, ah, bh);
-                MFMA_H(l, ah, bl);
-                MFMA_H(k, al, bh);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) qp[i] = __builtin_fmaf(l[i] + k[i], CW_INV, m[i]) * a.qscale;
-#ifdef CW_DEBUG
-            if (la < nwt && g_cw_dbg[1])
-                for (int i = 0; i < 4; ++i) g_cw_dbg[1][(size_t)(w0 + la) * C + ch + i] = qp[i];
-#endif
-        }
-        // the next tile's run (requested a tile ago); the one after it is requested now
-        CW_RUN_TAKE(nr0, nr1)
-        if (!has_n) nr0 = nr1 = 0;
-        CW_RUN_ISSUE(tile_n + 1)
-        int pw_n, pn_n;
-        int4 vi_n;
-        float4 xs_n;
-        CW_ROW_LOAD(r0, pw_n, pn_n, vi_n, xs_n)
-        CSTAMP(2)  // Q product
-        __syncthreads();  // this tile's max keys are consumed: the tile becomes the next tile's
-        CSTAMP(3)
-        CW_MAX_INIT(w0n, nwtn)
-#ifdef CW_STAMPS
-        cs_acc[14] += 1;
-#endif
-        int np = nr0;     // next tile's rows whose max is taken so far
+    int pw_n, pn_n;
+    int4 vi_n;
+    float4 xs_n;
+    CW_ROW_LOAD(Ra, pw_n, pn_n, vi_n, xs_n)
+    int gq = -1;  // the newest group whose q' exists (qpB; qpA: the group before it)
+    int jo = 0;   // the oldest group whose output rows are not written yet
+    f32x4 qpA = f32x4{0.f, 0.f, 0.f, 0.f}, qpB = qpA;
+    float cm = 0.f, cs = 0.f;  // carried (max, sum, sum p V) of the window open at the end of the previous 16 rows
+    f32x2 co01 = f32x2{0.f, 0.f}, co23 = co01;
+    int cseg = -0x7FFFFFFF;
 
-        // ---- the run, 16 rows at a time ------------------------------------------------------------------------------
-        float cm = 0.f, cs = 0.f;  // carried (max, sum, sum p V) of the window open at the end of the previous 16 rows
-        f32x2 co01 = f32x2{0.f, 0.f}, co23 = co01;
-        int cseg = -1;
-        bool first = true;
-        for (int rb = r0; rb < r1; rb += 16) {
-            const int row = min(rb + la, r1 - 1);
-            const bool rlive = rb + la < r1;
-            const int pw = pw_n, pnext = pn_n;
-            const int4 vi = vi_n;
-            const float4 xs = xs_n;
-            CW_ROW_LOAD(rb + 16, pw_n, pn_n, vi_n, xs_n)
-            CW_MAX_LOAD(np, nr1)
-            const bool rvalid = rlive && (unsigned int)(pw - w0) < (unsigned int)nwt;
-            const bool wend = row + 1 >= r1 || pnext != pw;  // the window's last row
-            // S1: h = relu(pos_proj.0 [rel ; centre] + b), this wave's 16 channels.  Pillar windows: the window's cell is
-            // the voxel's (x, y) and z / z_ws.  A lane forms only the components it feeds to the product (k slot g): the
-            // integer inputs are picked first, then one voxel centre and two window centres -- the same operations per
-            // component as cw_centre on all six (ref with_coords), a third of the instructions
-            {
-                const int wz = (vi.y * a.z_magic) >> 16;
-                const int iv = lane_pick4i(g, vi.w, vi.z, vi.y, 0), iw0 = lane_pick4i(g, vi.w, vi.z, wz, vi.w), iw1 = lane_pick4i(g, vi.z, wz, 0, 0);
-                const float wc0 = cw_centre(iw0, g_cw0, g_lo0), wc1 = cw_centre(iw1, g_cw1, g_lo1);
-                const float rel = cw_centre(iv, g_cv, g_lo0) - wc0;  // NOT masked in the CompressBlock (ref :372)
-                const float in0 = g < 3 ? rel : wc0, in1 = g < 2 ? wc1 : g == 2 ? 1.0f : 0.0f;
-                f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
-                MFMA4(p, w1a0, in0);
-                MFMA4(p, w1a1, in1);
-                h16x4 hi, lo;
-                cw_split4(fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f), hi, lo);
-                reinterpret_cast<h16x4 *>(hfrag + (ks * 2) * 64 + lane)[hs] = hi;
-                reinterpret_cast<h16x4 *>(hfrag + (ks * 2 + 1) * 64 + lane)[hs] = lo;
+    for (int rb = Ra; rb < Rb; rb += 16) {
+        const int row = min(rb + la, Rb - 1);
+        const bool rlive = rb + la < Rb;
+        const int pw = pw_n, pnext = pn_n;
+        const int4 vi = vi_n;
+        const float4 xs = xs_n;
+        CW_ROW_LOAD(rb + 16, pw_n, pn_n, vi_n, xs_n)
+        const bool rvalid = rlive && pw >= Wa && pw < Wb;  // (rows of a chunk are its windows' or in no window)
+        const bool wend = row + 1 >= Rb || pnext != pw;    // the window's last row
+        const int grow = (pw - Wa) >> 4, widx = (pw - Wa) & 15;
+        // ---- group switch: the rows reach a group whose queries do not exist yet --------------------------------------------
+        while (__ballot(rvalid && grow > gq) != 0ull) {
+            const int gw0 = Wa + 16 * (gq + 1), gw1 = min(gw0 + 16, Wb);
+            if (!mdone) {  // the rest of the group's rows (its max normally completes under the rows of the group before it)
+                __syncthreads();  // (the keys' initial values are in place)
+                do {
+                    CW_MAX_LOAD()
+                    CW_MAX_PUT(gw0, gw1)
+                } while (!mdone);
             }
-            CSTAMP(4)  // S1 (+ prefetch issue)
-            __syncthreads();
-            CSTAMP(5)
-            // S2: k_tok = xhat + relu(pos_proj.2 h + b), this wave's 16 channels
-            {
-                f32x4 m = f32x4{bp2.x, bp2.y, bp2.z, bp2.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
-#pragma unroll
-                for (int P = 0; P < NP; ++P) {
-                    const h16x8 bh = hfrag[(P * 2) * 64 + lane], bl = hfrag[(P * 2 + 1) * 64 + lane];
-                    MFMA_H(m, Wph[P], bh);
-                    MFMA_H(l, Wph[P], bl);
-                    MFMA_H(k, Wpl[P], bh);
-                }
+            __syncthreads();  // the keys are final; the previous rows' K / V products have read their fragments
+            {                 // q_tok, this wave's 16 channels of the 16 windows -> B fragments (in the K / V fragments' place)
+                const int4 k0 = *reinterpret_cast<const int4 *>(qmax + CW_QSLOT(la, ch));
                 h16x4 hi, lo;
-                cw_split4(xs.x + fmaxf(__builtin_fmaf(l[0] + k[0], CW_INV, m[0]), 0.f), xs.y + fmaxf(__builtin_fmaf(l[1] + k[1], CW_INV, m[1]), 0.f),
-                          xs.z + fmaxf(__builtin_fmaf(l[2] + k[2], CW_INV, m[2]), 0.f), xs.w + fmaxf(__builtin_fmaf(l[3] + k[3], CW_INV, m[3]), 0.f), hi, lo);
+                cw_split4(cw_unkey(k0.x), cw_unkey(k0.y), cw_unkey(k0.z), cw_unkey(k0.w), hi, lo);
                 reinterpret_cast<h16x4 *>(kfrag + (ks * 2) * 64 + lane)[hs] = hi;
                 reinterpret_cast<h16x4 *>(kfrag + (ks * 2 + 1) * 64 + lane)[hs] = lo;
             }
-            CSTAMP(6)  // S2
             __syncthreads();
-            CSTAMP(7)
-            // S3: K, V of head w; scores; segmented softmax-weighted sum over the row lanes
+            CW_MAX_INIT(gw1, cnt_pre)  // the max tile turns to the group after this one
+            cnt_pre = CW_CNT_LOAD(gw1 + 16);
+            mdone = gw1 >= Wb;  // (no group behind the chunk's last one)
+            // q' = scale log2(e) (Wq q_tok + bq): head w of the 16 queries, lane (la = window, g): channels 16 w + 4 g + i
             {
-                f32x4 km = f32x4{bk.x, bk.y, bk.z, bk.w}, kl = f32x4{0.f, 0.f, 0.f, 0.f}, kk = kl;
-                f32x4 vm = f32x4{bv.x, bv.y, bv.z, bv.w}, vl = kl, vk = kl;
+                f32x4 m = f32x4{bq.x, bq.y, bq.z, bq.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
+                const h16x8 *wf = wq_l + (size_t)wv * FR + lane;
 #pragma unroll
                 for (int P = 0; P < NP; ++P) {
                     const h16x8 bh = kfrag[(P * 2) * 64 + lane], bl = kfrag[(P * 2 + 1) * 64 + lane];
-                    MFMA_H(km, Wkh[P], bh);
-                    MFMA_H(vm, Wvh[P], bh);
-                    MFMA_H(kl, Wkh[P], bl);
-                    MFMA_H(vl, Wvh[P], bl);
-                    MFMA_H(kk, Wkl[P], bh);
-                    MFMA_H(vk, Wvl[P], bh);
+                    const h16x8 ah = wf[(P * 2) * 64], al = wf[(P * 2 + 1) * 64];
+                    MFMA_H(m, ah, bh);
+                    MFMA_H(l, ah, bl);
+                    MFMA_H(k, al, bh);
                 }
-                const int widx = rvalid ? pw - w0 : 0;
-                const int src = 4 * (16 * g + widx);
-                float sc = 0.f;
-                f32x4 o;
+                qpA = qpB;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qpB[i] = __builtin_fmaf(l[i] + k[i], CW_INV, m[i]) * a.qscale;
+#ifdef CW_DEBUG
+                if (gw0 + la < gw1 && g_cw_dbg[1])
+                    for (int i = 0; i < 4; ++i) g_cw_dbg[1][(size_t)(gw0 + la) * C + ch + i] = qpB[i];
+#endif
+            }
+            ++gq;
+#ifdef CW_STAMPS
+            cs_acc[14] += 1;
+#endif
+        }
+        CSTAMP(2)  // group switch (max rest, Q product)
+        const bool mrun = !mdone;  // this iteration carries a pass of the next group's max (wave-uniform)
+        if (mrun) CW_MAX_LOAD()
+        // S1: h = relu(pos_proj.0 [rel ; centre] + b), this wave's 16 channels.  Pillar windows: the window's cell is
+        // the voxel's (x, y) and z / z_ws.  A lane forms only the components it feeds to the product (k slot g): the
+        // integer inputs are picked first, then one voxel centre and two window centres -- the same operations per
+        // component as cw_centre on all six (ref with_coords), a third of the instructions
+        {
+            const int wz = (vi.y * a.z_magic) >> 16;
+            const int iv = lane_pick4i(g, vi.w, vi.z, vi.y, 0), iw0 = lane_pick4i(g, vi.w, vi.z, wz, vi.w), iw1 = lane_pick4i(g, vi.z, wz, 0, 0);
+            const float wc0 = cw_centre(iw0, g_cw0, g_lo0), wc1 = cw_centre(iw1, g_cw1, g_lo1);
+            const float rel = cw_centre(iv, g_cv, g_lo0) - wc0;  // NOT masked in the CompressBlock (ref :372)
+            const float in0 = g < 3 ? rel : wc0, in1 = g < 2 ? wc1 : g == 2 ? 1.0f : 0.0f;
+            f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+            MFMA4(p, w1a0, in0);
+            MFMA4(p, w1a1, in1);
+            h16x4 hi, lo;
+            cw_split4(fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f), hi, lo);
+            reinterpret_cast<h16x4 *>(hfrag + (ks * 2) * 64 + lane)[hs] = hi;
+            reinterpret_cast<h16x4 *>(hfrag + (ks * 2 + 1) * 64 + lane)[hs] = lo;
+        }
+        CSTAMP(4)  // S1 (+ prefetch issue)
+        __syncthreads();
+        CSTAMP(5)
+        // S2: k_tok = xhat + relu(pos_proj.2 h + b), this wave's 16 channels
+        {
+            f32x4 m = f32x4{bp2.x, bp2.y, bp2.z, bp2.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                const h16x8 bh = hfrag[(P * 2) * 64 + lane], bl = hfrag[(P * 2 + 1) * 64 + lane];
+                MFMA_H(m, Wph[P], bh);
+                MFMA_H(l, Wph[P], bl);
+                MFMA_H(k, Wpl[P], bh);
+            }
+            h16x4 hi, lo;
+            cw_split4(xs.x + fmaxf(__builtin_fmaf(l[0] + k[0], CW_INV, m[0]), 0.f), xs.y + fmaxf(__builtin_fmaf(l[1] + k[1], CW_INV, m[1]), 0.f),
+                      xs.z + fmaxf(__builtin_fmaf(l[2] + k[2], CW_INV, m[2]), 0.f), xs.w + fmaxf(__builtin_fmaf(l[3] + k[3], CW_INV, m[3]), 0.f), hi, lo);
+            reinterpret_cast<h16x4 *>(kfrag + (ks * 2) * 64 + lane)[hs] = hi;
+            reinterpret_cast<h16x4 *>(kfrag + (ks * 2 + 1) * 64 + lane)[hs] = lo;
+        }
+        CSTAMP(6)  // S2
+        __syncthreads();
+        CSTAMP(7)
+        // S3: K, V of head w; scores; segmented softmax-weighted sum over the row lanes
+        f32x2 o01, o23;
+        float m_, s_;
+        {
+            f32x4 km = f32x4{bk.x, bk.y, bk.z, bk.w}, kl = f32x4{0.f, 0.f, 0.f, 0.f}, kk = kl;
+            f32x4 vm = f32x4{bv.x, bv.y, bv.z, bv.w}, vl = kl, vk = kl;
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                const h16x8 bh = kfrag[(P * 2) * 64 + lane], bl = kfrag[(P * 2 + 1) * 64 + lane];
+                MFMA_H(km, Wkh[P], bh);
+                MFMA_H(vm, Wvh[P], bh);
+                MFMA_H(kl, Wkh[P], bl);
+                MFMA_H(vl, Wvh[P], bl);
+                MFMA_H(kk, Wkl[P], bh);
+                MFMA_H(vk, Wvl[P], bh);
+            }
+            // q' of the row's window: the rows of 16 consecutive rows belong to the newest group or to the one before it
+            const int src = 4 * (16 * g + (rvalid ? widx : 0));
+            const bool newest = grow == gq;
+            float qr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qr[i] = cw_float(__builtin_amdgcn_ds_bpermute(src, cw_bits(qpB[i])));
+            if (__ballot(rvalid && !newest) != 0ull) {  // (wave-uniform: the rows straddle two groups)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float qi = cw_float(__builtin_amdgcn_ds_bpermute(src, cw_bits(qp[i])));
-                    sc = __builtin_fmaf(__builtin_fmaf(kl[i] + kk[i], CW_INV, km[i]), qi, sc);
-                    o[i] = __builtin_fmaf(vl[i] + vk[i], CW_INV, vm[i]);
+                    const float qa = cw_float(__builtin_amdgcn_ds_bpermute(src, cw_bits(qpA[i])));
+                    qr[i] = newest ? qr[i] : qa;
                 }
-                sc += lane_xor16(sc);
-                sc += lane_xor32(sc);
-                CSTAMP(8)  // K, V, scores
+            }
+            float sc = 0.f;
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc = __builtin_fmaf(__builtin_fmaf(kl[i] + kk[i], CW_INV, km[i]), qr[i], sc);
+                o[i] = __builtin_fmaf(vl[i] + vk[i], CW_INV, vm[i]);
+            }
+            sc += lane_xor16(sc);
+            sc += lane_xor32(sc);
+            m_ = sc;
+            s_ = 1.0f;
+            o01 = f32x2{o[0], o[1]};
+            o23 = f32x2{o[2], o[3]};
+        }
+        CSTAMP(8)  // K, V, scores
 #ifdef CW_DEBUG
-                if (rvalid && g == 0 && g_cw_dbg[2]) g_cw_dbg[2][(size_t)row * NW + wv] = sc;
+        if (rvalid && g == 0 && g_cw_dbg[2]) g_cw_dbg[2][(size_t)row * NW + wv] = m_;
 #endif
-                float m_ = sc, s_ = 1.0f;
-                const int seg = rvalid ? pw : -1 - la;  // rows outside the tile's windows: segments of their own, never published
-                // (max, sum, sum p V) of two adjacent pieces of one window
+        const int seg = rvalid ? pw : -1 - la;  // rows outside the chunk's windows: segments of their own, never published
+        // (max, sum, sum p V) of two adjacent pieces of one window
 #define CW_COMBINE(mg_, pm_, ps_, po01_, po23_)                                                          \
     {                                                                                                   \
         const float nm_ = fmaxf(pm_, m_);                                                               \
@@ -470,17 +494,16 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
         o23 = __builtin_elementwise_fma(po23_, f32x2{ea_, ea_}, o23 * f32x2{eb_, eb_});                 \
         m_ = (mg_) ? nm_ : m_;                                                                          \
     }
-                f32x2 o01 = f32x2{o[0], o[1]}, o23 = f32x2{o[2], o[3]};
-                // the piece carried in from the previous 16 rows joins row lane 0
-                if (!first) {  // (wave-uniform)
-                    const bool mg0 = la == 0 && cseg == seg;
-                    CW_COMBINE(mg0, cm, cs, co01, co23)
-                }
-                // Hillis-Steele over the 16 row lanes; a step whose distance no window of these rows reaches is skipped
-                // (every DPP with all lanes active: a DPP source lane must be active)
-                const int pg1 = CW_DPP_I(seg, 0x111), pg2 = CW_DPP_I(seg, 0x112), pg4 = CW_DPP_I(seg, 0x114), pg8 = CW_DPP_I(seg, 0x118);
-                const bool mg1 = (la >= 1) & (pg1 == seg), mg2 = (la >= 2) & (pg2 == seg), mg4 = (la >= 4) & (pg4 == seg),
-                           mg8 = (la >= 8) & (pg8 == seg);
+        {  // the piece carried in from the previous 16 rows joins row lane 0
+            const bool mg0 = la == 0 && cseg == seg;
+            CW_COMBINE(mg0, cm, cs, co01, co23)
+        }
+        {
+            // Hillis-Steele over the 16 row lanes; a step whose distance no window of these rows reaches is skipped
+            // (every DPP with all lanes active: a DPP source lane must be active)
+            const int pg1 = CW_DPP_I(seg, 0x111), pg2 = CW_DPP_I(seg, 0x112), pg4 = CW_DPP_I(seg, 0x114), pg8 = CW_DPP_I(seg, 0x118);
+            const bool mg1 = (la >= 1) & (pg1 == seg), mg2 = (la >= 2) & (pg2 == seg), mg4 = (la >= 4) & (pg4 == seg),
+                       mg8 = (la >= 8) & (pg8 == seg);
 #define CW_STEP(ctrl_, mg_)                                                                             \
     {                                                                                                   \
         const float pm_ = CW_DPP_F(m_, ctrl_), ps_ = CW_DPP_F(s_, ctrl_);                               \
@@ -488,75 +511,78 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
         const f32x2 p01_ = f32x2{CW_DPP_F(a0_, ctrl_), CW_DPP_F(a1_, ctrl_)}, p23_ = f32x2{CW_DPP_F(a2_, ctrl_), CW_DPP_F(a3_, ctrl_)}; \
         CW_COMBINE(mg_, pm_, ps_, p01_, p23_)                                                           \
     }
-                if (__ballot(mg1) != 0ull) {
-                    CW_STEP(0x111, mg1)
-                    if (__ballot(mg2) != 0ull) {
-                        CW_STEP(0x112, mg2)
-                        if (__ballot(mg4) != 0ull) {
-                            CW_STEP(0x114, mg4)
-                            if (__ballot(mg8) != 0ull) CW_STEP(0x118, mg8)
-                        }
+            if (__ballot(mg1) != 0ull) {
+                CW_STEP(0x111, mg1)
+                if (__ballot(mg2) != 0ull) {
+                    CW_STEP(0x112, mg2)
+                    if (__ballot(mg4) != 0ull) {
+                        CW_STEP(0x114, mg4)
+                        if (__ballot(mg8) != 0ull) CW_STEP(0x118, mg8)
                     }
                 }
+            }
 #undef CW_STEP
 #undef CW_COMBINE
-                if (rvalid && wend) {  // head w of the window's attention output, normalised -> B fragment of the Wo product
-                    const float inv = 1.0f / s_;
-                    h16x4 hi, lo;
-                    cw_split4(o01[0] * inv, o01[1] * inv, o23[0] * inv, o23[1] * inv, hi, lo);
+        }
+        // ---- windows that end in these rows: head w of their attention output -> B fragment of the Wo product; a group
+        // whose last window ends here gets its output rows; ends of the group after it wait for that product
+        {
+            const int pend = rvalid && wend ? grow : -1;
+            const float inv = __builtin_amdgcn_rcpf(s_);  // (1 ulp; the three-launch form divides)
+            h16x4 hi, lo;
+            cw_split4(o01[0] * inv, o01[1] * inv, o23[0] * inv, o23[1] * inv, hi, lo);
+            for (;;) {
+                const bool mine = pend == jo;
+                if (mine) {
                     reinterpret_cast<h16x4 *>(ofrag + (ks * 2) * 64 + 16 * g + widx)[hs] = hi;
                     reinterpret_cast<h16x4 *>(ofrag + (ks * 2 + 1) * 64 + 16 * g + widx)[hs] = lo;
                 }
-                // carry: row lane 15's piece to row lane 0 of the next 16 rows (row_ror:1)
-                cm = CW_DPP_F(m_, 0x121);
-                cs = CW_DPP_F(s_, 0x121);
-                {
-                    const float a0_ = o01[0], a1_ = o01[1], a2_ = o23[0], a3_ = o23[1];
-                    co01 = f32x2{CW_DPP_F(a0_, 0x121), CW_DPP_F(a1_, 0x121)};
-                    co23 = f32x2{CW_DPP_F(a2_, 0x121), CW_DPP_F(a3_, 0x121)};
-                }
-                cseg = CW_DPP_I(seg, 0x121);
-                first = false;
-            }
-            CSTAMP(9)  // scan, publish
-            // the next tile's max, 32 rows per 16 rows of this tile (requested at the top of the iteration)
-            CW_MAX_PUT(w0n, nwtn)
-            np += 32;
-            CSTAMP(10)  // atomics
-#ifdef CW_STAMPS
-            cs_acc[15] += 1;
-#endif
-        }
-        if (r1 <= r0) __syncthreads();  // (no iteration ran: the keys' initial values must be in place)
-        for (; np < nr1; np += 32) {    // what is left of the next tile's rows (its run is longer than twice this one)
-            CW_MAX_LOAD(np, nr1)
-            CW_MAX_PUT(w0n, nwtn)
-        }
-        CSTAMP(11)  // rest of the next tile's max
-        __syncthreads();
-        CSTAMP(12)
-        // ---- O: out = Wo o + bo, this wave's 16 channels of the 16 windows ------------------------------------------------
-        {
-            f32x4 m = f32x4{bo.x, bo.y, bo.z, bo.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
-            const h16x8 *wf = wo_l + (size_t)wv * FR + lane;
+                const int ow0 = Wa + 16 * jo, ow1 = min(ow0 + 16, Wb);
+                if (__ballot(mine && pw == ow1 - 1) == 0ull) break;
+                CSTAMP(9)
+                __syncthreads();  // every head of the group's windows is in place
+                CSTAMP(12)
+                {  // out = Wo o + bo, this wave's 16 channels of the group's windows
+                    f32x4 m = f32x4{bo.x, bo.y, bo.z, bo.w}, l = f32x4{0.f, 0.f, 0.f, 0.f}, k = l;
+                    const h16x8 *wf = wo_l + (size_t)wv * FR + lane;
 #pragma unroll
-            for (int P = 0; P < NP; ++P) {
-                const h16x8 bh = ofrag[(P * 2) * 64 + lane], bl = ofrag[(P * 2 + 1) * 64 + lane];
-                const h16x8 ah = wf[(P * 2) * 64], al = wf[(P * 2 + 1) * 64];
-                MFMA_H(m, ah, bh);
-                MFMA_H(l, ah, bl);
-                MFMA_H(k, al, bh);
+                    for (int P = 0; P < NP; ++P) {
+                        const h16x8 bh = ofrag[(P * 2) * 64 + lane], bl = ofrag[(P * 2 + 1) * 64 + lane];
+                        const h16x8 ah = wf[(P * 2) * 64], al = wf[(P * 2 + 1) * 64];
+                        MFMA_H(m, ah, bh);
+                        MFMA_H(l, ah, bl);
+                        MFMA_H(k, al, bh);
+                    }
+                    if (ow0 + la < ow1)
+                        *reinterpret_cast<float4 *>(a.out + (size_t)(ow0 + la) * C + ch) =
+                            make_float4(__builtin_fmaf(l[0] + k[0], CW_INV, m[0]), __builtin_fmaf(l[1] + k[1], CW_INV, m[1]),
+                                        __builtin_fmaf(l[2] + k[2], CW_INV, m[2]), __builtin_fmaf(l[3] + k[3], CW_INV, m[3]));
+                }
+                ++jo;
+                CSTAMP(13)  // O product
+                if (__ballot(pend == jo) == 0ull) break;
+                __syncthreads();  // (the product has read the fragments)
             }
-            if (la < nwt)
-                *reinterpret_cast<float4 *>(a.out + (size_t)(w0 + la) * C + ch) =
-                    make_float4(__builtin_fmaf(l[0] + k[0], CW_INV, m[0]), __builtin_fmaf(l[1] + k[1], CW_INV, m[1]),
-                                __builtin_fmaf(l[2] + k[2], CW_INV, m[2]), __builtin_fmaf(l[3] + k[3], CW_INV, m[3]));
         }
-        CSTAMP(13)  // O product
-        if (!has_n) break;
-        tile = tile_n;
-        r0 = nr0;
-        r1 = nr1;
+        // carry: row lane 15's piece to row lane 0 of the next 16 rows (row_ror:1)
+        cm = CW_DPP_F(m_, 0x121);
+        cs = CW_DPP_F(s_, 0x121);
+        {
+            const float a0_ = o01[0], a1_ = o01[1], a2_ = o23[0], a3_ = o23[1];
+            co01 = f32x2{CW_DPP_F(a0_, 0x121), CW_DPP_F(a1_, 0x121)};
+            co23 = f32x2{CW_DPP_F(a2_, 0x121), CW_DPP_F(a3_, 0x121)};
+        }
+        cseg = CW_DPP_I(seg, 0x121);
+        CSTAMP(9)  // scan, publish
+        // the next group's max, 32 rows per 16 rows of the stream (requested at the top of the iteration)
+        if (mrun) {
+            const int gw0 = Wa + 16 * (gq + 1), gw1 = min(gw0 + 16, Wb);
+            CW_MAX_PUT(gw0, gw1)
+        }
+        CSTAMP(10)  // atomics
+#ifdef CW_STAMPS
+        cs_acc[15] += 1;
+#endif
     }
 #ifdef CW_STAMPS
     if (lane == 0 && blockIdx.x % 32 == 0) {
@@ -564,11 +590,10 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
     }
 #endif
 #undef CW_QSLOT
-#undef CW_RUN_ISSUE
-#undef CW_RUN_TAKE
 #undef CW_MAX_LOAD
 #undef CW_MAX_PUT
 #undef CW_MAX_INIT
+#undef CW_CNT_LOAD
 #undef CW_ROW_LOAD
 }
 
