@@ -499,11 +499,16 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
             CW_COMBINE(mg0, cm, cs, co01, co23)
         }
         {
-            // Hillis-Steele over the 16 row lanes; a step whose distance no window of these rows reaches is skipped
-            // (every DPP with all lanes active: a DPP source lane must be active)
-            const int pg1 = CW_DPP_I(seg, 0x111), pg2 = CW_DPP_I(seg, 0x112), pg4 = CW_DPP_I(seg, 0x114), pg8 = CW_DPP_I(seg, 0x118);
-            const bool mg1 = (la >= 1) & (pg1 == seg), mg2 = (la >= 2) & (pg2 == seg), mg4 = (la >= 4) & (pg4 == seg),
-                       mg8 = (la >= 8) & (pg8 == seg);
+            // LEFT FOLD over the row lanes: ((x0 + x1) + x2) + ... in row order, whatever the position of the window in these 16
+            // rows and wherever a window is cut by their end (the carried piece is the fold so far) -- the association, hence
+            // every bit of the result, is independent of how the level is cut into chunks and 16-row pieces: a scene's
+            // output does not depend on the scenes it shares a batch with.  Step k: the k-th row of every
+            // piece takes in the fold of the rows before it from the lane below (row_shr:1; every DPP with all lanes
+            // active: a DPP source lane must be active).  max(rows of a window in the piece) - 1 steps: 3.6 on average at
+            // 160k points against 2.3 for a scan tree, whose shape would depend on the cut.
+            const int pg1 = CW_DPP_I(seg, 0x111);
+            const unsigned int starts = (unsigned int)__ballot((la == 0) | (pg1 != seg)) & 0xFFFFu;  // (the same in the four lane rows)
+            const int pos = la - (31 - __clz((int)(starts & ((2u << la) - 1u))));  // row's place inside its piece
 #define CW_STEP(ctrl_, mg_)                                                                             \
     {                                                                                                   \
         const float pm_ = CW_DPP_F(m_, ctrl_), ps_ = CW_DPP_F(s_, ctrl_);                               \
@@ -511,15 +516,10 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
         const f32x2 p01_ = f32x2{CW_DPP_F(a0_, ctrl_), CW_DPP_F(a1_, ctrl_)}, p23_ = f32x2{CW_DPP_F(a2_, ctrl_), CW_DPP_F(a3_, ctrl_)}; \
         CW_COMBINE(mg_, pm_, ps_, p01_, p23_)                                                           \
     }
-            if (__ballot(mg1) != 0ull) {
-                CW_STEP(0x111, mg1)
-                if (__ballot(mg2) != 0ull) {
-                    CW_STEP(0x112, mg2)
-                    if (__ballot(mg4) != 0ull) {
-                        CW_STEP(0x114, mg4)
-                        if (__ballot(mg8) != 0ull) CW_STEP(0x118, mg8)
-                    }
-                }
+            for (int k = 1;; ++k) {
+                const bool mk = pos == k;
+                if (__ballot(mk) == 0ull) break;  // (wave-uniform)
+                CW_STEP(0x111, mk)
             }
 #undef CW_STEP
 #undef CW_COMBINE

@@ -123,6 +123,28 @@ def test_one_launch_compress_is_deterministic_and_ignores_stale_memory(monkeypat
     assert torch.equal(outs[0], outs[1])
 
 
+def test_one_launch_compress_does_not_depend_on_the_batch_composition(monkeypatch):
+    """a scene's rows are bit-identical whether it is processed alone or behind another scene -- the softmax sums
+    are a left fold in row order, independent of how the kernel cuts the level into chunks and 16-row pieces."""
+    from mssvt_amd.mssvt_utils import SparseTensor
+    blk = _compress_block()
+    both = _sp(60000, 2, 21)
+    new, p, _, _ = _attention_only(blk, both, True, monkeypatch)
+    nw = int(p.num_wins.item())
+    wb = p.win_ind[:nw, 0]
+    for b in range(2):
+        sel = both.indices[:, 0] == b
+        idx = both.indices[sel].clone()
+        idx[:, 0] = 0
+        one = SparseTensor(features=both.features[sel].clone(), indices=idx, spatial_shape=synthetic.GRID_SIZE,
+                           voxel_size=synthetic.VOXEL_SIZE, point_cloud_range=synthetic.POINT_CLOUD_RANGE, batch_size=1,
+                           hash_size=200003)
+        got, p1, _, _ = _attention_only(blk, one, True, monkeypatch)
+        n1 = int(p1.num_wins.item())
+        assert n1 == int((wb == b).sum())
+        assert torch.equal(got[:n1], new[:nw][wb == b])
+
+
 def test_shapes_outside_the_one_launch_form_keep_the_three_launch_form(monkeypatch):
     # a list capacity below the slab height can truncate a list: a window is then no run of rows
     blk = _compress_block(ws=(1, 1, 32), ns=8)
