@@ -85,6 +85,8 @@ __device__ __forceinline__ unsigned long long ls_first_slabs(const LsPart &P, co
     if (word == 0ull || x >= P.gx * P.wsx || y >= P.gy * P.wsy) return 0ull;
     const int x0 = x - x % P.wsx, y0 = y - y % P.wsy;
     unsigned long long earlier = 0ull;
+    // (all <= 15 words of a footprint requested together, predicated and unrolled, instead of these dependent loads: measured
+    // slower, 16.2 -> 17.6 us in k_col_emit: most columns of a window are the first or second of their footprint)
     for (int xx = x0; xx <= x; ++xx) {
         const int yend = xx < x ? y0 + P.wsy : y;
         for (int yy = y0; yy < yend; ++yy) earlier |= occ_b[(size_t)xx * Y + yy];
@@ -141,21 +143,25 @@ __global__ void __launch_bounds__(LS_COLS) k_col_emit(LsArgs a) {
     __shared__ unsigned long long pl_all;
     const int b = blockIdx.y, blk = blockIdx.x, ncol = a.X * a.Y, lane = lane_id(), wv = threadIdx.x / MSSVT_WAVE;
     if (a.pl_part >= 0 && threadIdx.x < MSSVT_WAVE) {
-        const int dzb = threadIdx.x;  // relative offset dz = dzb - 32
-        int qpos = -1;
-        for (int q = a.pl_n - 1; q >= 0; --q)
-            if (a.pl_table[q * 3 + 2] + 32 == dzb) qpos = q;  // first occurrence (a table lists an offset once)
-        pl_q_of[dzb] = qpos;
-        unsigned long long before = 0ull, all = 0ull;
-        for (int q = 0; q < a.pl_n; ++q) {
-            const int bit = a.pl_table[q * 3 + 2] + 32;
-            if ((unsigned int)bit < 64u) {
-                if (q < (int)threadIdx.x) before |= 1ull << bit;
-                all |= 1ull << bit;
-            }
+        // ONE load per lane (lane q = table entry q) and an OR scan across the lanes -- walking the table entry by entry
+        // was up to 2 x 64 dependent L2 round trips in front of every workgroup's first barrier
+        const int q = threadIdx.x;
+        const int bit = q < a.pl_n ? a.pl_table[q * 3 + 2] + 32 : -1;  // relative offset dz = bit - 32
+        const bool ok = (unsigned int)bit < 64u;
+        pl_q_of[q] = 0x7FFFFFFF;
+        wave_lds_sync();
+        if (ok) atomicMin(&pl_q_of[bit], q);  // (should an offset repeat, its first entry counts: the reference's walk)
+        wave_lds_sync();
+        if (pl_q_of[q] == 0x7FFFFFFF) pl_q_of[q] = -1;
+        const unsigned long long mine = ok ? 1ull << bit : 0ull;
+        unsigned long long incl = mine;
+        for (int off = 1; off < MSSVT_WAVE; off <<= 1) {
+            const unsigned long long t = __shfl_up(incl, off);
+            if (lane >= off) incl |= t;
         }
-        pl_before[threadIdx.x] = before;  // indexed by table position q = threadIdx.x
-        if (threadIdx.x == 0) pl_all = all;
+        const unsigned long long prev = __shfl_up(incl, 1);
+        pl_before[q] = lane >= 1 ? prev : 0ull;  // the offsets that come EARLIER in the table (indexed by table position)
+        if (q == MSSVT_WAVE - 1) pl_all = incl;
     }
     // ---- prefixes over the workgroups' sums ----------------------------------------------------------------
     {

@@ -917,10 +917,16 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
     // (heaviest key first)
     if (threadIdx.x <= max_key) {
         int run = 0, all = 0;
-        for (int gg = 0; gg < G && G > 1; ++gg) {
-            const int c = scratch[gg * (PO_KEYS + 1) + threadIdx.x];
-            run += gg < gidx ? c : 0;
-            all += c;
+        // (8 requests in flight: one by one the other workgroups' counts were G <= 64 dependent L2 round trips, most of this launch)
+        for (int g0 = 0; g0 < G && G > 1; g0 += 8) {
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = g0 + u < G ? scratch[(g0 + u) * (PO_KEYS + 1) + threadIdx.x] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                run += g0 + u < gidx ? c[u] : 0;
+                all += c[u];
+            }
         }
         int own = 0;
         for (int i = 0; i < PO_WAVES; ++i) {
@@ -933,10 +939,15 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
     }
     if (threadIdx.x == PO_WAVES * MSSVT_WAVE - 1) {
         int before = 0, all = 0;
-        for (int gg = 0; gg < G && G > 1; ++gg) {
-            const int c = scratch[gg * (PO_KEYS + 1) + PO_KEYS];
-            before += gg < gidx ? c : 0;
-            all += c;
+        for (int g0 = 0; g0 < G && G > 1; g0 += 8) {
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = g0 + u < G ? scratch[(g0 + u) * (PO_KEYS + 1) + PO_KEYS] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                before += g0 + u < gidx ? c[u] : 0;
+                all += c[u];
+            }
         }
         if (G == 1)
             for (int i = 0; i < PO_WAVES; ++i) all += wave_q[i];
@@ -944,15 +955,31 @@ __global__ void __launch_bounds__(PO_WAVES *MSSVT_WAVE) k_plan_order(const int *
         rows_all = all;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int k = max_key; k >= 1; --k) {
-            const int c = key_base[k];
-            key_base[k] = run;
-            run += c;
+    if (wv == 0) {
+        // key_base[k] = windows with more queries than k (heaviest key first): a descending exclusive prefix, 4 keys per
+        // lane + one wave scan instead of one thread walking up to 256 keys (PO_KEYS <= 4 x 64 + 1; key 0 -- windows
+        // without a query -- is not placed)
+        int c[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = max_key - (4 * lane + j);
+            c[j] = k >= 1 ? key_base[k] : 0;
+            sum += c[j];
         }
-        if (gidx == 0) {
-            *num_active = run;
+        int incl = sum;
+        for (int off = 1; off < MSSVT_WAVE; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = max_key - (4 * lane + j);
+            if (k >= 1) key_base[k] = run;
+            run += c[j];
+        }
+        if (gidx == 0 && lane == MSSVT_WAVE - 1) {
+            *num_active = incl;
             *num_rows = rows_all < row_capacity ? rows_all : row_capacity;  // rows past the capacity are dropped (caller's bound)
         }
     }
