@@ -10,7 +10,7 @@ What the reference does per Block with ~100 launches and >= 5B+2 host syncs
                          interpolation tables, shared by consecutive Blocks
     per Block            window attention (k_attn_q / k_attn_kv / k_attn_o, or k_attn_bf16), the FFN tail in one launch
                          (k_ffn_ws: interpolation + scatter + residual + norm2 + linear1 + ReLU + linear2 + next norm1)
-    CompressBlock        its plan, k_cmp_query_keys / k_cmp_kv / k_cmp_out, the FFN tail
+    CompressBlock        k_cmp_ws on a sorted pillar level (else its plan, k_cmp_query_keys / k_cmp_kv / k_cmp_out), the FFN tail
 
 with no host synchronisation until the end: window counts stay in device memory, per-window buffers
 are sized by their capacity (#voxels) and kernels read the live count.  The CompressBlock's data-dependent
