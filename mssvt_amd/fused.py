@@ -144,9 +144,6 @@ def _level_partitions(blocks):
     return todo
 
 
-_sorted_static = {}
-
-
 @_no_grad
 def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     """Level state from `mssvt_level_setup_sorted` (counts, occupancy columns, column bases, window partitions of
@@ -161,7 +158,9 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     B, H = int(B), int(H)
     # everything that only depends on the blocks and the grid: built once (the frame's front is host bound)
     skey = (tuple((id(b), b.max_num_wins, b.win1_size[0], b.win1_size[1], b.win1_size[2]) for b in blocks), B, X, Y, Z)
-    static = _sorted_static.get(skey)
+    # (owned by the level's first block, i.e. by the backbone module: no module-global references to Blocks)
+    cache = blocks[0].__dict__.setdefault("_sorted_static", {})
+    static = cache.get(skey)
     if static is None or any(a is not b for a, b in zip(static["blocks"], blocks)):
         todo = _level_partitions(blocks)
         k = len(todo)
@@ -170,9 +169,9 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
         # list that is not sorted, and a rejected level must read as EMPTY, not as garbage, until the frame is redone)
         sizes = [64, 64 * max(k, 1), al(B + 1), al(2 * B * X * Y), al(B), al(max(k, 1) * B)]
         ints_ = lambda rows: (ctypes.c_int * max(3 * k, 1))(*[int(v) for r in rows for v in r])  # noqa: E731
-        if len(_sorted_static) > 16:
-            _sorted_static.clear()
-        static = _sorted_static[skey] = dict(
+        if len(cache) > 16:
+            cache.clear()
+        static = cache[skey] = dict(
             blocks=list(blocks), todo=todo, k=k, sizes=sizes, offs=[sum(sizes[:i]) for i in range(len(sizes))],
             shapes=ints_([[[X, Y, Z][i] // b.win1_size[i] for i in range(3)] for b in todo]),
             wsizes=ints_([b.win1_size for b in todo]),
@@ -211,7 +210,7 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
         # later the copy has long landed, the forward never blocks on the GPU, and the host runs ahead of it (the frame's
         # front -- a dozen short launches -- was host bound: the GPU idled ~80 us per frame waiting for them).
         n = 64 * (k + 1)
-        host = _pinned_words(n, dev)
+        host = _pinned_words(blocks[0], n, dev)
         host.copy_(zero[:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -219,16 +218,18 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     return st
 
 
-_pinned = {}
-
-
-def _pinned_words(n, dev):
-    """A pinned int32 buffer of >= n words per device, reused by every forward (each forward reads its words before it
-    returns, so one is enough; allocating pinned memory per frame costs more than the frame's front)."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
-    t = _pinned.get(key)
+def _pinned_words(owner, n, dev):
+    """A pinned int32 buffer of >= n words, owned by the backbone (its first block) and specific to the device and the
+    stream of the forward: every forward reads its words before it returns, so one per (module, device, stream) is enough
+    -- two backbones, or one backbone driven on two streams, never read each other's words (allocating pinned memory per
+    frame costs more than the frame's front)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n, torch.cuda.current_stream(dev).cuda_stream)
+    store = owner.__dict__.setdefault("_pinned_words", {})
+    t = store.get(key)
     if t is None:
-        t = _pinned[key] = torch.empty(n, dtype=torch.int32, pin_memory=True)
+        if len(store) > 8:
+            store.clear()
+        t = store[key] = torch.empty(n, dtype=torch.int32, pin_memory=True)
     return t
 
 

@@ -2,6 +2,7 @@
 On a tiny scene (2k points) the GPU is never the limiter, so the wall time per frame of a free-running loop IS the host's
 own time per frame; the 160k-point rows show what the benchmark frame gets."""
 import os, sys, time
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # as bench.py (mssvt_amd.use_device_kernargs)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

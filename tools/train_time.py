@@ -1,6 +1,7 @@
 """Time a training step (forward + backward + SGD) of the backbone on the bench scene, compact path vs operator
 path, with peak memory (investigation helper; usage: python tools/train_time.py [batch] [points])."""
 import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # as bench.py (mssvt_amd.use_device_kernargs)
 import sys
 import time
 
