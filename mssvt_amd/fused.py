@@ -144,6 +144,10 @@ def _level_partitions(blocks):
     return todo
 
 
+_level_static_no_blocks = {}  # (a level set up for no block at all -- tests, tools: nothing of a module is referenced)
+_pinned_no_owner = {}
+
+
 @_no_grad
 def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     """Level state from `mssvt_level_setup_sorted` (counts, occupancy columns, column bases, window partitions of
@@ -159,7 +163,7 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
     # everything that only depends on the blocks and the grid: built once (the frame's front is host bound)
     skey = (tuple((id(b), b.max_num_wins, b.win1_size[0], b.win1_size[1], b.win1_size[2]) for b in blocks), B, X, Y, Z)
     # (owned by the level's first block, i.e. by the backbone module: no module-global references to Blocks)
-    cache = blocks[0].__dict__.setdefault("_sorted_static", {})
+    cache = blocks[0].__dict__.setdefault("_sorted_static", {}) if blocks else _level_static_no_blocks
     static = cache.get(skey)
     if static is None or any(a is not b for a, b in zip(static["blocks"], blocks)):
         todo = _level_partitions(blocks)
@@ -210,7 +214,7 @@ def _sorted_level(blocks, indices, B, H, spatial_shape, early_readback=False):
         # later the copy has long landed, the forward never blocks on the GPU, and the host runs ahead of it (the frame's
         # front -- a dozen short launches -- was host bound: the GPU idled ~80 us per frame waiting for them).
         n = 64 * (k + 1)
-        host = _pinned_words(blocks[0], n, dev)
+        host = _pinned_words(blocks[0] if blocks else None, n, dev)
         host.copy_(zero[:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -224,7 +228,7 @@ def _pinned_words(owner, n, dev):
     -- two backbones, or one backbone driven on two streams, never read each other's words (allocating pinned memory per
     frame costs more than the frame's front)."""
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), n, torch.cuda.current_stream(dev).cuda_stream)
-    store = owner.__dict__.setdefault("_pinned_words", {})
+    store = owner.__dict__.setdefault("_pinned_words", {}) if owner is not None else _pinned_no_owner
     t = store.get(key)
     if t is None:
         if len(store) > 8:
