@@ -10,19 +10,26 @@
 //
 // One workgroup of C / 16 waves per CU; wave w keeps, as split-fp16 MFMA A-fragments (see ffn.hip, k_ffn_ws) in REGISTERS for
 // the whole launch, rows [16 w, 16 w + 16) of pos_proj.2, Wk and Wv -- i.e. everything of HEAD w -- and reads its rows of
-// Wq and Wo from LDS (used once per 16 windows).  A tile = 16 consecutive windows = one run of rows [r0, r1):
-//   Q    the rows once, coalesced: channel-wise max per window through LDS integer atomics (order independent: exact),
-//        q' = scale log2(e) (Wq q_tok + bq): wave w ends with head w of the 16 queries in registers          [2 barriers]
-//   per 16 rows of the run:
+// Wq and Wo from LDS (used once per 16 windows).  The workgroup owns a CHUNK: consecutive windows = consecutive rows holding
+// 1 / gridDim of the cost (rows and windows weighed 8 : 5), found by 4096 probes of pair_win.  The chunk is walked as a
+// STREAM of 16-row pieces, whatever the windows; windows are taken in GROUPS of 16 for the two window-side products:
+//   per piece of 16 rows:
 //   S1   h = relu(pos_proj.0 [rel ; centre] + b): each wave its 16 channels, split, published as B fragments  [barrier]
 //   S2   k_tok = xhat + relu(pos_proj.2 h + b): each wave its 16 channels, split, published                   [barrier]
-//   S3   K and V of head w; score = q' . K (q' of the row's window by ds_bpermute); the softmax-weighted sum of V over
-//        each window's rows as a SEGMENTED SCAN over the 16 row lanes (the rows of a window are adjacent lanes; DPP
-//        row shifts; the running (max, sum, sum p V) of a window that continues in the next 16 rows is carried in
-//        registers); a window's last row normalises, splits and publishes head w of the attention output
-//   O    out = Wo o + bo for the 16 windows, each wave its 16 channels, whole rows of `out`                   [barrier]
-// Deterministic: no floating-point atomics, fixed association inside a window.  Differences to compress_fused.hip:
-// summation order of the softmax (scan tree instead of slot order) and 2^x instead of e^x -- rounding only.
+//   S3   K and V of head w; score = q' . K (q' of the row's window by ds_bpermute from the lane that holds it); the
+//        softmax-weighted sum of V over each window's rows as a LEFT FOLD over the 16 row lanes (the rows of a window are
+//        adjacent lanes; DPP row_shr:1; the running (max, sum, sum p V) of a window that continues in the next piece is
+//        carried in registers); a window's last row normalises, splits and publishes head w of the attention output
+//   per group of 16 windows, switched in flight:
+//   max  the channel-wise max of the NEXT group's rows (the query tokens, ref :370), 32 rows per piece of the stream,
+//        coalesced, through LDS integer atomics on order-preserving keys (order independent: exact)
+//   Q    when the stream reaches the group: q' = scale log2(e) (Wq q_tok + bq), wave w ends with head w of the 16 queries
+//        in registers (the queries of two groups are held: a piece straddles at most two)               [2 barriers]
+//   O    when the group's last window ends: out = Wo o + bo, each wave its 16 channels of the 16 output rows   [barrier]
+// Deterministic, and independent of the chunking: no floating-point atomics, and the association inside a window (left fold in
+// row order, the carried piece as its prefix) does not depend on where the pieces or the chunks are cut -- a scene's rows are
+// bit-identical whatever it shares a batch with.  Differences to compress_fused.hip: summation order of the softmax (row
+// order instead of list-slot order), 2^x instead of e^x, rcp instead of a division -- rounding only.
 #include "common.hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
