@@ -1,4 +1,4 @@
-"""``CenterHead`` (inference) -- the dense head of the CenterPoint detector that mssvt.yaml configures.
+"""``CenterHead`` -- the dense head of the CenterPoint detector that mssvt.yaml configures.
 
 Drop-in for the reference's pcdet/models/dense_heads/center_head.py: ``SeparateHead`` (:11-46) and ``CenterHead``
 (:49-103, forward :350-381, ``generate_predicted_boxes`` :252-331) with the same constructor arguments, config keys
@@ -6,8 +6,10 @@ and **state-dict keys** (``shared_conv.{0,1}.*``, ``heads_list.{i}.{hm,center,ce
 reference checkpoint loads by key.  Decoding follows centernet_utils.decode_bbox_from_heatmap (:154-216): top-K peaks of
 the sigmoid heat map, sub-cell centre offsets, exp() sizes, atan2 heading, centre-range and score filters; then the
 class-agnostic rotated NMS of model_nms_utils.class_agnostic_nms (:6-38) on the device (mssvt_amd/iou3d_nms_utils.py).
-Training targets / losses (assign_targets, get_loss: :105-250) are outside this build's scope: the head raises in
-training mode instead of silently returning nothing."""
+Training (``.train()``): ``assign_targets`` (:103-214: Gaussian heat maps with CornerNet's radius, sub-cell offsets, log sizes,
+cos / sin headings, flat cell indices, masks) and ``get_loss`` (:220-250: CenterNet focal loss on the clamped sigmoid + masked
+L1 on the gathered regression maps, ``code_weights`` / ``loc_weight``) -- pinned to a training step of the reference's own
+module with its own loss classes (tests/golden/det_head_train.npz: targets, loss terms, every parameter gradient)."""
 import copy
 
 import numpy as np
@@ -96,6 +98,57 @@ def decode_bbox_from_heatmap(heatmap, rot_cos, rot_sin, center, center_z, dim, p
             for b in range(B)]
 
 
+def gaussian_radius(height, width, min_overlap):
+    """CornerNet's radius: the smallest of the three roots that keep a shifted box above `min_overlap` IoU
+    (ref centernet_utils.py:9-35); vectorised over the objects."""
+    s, p = height + width, height * width
+    r1 = (s + (s * s - 4.0 * p * (1.0 - min_overlap) / (1.0 + min_overlap)).sqrt()) / 2.0
+    r2 = (2.0 * s + (4.0 * s * s - 16.0 * (1.0 - min_overlap) * p).sqrt()) / 2.0
+    b3 = -2.0 * min_overlap * s
+    r3 = (b3 + (b3 * b3 - 16.0 * min_overlap * (min_overlap - 1.0) * p).sqrt()) / 2.0
+    return torch.min(torch.min(r1, r2), r3)
+
+
+def splat_gaussian(heatmap, cx, cy, radius):
+    """max-merge a (2 r + 1)^2 Gaussian (sigma = (2 r + 1) / 6, evaluated in float64, entries below eps x peak dropped)
+    centred on cell (cx, cy) into `heatmap` (H, W), clipped at the borders (ref centernet_utils.py:38-69)."""
+    H, W = heatmap.shape
+    ax = np.arange(-radius, radius + 1, dtype=np.float64)
+    sigma = (2 * radius + 1) / 6.0
+    g = np.exp(-(ax[None, :] ** 2 + ax[:, None] ** 2) / (2.0 * sigma * sigma))
+    g[g < np.finfo(g.dtype).eps * g.max()] = 0
+    left, right = min(cx, radius), min(W - cx, radius + 1)
+    top, bottom = min(cy, radius), min(H - cy, radius + 1)
+    if right + left <= 0 or bottom + top <= 0:
+        return
+    patch = torch.from_numpy(g[radius - top:radius + bottom, radius - left:radius + right]).to(heatmap.device).float()
+    region = heatmap[cy - top:cy + bottom, cx - left:cx + right]
+    if min(patch.shape) > 0 and min(region.shape) > 0:
+        torch.max(region, patch, out=region)
+
+
+def centernet_focal_loss(pred, gt):
+    """ref loss_utils.py:264-299 (CornerNet's penalty-reduced focal loss): pred = clamped sigmoid, gt = Gaussian heat map."""
+    pos = gt.eq(1).float()
+    neg = gt.lt(1).float()
+    pos_term = (torch.log(pred) * torch.pow(1 - pred, 2) * pos).sum()
+    neg_term = (torch.log(1 - pred) * torch.pow(pred, 2) * torch.pow(1 - gt, 4) * neg).sum()
+    num_pos = pos.sum()
+    return -neg_term if num_pos == 0 else -(pos_term + neg_term) / num_pos
+
+
+def centernet_reg_loss(maps, mask, ind, target):
+    """ref loss_utils.py:314-386: L1 between the regression maps gathered at the objects' cells and the targets, per code
+    dimension, over the masked objects of the whole batch / their number.  maps (B, D, H, W), ind / mask (B, M), target (B, M, D)."""
+    B, D = maps.shape[0], maps.shape[1]
+    flat = maps.permute(0, 2, 3, 1).reshape(B, -1, D)
+    pred = flat.gather(1, ind.unsqueeze(2).expand(-1, -1, D))
+    num = mask.float().sum()
+    m = mask.unsqueeze(2).expand_as(target).float() * (~torch.isnan(target)).float()
+    per_dim = torch.abs(pred * m - target * m).sum(dim=(0, 1))
+    return per_dim / torch.clamp_min(num, 1.0)
+
+
 class CenterHead(nn.Module):
     def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, voxel_size,
                  predict_boxes_when_training=True):
@@ -166,12 +219,95 @@ class CenterHead(nn.Module):
             ret[k]["pred_labels"] = torch.cat(ret[k]["pred_labels"], dim=0) + 1
         return ret
 
+    def assign_target_of_single_head(self, num_classes, gt_boxes, feature_map_size, feature_map_stride, num_max_objs=500,
+                                     gaussian_overlap=0.1, min_radius=2):
+        """gt_boxes (n, 8+) [x, y, z, dx, dy, dz, heading, ..., class in 1..num_classes] of ONE sample and head ->
+        heat map (classes, H, W), target boxes (M, 8+), flat cell indices (M), mask (M)  (ref :103-158)."""
+        W, H = int(feature_map_size[0]), int(feature_map_size[1])
+        heatmap = gt_boxes.new_zeros(num_classes, H, W)
+        ret_boxes = gt_boxes.new_zeros((num_max_objs, gt_boxes.shape[-1]))
+        inds = gt_boxes.new_zeros(num_max_objs).long()
+        mask = gt_boxes.new_zeros(num_max_objs).long()
+        n = min(num_max_objs, gt_boxes.shape[0])
+        if n == 0:
+            return heatmap, ret_boxes, inds, mask
+        g = gt_boxes[:n]
+        cx = torch.clamp((g[:, 0] - self.point_cloud_range[0]) / self.voxel_size[0] / feature_map_stride, min=0, max=W - 0.5)
+        cy = torch.clamp((g[:, 1] - self.point_cloud_range[1]) / self.voxel_size[1] / feature_map_stride, min=0, max=H - 0.5)
+        centre = torch.stack((cx, cy), dim=-1)
+        cell = centre.int()
+        dx = g[:, 3] / self.voxel_size[0] / feature_map_stride
+        dy = g[:, 4] / self.voxel_size[1] / feature_map_stride
+        radius = torch.clamp_min(gaussian_radius(dx, dy, gaussian_overlap).int(), min=min_radius)
+        ok = (dx > 0) & (dy > 0) & (cell[:, 0] >= 0) & (cell[:, 0] <= W) & (cell[:, 1] >= 0) & (cell[:, 1] <= H)
+        cls = (g[:, -1] - 1).long()
+        for k in torch.nonzero(ok).flatten().tolist():  # (the Gaussians overlap: max-merged in object order)
+            splat_gaussian(heatmap[int(cls[k])], int(cell[k, 0]), int(cell[k, 1]), int(radius[k]))
+        inds[:n][ok] = (cell[:, 1].long() * W + cell[:, 0].long())[ok]
+        mask[:n] = ok.long()
+        cols = [centre - cell.to(g.dtype), g[:, 2:3], g[:, 3:6].log(), torch.cos(g[:, 6:7]), torch.sin(g[:, 6:7])]
+        if g.shape[1] > 8:
+            cols.append(g[:, 7:-1])
+        ret_boxes[:n][ok] = torch.cat(cols, dim=1)[ok]  # (skipped objects keep zero rows)
+        return heatmap, ret_boxes, inds, mask
+
+    def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
+        """gt_boxes (B, M, 8+) with the class id (1-based over class_names, 0 = padding) last; feature_map_size (H, W)
+        -> per head: heatmaps (B, c, H, W), target_boxes (B, M', 8+), inds / masks (B, M')  (ref :160-214).  As in the
+        reference a box reaches a head with its class re-numbered inside that head, and the re-numbering is written into the
+        working copy of the boxes that the FOLLOWING heads read their class names from (ref :190-193)."""
+        size_xy = list(feature_map_size)[::-1]
+        tcfg = _get(self.model_cfg, "TARGET_ASSIGNER_CONFIG")
+        work = gt_boxes.clone()
+        names = ["bg"] + self.class_names
+        out = dict(heatmaps=[], target_boxes=[], inds=[], masks=[], heatmap_masks=[])
+        for head_names in self.class_names_each_head:
+            per_sample = []
+            for b in range(work.shape[0]):
+                boxes = work[b]
+                labels = boxes[:, -1].long().tolist()
+                rows = [i for i, c in enumerate(labels) if names[c] in head_names]
+                for i in rows:
+                    boxes[i, -1] = head_names.index(names[labels[i]]) + 1
+                sel = boxes[rows] if rows else boxes[:0]
+                per_sample.append(self.assign_target_of_single_head(
+                    num_classes=len(head_names), gt_boxes=sel.cpu(), feature_map_size=size_xy,
+                    feature_map_stride=_get(tcfg, "FEATURE_MAP_STRIDE"), num_max_objs=_get(tcfg, "NUM_MAX_OBJS"),
+                    gaussian_overlap=_get(tcfg, "GAUSSIAN_OVERLAP"), min_radius=_get(tcfg, "MIN_RADIUS")))
+            for key, j in (("heatmaps", 0), ("target_boxes", 1), ("inds", 2), ("masks", 3)):
+                out[key].append(torch.stack([t[j] for t in per_sample], dim=0).to(gt_boxes.device))
+        return out
+
+    def get_loss(self):
+        """ref :220-250: per head the focal loss of the clamped sigmoid heat map + loc_weight x sum(code_weights x L1)."""
+        weights = _get(_get(self.model_cfg, "LOSS_CONFIG"), "LOSS_WEIGHTS")
+        order = list(_get(self.separate_head_cfg, "HEAD_ORDER"))
+        loss, tb = 0, {}
+        for idx, pd in enumerate(self.forward_ret_dict["pred_dicts"]):
+            td = self.forward_ret_dict["target_dicts"]
+            hm = torch.clamp(pd["hm"].sigmoid(), min=1e-4, max=1 - 1e-4)
+            hm_loss = centernet_focal_loss(hm, td["heatmaps"][idx])
+            reg = centernet_reg_loss(torch.cat([pd[name] for name in order], dim=1), td["masks"][idx], td["inds"][idx],
+                                     td["target_boxes"][idx])
+            loc_loss = (reg * reg.new_tensor(list(weights["code_weights"]))).sum() * weights["loc_weight"]
+            loss = loss + hm_loss + loc_loss
+            tb["hm_loss_head_%d" % idx] = hm_loss.item()
+            tb["loc_loss_head_%d" % idx] = loc_loss.item()
+        tb["rpn_loss"] = loss.item()
+        return loss, tb
+
     def forward(self, data_dict):
-        if self.training:
-            raise NotImplementedError("mssvt_amd CenterHead is inference-only: target assignment and the CenterNet losses "
-                                      "(ref center_head.py:105-250) are outside this build's scope; call .eval()")
         x = self.shared_conv(data_dict["spatial_features_2d"])
         pred_dicts = [head(x) for head in self.heads_list]
+        if self.training:
+            self.forward_ret_dict["target_dicts"] = self.assign_targets(
+                data_dict["gt_boxes"], feature_map_size=data_dict["spatial_features_2d"].shape[2:])
         self.forward_ret_dict["pred_dicts"] = pred_dicts
-        data_dict["final_box_dicts"] = self.generate_predicted_boxes(data_dict["batch_size"], pred_dicts)
+        if not self.training or self.predict_boxes_when_training:
+            with torch.no_grad():
+                boxes = self.generate_predicted_boxes(data_dict["batch_size"], pred_dicts)
+            if self.training:
+                data_dict["pred_box_dicts"] = boxes  # (the reference re-orders them into `rois` for a second stage: not built)
+            else:
+                data_dict["final_box_dicts"] = boxes
         return data_dict

@@ -110,10 +110,11 @@ class CenterPoint(nn.Module):
             predict_boxes_when_training=bool(self.model_cfg.get("ROI_HEAD", False)), voxel_size=info["voxel_size"])
 
     def forward(self, batch_dict):
-        if self.training:
-            raise NotImplementedError("training losses are outside this build's scope (ref centerpoint.py:13-32)")
         for m in self.module_list:
             batch_dict = m(batch_dict)
+        if self.training:  # ref centerpoint.py:13-32: ({'loss': ...}, tb_dict, disp_dict)
+            loss, tb_dict = self.dense_head.get_loss()
+            return dict(loss=loss), dict(loss_rpn=loss.item(), **tb_dict), {}
         return self.post_processing(batch_dict)
 
     def post_processing(self, batch_dict):

@@ -5,8 +5,12 @@ constructor, ``forward(batch_dict)`` keys, ``get_output_feature_dim`` and state-
 The index part (``torch.unique`` of the merged coordinate) runs in the bitmap voxelizer
 (``csrc/voxelize.hip``), ``scatter_mean`` / ``scatter_max`` of the un-vendored torch_scatter package in
 ``csrc/vfe.hip``; the tiny per-point PFN layers (Linear + BatchNorm1d + ReLU) stay torch modules.
-Inference only: the reductions carry no autograd.  Points outside the grid are kept in the arrays (their
-voxel id is -1) instead of being filtered out, so nothing is compacted or synchronised.
+Inference (eval mode / no grad): the HIP reductions; points outside the grid are kept in the arrays (their voxel id
+is -1) instead of being filtered out, so nothing is compacted or synchronised.  Training (``.train()`` with autograd
+on): the reference's semantics in differentiable torch operations -- out-of-grid points are DROPPED before the PFN, so
+BatchNorm1d sees exactly the reference's rows (dynamic_vfe.py:85-91), the per-voxel mean is an ``index_add``, the
+per-voxel max a ``scatter_reduce('amax')`` (gradient to the maximal rows; pinned to a training step of the reference's
+module by tests/golden/dynamic_vfe_train_*.npz: output, every parameter gradient, the BatchNorm buffers).
 """
 import ctypes
 
@@ -72,14 +76,58 @@ class DynamicVFE(nn.Module):
     def get_output_feature_dim(self):
         return self.num_point_features
 
-    @torch.no_grad()
     def forward(self, batch_dict, **kwargs):
         if self.training:
-            # inference-only drop-in: the per-voxel reductions carry no autograd and BatchNorm1d would see the
-            # out-of-grid rows the reference filters out before the PFN (dynamic_vfe.py:89-91) -- a training
-            # pipeline must not silently freeze the PFN weights / skew the running statistics
-            raise RuntimeError("mssvt_amd DynamicVFE is forward-only (eval mode); call .eval() -- "
-                               "training the PFN layers is not supported by this drop-in")
+            # BatchNorm1d on batch statistics must see exactly the rows the reference feeds it, and the reductions must
+            # carry gradients: the differentiable branch (also under no_grad in train mode: the running statistics move)
+            return self._forward_train(batch_dict)
+        with torch.no_grad():
+            return self._forward_eval(batch_dict)
+
+    def _forward_train(self, batch_dict):
+        """ref dynamic_vfe.py:71-131 with torch_scatter's two reductions as differentiable torch operations."""
+        pts = batch_dict['points']
+        dev = pts.device
+        lo = torch.tensor(self.point_cloud_range_l[:3], dtype=pts.dtype, device=dev)
+        grid = torch.tensor(self.grid_size_l, dtype=torch.int32, device=dev)
+        cell = torch.floor((pts[:, 1:4] - lo) / self.voxel_size_t.to(pts.dtype)).int()  # ref :85
+        keep = ((cell >= 0) & (cell < grid)).all(dim=1)
+        pts, cell = pts[keep], cell[keep]
+        gx, gy, gz = self.grid_size_l
+        key = ((pts[:, 0].long() * gx + cell[:, 0].long()) * gy + cell[:, 1].long()) * gz + cell[:, 2].long()  # ref :89-92
+        keys, inv = torch.unique(key, return_inverse=True)  # sorted: (b, x, y, z) order, as the voxelizer's
+        N = keys.shape[0]
+
+        def per_voxel_mean(v):
+            tot = torch.zeros((N, v.shape[1]), dtype=v.dtype, device=dev).index_add(0, inv, v)
+            cnt = torch.zeros(N, dtype=v.dtype, device=dev).index_add(0, inv, torch.ones_like(inv, dtype=v.dtype))
+            return tot / cnt.clamp(min=1).unsqueeze(1)
+
+        def per_voxel_max(v):
+            idx = inv.unsqueeze(1).expand_as(v)
+            return torch.zeros((N, v.shape[1]), dtype=v.dtype, device=dev).scatter_reduce(0, idx, v, "amax", include_self=False)
+
+        xyz = pts[:, 1:4]
+        cols = [pts[:, 1:self.num_point_features_in + 1]]
+        if self.with_cluster_center:
+            cols.append(xyz - per_voxel_mean(xyz)[inv])
+        if self.with_voxel_center:
+            cols.append(xyz - (cell.to(pts.dtype) * self.voxel_size_t + self.xyz_offset))
+        if self.with_distance:
+            cols.append(torch.norm(xyz, p=2, dim=1, keepdim=True))
+        x = torch.cat(cols, dim=-1)
+        for i, blk in enumerate(self.pfn):
+            x = blk(x)
+            if i < len(self.pfn) - 1:
+                x = torch.cat((x, per_voxel_max(x)[inv]), dim=-1)
+        b = keys // (gx * gy * gz)
+        rem = keys % (gx * gy * gz)
+        coords = torch.stack((b, rem % gz, (rem // gz) % gy, rem // (gy * gz)), dim=1).int()  # [b, z, y, x] (ref :122-126)
+        batch_dict['voxel_features'] = per_voxel_max(x).contiguous()
+        batch_dict['voxel_coords'] = coords.contiguous()
+        return batch_dict
+
+    def _forward_eval(self, batch_dict):
         points = batch_dict['points'].contiguous()  # (P, 1 + F) rows [b, x, y, z, intensity, ...]
         batch_size = batch_dict['batch_size']
         voxel_coords, pv = voxelize.voxelize(points, self.point_cloud_range_l, self.voxel_size_l, self.grid_size_l,

@@ -88,6 +88,62 @@ def load_reference():
     return bev, head
 
 
+def load_reference_losses():
+    """The reference's own CenterNet losses (pcdet/utils/loss_utils.py:264-386) for the training golden: the module is
+    imported unmodified; its one import that needs compiled extensions (box_utils, unused by these two losses) is an empty
+    stand-in module."""
+    box = types.ModuleType("pcdet.utils.box_utils")
+    sys.modules["pcdet.utils.box_utils"] = box
+    sys.modules["pcdet.utils"].box_utils = box
+    sys.modules.pop("pcdet.utils.loss_utils", None)
+    real = importlib.import_module("pcdet.utils.loss_utils")
+    sys.modules["pcdet.utils"].loss_utils = real
+    return real
+
+
+def gen_head_training_step(head_mod):
+    """One TRAINING step of the reference's CenterHead (ref center_head.py:103-250, 350-378): target assignment
+    (Gaussian heat maps, regression targets, indices, masks), the CenterNet focal + L1 losses, every parameter gradient."""
+    real_losses = load_reference_losses()
+    head_mod.loss_utils = real_losses
+    A = ref_import.AttrDict.wrap
+    cfg = dict(HEAD)
+    cfg["LOSS_CONFIG"] = dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=2.0, code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2]))
+    torch.manual_seed(21)
+    head = head_mod.CenterHead(A(cfg), 64, len(CLASSES), CLASSES, np.array(GRID), np.array(PCR), VOXEL,
+                               predict_boxes_when_training=False).train()
+    B, M = 2, 14
+    g = torch.Generator().manual_seed(5)
+    gt = torch.zeros(B, M, 8)
+    for b in range(B):
+        n = M - 3 * b  # the rest stays zero padding (class 0 = background: skipped)
+        gt[b, :n, 0:2] = (torch.rand(n, 2, generator=g) - 0.5) * 36.0
+        gt[b, :n, 2] = torch.rand(n, generator=g) * 2.0 - 1.0
+        gt[b, :n, 3:6] = torch.rand(n, 3, generator=g) * torch.tensor([4.0, 2.0, 1.5]) + torch.tensor([0.5, 0.4, 0.8])
+        gt[b, :n, 6] = (torch.rand(n, generator=g) - 0.5) * 6.28
+        gt[b, :n, 7] = torch.randint(1, 4, (n,), generator=g).float()
+    gt[0, 1, 0:2] = gt[0, 0, 0:2] + 0.3  # two objects whose Gaussians overlap / share a cell neighbourhood
+    gt[1, 2, 0] = 19.1                   # an object at the border of the range: the Gaussian is clipped
+    x = torch.randn(B, 64, GRID[1], GRID[0], generator=g)
+    sd0 = {k: v.clone() for k, v in head.state_dict().items()}
+    head(dict(spatial_features_2d=x, batch_size=B, gt_boxes=gt.clone()))
+    loss, tb = head.get_loss()
+    loss.backward()
+    td = head.forward_ret_dict["target_dicts"]
+    d = dict(spatial_features_2d=x.numpy(), gt_boxes=gt.numpy(), batch_size=B, loss=float(loss.item()),
+             tb_json=json.dumps({k: float(v) for k, v in tb.items()}),
+             cfg_json=json.dumps(dict(HEAD=cfg, CLASSES=CLASSES, PCR=PCR, VOXEL=VOXEL, GRID=GRID, input_channels=64)))
+    for i in range(len(td["heatmaps"])):
+        d["target%d.heatmaps" % i] = td["heatmaps"][i].numpy()
+        d["target%d.target_boxes" % i] = td["target_boxes"][i].numpy()
+        d["target%d.inds" % i] = td["inds"][i].numpy()
+        d["target%d.masks" % i] = td["masks"][i].numpy()
+    d.update({"head." + k: v.numpy() for k, v in sd0.items()})
+    d.update({"grad." + k: v.grad.numpy() for k, v in head.named_parameters() if v.grad is not None})
+    np.savez_compressed(os.path.join(OUT, "det_head_train.npz"), **d)
+    print("det_head_train: loss", float(loss.item()), tb, "objects", int(td["masks"][0].sum()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     bev_mod, head_mod = load_reference()
@@ -128,6 +184,7 @@ def main():
     # the full detector's state-dict keys as the reference modules name them (checkpoint compatibility by key):
     # vfe / backbone_3d keys are pinned by the round-1 goldens; here backbone_2d.* and dense_head.* of mssvt.yaml
     print("head keys", len(head.state_dict()), "bev keys", len(bev.state_dict()))
+    gen_head_training_step(head_mod)
 
 
 if __name__ == "__main__":

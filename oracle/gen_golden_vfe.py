@@ -46,8 +46,10 @@ def _torch_scatter_restatement():
         assert dim == 0 and index.dim() == 1
         n = int(index.max()) + 1
         idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
-        out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).scatter_reduce_(0, idx, src, "amax",
-                                                                                         include_self=False)
+        # (out-of-place: differentiable.  Its gradient goes to the maximal rows, split between exact ties -- torch_scatter sends
+        # it to ONE arg-max row; the VFE takes the max of ReLU outputs, whose only realistic ties are at 0, where the
+        # ReLU's own backward is 0: the two conventions give the same parameter gradients)
+        out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).scatter_reduce(0, idx, src, "amax", include_self=False)
         return out, None  # the VFE only takes [0]
 
     mod.scatter_mean, mod.scatter_max = scatter_mean, scatter_max
@@ -89,10 +91,42 @@ def run(mod, name, filters, pts, B, seed, cluster=True, centre=True):
     print(name, "points", p.shape[0], "voxels", d["voxel_coords"].shape[0], "features", d["voxel_features"].shape)
 
 
+def run_train(mod, name, filters, pts, B, seed):
+    """One TRAINING step of the reference's DynamicVFE (train mode: BatchNorm on batch statistics, running statistics
+    updated; ref dynamic_vfe.py:71-131): output, the gradient of sum(voxel_features * R) with respect to every parameter,
+    and the BatchNorm buffers after the forward."""
+    p = synthetic.make_batch_points(pts, B, seed)
+    p[::53, 1] += 500.0
+    cfg = ref_import.AttrDict.wrap(dict(NUM_FILTERS=filters, WITH_CLUSTER_CENTER=True, WITH_VOXEL_CENTER=True))
+    torch.manual_seed(800 + seed)
+    vfe = mod.DynamicVFE(cfg, 5, list(synthetic.VOXEL_SIZE), list(synthetic.GRID_SIZE), list(synthetic.POINT_CLOUD_RANGE)).train()
+    with torch.no_grad():
+        for m in vfe.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    sd0 = {k: v.clone() for k, v in vfe.state_dict().items()}
+    out = vfe(dict(points=torch.from_numpy(p), batch_size=B))
+    R = torch.randn(out["voxel_features"].shape, generator=torch.Generator().manual_seed(seed))
+    (out["voxel_features"] * R).sum().backward()
+    d = dict(points=p, batch_size=B, num_filters=np.array(filters), weight_of_the_loss=R.numpy(),
+             voxel_features=out["voxel_features"].detach().numpy(), voxel_coords=out["voxel_coords"].numpy(),
+             voxel_size=np.array(synthetic.VOXEL_SIZE), grid_size=np.array(synthetic.GRID_SIZE),
+             point_cloud_range=np.array(synthetic.POINT_CLOUD_RANGE))
+    d.update({"sd." + k: v.numpy() for k, v in sd0.items()})
+    d.update({"grad." + k: v.grad.numpy() for k, v in vfe.named_parameters()})
+    d.update({"after." + k: v.numpy() for k, v in vfe.state_dict().items() if "running" in k or "num_batches" in k})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "points", p.shape[0], "voxels", d["voxel_coords"].shape[0], "grads", sum(1 for k in d if k.startswith("grad.")))
+
+
 def main():
     mod = load_reference_vfe()
     run(mod, "dynamic_vfe_64_128", [64, 128], 6000, 2, 50)
     run(mod, "dynamic_vfe_16", [16], 1500, 3, 51)
+    run_train(mod, "dynamic_vfe_train_32_64", [32, 64], 3000, 2, 52)
     gen_height_compression()
 
 

@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from mssvt_amd.base_bev_backbone import BaseBEVBackbone
@@ -61,14 +62,12 @@ def test_bev_backbone_and_center_head_match_the_reference_run(golden_dir):
     check_against_golden(d, bev, head)
 
 
-def test_center_head_refuses_training_mode(golden_dir):
+def test_center_head_training_mode_needs_ground_truth(golden_dir):
+    """train mode assigns targets (tests/test_head_train_cpu.py pins them to the reference): without gt_boxes it fails loudly"""
     _, _, head = build_from_golden(golden_dir)
     head.train()
-    try:
+    with pytest.raises(KeyError):
         head(dict(spatial_features_2d=torch.zeros(1, 64, 8, 8), batch_size=1))
-        raise AssertionError("training mode must raise")
-    except NotImplementedError:
-        pass
 
 
 def test_detector_topology_keys_and_checkpoint_by_key(tmp_path):

@@ -78,3 +78,39 @@ def test_centerpoint_detector_end_to_end():
         assert bool(torch.isfinite(p["pred_boxes"]).all()) and int(p["pred_labels"].min()) >= 1 and int(p["pred_labels"].max()) <= 3
         assert torch.equal(p["pred_boxes"], q["pred_boxes"]) and torch.equal(p["pred_scores"], q["pred_scores"])  # deterministic
         assert bool((p["pred_scores"][:-1] >= p["pred_scores"][1:]).all())
+
+
+def test_centerpoint_detector_training_step():
+    """The whole detector in train mode (ref detectors/centerpoint.py:9-32): points + ground-truth boxes -> DynamicVFE (batch
+    statistics, differentiable reductions) -> MsSVT backbone (compact training path) -> BEV backbone -> CenterHead targets and
+    losses -> backward.  Every stage's parameters receive a finite gradient; two identical steps agree up to
+    the order of the framework's atomic sums (the differentiable VFE reductions, MIOpen's convolutions)."""
+    from mssvt_amd import centerpoint
+    B = 2
+    pts = torch.from_numpy(synthetic.make_batch_points(20000, B, 77)).to(DEV)
+    rng = np.random.default_rng(3)
+    gt = np.zeros((B, 10, 8), np.float32)
+    for b in range(B):
+        n = 8 - 2 * b
+        gt[b, :n, 0:2] = rng.uniform(-40, 40, (n, 2))
+        gt[b, :n, 2] = rng.uniform(-1, 1, n)
+        gt[b, :n, 3:6] = rng.uniform([1.5, 0.8, 1.0], [5.0, 2.5, 2.0], (n, 3))
+        gt[b, :n, 6] = rng.uniform(-3.1, 3.1, n)
+        gt[b, :n, 7] = rng.integers(1, 4, n)
+    losses = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        det = centerpoint.build_detector().to(DEV).train()
+        ret, tb, _ = det(dict(points=pts, batch_size=B, gt_boxes=torch.from_numpy(gt).to(DEV)))
+        loss = ret["loss"]
+        assert bool(torch.isfinite(loss)) and loss.item() > 0 and abs(tb["loss_rpn"] - loss.item()) < 1e-4 * loss.item()
+        loss.backward()
+        groups = {"vfe": 0, "backbone_3d": 0, "backbone_2d": 0, "dense_head": 0}
+        for k, v in det.named_parameters():
+            g = k.split(".")[0]
+            if v.grad is not None and g in groups:
+                assert bool(torch.isfinite(v.grad).all()), k
+                groups[g] += int(v.grad.abs().sum() > 0)
+        assert all(n > 0 for n in groups.values()), groups
+        losses.append(loss.item())
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[0])
