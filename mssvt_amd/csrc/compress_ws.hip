@@ -446,19 +446,11 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
         f32x2 o01, o23;
         float m_, s_;
         {
-            f32x4 km = f32x4{bk.x, bk.y, bk.z, bk.w}, kl = f32x4{0.f, 0.f, 0.f, 0.f}, kk = kl;
-            f32x4 vm = f32x4{bv.x, bv.y, bv.z, bv.w}, vl = kl, vk = kl;
-#pragma unroll
-            for (int P = 0; P < NP; ++P) {
-                const h16x8 bh = kfrag[(P * 2) * 64 + lane], bl = kfrag[(P * 2 + 1) * 64 + lane];
-                MFMA_H(km, Wkh[P], bh);
-                MFMA_H(vm, Wvh[P], bh);
-                MFMA_H(kl, Wkh[P], bl);
-                MFMA_H(vl, Wvh[P], bl);
-                MFMA_H(kk, Wkl[P], bh);
-                MFMA_H(vk, Wvl[P], bh);
-            }
-            // q' of the row's window: the rows of 16 consecutive rows belong to the newest group or to the one before it
+            // q' of the row's window: the rows of 16 consecutive rows belong to the newest group or to the one before it.
+            // Requested BEFORE the products, and with them every branch of this block: between the last MFMA and the first
+            // read of an accumulator there must be NO control flow -- the compiler pads that distance with s_nop inside a basic
+            // block only; behind a branch the sums were read a few clocks early, i.e. without their last term (1e-4 errors
+            // that came and went with the instruction schedule)
             const int src = 4 * (16 * g + (rvalid ? widx : 0));
             const bool newest = grow == gq;
             float qr[4];
@@ -470,6 +462,18 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
                     const float qa = cw_float(__builtin_amdgcn_ds_bpermute(src, cw_bits(qpA[i])));
                     qr[i] = newest ? qr[i] : qa;
                 }
+            }
+            f32x4 km = f32x4{bk.x, bk.y, bk.z, bk.w}, kl = f32x4{0.f, 0.f, 0.f, 0.f}, kk = kl;
+            f32x4 vm = f32x4{bv.x, bv.y, bv.z, bv.w}, vl = kl, vk = kl;
+#pragma unroll
+            for (int P = 0; P < NP; ++P) {
+                const h16x8 bh = kfrag[(P * 2) * 64 + lane], bl = kfrag[(P * 2 + 1) * 64 + lane];
+                MFMA_H(km, Wkh[P], bh);
+                MFMA_H(vm, Wvh[P], bh);
+                MFMA_H(kl, Wkh[P], bl);
+                MFMA_H(vl, Wvh[P], bl);
+                MFMA_H(kk, Wkl[P], bh);
+                MFMA_H(vk, Wvl[P], bh);
             }
             float sc = 0.f;
             float o[4];
@@ -501,10 +505,6 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
         o23 = __builtin_elementwise_fma(po23_, f32x2{ea_, ea_}, o23 * f32x2{eb_, eb_});                 \
         m_ = (mg_) ? nm_ : m_;                                                                          \
     }
-        {  // the piece carried in from the previous 16 rows joins row lane 0
-            const bool mg0 = la == 0 && cseg == seg;
-            CW_COMBINE(mg0, cm, cs, co01, co23)
-        }
         {
             // LEFT FOLD over the row lanes: ((x0 + x1) + x2) + ... in row order, whatever the position of the window in these 16
             // rows and wherever a window is cut by their end (the carried piece is the fold so far) -- the association, hence
@@ -518,6 +518,34 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
             const int pg1 = CW_DPP_I(seg, 0x111);
             const unsigned int starts = (unsigned int)__ballot((la == 0) | (pg1 != seg)) & 0xFFFFu;  // (the same in the four lane rows)
             const int pos = la - (31 - __clz((int)(starts & ((2u << la) - 1u))));  // row's place inside its piece
+            const bool cont0 = la == 0 && cseg == seg;  // row lane 0 continues the window open at the end of the previous piece
+            // A window's weights are taken against ONE reference exponent, the score of its FIRST row (carried on with
+            // the open window): p = 2^(score - ref), and the fold is then plain additions of p and p V -- 5 DPP moves + 5
+            // fused multiply-adds per step instead of a two-exponential merge of (max, sum, sum p V) states (timing-only
+            // ablation: the merge fold was 15 of the kernel's 78 us).  Same quotient sum p V / sum p; cut-independent like
+            // the merge (the reference belongs to the window).  Rows more than 2^100 above their reference (69 nats:
+            // unheard of behind a LayerNorm) would overflow the sums: such a piece -- a wave-uniform decision -- takes
+            // the merge form, which moves the reference (tests: scores 60 x apart).
+            const float ref = cw_float(__builtin_amdgcn_ds_bpermute(4 * (lane - pos), cw_bits(cont0 ? cm : m_)));
+            const float dexp = m_ - ref;
+            if (__ballot(rvalid && !(dexp <= 100.0f)) == 0ull) {
+                const float pw2 = __builtin_amdgcn_exp2f(dexp);
+                const float c0 = cont0 ? 1.0f : 0.0f;
+                s_ = __builtin_fmaf(cs, c0, pw2);
+                o01 = __builtin_elementwise_fma(co01, f32x2{c0, c0}, o01 * f32x2{pw2, pw2});
+                o23 = __builtin_elementwise_fma(co23, f32x2{c0, c0}, o23 * f32x2{pw2, pw2});
+                m_ = ref;
+                for (int k = 1;; ++k) {
+                    const bool mk = pos == k;
+                    if (__ballot(mk) == 0ull) break;  // (wave-uniform)
+                    const float kf = mk ? 1.0f : 0.0f;
+                    const float a0_ = o01[0], a1_ = o01[1], a2_ = o23[0], a3_ = o23[1];
+                    s_ = __builtin_fmaf(CW_DPP_F(s_, 0x111), kf, s_);
+                    o01 = f32x2{__builtin_fmaf(CW_DPP_F(a0_, 0x111), kf, a0_), __builtin_fmaf(CW_DPP_F(a1_, 0x111), kf, a1_)};
+                    o23 = f32x2{__builtin_fmaf(CW_DPP_F(a2_, 0x111), kf, a2_), __builtin_fmaf(CW_DPP_F(a3_, 0x111), kf, a3_)};
+                }
+            } else {
+                CW_COMBINE(cont0, cm, cs, co01, co23)  // the piece carried in from the previous 16 rows joins row lane 0
 #define CW_STEP(ctrl_, mg_)                                                                             \
     {                                                                                                   \
         const float pm_ = CW_DPP_F(m_, ctrl_), ps_ = CW_DPP_F(s_, ctrl_);                               \
@@ -525,10 +553,11 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
         const f32x2 p01_ = f32x2{CW_DPP_F(a0_, ctrl_), CW_DPP_F(a1_, ctrl_)}, p23_ = f32x2{CW_DPP_F(a2_, ctrl_), CW_DPP_F(a3_, ctrl_)}; \
         CW_COMBINE(mg_, pm_, ps_, p01_, p23_)                                                           \
     }
-            for (int k = 1;; ++k) {
-                const bool mk = pos == k;
-                if (__ballot(mk) == 0ull) break;  // (wave-uniform)
-                CW_STEP(0x111, mk)
+                for (int k = 1;; ++k) {
+                    const bool mk = pos == k;
+                    if (__ballot(mk) == 0ull) break;  // (wave-uniform)
+                    CW_STEP(0x111, mk)
+                }
             }
 #undef CW_STEP
 #undef CW_COMBINE
@@ -562,10 +591,11 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
                         MFMA_H(l, ah, bl);
                         MFMA_H(k, al, bh);
                     }
-                    if (ow0 + la < ow1)
-                        *reinterpret_cast<float4 *>(a.out + (size_t)(ow0 + la) * C + ch) =
-                            make_float4(__builtin_fmaf(l[0] + k[0], CW_INV, m[0]), __builtin_fmaf(l[1] + k[1], CW_INV, m[1]),
-                                        __builtin_fmaf(l[2] + k[2], CW_INV, m[2]), __builtin_fmaf(l[3] + k[3], CW_INV, m[3]));
+                    // (formed before the predicated store: no branch between the products and the reads of their sums)
+                    const float4 res = make_float4(__builtin_fmaf(l[0] + k[0], CW_INV, m[0]), __builtin_fmaf(l[1] + k[1], CW_INV, m[1]),
+                                                   __builtin_fmaf(l[2] + k[2], CW_INV, m[2]), __builtin_fmaf(l[3] + k[3], CW_INV, m[3]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ow0 + la < ow1) *reinterpret_cast<float4 *>(a.out + (size_t)(ow0 + la) * C + ch) = res;
                 }
                 ++jo;
                 CSTAMP(13)  // O product

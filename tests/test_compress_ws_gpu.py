@@ -111,6 +111,24 @@ def test_one_launch_compress_attention_matches_float64(points, B, ws, ns, monkey
     assert float((old[:nw] - new[:nw]).abs().max()) <= 2e-5 * scale
 
 
+def test_one_launch_compress_with_scores_far_apart(monkeypatch):
+    """Scores of a window more than 2^100 apart (queries scaled up 60 x): the pieces that hold such rows take the merge form of
+    the fold (the reference exponent moves), the others the plain sums -- one result, the float64 softmax."""
+    blk = _compress_block()
+    with torch.no_grad():
+        blk.ms_attn.to_qs[0].weight.mul_(60.0)
+        blk.ms_attn.to_qs[0].bias.mul_(60.0)
+    sp = _sp(60000, 1, 8)
+    new, p, xhat, calls = _attention_only(blk, sp, True, monkeypatch)
+    assert "mssvt_compress_ws" in calls
+    nw = int(p.num_wins.item())
+    want = _reference_f64(blk, sp, p, xhat)
+    scale = max(1.0, float(want.abs().max()))
+    # (scores of magnitude ~1e3 carry an absolute error ~1e-4 in fp32: the weights of near-tied rows move by that much)
+    err = (new[:nw].double() - want).abs()
+    assert float(err.max()) <= 2e-3 * scale and float(err.mean()) <= 2e-5 * scale
+
+
 def test_one_launch_compress_is_deterministic_and_ignores_stale_memory(monkeypatch):
     blk = _compress_block()
     outs = []
