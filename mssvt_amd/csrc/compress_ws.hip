@@ -519,17 +519,17 @@ __global__ void __launch_bounds__((C / 16) * MSSVT_WAVE, 1) k_cmp_ws(CwArgs a, c
             const unsigned int starts = (unsigned int)__ballot((la == 0) | (pg1 != seg)) & 0xFFFFu;  // (the same in the four lane rows)
             const int pos = la - (31 - __clz((int)(starts & ((2u << la) - 1u))));  // row's place inside its piece
             const bool cont0 = la == 0 && cseg == seg;  // row lane 0 continues the window open at the end of the previous piece
-            // A window's weights are taken against ONE reference exponent, the score of its FIRST row (carried on with
-            // the open window): p = 2^(score - ref), and the fold is then plain additions of p and p V -- 5 DPP moves + 5
-            // fused multiply-adds per step instead of a two-exponential merge of (max, sum, sum p V) states (timing-only
-            // ablation: the merge fold was 15 of the kernel's 78 us).  Same quotient sum p V / sum p; cut-independent like
-            // the merge (the reference belongs to the window).  Rows more than 2^100 above their reference (69 nats:
-            // unheard of behind a LayerNorm) would overflow the sums: such a piece -- a wave-uniform decision -- takes
-            // the merge form, which moves the reference (tests: scores 60 x apart).
-            const float ref = cw_float(__builtin_amdgcn_ds_bpermute(4 * (lane - pos), cw_bits(cont0 ? cm : m_)));
-            const float dexp = m_ - ref;
-            if (__ballot(rvalid && !(dexp <= 100.0f)) == 0ull) {
-                const float pw2 = __builtin_amdgcn_exp2f(dexp);
+            // The weights are taken WITHOUT a reference exponent, p = 2^score, and the fold is then plain additions of p and
+            // p V -- 5 DPP moves + 5 fused multiply-adds per step instead of a two-exponential merge of (max, sum, sum p V)
+            // states (timing-only ablation: the merge fold was 15 of the kernel's 78 us).  Same quotient sum p V / sum p, and
+            // cut-independent like the merge: p depends on the row alone.  Allowed while every score of the piece lies in
+            // [-100, 100] (2^+-100: the sums of <= 32 rows neither overflow nor vanish; scores behind a LayerNorm are two
+            // orders of magnitude smaller) and no window comes in with a moved reference; else the piece -- a wave-uniform
+            // decision -- takes the merge form (tests: scores 60 x apart).  (m, s, o) = (reference, sum p, sum p V) in both.
+            // (every lane is tested, also rows that belong to no window: their p is multiplied by 0, which must not be 0 x inf)
+            if (__ballot(!(__builtin_fabsf(m_) <= 100.0f) || (cont0 && cm != 0.0f)) == 0ull) {
+                const float pw2 = __builtin_amdgcn_exp2f(m_);
+                const float ref = 0.0f;
                 const float c0 = cont0 ? 1.0f : 0.0f;
                 s_ = __builtin_fmaf(cs, c0, pw2);
                 o01 = __builtin_elementwise_fma(co01, f32x2{c0, c0}, o01 * f32x2{pw2, pw2});
