@@ -244,7 +244,10 @@ int mssvt_level_setup_sorted_pillars(
  * Optional resolved metadata (kmeta1 == NULL: skipped; each qmeta_* may be NULL on its own): qmeta_* (cap,max_num_*,4), kmeta1/2
  * (cap,K,4) f32 = (voxel centre - window centre in metres, bits of the global feature row or
  * -1 for empty / masked slots); wcentre (cap,4) = window centre; nq_valid (3,cap) = valid odd /
- * even / win1 entries per window.  indices (N,4) voxel coords.
+ * even / win1 entries per window.  indices (N,4) voxel coords.  With the metadata asked for, the list rows ind_*, the key
+ * indices / masks k_ind* / k_mask* and the owner_* arrays may each be NULL (the fused consumers read the metadata and the
+ * interpolation tables: mssvt_frame_forward passes none of them); the weights of the tables use the hardware's square root
+ * and reciprocal (1 ulp each).
  * column_vbase / level_status_dev (optional, with occ_columns; from mssvt_level_setup_sorted): for a voxel list sorted
  * by (b,x,y,z) the index of an occupied cell is column_vbase + popcount(column word below z) and the hash is not
  * probed at all (xyz_to_vidx may then be NULL); when level_status_dev[0] has ST_UNSORTED (8) set the hash is used.

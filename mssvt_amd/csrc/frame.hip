@@ -154,7 +154,7 @@ struct Layout {
     // -1 arena
     int *neg0;
     size_t neg_ints;
-    int *owners, *tab_rows, *pair_win;
+    int *tab_rows, *pair_win;
     // zero region
     int *zero0;
     size_t zero_ints;
@@ -164,8 +164,7 @@ struct Layout {
     // the rest
     int *cnt, *vbase, *scratch, *win_blk, *vcount_blk;
     float *xhat0;
-    int *ind_odd, *ind_even, *ind_win1, *k_ind[2], *win_vstart, *nq_valid;
-    unsigned char *k_mask[2];
+    int *win_vstart, *nq_valid;
     float *qmeta[3], *kmeta[2], *wcentre, *tab_w;
     int n_tabs, tab_pat[4], tab_interp[4];
     int n_pat, pats[3];
@@ -205,7 +204,6 @@ void make_layout(const Frame &f, int n, char *base, Layout &L) {
     }
     // ---- -1 arena
     L.neg0 = b.take<int>(0);
-    L.owners = b.take<int>(ints_al(3 * cap));
     L.tab_rows = b.take<int>(ints_al((size_t)L.n_tabs * N * 4));
     L.pair_win = b.take<int>(ints_al(cap));
     L.c_k_ind = b.take<int>(ints_al(cap * (size_t)(f.has_cmp ? f.cmp.ns : 1)));  // (the level set-up writes the listed slots only)
@@ -236,14 +234,9 @@ void make_layout(const Frame &f, int n, char *base, Layout &L) {
     L.win_blk = b.take<int>(N * 4);
     L.vcount_blk = b.take<int>(B);
     L.xhat0 = b.take<float>(N * C);
-    L.ind_odd = b.take<int>(cap * p.n_o);
-    L.ind_even = b.take<int>(cap * p.n_e);
-    L.ind_win1 = b.take<int>(cap * p.n1);
-    for (int g = 0; g < 2; ++g) {
-        L.k_ind[g] = b.take<int>(cap * p.K);
-        L.k_mask[g] = b.take<unsigned char>(cap * p.K);
-        L.kmeta[g] = b.take<float>(cap * p.K * 4);
-    }
+    // (the plan's list rows, key indices / masks and owner arrays are not asked for: its consumers here read the resolved
+    // metadata and the interpolation tables)
+    for (int g = 0; g < 2; ++g) L.kmeta[g] = b.take<float>(cap * p.K * 4);
     L.win_vstart = b.take<int>(cap);
     for (int l = 0; l < 3; ++l) L.qmeta[l] = nullptr;
     for (int i = 0; i < L.n_pat; ++i) {
@@ -547,7 +540,6 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
     // ---- window plan of the Blocks, with the interpolation tables of every (pattern, interpolation) variant
     const float mn3[3] = {f->range[0], f->range[1], f->range[2]};
     const float wsm[3] = {f->vs[0] * p.ws[0], f->vs[1] * p.ws[1], f->vs[2] * p.ws[2]};
-    int *owner_win1 = L.owners, *owner_odd = L.owners + cap, *owner_even = L.owners + 2 * (size_t)cap;
     {
         int tab_list[4], tab_zero[4];
         int *tab_row[4];
@@ -560,8 +552,8 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
         }
         FR_TRY(mssvt_window_plan_two(
             X, Y, Z, p.ws[0], p.ws[1], p.ws[2], p.n_o, p.n_e, p.n1, p.n2, H, B, p.num_o, p.num_e, p.num_1, p.num_2, p.t_o, p.t_e,
-            p.t_1, p.t_2, p.K, L.win_blk, L.hdr[0] + 1, cap, nullptr, L.cnt, L.ind_odd, L.ind_even, L.ind_win1, L.k_ind[0],
-            L.k_ind[1], L.k_mask[0], L.k_mask[1], L.win_vstart, owner_win1, owner_odd, owner_even, indices, f->vs, mn3, wsm,
+            p.t_1, p.t_2, p.K, L.win_blk, L.hdr[0] + 1, cap, nullptr, L.cnt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+            nullptr, L.win_vstart, nullptr, nullptr, nullptr, indices, f->vs, mn3, wsm,  // (lists / key indices / owners: nobody reads them here)
             L.qmeta[0], L.qmeta[1], L.qmeta[2], L.kmeta[0], L.kmeta[1], L.wcentre, L.nq_valid, L.occ, p.fp4, p.packed_offsets,
             L.vbase, L.status, L.vcount_blk, L.n_tabs, tab_list, L.tab_interp, tab_zero, tab_row, tab_w, stream));
     }

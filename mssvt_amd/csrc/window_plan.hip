@@ -274,17 +274,18 @@ __device__ __forceinline__ unsigned long long lanes_below(int k) {
 // array of its voxels.
 __device__ __forceinline__ void plan_emit_list(int w, int lane, int maxn, int nv, int first, const int *hsv, const float4 *hmeta,
                                                int *ind, float4 *qmeta, int *owner, int vstart) {
+    if (!ind && !qmeta && !owner) return;  // (nobody wants this list's rows: the whole-frame call skips what only the operator-level tests read)
     for (int k = lane; k < maxn; k += MSSVT_WAVE) {
         const bool valid = k < nv;
         const int e = valid ? first + k : 0;
         const int sv = valid ? hsv[e] : MSSVT_EMPTY;
-        ind[(size_t)w * maxn + k] = sv;
+        if (ind) ind[(size_t)w * maxn + k] = sv;
         if (qmeta) {
             const float4 m = hmeta[e];  // (component-wise select: a float4 select goes through scratch)
             qmeta[(size_t)w * maxn + k] = make_float4(valid ? m.x : 0.f, valid ? m.y : 0.f, valid ? m.z : 0.f,
                                                        valid ? m.w : __builtin_bit_cast(float, -1));
         }
-        if (valid) atomicMax(owner + vstart + sv, w * maxn + k);
+        if (valid && owner) atomicMax(owner + vstart + sv, w * maxn + k);
     }
 }
 
@@ -511,8 +512,8 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
                 const int first = a.tabs[ti].list == 1 ? cnt_odd : 0;
                 const int nvl = a.tabs[ti].list == 0 ? nO : a.tabs[ti].list == 1 ? nE : n1, maxn = a.tabs[ti].maxn;
                 const int ncand = a.tabs[ti].interp ? nvl + min(3, maxn - nvl) : 0;
-                float *kx = cand + 4 * (ti - t0) * a.tab_q, *ky = kx + a.tab_q, *kz = ky + a.tab_q;
-                int *kvalid = reinterpret_cast<int *>(kz + a.tab_q);
+                // one 16-byte entry per candidate: (x, y, z, slot << 1 | valid) -- one LDS read per candidate in the search below
+                float4 *kc = reinterpret_cast<float4 *>(cand) + (ti - t0) * a.tab_q;
                 for (int k = lane; k < ncand; k += MSSVT_WAVE) {
                     float x = 0.f, y = 0.f, z = 0.f;
                     if (k < nvl) {
@@ -522,8 +523,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
                         y = plan_centre(cy + oy, a.vsy, a.miny);
                         z = plan_centre(cz + oz, a.vsz, a.minz);
                     }
-                    kx[k] = x; ky[k] = y; kz[k] = z;
-                    kvalid[k] = (k << 1) | (k < nvl ? 1 : 0);  // slot, valid bit
+                    kc[k] = make_float4(x, y, z, __builtin_bit_cast(float, (k << 1) | (k < nvl ? 1 : 0)));  // slot, valid bit
                 }
                 if (tl == ti - t0) {
                     nc_mine = ncand; first_mine = first; maxn_mine = maxn; zero_mine = a.tabs[ti].zero_row;
@@ -532,8 +532,7 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
                 }
             }
             wave_lds_sync();
-            const float *kx = cand + 4 * tl * a.tab_q, *ky = kx + a.tab_q, *kz = ky + a.tab_q;
-            const int *kvalid = reinterpret_cast<const int *>(kz + a.tab_q);
+            const float4 *kc = reinterpret_cast<const float4 *>(cand) + tl * a.tab_q;
             if (row_mine != nullptr && !interp_mine) {  // ref mssvt_backbone.py:327-330: only the query voxels are updated
                 for (int k = lane % per; k < nvl_mine; k += per) {
                     const int v = hsv[first_mine + k];
@@ -552,19 +551,24 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
                     float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
                     int c1 = -1, c2 = -1, c3 = -1;
                     for (int k = 0; k < nc_mine; ++k) {
-                        const float dx = ux - kx[k], dy = uy - ky[k], dz = uz - kz[k];
+                        const float4 kp = kc[k];
+                        const float dx = ux - kp.x, dy = uy - kp.y, dz = uz - kp.z;
                         const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                         if (d < b1) { b3 = b2; c3 = c2; b2 = b1; c2 = c1; b1 = d; c1 = k; }
                         else if (d < b2) { b3 = b2; c3 = c2; b2 = d; c2 = k; }
                         else if (d < b3) { b3 = d; c3 = k; }
                     }
                     // fewer than three candidates (nq < 3): the reference leaves index 0 / distance 1e40 -> weight ~0
-                    const int m1 = c1 >= 0 ? kvalid[c1] : 0, m2 = c2 >= 0 ? kvalid[c2] : 0, m3 = c3 >= 0 ? kvalid[c3] : 0;
-                    const float d1 = fmaxf(c1 >= 0 ? sqrtf(b1) : INFINITY, 1e-10f), d2 = fmaxf(c2 >= 0 ? sqrtf(b2) : INFINITY, 1e-10f),
-                                d3 = fmaxf(c3 >= 0 ? sqrtf(b3) : INFINITY, 1e-10f);
-                    float w1 = 1.0f / d1, w2 = 1.0f / d2, w3 = 1.0f / d3;
-                    const float norm = (w1 + w2) + w3;
-                    w1 /= norm; w2 /= norm; w3 /= norm;
+                    const int m1 = c1 >= 0 ? __builtin_bit_cast(int, kc[c1].w) : 0, m2 = c2 >= 0 ? __builtin_bit_cast(int, kc[c2].w) : 0,
+                              m3 = c3 >= 0 ? __builtin_bit_cast(int, kc[c3].w) : 0;
+                    // (hardware square root / reciprocal, 1 ulp each: the IEEE-exact library forms are ~85 instructions per voxel
+                    // for weights whose consumers carry an fp32 tolerance; the reference itself mixes float and double here)
+                    const float d1 = fmaxf(c1 >= 0 ? __builtin_amdgcn_sqrtf(b1) : INFINITY, 1e-10f),
+                                d2 = fmaxf(c2 >= 0 ? __builtin_amdgcn_sqrtf(b2) : INFINITY, 1e-10f),
+                                d3 = fmaxf(c3 >= 0 ? __builtin_amdgcn_sqrtf(b3) : INFINITY, 1e-10f);
+                    float w1 = __builtin_amdgcn_rcpf(d1), w2 = __builtin_amdgcn_rcpf(d2), w3 = __builtin_amdgcn_rcpf(d3);
+                    const float rnorm = __builtin_amdgcn_rcpf((w1 + w2) + w3);
+                    w1 *= rnorm; w2 *= rnorm; w3 *= rnorm;
                     if (!(m1 & 1) || c1 < 0) w1 = 0.f;  // empty slots carry zero features
                     if (!(m2 & 1) || c2 < 0) w2 = 0.f;
                     if (!(m3 & 1) || c3 < 0) w3 = 0.f;
@@ -606,17 +610,19 @@ __global__ void __launch_bounds__(PLAN_MAX_WPB *MSSVT_WAVE, FPS_TPL <= 4 ? PLAN_
             fps_on_list_regs<FPS_TPL >= 16 ? 16 : 1>(hpk, nv, n, K, bs, fps_out, lane);
         wave_lds_sync();
         PSTAMP()
-        int *kout = (scale ? a.k_ind2 : a.k_ind1) + (size_t)w * K;
-        unsigned char *mout = (scale ? a.k_mask2 : a.k_mask1) + (size_t)w * K;
+        int *kout0 = scale ? a.k_ind2 : a.k_ind1;
+        unsigned char *mout0 = scale ? a.k_mask2 : a.k_mask1;
+        int *kout = kout0 ? kout0 + (size_t)w * K : nullptr;
+        unsigned char *mout = mout0 ? mout0 + (size_t)w * K : nullptr;
         for (int j = lane; j < K; j += MSSVT_WAVE) {
             const int f = fps_out[j];
             const bool entry = f < nv;  // a list entry (else an empty slot: index -1, offset (0,0,0))
             // ref :253-256: the index is round-tripped through fp32 and "(x + 0.1).int()"
             // truncates toward zero -> a picked EMPTY slot (-1) becomes voxel 0 of the sample
             const int kid = (int)((float)(entry ? hsv[f] : MSSVT_EMPTY) + 0.1f);
-            kout[j] = kid;
+            if (kout) kout[j] = kid;
             const bool masked = (j > 0 && f == 0) || kid < 0;
-            mout[j] = (unsigned char)(masked ? 1 : 0);
+            if (mout) mout[j] = (unsigned char)(masked ? 1 : 0);
             if (a.kmeta1) {
                 float4 m = none;
                 if (!masked) {
@@ -667,9 +673,10 @@ extern "C" int mssvt_window_plan_two(
     const int *host_footprint4, const int *packed_offsets, const int *column_vbase, const int *level_status_dev,
     const int *win_counts_dev, int num_tabs, const int *host_tab_list, const int *host_tab_interp,
     const int *host_tab_zero_row, int *const *host_tab_row, float *const *host_tab_w, void *stream) {
-    if (!win_indices || !num_wins_dev || !v_bs_cnt || !ind_odd || !ind_even ||
-        !ind_win1 || !k_ind1 || !k_ind2 || !k_mask1 || !k_mask2 || !win_vstart || !owner_win1 ||
-        !owner_odd || !owner_even || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
+    // (ind_* / k_ind* / k_mask* / owner_*: each optional when the resolved metadata is asked for -- the fused consumers read
+    // kmeta / qmeta / the tables; without metadata they are the call's only outputs)
+    const bool lists_wanted = ind_odd && ind_even && ind_win1 && k_ind1 && k_ind2 && k_mask1 && k_mask2 && owner_win1 && owner_odd && owner_even;
+    if (!win_indices || !num_wins_dev || !v_bs_cnt || !win_vstart || (!kmeta1 && !lists_wanted) || hash_size <= 0 || key_num_sample <= 0 || max_num_win1 <= 0 ||
         max_num_win2 <= 0 || max_num_odd <= 0 || max_num_even <= 0 || (column_vbase && !level_status_dev))
         return MSSVT_E_BADARG;
     if (win_capacity <= 0) return MSSVT_OK;
