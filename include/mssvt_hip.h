@@ -220,7 +220,7 @@ int mssvt_level_setup_sorted(int num_voxels, int batch_size, int x_max, int y_ma
 /* mssvt_level_setup_sorted that also writes the K4 lists of partition `pillar_set` -- pillar windows [1,1,z], offsets of
  * vox_query_win1 (num_win1 <= 64 rows) with x = y = 0 -- i.e. the outputs of mssvt_window_plan_one(disjoint_lists = 2,
  * with_pad = 0) for that partition (k_ind (cap,max_num_win1), win_vstart, win_cnt, pair_base (cap), pair_win / pair_vox (N);
- * pair_win AND k_ind pre-filled with -1 -- only listed slots are written --; pair_base / pair_vox may be NULL:
+ * pair_win AND k_ind pre-filled with -1 -- only listed slots are written --; k_ind / pair_base / pair_vox may be NULL:
  * mssvt_compress_fused reads neither; table z offsets in [-32, 31]): every such window is a slab of ONE column's occupancy word, so its list falls out where
  * the window is numbered, without a launch of its own (ref gather_one_window_voxels, ms_sparse_attention_gpu.cu:383-433).
  * MSSVT_E_TOOLARGE: the partition's windows are not pillars.                                                        */
@@ -455,17 +455,17 @@ int mssvt_compress_fused(
  * and Wv as MFMA fragments in registers (wave h = head h), Wq / Wo in LDS; the key tokens, K, V, the scores and the
  * projected queries never leave the CU (csrc/compress_ws.hip).  packed: mssvt_compress_ws_packed_bytes(C) bytes written by
  * mssvt_compress_ws_pack from pos_proj.2 (C,C), to_q (C,C), to_kv (2C,C), proj (C,C) -- once per parameter version.
+ * Of the K4 plan it reads win_cnt and pair_win only (the lists themselves are runs of rows).
  * MSSVT_E_TOOLARGE: shape not covered (use mssvt_compress_fused).  Deterministic; differs from mssvt_compress_fused by the
  * association of the softmax sums only.                                                                              */
 long long mssvt_compress_ws_packed_bytes(int C);
 int mssvt_compress_ws_pack(int C, const float *Wpos2, const float *Wq, const float *Wkv, const float *Wo, void *packed,
                            void *stream);
 int mssvt_compress_ws(int C, int head_dim, float scale, int z_ws, int max_num_win1, int num_voxels, const int *num_wins_dev,
-                      int win_capacity, const int *indices, const int *k_ind, const int *win_vstart, const int *win_cnt,
-                      const int *pair_win, const float *host_voxel_size3, const float *host_range_min3,
-                      const float *host_win_size3, const float *xhat, const float *Wpos1, const float *bpos1,
-                      const float *bpos2, const float *bq, const float *bkv, const float *bo, const void *packed, float *out,
-                      void *stream);
+                      int win_capacity, const int *indices, const int *win_cnt, const int *pair_win,
+                      const float *host_voxel_size3, const float *host_range_min3, const float *host_win_size3,
+                      const float *xhat, const float *Wpos1, const float *bpos1, const float *bpos2, const float *bq,
+                      const float *bkv, const float *bo, const void *packed, float *out, void *stream);
 
 /* Backward of mssvt_layer_norm (training path; autograd's LayerNorm backward in the reference): dx (N,C), dweight (C),
  * dbias (C) from x, dy; mean / rstd are recomputed.  The column sums are per-workgroup partial rows in `workspace`

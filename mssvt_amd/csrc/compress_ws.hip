@@ -50,7 +50,7 @@ struct CwArgs {
     float qscale;  // attention scale x log2(e)
     const int *num_wins;                      // device
     const int *indices;                       // (N, 4) [b, z, y, x]
-    const int *k_ind, *win_vstart, *win_cnt;  // K4 lists: only the run [vstart + min(list), + cnt) is taken from them
+    const int *win_cnt;                       // voxels of every window (a list of max_num_win1 entries is not zero padded)
     const int *pair_win;                      // (N) window of every voxel, -1: in no list (cells above the window grid)
     float vsx, vsy, vsz, minx, miny, minz, wsx, wsy, wsz;
     const float *xhat;
@@ -655,12 +655,12 @@ extern "C" int mssvt_compress_ws_pack(int C, const float *Wpos2, const float *Wq
 // x_ws = y_ws = 1 with max_num_win1 >= z_ws and <= 32 (no list is truncated: a window is one run of rows), one head group,
 // head_dim 16, C = 128, operands inside the fp16 range (fused._compress_f16_ok).  MSSVT_E_TOOLARGE for other shapes.
 extern "C" int mssvt_compress_ws(int C, int head_dim, float scale, int z_ws, int max_num_win1, int num_voxels,
-                                 const int *num_wins_dev, int win_capacity, const int *indices, const int *k_ind, const int *win_vstart,
-                                 const int *win_cnt, const int *pair_win, const float *host_voxel_size3,
+                                 const int *num_wins_dev, int win_capacity, const int *indices, const int *win_cnt,
+                                 const int *pair_win, const float *host_voxel_size3,
                                  const float *host_range_min3, const float *host_win_size3, const float *xhat, const float *Wpos1,
                                  const float *bpos1, const float *bpos2, const float *bq, const float *bkv, const float *bo,
                                  const void *packed, float *out, void *stream) {
-    if (!num_wins_dev || !indices || !k_ind || !win_vstart || !win_cnt || !pair_win || !host_voxel_size3 ||
+    if (!num_wins_dev || !indices || !win_cnt || !pair_win || !host_voxel_size3 ||
         !host_range_min3 || !host_win_size3 || !xhat || !Wpos1 || !bpos1 || !bpos2 || !bq || !bkv || !bo || !packed || !out ||
         max_num_win1 <= 0 || num_voxels < 0 || win_capacity <= 0 || z_ws <= 0)
         return MSSVT_E_BADARG;
@@ -669,7 +669,7 @@ extern "C" int mssvt_compress_ws(int C, int head_dim, float scale, int z_ws, int
     CwArgs a;
     a.ns = max_num_win1; a.num_voxels = num_voxels; a.z_magic = 65536 / z_ws + 1; a.qscale = scale * CW_LOG2E;
     a.num_wins = num_wins_dev; a.indices = indices;
-    a.k_ind = k_ind; a.win_vstart = win_vstart; a.win_cnt = win_cnt; a.pair_win = pair_win;
+    a.win_cnt = win_cnt; a.pair_win = pair_win;
     a.vsx = host_voxel_size3[0]; a.vsy = host_voxel_size3[1]; a.vsz = host_voxel_size3[2];
     a.minx = host_range_min3[0]; a.miny = host_range_min3[1]; a.minz = host_range_min3[2];
     a.wsx = host_win_size3[0]; a.wsy = host_win_size3[1]; a.wsz = host_win_size3[2];

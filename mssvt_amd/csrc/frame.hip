@@ -206,7 +206,8 @@ void make_layout(const Frame &f, int n, char *base, Layout &L) {
     L.neg0 = b.take<int>(0);
     L.tab_rows = b.take<int>(ints_al((size_t)L.n_tabs * N * 4));
     L.pair_win = b.take<int>(ints_al(cap));
-    L.c_k_ind = b.take<int>(ints_al(cap * (size_t)(f.has_cmp ? f.cmp.ns : 1)));  // (the level set-up writes the listed slots only)
+    // (the K4 lists themselves only for the three-launch form; the level set-up writes the listed slots only)
+    L.c_k_ind = f.has_cmp && !f.cmp.ws_packed ? b.take<int>(ints_al(cap * (size_t)f.cmp.ns)) : nullptr;
     b.off = al256(b.off);
     L.neg_ints = (size_t)(b.base + b.off - reinterpret_cast<char *>(L.neg0)) / 4;
     // work orders (fused._work_order / prepare_group): row capacity = max over the patterns of min(N * overlap, cap * nq)
@@ -614,8 +615,8 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
     // ---- CompressBlock: pillar plan, attention (three launches), FFN tail over the live windows
     const float cwsm[3] = {f->vs[0] * c.ws[0], f->vs[1] * c.ws[1], f->vs[2] * c.ws[2]};
     if (c.ws_packed) {
-        FR_TRY(mssvt_compress_ws(C, c.head_dim, c.scale, c.ws[2], c.ns, n, L.hdr[1] + 1, cap, indices, L.c_k_ind, L.c_win_vstart,
-                                 L.c_win_cnt, L.pair_win, f->vs, mn3, cwsm, xhat, c.Wp1, c.bp1, c.bp2, c.bq, c.bkv, c.bo, c.ws_packed,
+        FR_TRY(mssvt_compress_ws(C, c.head_dim, c.scale, c.ws[2], c.ns, n, L.hdr[1] + 1, cap, indices, L.c_win_cnt, L.pair_win,
+                                 f->vs, mn3, cwsm, xhat, c.Wp1, c.bp1, c.bp2, c.bq, c.bkv, c.bo, c.ws_packed,
                                  L.c_new, stream));
     } else {
         FR_TRY(mssvt_compress_fused(C, c.head_dim, c.scale, c.ns, n, L.hdr[1] + 1, cap, out_indices, indices, L.c_k_ind, L.c_win_vstart,

@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(LS_COLS) k_col_emit(LsArgs a) {
                         if (slot < a.pl_max) {
                             const int sz = cz + dzb - 32;
                             const int sv = ex[0] + __popcll(word & ((1ull << sz) - 1ull));
-                            row[slot] = sv;
+                            if (a.pl_k_ind) row[slot] = sv;  // (optional: mssvt_compress_ws takes the windows as runs of rows)
                             a.pl_pair_win[vstart + sv] = W;
                             if (a.pl_pair_vox) a.pl_pair_vox[vstart + sv] = vstart + sv;
                         }
@@ -365,7 +365,7 @@ static int level_setup_sorted_impl(int num_voxels, int batch_size, int x_max, in
     a.pl_k_ind = a.pl_vstart = a.pl_cnt = a.pl_base = a.pl_pair_win = a.pl_pair_vox = nullptr;
     if (pl) {
         if (pl->part < 0 || pl->part >= num_sets || pl->max_win1 <= 0 || pl->n_win1 < 1 || pl->n_win1 > MSSVT_WAVE || !pl->table ||
-            !pl->k_ind || !pl->vstart || !pl->cnt || !pl->pair_win)
+            !pl->vstart || !pl->cnt || !pl->pair_win)
             return MSSVT_E_BADARG;
         if (a.p[pl->part].wsx != 1 || a.p[pl->part].wsy != 1) return MSSVT_E_TOOLARGE;  // pillar windows only
         a.pl_part = pl->part; a.pl_max = pl->max_win1; a.pl_n = pl->n_win1; a.pl_table = pl->table;

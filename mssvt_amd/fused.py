@@ -1327,7 +1327,7 @@ def _compress_forward_fused(block, sp, xhat, x_in):
         # a sorted pillar level: every window is a run of consecutive rows -> ONE launch, nothing handed through memory
         new = f32(cap_w, C)
         _lib.call("mssvt_compress_ws", _i(C), _i(ma.per_head_dim), _f(ma.scale), _i(block.win1_size[2]), _i(ns), _i(N),
-                  _P(p.num_wins), _i(cap_w), _P(sp.indices), _P(p.k_ind), _P(p.win_vstart), _P(p.win_cnt), _P(p.pair_win),
+                  _P(p.num_wins), _i(cap_w), _P(sp.indices), _P(p.win_cnt), _P(p.pair_win),
                   vs3, mn3, ws3, _P(xhat), _P(block.pos_proj[0].weight), _P(block.pos_proj[0].bias),
                   _P(block.pos_proj[2].bias), _P(ma.to_qs[0].bias), _P(ma.to_kvs[0].bias), _P(ma.projs[0].bias),
                   _P(packed), _P(new), _lib.stream())
