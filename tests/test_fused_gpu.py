@@ -106,7 +106,7 @@ def test_fused_ffn_kernel_matches_torch(C, FF, n):
 @pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("C,FF,n", [(128, 256, 74270), (128, 256, 5000), (64, 128, 1000), (32, 64, 129), (128, 256, 7), (64, 128, 16)])
 def test_ffn_single_launch_split_fp16_matches_float64(C, FF, n, packed):
-    """k_ffn_ws (phases = 4: register-stationary weights, every fp32 operand split exactly into two fp16 halves, 3 MFMAs
+    """k_ffn_ws (phases = 4: register-stationary weights, every fp32 operand carried as two fp16 halves (22 of its 24 mantissa bits: not an exact split), 3 MFMAs
     per product sum) against a float64 restatement: the error of the fp32-instruction kernels (phases = 3), far inside
     the fp32 parity tolerance; with the weight fragments pre-split (mssvt_ffn_pack_weights) and split in the kernel."""
     import ctypes
