@@ -596,6 +596,33 @@ int mssvt_segment_sum_rows(int C, int n_dst, const int *csr_off, const int *csr_
 int mssvt_segment_sum_rows_ranges(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
                                   const float *csr_w, const float *src, float *dst, void *stream);
 
+/* The same sum on C columns of wider rows: src / dst row strides in floats (multiples of 4, >= C; both pointers at the
+ * first of the C columns), and dst either written (accumulate 0) or added to (1: dst[d] = dst[d] + sum, one add per
+ * element).  The gradient of a gather of a column range -- a head group of a Block, ref mssvt_backbone.py:260-268 --
+ * lands in that range of the full-width gradient without a zero-filled temporary and an add.                    */
+int mssvt_segment_sum_rows_strided(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
+                                   const float *csr_w, const float *src, int src_stride, float *dst, int dst_stride,
+                                   int accumulate, void *stream);
+
+/* Tokens of a Block's attention on compact rows (training path):
+ *   tok[r][c] = (src ? src[rows[r]][c0+c] : 0) + relu(b[c0+c] + sum_{j<6} W6[c0+c][j] geo8[r][j]),  r < M, c < cg
+ * = gathered feature + positional embedding of (offset to the window centre, window centre) (ref pos_proj,
+ * mssvt_backbone.py:43-47, token sums :270-285; padded gathers group_features_gpu.cu:52-84, group_points_gpu.cu:56-91).
+ * src (N,C) f32 or NULL, rows (M) int32, geo8 (M,8) f32 (columns 6, 7 unused), W6 (Ctot,6) / b (Ctot) = the Conv1d(6,C,1)
+ * parameters, tok (M,cg) f32; cg in {16,32,64,128,256}, c0 % 4 == 0.
+ * Backward of the embedding: _partial writes the slab of one token set (mssvt_train_tok_slab_floats(M,cg) floats) from
+ * dtok (M,cg), the ReLU mask recomputed from geo8; _reduce adds the slabs of up to 4 token sets (host arrays: rows M,
+ * first channel c0, width cg, slab address per set; sets with M <= 0 are skipped) in a fixed order into dW6 (C,6) and
+ * db (C) (channels no set covers get 0).  The gradient of src is mssvt_segment_sum_rows_strided over the inverted
+ * index of `rows`.  No atomics: bit-identical run to run.                                                        */
+int mssvt_train_tok_forward(int M, int C, int c0, int cg, const int *rows, const float *src, const float *geo8,
+                            const float *W6, const float *b, float *tok, void *stream);
+long long mssvt_train_tok_slab_floats(int M, int cg);
+int mssvt_train_tok_backward_partial(int M, int c0, int cg, const float *geo8, const float *W6, const float *b,
+                                     const float *dtok, float *slab, void *stream);
+int mssvt_train_tok_backward_reduce(int C, int num_sets, const int *host_M, const int *host_c0, const int *host_cg,
+                                    const float *const *host_slabs, float *dW, float *db, void *stream);
+
 /* ========================================================================
  * Post-processing behind the backbone: rotated BEV NMS of CenterHead's boxes.
  * ref: iou3d_nms_cuda.nms_gpu, pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:90-135 (host loop) +

@@ -30,7 +30,8 @@ def lib():
         lib_.mssvt_hip_status_string.restype = ctypes.c_char_p
         for name in ("mssvt_hash_workspace_ints", "mssvt_nms_workspace_bytes", "mssvt_linear_wgrad_workspace_floats",
                      "mssvt_csr_transpose_workspace_bytes", "mssvt_ffn_packed_bytes", "mssvt_level_sorted_scratch_ints",
-                     "mssvt_attn_packed_bytes", "mssvt_frame_workspace_bytes", "mssvt_compress_ws_packed_bytes"):
+                     "mssvt_attn_packed_bytes", "mssvt_frame_workspace_bytes", "mssvt_compress_ws_packed_bytes",
+                     "mssvt_train_tok_slab_floats"):
             getattr(lib_, name).restype = ctypes.c_longlong
         global TYPED
         TYPED = _declare(lib_)

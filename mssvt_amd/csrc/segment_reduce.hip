@@ -19,7 +19,8 @@
 
 template <int LPR>  // lanes per row (power of two <= 64): 64 / LPR destination rows per wavefront
 __global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, const int *seg_start, const int *seg_end,
-                                                          const int *idx, const float *w, const float *src, float *dst) {
+                                                          const int *idx, const float *w, const float *src, int src_stride,
+                                                          float *dst, int dst_stride, int accumulate) {
     constexpr int RPW = MSSVT_WAVE / LPR;
     const int lane = lane_id(), sub = lane / LPR, l = lane % LPR;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / MSSVT_WAVE;
@@ -32,8 +33,8 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, cons
         int e = e0;
         for (; e + 1 < e1; e += 2) {
             const int r0 = idx[e], r1 = idx[e + 1];
-            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)r0 * C + c);
-            const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)r1 * C + c);
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)r0 * src_stride + c);
+            const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)r1 * src_stride + c);
             const float w0 = w ? w[e] : 1.0f, w1 = w ? w[e + 1] : 1.0f;
             acc.x = __builtin_fmaf(w0, v0.x, acc.x); acc.y = __builtin_fmaf(w0, v0.y, acc.y);
             acc.z = __builtin_fmaf(w0, v0.z, acc.z); acc.w = __builtin_fmaf(w0, v0.w, acc.w);
@@ -41,12 +42,17 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, cons
             acc.z = __builtin_fmaf(w1, v1.z, acc.z); acc.w = __builtin_fmaf(w1, v1.w, acc.w);
         }
         if (e < e1) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)idx[e] * C + c);
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)idx[e] * src_stride + c);
             const float w0 = w ? w[e] : 1.0f;
             acc.x = __builtin_fmaf(w0, v0.x, acc.x); acc.y = __builtin_fmaf(w0, v0.y, acc.y);
             acc.z = __builtin_fmaf(w0, v0.z, acc.z); acc.w = __builtin_fmaf(w0, v0.w, acc.w);
         }
-        *reinterpret_cast<float4 *>(dst + (size_t)d * C + c) = acc;
+        float4 *out = reinterpret_cast<float4 *>(dst + (size_t)d * dst_stride + c);
+        if (accumulate) {  // dst += the list's sum (one add per element: the order stays fixed)
+            const float4 o = *out;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        *out = acc;
     }
 }
 
@@ -57,6 +63,9 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, cons
 extern "C" int mssvt_segment_sum_rows_ranges(int C, int n_dst, const int *seg_start, const int *seg_end,
                                              const int *csr_idx, const float *csr_w, const float *src, float *dst,
                                              void *stream);
+extern "C" int mssvt_segment_sum_rows_strided(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
+                                              const float *csr_w, const float *src, int src_stride, float *dst, int dst_stride,
+                                              int accumulate, void *stream);
 
 extern "C" int mssvt_segment_sum_rows(int C, int n_dst, const int *csr_off, const int *csr_idx, const float *csr_w,
                                       const float *src, float *dst, void *stream) {
@@ -67,16 +76,25 @@ extern "C" int mssvt_segment_sum_rows(int C, int n_dst, const int *csr_off, cons
 extern "C" int mssvt_segment_sum_rows_ranges(int C, int n_dst, const int *seg_start, const int *seg_end,
                                              const int *csr_idx, const float *csr_w, const float *src, float *dst,
                                              void *stream) {
+    return mssvt_segment_sum_rows_strided(C, n_dst, seg_start, seg_end, csr_idx, csr_w, src, C, dst, C, 0, stream);
+}
+
+// The same sum on C columns of wider rows (src / dst row strides in floats, both pointers at the first column), written
+// or ADDED to dst: the gradient of a gather of a column range lands in that range of the full-width gradient without a
+// zero-filled temporary and an add (the head groups of a Block: train_path._Tokens).
+extern "C" int mssvt_segment_sum_rows_strided(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
+                                              const float *csr_w, const float *src, int src_stride, float *dst, int dst_stride,
+                                              int accumulate, void *stream) {
     const int *csr_off = seg_start;
     if (!seg_start || !seg_end || !csr_idx || !src || !dst || C <= 0 || n_dst < 0) return MSSVT_E_BADARG;
-    if (C & 3) return MSSVT_E_BADARG;  // 16-byte row pieces
+    if ((C & 3) || (src_stride & 3) || (dst_stride & 3) || src_stride < C || dst_stride < C) return MSSVT_E_BADARG;  // 16-byte row pieces
     if (n_dst == 0) return MSSVT_OK;
     hipStream_t st = (hipStream_t)stream;
     const int q = C / 4;
 #define SEG_LAUNCH(lpr)                                                                                    \
     {                                                                                                      \
         const int rpw = MSSVT_WAVE / lpr, waves = divup(n_dst, rpw);                                        \
-        k_segment_sum_rows<lpr><<<divup(waves, 4), 256, 0, st>>>(C, n_dst, csr_off, seg_end, csr_idx, csr_w, src, dst); \
+        k_segment_sum_rows<lpr><<<divup(waves, 4), 256, 0, st>>>(C, n_dst, csr_off, seg_end, csr_idx, csr_w, src, src_stride, dst, dst_stride, accumulate); \
     }
     if (q <= 4) SEG_LAUNCH(4)
     else if (q <= 8) SEG_LAUNCH(8)

@@ -1,0 +1,193 @@
+// train_tok.hip -- the tokens of a Block's attention on compact rows, forward and backward (training path, SURVEY.md
+// section 8 f3).
+//
+//     tok[r][c] = x̂[rows[r]][c0 + c]  +  relu( b[c0 + c] + sum_{j < 6} W[c0 + c][j] * geo[r][j] )        c < cg
+//
+// = the gathered voxel feature plus the positional embedding of (offset to the window centre, window centre)
+// (ref mssvt_backbone.py:43-47 pos_proj = Conv1d(6, C, 1) + ReLU, :270-285 the token sums; the padded gathers K5 /
+// K10: group_features_gpu.cu:52-84, group_points_gpu.cu:56-91).  Autograd builds this from a column slice, a gather, a
+// concatenation, a zero pad of the 6-wide weight, a library GEMM with K = 8, a clamp and an add -- nine launches
+// forward, more backward, per token set (a Block has four: queries and keys of two head groups).  Here: one launch
+// forward; backward = the deterministic segmented sum of segment_reduce.hip into a column range of dx̂ (strided entry
+// point there) + the weight / bias gradient below.  The ReLU mask is recomputed from `geo` (six FMAs) instead of being
+// stored: the same instructions in the same order as the forward, so the sign is the same bit for bit.
+//
+// Weight gradient: dW[c][j] = sum_r m[r][c] dtok[r][c] geo[r][j], db[c] = sum_r m[r][c] dtok[r][c]; a lane owns four
+// channels and walks its rows in ascending order (7 x 4 accumulators), the lane groups of a workgroup are added in group
+// order through LDS, the workgroups' slabs in slice order by k_tok_bwd_reduce (which also adds the token sets that share
+// channels: the queries cover every channel, each key set its head group's): no atomics, bit-identical run to run.
+#include "common.hip.h"
+
+#define TOK_FMA6(P_, W_, GA_, GB_)                                                            \
+    P_ = __builtin_fmaf((W_)[0], (GA_).x, P_); P_ = __builtin_fmaf((W_)[1], (GA_).y, P_);     \
+    P_ = __builtin_fmaf((W_)[2], (GA_).z, P_); P_ = __builtin_fmaf((W_)[3], (GA_).w, P_);     \
+    P_ = __builtin_fmaf((W_)[4], (GB_).x, P_); P_ = __builtin_fmaf((W_)[5], (GB_).y, P_)
+
+template <int LPR>  // lanes per row = cg / 4
+__global__ void __launch_bounds__(256) k_tok_fwd(int M, int Csrc, int c0, const int *rows, const float *src, const float4 *geo,
+                                                 const float *W6, const float *b, float *tok) {
+    constexpr int RPW = MSSVT_WAVE / LPR, CG = 4 * LPR;
+    const int lane = lane_id(), sub = lane / LPR, l = lane % LPR;
+    const int c = c0 + 4 * l;
+    float w[4][6], bb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bb[i] = b[c + i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) w[i][j] = W6[(c + i) * 6 + j];
+    }
+    const int nw = gridDim.x * 4, wave = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE;
+    for (int r = wave * RPW + sub; r < M; r += nw * RPW) {
+        const float4 g0 = geo[2 * r], g1 = geo[2 * r + 1];
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src) x = *reinterpret_cast<const float4 *>(src + (size_t)rows[r] * Csrc + c);
+        float p0 = bb[0], p1 = bb[1], p2 = bb[2], p3 = bb[3];
+        TOK_FMA6(p0, w[0], g0, g1); TOK_FMA6(p1, w[1], g0, g1); TOK_FMA6(p2, w[2], g0, g1); TOK_FMA6(p3, w[3], g0, g1);
+        x.x += fmaxf(p0, 0.f); x.y += fmaxf(p1, 0.f); x.z += fmaxf(p2, 0.f); x.w += fmaxf(p3, 0.f);
+        *reinterpret_cast<float4 *>(tok + (size_t)r * CG + 4 * l) = x;
+    }
+}
+
+// slab layout: [slice][cg][8] floats (j < 6: dW, 6: db, 7: unused)
+template <int LPR>
+__global__ void __launch_bounds__(256) k_tok_bwd_partial(int M, int c0, const float4 *geo, const float *W6, const float *b,
+                                                         const float *dtok, int rows_per_slice, float *slab) {
+    constexpr int CG = 4 * LPR, GROUPS = 256 / LPR;
+    __shared__ float red[28 * 256];
+    const int l = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const int c = c0 + 4 * l;
+    float w[4][6], bb[4], acc[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bb[i] = b[c + i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) w[i][j] = W6[(c + i) * 6 + j];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = 0.f;
+    }
+    const int m0 = blockIdx.x * rows_per_slice, m1 = min(M, m0 + rows_per_slice);
+    for (int r = m0 + grp; r < m1; r += GROUPS) {
+        const float4 g0 = geo[2 * r], g1 = geo[2 * r + 1];
+        const float4 d = *reinterpret_cast<const float4 *>(dtok + (size_t)r * CG + 4 * l);
+        const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float p = bb[i];
+            TOK_FMA6(p, w[i], g0, g1);
+            const float v = p > 0.f ? dd[i] : 0.f;
+            acc[i][0] = __builtin_fmaf(v, g0.x, acc[i][0]); acc[i][1] = __builtin_fmaf(v, g0.y, acc[i][1]);
+            acc[i][2] = __builtin_fmaf(v, g0.z, acc[i][2]); acc[i][3] = __builtin_fmaf(v, g0.w, acc[i][3]);
+            acc[i][4] = __builtin_fmaf(v, g1.x, acc[i][4]); acc[i][5] = __builtin_fmaf(v, g1.y, acc[i][5]);
+            acc[i][6] += v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) red[(i * 7 + j) * 256 + threadIdx.x] = acc[i][j];
+    __syncthreads();
+    float *out = slab + (size_t)blockIdx.x * CG * 8;
+    for (int v = threadIdx.x; v < LPR * 28; v += 256) {
+        const int ll = v % LPR, k = v / LPR;  // k = i * 7 + j
+        float s = 0.f;
+        for (int gq = 0; gq < GROUPS; ++gq) s += red[k * 256 + gq * LPR + ll];
+        out[(4 * ll + k / 7) * 8 + k % 7] = s;
+    }
+}
+
+struct TokSlabs {
+    const float *slab[4];
+    int slices[4], c0[4], cg[4];
+    int n;
+};
+
+// one wave per channel: lane = 8 * (slice group) + j; slices of a group in ascending order, the groups in group order,
+// the token sets in argument order
+__global__ void __launch_bounds__(256) k_tok_bwd_reduce(int Ctot, TokSlabs a, float *dW, float *db) {
+    const int lane = lane_id(), j = lane & 7, sg = lane >> 3;
+    const int c = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE;
+    if (c >= Ctot) return;
+    float total = 0.f;
+    for (int k = 0; k < a.n; ++k) {
+        if (c < a.c0[k] || c >= a.c0[k] + a.cg[k]) continue;  // wave-uniform
+        const float *p = a.slab[k] + (size_t)(c - a.c0[k]) * 8 + j;
+        float v = 0.f;
+        for (int s = sg; s < a.slices[k]; s += 8) v += p[(size_t)s * a.cg[k] * 8];
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += __shfl(v, 8 * q + j);
+        total += sum;
+    }
+    if (sg == 0) {
+        if (j < 6) dW[(size_t)c * 6 + j] = total;
+        else if (j == 6 && db) db[c] = total;
+    }
+}
+
+static int tok_slices(int M, int cg) {
+    const int groups = 256 / (cg / 4);
+    int s = divup(M, (long long)groups * 8);  // >= 8 rows per lane group
+    return s < 1 ? 1 : (s > 512 ? 512 : s);
+}
+
+extern "C" int mssvt_train_tok_forward(int M, int C, int c0, int cg, const int *rows, const float *src, const float *geo8,
+                                       const float *W6, const float *b, float *tok, void *stream) {
+    if (M < 0 || c0 < 0 || cg <= 0 || (c0 & 3) || !geo8 || !W6 || !b || !tok || (src && (!rows || C < c0 + cg || (C & 3))))
+        return MSSVT_E_BADARG;
+    if (M == 0) return MSSVT_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define TOK_FWD(lpr)                                                                                                   \
+    case 4 * lpr: {                                                                                                    \
+        const int rpw = MSSVT_WAVE / lpr;                                                                               \
+        k_tok_fwd<lpr><<<divup(M, rpw * 16), 256, 0, st>>>(M, C, c0, rows, src, (const float4 *)geo8, W6, b, tok);      \
+        break;                                                                                                         \
+    }
+    switch (cg) {
+        TOK_FWD(4) TOK_FWD(8) TOK_FWD(16) TOK_FWD(32) TOK_FWD(64)
+        default: return MSSVT_E_BADARG;
+    }
+#undef TOK_FWD
+    return mssvt_launch_status();
+}
+
+extern "C" long long mssvt_train_tok_slab_floats(int M, int cg) {
+    if (M <= 0 || cg <= 0 || cg > 256) return 0;
+    return (long long)tok_slices(M, cg) * cg * 8;
+}
+
+extern "C" int mssvt_train_tok_backward_partial(int M, int c0, int cg, const float *geo8, const float *W6, const float *b,
+                                                const float *dtok, float *slab, void *stream) {
+    if (M <= 0 || c0 < 0 || cg <= 0 || (c0 & 3) || !geo8 || !W6 || !b || !dtok || !slab) return MSSVT_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int slices = tok_slices(M, cg);
+    const int rps = divup(M, slices);
+#define TOK_BWD(lpr)                                                                                                    \
+    case 4 * lpr:                                                                                                       \
+        k_tok_bwd_partial<lpr><<<slices, 256, 0, st>>>(M, c0, (const float4 *)geo8, W6, b, dtok, rps, slab);             \
+        break;
+    switch (cg) {
+        TOK_BWD(4) TOK_BWD(8) TOK_BWD(16) TOK_BWD(32) TOK_BWD(64)
+        default: return MSSVT_E_BADARG;
+    }
+#undef TOK_BWD
+    return mssvt_launch_status();
+}
+
+extern "C" int mssvt_train_tok_backward_reduce(int C, int num_sets, const int *host_M, const int *host_c0, const int *host_cg,
+                                               const float *const *host_slabs, float *dW, float *db, void *stream) {
+    if (C <= 0 || num_sets < 0 || num_sets > 4 || !dW || (num_sets && (!host_M || !host_c0 || !host_cg || !host_slabs)))
+        return MSSVT_E_BADARG;
+    TokSlabs a;
+    a.n = 0;
+    for (int k = 0; k < num_sets; ++k) {
+        if (host_M[k] <= 0) continue;  // an empty token set adds nothing
+        if (!host_slabs[k]) return MSSVT_E_BADARG;
+        a.slab[a.n] = host_slabs[k];
+        a.slices[a.n] = tok_slices(host_M[k], host_cg[k]);
+        a.c0[a.n] = host_c0[k];
+        a.cg[a.n] = host_cg[k];
+        ++a.n;
+    }
+    k_tok_bwd_reduce<<<divup(C, 4), 256, 0, (hipStream_t)stream>>>(C, a, dW, db);
+    return mssvt_launch_status();
+}

@@ -110,6 +110,27 @@ class Segments(object):
         return dst
 
 
+def _sum_into(seg, src, dst, c0, accumulate):
+    """Segments.sum of `src` (M, cg) written / added to columns [c0, c0 + cg) of `dst` (n_dst, C): no temporary."""
+    cg = src.shape[1]
+    view = dst[:, c0:c0 + cg]
+    if seg.idx is None or seg.idx.numel() == 0 or seg.n_dst == 0:
+        if not accumulate:
+            view.zero_()
+        return
+    if seg.pending is not None:
+        seg._cut(int(seg.pending.item()))
+    src = src.contiguous()
+    _lib.call("mssvt_segment_sum_rows_strided", _i(cg), _i(seg.n_dst), _lib.ptr(seg.start), _lib.ptr(seg.end), _lib.ptr(seg.idx),
+              _lib.ptr(seg.w), _lib.ptr(src), _i(cg), ctypes.c_void_p(view.data_ptr()), _i(dst.stride(0)),
+              _i(1 if accumulate else 0), _lib.stream())
+    h = seg.heavy
+    if h is not None:  # the long lists (empty ranges above: 0 written / added), chunk sums added in chunk order
+        part = _ranges_sum(src, h["c_start"], h["c_end"], seg.idx, seg.w, h["n_chunks"])
+        tot = _ranges_sum(part, h["p_start"], h["p_end"], h["p_idx"], None, h["rows"].numel())
+        view[h["rows"]] = (view[h["rows"]] + tot) if accumulate else tot
+
+
 def segment_sum_rows(src, off, idx, w, n_dst):
     """dst[d] = sum_{e in [off[d], off[d+1])} w[e] * src[idx[e]] in ascending e (HIP, deterministic)."""
     return _ranges_sum(src, off[:-1], off[1:], idx, w, n_dst)
@@ -337,6 +358,89 @@ def ffn(block, x):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# tokens = gathered features + positional embedding (csrc/train_tok.hip)
+# ---------------------------------------------------------------------------------------------------------
+
+TOK_WIDTHS = (16, 32, 64, 128, 256)
+TOKENS = True  # False: the autograd composition (gather_sum + _pos6), kept for A/B and for widths outside TOK_WIDTHS
+
+
+class _Tokens(torch.autograd.Function):
+    """All token sets of a Block in one node: ``tok_k = xhat[rows_k][:, c0_k:c1_k] + relu(pos_proj(geo_k))[:, c0_k:c1_k]``
+    for every set k of `parts` (dicts: rows int32 (M), geo (M, 8), csr = Csr.gather(rows, N), c0, c1).  One launch per
+    set forward; backward = one strided segmented sum per set straight into its columns of d xhat, one weight-gradient
+    slab per set and one ordered reduce (ref pos_proj mssvt_backbone.py:43-47, token sums :270-285)."""
+
+    @staticmethod
+    def forward(ctx, xhat, w6, b6, parts):
+        xhat, w, b = xhat.contiguous(), w6.detach().contiguous(), b6.detach().contiguous()
+        N, C = xhat.shape
+        outs = []
+        for pt in parts:
+            M, c0, cg = pt["rows"].numel(), pt["c0"], pt["c1"] - pt["c0"]
+            tok = torch.empty((M, cg), dtype=torch.float32, device=xhat.device)
+            if M:
+                _lib.call("mssvt_train_tok_forward", _i(M), _i(C), _i(c0), _i(cg), _lib.ptr(pt["rows"]), _lib.ptr(xhat),
+                          _lib.ptr(pt["geo"]), _lib.ptr(w), _lib.ptr(b), _lib.ptr(tok), _lib.stream())
+            outs.append(tok)
+        ctx.save_for_backward(w, b)
+        ctx.parts, ctx.shape, ctx.wshape = parts, (N, C), tuple(w6.shape)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        w, b = ctx.saved_tensors
+        parts = ctx.parts
+        N, C = ctx.shape
+        dev = w.device
+        grads = [torch.zeros((pt["rows"].numel(), pt["c1"] - pt["c0"]), dtype=torch.float32, device=dev) if g is None
+                 else g.contiguous() for g, pt in zip(grads, parts)]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            ranges = sorted(set((pt["c0"], pt["c1"]) for pt in parts))
+            tiled = ranges[0][0] == 0 and ranges[-1][1] == C and all(a[1] == b_[0] for a, b_ in zip(ranges, ranges[1:]))
+            dx = (torch.empty if tiled else torch.zeros)((N, C), dtype=torch.float32, device=dev)
+            seen = set()
+            for pt, g in zip(parts, grads):
+                key = (pt["c0"], pt["c1"])
+                _sum_into(pt["csr"].bwd, g, dx, pt["c0"], key in seen)
+                seen.add(key)
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            n = len(parts)
+            Ms = [pt["rows"].numel() for pt in parts]
+            sizes = [int(_lib.lib().mssvt_train_tok_slab_floats(_i(M), _i(pt["c1"] - pt["c0"]))) for M, pt in zip(Ms, parts)]
+            slab = torch.empty((max(1, sum(sizes)),), dtype=torch.float32, device=dev)
+            addr, at = [], 0
+            for pt, g, M, sz in zip(parts, grads, Ms, sizes):
+                a = slab.data_ptr() + 4 * at
+                addr.append(a)
+                at += sz
+                if M:
+                    _lib.call("mssvt_train_tok_backward_partial", _i(M), _i(pt["c0"]), _i(pt["c1"] - pt["c0"]), _lib.ptr(pt["geo"]),
+                              _lib.ptr(w), _lib.ptr(b), _lib.ptr(g), ctypes.c_void_p(a), _lib.stream())
+            dw = torch.empty((C, 6), dtype=torch.float32, device=dev)
+            db = torch.empty((C,), dtype=torch.float32, device=dev)
+            arr = ctypes.c_int * n
+            _lib.call("mssvt_train_tok_backward_reduce", _i(C), _i(n), arr(*Ms), arr(*[pt["c0"] for pt in parts]),
+                      arr(*[pt["c1"] - pt["c0"] for pt in parts]), (ctypes.c_void_p * n)(*addr), _lib.ptr(dw), _lib.ptr(db),
+                      _lib.stream())
+            dw = dw.reshape(ctx.wshape)
+        return dx, dw, db, None
+
+
+def tokens(xhat, conv, parts):
+    """Token sets of `parts` (see _Tokens) for a Conv1d(6, C, 1) positional embedding `conv`."""
+    return _Tokens.apply(xhat, conv.weight, conv.bias, parts)
+
+
+def tokens_supported(block, C):
+    conv = block.pos_proj[0]
+    return (TOKENS and all(cg in TOK_WIDTHS for cg in block.ms_attn.scale_dims) and conv.bias is not None
+            and tuple(conv.weight.shape[:2]) == (C, 6) and len(block.ms_attn.scale_dims) <= 2)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # Block
 # ---------------------------------------------------------------------------------------------------------
 
@@ -375,6 +479,8 @@ def _block_index_sets(block, sp, p):
     s["q_win"] = od["row_src"][:R, 0].long()
     s["q_csr"] = Csr.gather(s["q_rows"], N)
     s["centre"] = p.wcentre[:nw, :3].contiguous()
+    pad2 = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+    s["q_geo"] = torch.cat([s["q_rel"], s["centre"][s["q_win"]], pad2.expand(R, 2)], dim=1).contiguous()  # (R, 8)
     # valid key slots of each scale, window-major (FPS pick order inside a window)
     s["keys"] = []
     for g in range(2):
@@ -390,7 +496,9 @@ def _block_index_sets(block, sp, p):
         k_rel = km[..., :3].reshape(-1, 3)[flat].contiguous()
         wins = dict(q_off=od["q_off"][:nw].contiguous(), q_cnt=od["nq_valid"][:nw].contiguous(),
                     k_off=koff.int().contiguous(), k_cnt=nk.int().contiguous())
-        s["keys"].append(dict(k_rows=k_rows, k_rel=k_rel, k_win=k_win, k_csr=Csr.gather(k_rows, N), wins=wins))
+        k_geo = torch.cat([k_rel, s["centre"][k_win], pad2.expand(k_rel.shape[0], 2)], dim=1).contiguous()
+        s["keys"].append(dict(k_rows=k_rows.contiguous(), k_rel=k_rel, k_win=k_win, k_geo=k_geo, k_csr=Csr.gather(k_rows, N),
+                              wins=wins))
     # interpolation / scatter table: 3 compact attention rows + weights per voxel (row R = the zero row)
     interp = key[1]
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
@@ -439,15 +547,33 @@ def block_forward(block, sp):
     R, ma = s["R"], block.ms_attn
     hd = ma.per_head_dim
     if R > 0:
-        cq = s["centre"][s["q_win"]]
-        tok_q = gather_sum(xhat, s["q_csr"]) + _pos6(block.pos_proj[0], s["q_rel"], cq)
+        fast = tokens_supported(block, C)
+        if fast:  # the four token sets (queries and keys of both head groups) as one autograd node
+            parts, c0 = [], 0
+            for g, cg in enumerate(ma.scale_dims):
+                parts.append(dict(rows=s["q_rows"], geo=s["q_geo"], csr=s["q_csr"], c0=c0, c1=c0 + cg))
+                c0 += cg
+            c0 = 0
+            for g, cg in enumerate(ma.scale_dims):
+                ks = s["keys"][g]
+                parts.append(dict(rows=ks["k_rows"], geo=ks["k_geo"], csr=ks["k_csr"], c0=c0, c1=c0 + cg))
+                c0 += cg
+            toks = tokens(xhat, block.pos_proj[0], parts)
+        else:
+            cq = s["centre"][s["q_win"]]
+            tok_q = gather_sum(xhat, s["q_csr"]) + _pos6(block.pos_proj[0], s["q_rel"], cq)
         outs, c0 = [], 0
+        ng = len(ma.scale_dims)
         for g, (heads, cg) in enumerate(zip(ma.num_heads, ma.scale_dims)):
             c1 = c0 + cg
             ks = s["keys"][g]
-            tok_k = gather_sum(xhat[:, c0:c1].contiguous(), ks["k_csr"]) + _pos6(
-                block.pos_proj[0], ks["k_rel"], s["centre"][ks["k_win"]], c0, c1)
-            q = linear(ma.to_qs[g], tok_q[:, c0:c1].contiguous()) * ma.scale  # (R, cg)
+            if fast:
+                tok_qg, tok_k = toks[g], toks[ng + g]
+            else:
+                tok_k = gather_sum(xhat[:, c0:c1].contiguous(), ks["k_csr"]) + _pos6(
+                    block.pos_proj[0], ks["k_rel"], s["centre"][ks["k_win"]], c0, c1)
+                tok_qg = tok_q[:, c0:c1].contiguous()
+            q = linear(ma.to_qs[g], tok_qg) * ma.scale  # (R, cg)
             kv = linear(ma.to_kvs[g], tok_k)  # (Kg, 2 cg) = [K | V]
             o = pair_attention(q, kv, ks["wins"], heads, hd)  # (R, cg)
             outs.append(linear(ma.projs[g], o.reshape(R, cg)))
