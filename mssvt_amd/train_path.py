@@ -68,25 +68,36 @@ class Segments(object):
             self._cut(int(longest))
 
     def _cut(self, longest):
+        """Long lists -> fixed chunks.  No host wait: the number of long lists and of their chunks is bounded by the entry
+        count (a long list has more than CHUNK entries), the tables are built at that size and padded with empty chunks."""
         self.pending = None
         if longest <= CHUNK:
             return
         off = self.off
-        counts = off[1:] - off[:-1]
-        heavy = counts > CHUNK
         dev = off.device
+        nnz = int(self.idx.numel())
+        H, M2 = nnz // (CHUNK + 1) + 1, 2 * (nnz // CHUNK) + 2
+        counts = (off[1:] - off[:-1]).long()
+        heavy = counts > CHUNK
         self.end = torch.where(heavy, self.start, off[1:]).contiguous()  # heavy rows: empty here, filled below
-        hd = torch.nonzero(heavy, as_tuple=True)[0]
-        hs, hc = self.start[hd].long(), counts[hd].long()
-        nch = (hc + CHUNK - 1) // CHUNK
-        M2 = int(nch.sum().item())
-        which = torch.repeat_interleave(torch.arange(hd.numel(), device=dev), nch, output_size=M2)
-        first = torch.cumsum(nch, 0) - nch
-        j = torch.arange(M2, device=dev) - first[which]
-        c_start = (hs[which] + j * CHUNK)
+        hd = _nonzero_known(heavy, H, fill=-1)
+        real = hd >= 0
+        hd = hd.clamp(min=0)
+        hs = self.start[hd].long()
+        hc = torch.where(real, counts[hd], torch.zeros_like(hd))
+        nch = (hc + CHUNK - 1) // CHUNK  # 0 for the padding
+        last = torch.cumsum(nch, 0)
+        first = last - nch
+        m = torch.arange(M2, device=dev)
+        which = torch.searchsorted(last, m, right=True)  # the long list chunk m belongs to; H past the last chunk
+        used = which < H
+        which = which.clamp(max=H - 1)
+        c_start = hs[which] + (m - first[which]) * CHUNK
         c_end = torch.minimum(c_start + CHUNK, hs[which] + hc[which])
-        self.heavy = dict(rows=hd, c_start=c_start.int().contiguous(), c_end=c_end.int().contiguous(),
-                          p_start=first.int().contiguous(), p_end=(first + nch).int().contiguous(),
+        zero = torch.zeros_like(c_start)
+        self.heavy = dict(rows=hd, c_start=torch.where(used, c_start, zero).int().contiguous(),
+                          c_end=torch.where(used, c_end, zero).int().contiguous(),
+                          p_start=first.int().contiguous(), p_end=last.int().contiguous(),
                           p_idx=torch.arange(M2, dtype=torch.int32, device=dev), n_chunks=M2)
 
     @staticmethod
@@ -106,7 +117,8 @@ class Segments(object):
         h = self.heavy
         if h is not None:
             part = _ranges_sum(src, h["c_start"], h["c_end"], self.idx, self.w, h["n_chunks"])
-            dst[h["rows"]] = _ranges_sum(part, h["p_start"], h["p_end"], h["p_idx"], None, h["rows"].numel())
+            # (the kernel above left the long lists' rows zero; padding rows add an exact 0 to row 0)
+            dst.index_add_(0, h["rows"], _ranges_sum(part, h["p_start"], h["p_end"], h["p_idx"], None, h["rows"].numel()))
         return dst
 
 
@@ -128,7 +140,35 @@ def _sum_into(seg, src, dst, c0, accumulate):
     if h is not None:  # the long lists (empty ranges above: 0 written / added), chunk sums added in chunk order
         part = _ranges_sum(src, h["c_start"], h["c_end"], seg.idx, seg.w, h["n_chunks"])
         tot = _ranges_sum(part, h["p_start"], h["p_end"], h["p_idx"], None, h["rows"].numel())
-        view[h["rows"]] = (view[h["rows"]] + tot) if accumulate else tot
+        view.index_add_(0, h["rows"], tot)  # 0 (written) or the earlier sum (accumulated) + the long lists' sums
+
+
+_deferred = []  # Segments whose longest-list word has not been read yet
+
+
+def _read_sizes(words):
+    """int32 device words -> host ints, in one host wait shared with every pending longest-list word."""
+    segs = [g for g in _deferred if g.pending is not None]
+    del _deferred[:]
+    n = words.numel()
+    host = torch.cat([words.reshape(-1).int()] + [g.pending for g in segs]).tolist()
+    for g, longest in zip(segs, host[n:]):
+        g._cut(longest)
+    return host[:n]
+
+
+def _nonzero_known(mask, count, fill=None):
+    """Positions of the true entries of a 1-D mask, ascending, without the host wait torch.nonzero needs for its output
+    shape: `count` is their number, or with `fill` an upper bound (the tail is padded with `fill`)."""
+    if hasattr(torch, "nonzero_static"):
+        try:
+            return torch.nonzero_static(mask, size=count, fill_value=-1 if fill is None else fill)[:, 0]
+        except (RuntimeError, NotImplementedError):
+            pass
+    pos = torch.nonzero(mask, as_tuple=True)[0]
+    if fill is not None:
+        pos = torch.cat([pos, pos.new_full((count - pos.numel(),), fill)])
+    return pos
 
 
 def segment_sum_rows(src, off, idx, w, n_dst):
@@ -152,9 +192,10 @@ class Csr(object):
     gradient scatter-add into a segmented sum; mssvt_csr_transpose, csrc/csr_transpose.hip: no host sync).  Built once
     per index set and reused by every block sharing the plan.  `drop_src`: a source row whose gradient is not needed (the
     constant zero row): its list is left empty.  `off` None: a plain row gather.  `fwd_longest`: the caller's bound on
-    the entries per destination (<= CHUNK for everything this file builds)."""
+    the entries per destination (<= CHUNK for everything this file builds); `bwd_longest`: the same for the inverted
+    lists (None: the word the transpose leaves on the device, read later)."""
 
-    def __init__(self, off, idx, w, n_src, drop_src=None, fwd_longest=None):
+    def __init__(self, off, idx, w, n_src, drop_src=None, fwd_longest=None, bwd_longest=None):
         dev = idx.device
         idx = idx.int().contiguous()
         nnz = idx.numel()
@@ -173,13 +214,14 @@ class Csr(object):
             fwd_longest = 1
         self.off, self.idx, self.w = off, idx, w
         self.fwd = Segments(off, idx, w, longest=fwd_longest)
-        self.bwd = Segments(t_off, t_idx, t_w, longest=longest)
+        # (the cut of long lists is a matter of speed only: a caller that knows its lists are short says so and saves the read)
+        self.bwd = Segments(t_off, t_idx, t_w, longest=longest if bwd_longest is None else bwd_longest)
         self.t_off, self.t_idx, self.t_w = t_off, t_idx, t_w
 
     @staticmethod
-    def gather(idx, n_src):
+    def gather(idx, n_src, bwd_longest=None):
         """Plain row gather dst[i] = src[idx[i]]."""
-        return Csr(None, idx, None, n_src)
+        return Csr(None, idx, None, n_src, bwd_longest=bwd_longest)
 
 
 class _SegmentSum(torch.autograd.Function):
@@ -459,46 +501,82 @@ def _pair_attention_covers(ma):
 
 
 @torch.no_grad()
+def _plan_index_sets(block, sp, p):
+    """What the Blocks of a plan share: the window count, the compact key rows of both scales (their inverted indices,
+    geometry, per-window ranges) and the query rows' count of EVERY query pattern of the plan's Blocks -- all sizes in
+    ONE host read, before the first Block runs: the later Blocks of the plan add no host wait of their own."""
+    common = getattr(p, "train_common", None)
+    if common is not None and block.cbs_pattern in common["pats"]:
+        return common
+    dev = sp.indices.device
+    N = sp.indices.shape[0]
+    group = [b for b in (getattr(sp, "_plan_group", None) or ()) if b.plan_key() == block.plan_key()
+             and fused._qmeta(b, p) is not None]
+    pats = {}
+    for b in [block] + group:
+        if b.cbs_pattern not in pats:
+            q_ind, nq, owner_q = fused._query(b, p)
+            pats[b.cbs_pattern] = dict(q_ind=q_ind, nq=nq, owner_q=owner_q, od=fused._work_order(b, p, nq, N))
+    order = sorted(pats)
+    # valid key slots of each scale (windows past num_wins hold stale memory: masked on the device)
+    in_use = torch.arange(p.cap, device=dev).unsqueeze(1) < p.num_wins
+    valid_g, rows_g = [], []
+    for g in range(2):
+        rows = p.kmeta[g][..., 3].contiguous().view(torch.int32)  # (cap, K)
+        rows_g.append(rows)
+        valid_g.append(((rows >= 0) & in_use).reshape(-1))
+    words = [p.num_wins.reshape(1)] + [v.sum().int().reshape(1) for v in valid_g] + [pats[k]["od"]["n_rows"].reshape(1)
+                                                                                     for k in order]
+    host = _read_sizes(torch.cat(words))
+    nw = host[0]
+    for k, R in zip(order, host[3:]):
+        pats[k]["R"] = R
+    centre = p.wcentre[:nw, :3].contiguous()
+    pad2 = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+    keys = []  # valid key slots of each scale, window-major (FPS pick order inside a window)
+    for g, Kg in enumerate(host[1:3]):
+        km = p.kmeta[g]
+        K = km.shape[1]
+        flat = _nonzero_known(valid_g[g], Kg)
+        k_win = flat // K
+        nk = valid_g[g].reshape(p.cap, K)[:nw].sum(1)  # keys per window
+        koff = torch.cumsum(nk, 0) - nk
+        k_rows = rows_g[g].reshape(-1)[flat].contiguous()
+        k_rel = km[..., :3].reshape(-1, 3)[flat].contiguous()
+        k_geo = torch.cat([k_rel, centre[k_win], pad2.expand(k_rel.shape[0], 2)], dim=1).contiguous()
+        keys.append(dict(k_rows=k_rows, k_rel=k_rel, k_win=k_win, k_geo=k_geo, k_csr=Csr.gather(k_rows, N),
+                         k_off=koff.int().contiguous(), k_cnt=nk.int().contiguous()))
+    _deferred.extend(k["k_csr"].bwd for k in keys)
+    common = p.train_common = dict(nw=nw, centre=centre, keys=keys, pats=pats, pad2=pad2)
+    p.train_sets = {}
+    return common
+
+
+@torch.no_grad()
 def _block_index_sets(block, sp, p):
     """Compact index sets of (plan, cbs_pattern): cached on the plan, shared by the Blocks that use it."""
-    cache = getattr(p, "train_sets", None)
-    if cache is None:
-        cache = p.train_sets = {}
+    common = _plan_index_sets(block, sp, p)
+    cache = p.train_sets
     key = (block.cbs_pattern, 1 if block.use_feature_interpolation else 0)
     if key in cache:
         return cache[key]
     dev = sp.indices.device
     N = sp.indices.shape[0]
-    q_ind, nq, owner_q = fused._query(block, p)
-    od = fused._work_order(block, p, nq, N)
-    nw, R = torch.cat([p.num_wins.reshape(1), od["n_rows"].reshape(1)]).tolist()  # host values: one sync
-    s = {"nw": nw, "R": R, "nq": nq}
-    meta = od["row_meta"][:R]
-    s["q_rows"] = meta[:, 3].contiguous().view(torch.int32)
-    s["q_rel"] = meta[:, :3].contiguous()
-    s["q_win"] = od["row_src"][:R, 0].long()
-    s["q_csr"] = Csr.gather(s["q_rows"], N)
-    s["centre"] = p.wcentre[:nw, :3].contiguous()
-    pad2 = torch.zeros((1, 2), dtype=torch.float32, device=dev)
-    s["q_geo"] = torch.cat([s["q_rel"], s["centre"][s["q_win"]], pad2.expand(R, 2)], dim=1).contiguous()  # (R, 8)
-    # valid key slots of each scale, window-major (FPS pick order inside a window)
-    s["keys"] = []
-    for g in range(2):
-        km = p.kmeta[g][:nw]
-        K = km.shape[1]
-        rows = km[..., 3].contiguous().view(torch.int32)
-        valid = rows >= 0
-        flat = torch.nonzero(valid.reshape(-1), as_tuple=True)[0]  # the one sync of this scale: every size follows from it
-        k_win = flat // K
-        nk = valid.sum(1)  # keys per window
-        koff = torch.cumsum(nk, 0) - nk
-        k_rows = rows.reshape(-1)[flat]
-        k_rel = km[..., :3].reshape(-1, 3)[flat].contiguous()
-        wins = dict(q_off=od["q_off"][:nw].contiguous(), q_cnt=od["nq_valid"][:nw].contiguous(),
-                    k_off=koff.int().contiguous(), k_cnt=nk.int().contiguous())
-        k_geo = torch.cat([k_rel, s["centre"][k_win], pad2.expand(k_rel.shape[0], 2)], dim=1).contiguous()
-        s["keys"].append(dict(k_rows=k_rows.contiguous(), k_rel=k_rel, k_win=k_win, k_geo=k_geo, k_csr=Csr.gather(k_rows, N),
-                              wins=wins))
+    pat = common["pats"][block.cbs_pattern]
+    q_ind, nq, owner_q, od, R, nw = pat["q_ind"], pat["nq"], pat["owner_q"], pat["od"], pat["R"], common["nw"]
+    s = {"nw": nw, "R": R, "nq": nq, "centre": common["centre"]}
+    qs = pat.get("q_sets")
+    if qs is None:  # the query rows of this pattern (shared by its with / without interpolation variants)
+        meta = od["row_meta"][:R]
+        qs = {"q_rows": meta[:, 3].contiguous().view(torch.int32), "q_rel": meta[:, :3].contiguous(),
+              "q_win": od["row_src"][:R, 0].long()}
+        qs["q_csr"] = Csr.gather(qs["q_rows"], N)
+        qs["q_geo"] = torch.cat([qs["q_rel"], s["centre"][qs["q_win"]], common["pad2"].expand(R, 2)], dim=1).contiguous()
+        qs["keys"] = [dict(k, wins=dict(q_off=od["q_off"][:nw].contiguous(), q_cnt=od["nq_valid"][:nw].contiguous(),
+                                        k_off=k["k_off"], k_cnt=k["k_cnt"])) for k in common["keys"]]
+        _deferred.append(qs["q_csr"].bwd)
+        pat["q_sets"] = qs
+    s.update(qs)
     # interpolation / scatter table: 3 compact attention rows + weights per voxel (row R = the zero row)
     interp = key[1]
     upd_ind, n_upd, owner = (p.ind_win1, block.max_num_win1, p.owner_win1) if interp else (q_ind, nq, owner_q)
@@ -519,7 +597,9 @@ def _block_index_sets(block, sp, p):
     s["interp_csr"] = Csr(off3, idx3.reshape(-1).contiguous(), w3.reshape(-1).contiguous(), R + 1, drop_src=R,
                           fwd_longest=3)
     s["owned"] = owned
-    Segments.resolve_all([s["q_csr"].bwd, s["interp_csr"].bwd] + [k["k_csr"].bwd for k in s["keys"]])  # one host sync
+    # the longest-list words of the four inverted indices ride with the next host read (_read_sizes), or are read on
+    # first use: no host wait of their own
+    _deferred.append(s["interp_csr"].bwd)
     cache[key] = s
     return s
 
@@ -610,7 +690,8 @@ def _compress_index_sets(block, sp, p):
     N, nw, ns = sp.indices.shape[0], p.nw, block.max_num_win1
     k = p.k_ind[:nw]
     valid = k >= 0
-    flat = torch.nonzero(valid.reshape(-1), as_tuple=True)[0]  # one sync: the pair count
+    P, = _read_sizes(valid.sum().reshape(1))  # one sync: the pair count (+ the pending words of the Blocks' index sets)
+    flat = _nonzero_known(valid.reshape(-1), P)
     pair_win = flat // ns
     pair_vox = (k.reshape(-1)[flat].long() + p.win_vstart[:nw].long()[pair_win]).int().contiguous()
     cnt = valid.sum(1)
@@ -618,8 +699,7 @@ def _compress_index_sets(block, sp, p):
     centre = _metric(p.win_ind[:nw], sp.point_cloud_range, p.win_size_m)
     wins = dict(q_off=torch.arange(nw, dtype=torch.int32, device=dev), q_cnt=torch.ones(nw, dtype=torch.int32, device=dev),
                 k_off=(torch.cumsum(cnt, 0) - cnt).int().contiguous(), k_cnt=cnt.int().contiguous())
-    vox_csr = Csr.gather(pair_vox, N)
-    Segments.resolve_all([vox_csr.bwd])
+    vox_csr = Csr.gather(pair_vox, N, bwd_longest=1)  # windows are disjoint: a voxel is on one list, once
     return dict(pair_win=pair_win, cnt=cnt, vox_csr=vox_csr, centre=centre, wins=wins,
                 rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(), full=(cnt >= ns))
 
