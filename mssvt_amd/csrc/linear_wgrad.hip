@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(int slices, int Cin, int C
     const int q = blockIdx.x * 32 + ql;  // (tile, lane)
     f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q < tiles * 64)
+#pragma unroll 4  // the loads of four slices in flight, added in slice order
         for (int s = grp; s < slices; s += 8) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + ((size_t)s * tiles * 64 + q) * 4);
             sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];

@@ -47,6 +47,10 @@
         }                                                                                          \
     }
 
+// e^x as one multiply and the hardware exp2 (relative error ~ |x| 2^-24: the library expf is ~15 instructions, and with a
+// lane per channel every lane of a head evaluates it -- two thirds of the kernels' issue slots went there)
+__device__ __forceinline__ float pa_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 template <int HD>
 __device__ __forceinline__ float head_sum(float v) {
     if (HD >= 2) v += DPP_MOV(v, 0xB1);   // quad_perm [1,0,3,2]
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(PA_WAVES *MSSVT_WAVE) k_pair_attn_fwd(int nw, 
                     for (int r = 0; r < CPL; ++r) {
                         const float s = head_sum<HD>(qv[b][r] * kc[u][r]);
                         const float mn = fmaxf(m[b][r], s);
-                        const float corr = expf(m[b][r] - mn), p = expf(s - mn);
+                        const float corr = pa_exp(m[b][r] - mn), p = pa_exp(s - mn);
                         l[b][r] = l[b][r] * corr + p;
                         o[b][r] = o[b][r] * corr + p * vc[u][r];
                         m[b][r] = mn;
@@ -194,7 +198,7 @@ __global__ void __launch_bounds__(PA_WAVES *MSSVT_WAVE) k_pair_attn_dq(int nw, i
 #pragma unroll
                     for (int r = 0; r < CPL; ++r) {
                         const float s = head_sum<HD>(qv[b][r] * kc[u][r]);
-                        const float p = expf(s - ls[b][r]);
+                        const float p = pa_exp(s - ls[b][r]);
                         const float dp = head_sum<HD>(dov[b][r] * vc[u][r]);
                         dqa[b][r] += p * (dp - delta[b][r]) * kc[u][r];
                     }
@@ -259,7 +263,7 @@ __global__ void __launch_bounds__(PA_WAVES *MSSVT_WAVE) k_pair_attn_dkv(int nw, 
 #pragma unroll
                     for (int r = 0; r < CPL; ++r) {
                         const float s = head_sum<HD>(qc[u][r] * kk[b][r]);
-                        const float p = expf(s - lc[u][r]);
+                        const float p = pa_exp(s - lc[u][r]);
                         const float dp = head_sum<HD>(gc[u][r] * vv[b][r]);
                         dv[b][r] += p * gc[u][r];
                         dk[b][r] += p * (dp - dl[u][r]) * qc[u][r];

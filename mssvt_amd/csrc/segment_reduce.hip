@@ -29,23 +29,33 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, cons
     const int e0 = seg_start[d], e1 = seg_end[d];
     for (int c = 4 * l; c < C; c += 4 * LPR) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // two contribution rows in flight; the ADD order stays e0, e0 + 1, ... (fixed)
-        int e = e0;
-        for (; e + 1 < e1; e += 2) {
-            const int r0 = idx[e], r1 = idx[e + 1];
+        // four contribution rows in flight (indices first, then the rows: two round trips per four entries; most lists
+        // of the training path -- keys per voxel, 3-NN rows -- are done in one pass); entries past the end re-read the
+        // last one and are not added; the ADD order stays e0, e0 + 1, ... (fixed)
+        for (int e = e0; e < e1; e += 4) {
+            const int last = e1 - 1;
+            const int i1 = min(e + 1, last), i2 = min(e + 2, last), i3 = min(e + 3, last);
+            const int r0 = idx[e], r1 = idx[i1], r2 = idx[i2], r3 = idx[i3];
+            float w0 = 1.0f, w1 = 1.0f, w2 = 1.0f, w3 = 1.0f;
+            if (w) { w0 = w[e]; w1 = w[i1]; w2 = w[i2]; w3 = w[i3]; }
             const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)r0 * src_stride + c);
             const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)r1 * src_stride + c);
-            const float w0 = w ? w[e] : 1.0f, w1 = w ? w[e + 1] : 1.0f;
+            const float4 v2 = *reinterpret_cast<const float4 *>(src + (size_t)r2 * src_stride + c);
+            const float4 v3 = *reinterpret_cast<const float4 *>(src + (size_t)r3 * src_stride + c);
             acc.x = __builtin_fmaf(w0, v0.x, acc.x); acc.y = __builtin_fmaf(w0, v0.y, acc.y);
             acc.z = __builtin_fmaf(w0, v0.z, acc.z); acc.w = __builtin_fmaf(w0, v0.w, acc.w);
-            acc.x = __builtin_fmaf(w1, v1.x, acc.x); acc.y = __builtin_fmaf(w1, v1.y, acc.y);
-            acc.z = __builtin_fmaf(w1, v1.z, acc.z); acc.w = __builtin_fmaf(w1, v1.w, acc.w);
-        }
-        if (e < e1) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)idx[e] * src_stride + c);
-            const float w0 = w ? w[e] : 1.0f;
-            acc.x = __builtin_fmaf(w0, v0.x, acc.x); acc.y = __builtin_fmaf(w0, v0.y, acc.y);
-            acc.z = __builtin_fmaf(w0, v0.z, acc.z); acc.w = __builtin_fmaf(w0, v0.w, acc.w);
+            if (e + 1 < e1) {
+                acc.x = __builtin_fmaf(w1, v1.x, acc.x); acc.y = __builtin_fmaf(w1, v1.y, acc.y);
+                acc.z = __builtin_fmaf(w1, v1.z, acc.z); acc.w = __builtin_fmaf(w1, v1.w, acc.w);
+            }
+            if (e + 2 < e1) {
+                acc.x = __builtin_fmaf(w2, v2.x, acc.x); acc.y = __builtin_fmaf(w2, v2.y, acc.y);
+                acc.z = __builtin_fmaf(w2, v2.z, acc.z); acc.w = __builtin_fmaf(w2, v2.w, acc.w);
+            }
+            if (e + 3 < e1) {
+                acc.x = __builtin_fmaf(w3, v3.x, acc.x); acc.y = __builtin_fmaf(w3, v3.y, acc.y);
+                acc.z = __builtin_fmaf(w3, v3.z, acc.z); acc.w = __builtin_fmaf(w3, v3.w, acc.w);
+            }
         }
         float4 *out = reinterpret_cast<float4 *>(dst + (size_t)d * dst_stride + c);
         if (accumulate) {  // dst += the list's sum (one add per element: the order stays fixed)

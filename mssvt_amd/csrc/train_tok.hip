@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(256) k_tok_bwd_reduce(int Ctot, TokSlabs a, fl
         if (c < a.c0[k] || c >= a.c0[k] + a.cg[k]) continue;  // wave-uniform
         const float *p = a.slab[k] + (size_t)(c - a.c0[k]) * 8 + j;
         float v = 0.f;
+#pragma unroll 4
         for (int s = sg; s < a.slices[k]; s += 8) v += p[(size_t)s * a.cg[k] * 8];
         float sum = 0.f;
 #pragma unroll

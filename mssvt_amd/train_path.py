@@ -82,7 +82,8 @@ class Segments(object):
         self.end = torch.where(heavy, self.start, off[1:]).contiguous()  # heavy rows: empty here, filled below
         hd = _nonzero_known(heavy, H, fill=-1)
         real = hd >= 0
-        hd = hd.clamp(min=0)
+        # (padding entries name distinct rows: their exact zeros are added without piling onto one address)
+        hd = torch.where(real, hd, torch.arange(H, device=dev) % max(self.n_dst, 1))
         hs = self.start[hd].long()
         hc = torch.where(real, counts[hd], torch.zeros_like(hd))
         nch = (hc + CHUNK - 1) // CHUNK  # 0 for the padding
@@ -624,6 +625,7 @@ def block_forward(block, sp):
     xhat = layer_norm(block.norm1, x_in)
     p = fused.two_scale_plan(block, sp)
     s = _block_index_sets(block, sp, p)
+    _compress_ahead(sp)
     R, ma = s["R"], block.ms_attn
     hd = ma.per_head_dim
     if R > 0:
@@ -704,6 +706,37 @@ def _compress_index_sets(block, sp, p):
                 rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(), full=(cnt >= ns))
 
 
+def _compress_sets(block, sp):
+    """(plan, index sets) of the CompressBlock that closes this level -- built ahead by the level's first Block when there
+    is one (`_compress_ahead`), else here: K2 + K4 on the device and the host reads of the output shape / pair count."""
+    ahead = getattr(sp, "_train_cmp", None)
+    if ahead and ahead[0] is block and ahead[1] is sp.indices:
+        st = getattr(sp, "_level", None)
+        if st is not None and len(st.get("status_words", [])) > ahead[4]:
+            st["status_checked"] = False
+            fused.check_level_status(sp)  # plans made after the early read: their overflow words
+        return ahead[2], ahead[3]
+    p = fused.one_scale_plan(block, sp)
+    return p, _compress_index_sets(block, sp, p)
+
+
+def _compress_ahead(sp):
+    """The CompressBlock's plan and index sets depend on the voxel indices only: the level's first Block builds them, so
+    that their host reads happen while the queue is still short -- a read after the Blocks waits for all of them and
+    leaves the device idle until the host has caught up again (1.6 ms per step went there)."""
+    cmp_blk = getattr(sp, "_next_compress", None)
+    if cmp_blk is None or getattr(sp, "_train_cmp", None) is not None:
+        return
+    sp._train_cmp = ()
+    C = sp.features.shape[1]
+    if not (compress_supported(cmp_blk, sp) and cmp_blk.linear1.in_features == C):
+        return
+    p = fused.one_scale_plan(cmp_blk, sp)
+    st = getattr(sp, "_level", None)
+    sp._train_cmp = (cmp_blk, sp.indices, p, _compress_index_sets(cmp_blk, sp, p),
+                     len(st.get("status_words", [])) if st is not None else 0)
+
+
 def _metric(indices, point_cloud_range, cell):
     from .mssvt_backbone import metric_centres
     return metric_centres(indices, point_cloud_range, cell)
@@ -715,8 +748,7 @@ def compress_forward(block, sp):
         return block.forward_ops(sp)
     x = layer_norm(block.norm1, sp.features)
     C = x.shape[1]
-    p = fused.one_scale_plan(block, sp)  # K2 + K4 on the device, one host sync (the output shape)
-    s = _compress_index_sets(block, sp, p)
+    p, s = _compress_sets(block, sp)
     ma = block.ms_attn
     heads, hd = ma.num_heads[0], ma.per_head_dim
     xk = gather_sum(x, s["vox_csr"])  # (P, C) window-major key features
