@@ -320,18 +320,25 @@ def wgrad_supported(cin, cout):
 
 
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b over compact rows.  dx is a library GEMM (tall output: fine); dW = dY^T X and db reduce over the
-    ROWS into a <= 256 x 128 result, which library GEMMs do at 7 % of the matrix pipe: one split-K MFMA launch here."""
+    """y = x W^T + b (optionally relu'd in place) over compact rows.  y and dx are library GEMMs (tall outputs: a
+    hand-written fp32-MFMA kernel with the weight matrix in LDS was measured at 0.4 - 0.7 of the library's rate on these
+    shapes and removed); dW = dY^T X and db reduce over the ROWS into a <= 256 x 128 result, which library GEMMs do at 7 %
+    of the matrix pipe: one split-K MFMA launch here."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, b, relu=False):
+        y = F.linear(x, w, b)
+        if relu:
+            y = y.clamp_(min=0)
+        ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = b is not None
-        return F.linear(x, w, b)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
+        if y is not None:
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)  # relu: the gradient where the output is positive
         dy = dy.contiguous()
         dx = dy @ w if ctx.needs_input_grad[0] else None
         dw = db = None
@@ -344,18 +351,18 @@ class _Linear(torch.autograd.Function):
             if M > 0:
                 _lib.call("mssvt_linear_wgrad", _i(M), _i(cin), _i(cout), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw),
                           _lib.ptr(db), _lib.ptr(_wgrad_workspace(x.device, M, cin, cout)), _lib.stream())
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(mod, x, scale_rows=None):
-    """``mod(x)`` for an nn.Linear (or a weight / bias pair) with the deterministic weight gradient."""
+def linear(mod, x, relu=False):
+    """``mod(x)`` (``relu(mod(x))``) for an nn.Linear (or a weight / bias pair) with the deterministic weight gradient."""
     w, b = (mod.weight, mod.bias) if hasattr(mod, "weight") else mod
     if w.dim() == 3:
         w = w.squeeze(-1)  # Conv1d(k = 1)
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and wgrad_supported(w.shape[1], w.shape[0])
             and torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad))):
-        return F.linear(x, w, b)
-    return _Linear.apply(x, w, b)
+        return F.relu(F.linear(x, w, b)) if relu else F.linear(x, w, b)
+    return _Linear.apply(x, w, b, relu)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -397,7 +404,11 @@ def layer_norm(norm, x):
 
 def ffn(block, x):
     """block._ffn with the deterministic weight gradients (ref mssvt_backbone.py:341-343)."""
-    return linear(block.linear2, block.dropout1(block.activation(linear(block.linear1, layer_norm(block.norm2, x)))))
+    if isinstance(block.activation, torch.nn.ReLU):  # the clamp rides in the first product's epilogue
+        h = linear(block.linear1, layer_norm(block.norm2, x), relu=True)
+    else:
+        h = block.activation(linear(block.linear1, layer_norm(block.norm2, x)))
+    return linear(block.linear2, block.dropout1(h))
 
 
 # ---------------------------------------------------------------------------------------------------------

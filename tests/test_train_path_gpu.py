@@ -254,3 +254,92 @@ def test_layer_norm_backward_kernel(N, C):
     for got, ref, what in zip(res[0], (yd.detach(), xd.grad, wd.grad, bd.grad), ("y", "dx", "dw", "db")):
         err = float((got.cpu().double() - ref).abs().max())
         assert err <= 3e-6 * max(1.0, float(ref.abs().max())) * max(1.0, N ** 0.5 / 16), (what, err)
+
+
+@pytest.mark.parametrize("C,dims,N,R,K", [(128, (64, 64), 5000, 3000, (9000, 12000)), (32, (16, 16), 300, 100, (700, 1)),
+                                          (256, (128, 128), 2000, 1, (0, 5000)), (64, (32, 32), 50, 0, (64, 64))])
+def test_token_kernels_match_the_autograd_composition(C, dims, N, R, K):
+    """train_path.tokens (csrc/train_tok.hip: gather + positional embedding of the four token sets of a Block as one node)
+    against the composition it replaces (gather_sum of a column slice + _pos6) in float64, values and all three gradients;
+    two backward passes agree bit for bit."""
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(C + N)
+    conv = torch.nn.Conv1d(6, C, 1).to(DEV)
+    xhat = torch.randn(N, C, generator=g).to(DEV).requires_grad_(True)
+    parts, c0 = [], 0
+    sets = []
+    for M in (R, R) + tuple(K):
+        rows = torch.randint(0, N, (M,), generator=g).int().to(DEV)
+        if M > 600:
+            rows[::2] = 3  # a long list in the inverted index (cut into chunks)
+        geo = torch.cat([torch.randn(M, 6, generator=g), torch.zeros(M, 2)], 1).to(DEV)
+        sets.append((rows, geo, train_path.Csr.gather(rows, N)))
+    for k, (rows, geo, csr) in enumerate(sets):
+        g_i = k % 2
+        c0 = sum(dims[:g_i])
+        parts.append(dict(rows=rows, geo=geo, csr=csr, c0=c0, c1=c0 + dims[g_i]))
+    ws = [torch.randn(p["rows"].numel(), p["c1"] - p["c0"], generator=g).to(DEV) for p in parts]
+
+    def run():
+        for t in (xhat, conv.weight, conv.bias):
+            t.grad = None
+        toks = train_path.tokens(xhat, conv, parts)
+        sum((t * w).sum() for t, w in zip(toks, ws)).backward()
+        return [t.detach() for t in toks], xhat.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()
+
+    toks, gx, gw, gb = run()
+    toks2, gx2, gw2, gb2 = run()
+    assert all(torch.equal(a, b) for a, b in zip(toks, toks2)) and torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    xd = xhat.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().squeeze(-1).requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True)
+    loss = 0
+    for p, w, t in zip(parts, ws, toks):
+        ref = xd[p["rows"].long()][:, p["c0"]:p["c1"]] + torch.relu(p["geo"][:, :6].double() @ wd[p["c0"]:p["c1"]].T + bd[p["c0"]:p["c1"]])
+        if t.numel():
+            assert float((t.double() - ref.detach()).abs().max()) <= 1e-5 * max(1.0, float(ref.detach().abs().max()))
+        loss = loss + (ref * w.double()).sum()
+    loss.backward()
+    for got, want, what in ((gx, xd.grad, "d xhat"), (gw.squeeze(-1), wd.grad, "d weight"), (gb, bd.grad, "d bias")):
+        err, scale = float((got.double() - want).abs().max()), max(1.0, float(want.abs().max()))
+        assert err <= 2e-5 * scale * max(1.0, (max(K) ** 0.5) / 16), (what, err, scale)
+
+
+def test_strided_segment_sum_writes_and_accumulates_into_a_column_range():
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(5)
+    R, N, C, c0, cg = 9000, 400, 96, 32, 48
+    idx = torch.randint(0, N, (R,), generator=g)
+    idx[::2] = 11  # ~4.5k entries on one row: the chunked path
+    csr = train_path.Csr.gather(idx.int().to(DEV), N)
+    src = torch.randn(R, cg, generator=g).to(DEV)
+    want = torch.zeros(N, cg, dtype=torch.float64).index_add_(0, idx, src.cpu().double())
+    dst = torch.full((N, C), 7.0, device=DEV)
+    train_path._sum_into(csr.bwd, src, dst, c0, False)
+    assert csr.bwd.heavy is not None
+    assert float((dst[:, c0:c0 + cg].cpu().double() - want).abs().max()) < 1e-3
+    assert bool((dst[:, :c0] == 7.0).all()) and bool((dst[:, c0 + cg:] == 7.0).all())
+    train_path._sum_into(csr.bwd, src, dst, c0, True)
+    assert float((dst[:, c0:c0 + cg].cpu().double() - 2 * want).abs().max()) < 2e-3
+    assert bool((dst[:, :c0] == 7.0).all()) and bool((dst[:, c0 + cg:] == 7.0).all())
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_with_the_relu_epilogue_matches_the_library_composition(relu):
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(3)
+    lin = torch.nn.Linear(64, 128).to(DEV)
+    x = torch.randn(5000, 64, generator=g).to(DEV)
+    dy = torch.randn(5000, 128, generator=g).to(DEV)
+    xr = x.clone().requires_grad_(True)
+    out = train_path.linear(lin, xr, relu=relu)
+    (out * dy).sum().backward()
+    gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+    lin.weight.grad = lin.bias.grad = None
+    x2 = x.clone().requires_grad_(True)
+    o2 = lin(x2)
+    o2 = o2.relu() if relu else o2
+    (o2 * dy).sum().backward()
+    assert torch.equal(out.detach(), o2.detach()) and torch.equal(xr.grad, x2.grad)
+    assert float((gw - lin.weight.grad).abs().max()) <= 2e-4 * max(1.0, float(lin.weight.grad.abs().max()))
+    assert float((gb - lin.bias.grad).abs().max()) <= 2e-4 * max(1.0, float(lin.bias.grad.abs().max()))

@@ -50,12 +50,14 @@ for _ in range(n):
     print("forward issue %.2f ms (+%.2f to drain), backward issue %.2f ms (+%.2f to drain)" % (
         (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
 pr = cProfile.Profile()
-pr.enable()
 for _ in range(n):
-    fwd().backward()
+    torch.cuda.synchronize()
+    pr.enable()
+    loss = fwd()
+    pr.disable()
+    loss.backward()
     opt.step()
 torch.cuda.synchronize()
-pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
-st.sort_stats("cumtime").print_stats("mssvt_amd", 30)
+st.sort_stats("tottime").print_stats(40)
+st.sort_stats("cumtime").print_stats("mssvt_amd", 45)
