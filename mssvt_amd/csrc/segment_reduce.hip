@@ -32,7 +32,25 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, cons
         // four contribution rows in flight (indices first, then the rows: two round trips per four entries; most lists
         // of the training path -- keys per voxel, 3-NN rows -- are done in one pass); entries past the end re-read the
         // last one and are not added; the ADD order stays e0, e0 + 1, ... (fixed)
-        for (int e = e0; e < e1; e += 4) {
+        int e = e0;
+        // long lists (the fixed chunks of a heavy destination: 256 entries on one lane group) eight rows at a time
+        for (; e + 8 <= e1; e += 8) {
+            int r[8];
+            float wv[8];
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = idx[e + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w ? w[e + u] : 1.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)r[u] * src_stride + c);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc.x = __builtin_fmaf(wv[u], v[u].x, acc.x); acc.y = __builtin_fmaf(wv[u], v[u].y, acc.y);
+                acc.z = __builtin_fmaf(wv[u], v[u].z, acc.z); acc.w = __builtin_fmaf(wv[u], v[u].w, acc.w);
+            }
+        }
+        for (; e < e1; e += 4) {
             const int last = e1 - 1;
             const int i1 = min(e + 1, last), i2 = min(e + 2, last), i3 = min(e + 3, last);
             const int r0 = idx[e], r1 = idx[i1], r2 = idx[i2], r3 = idx[i3];
