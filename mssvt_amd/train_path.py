@@ -144,7 +144,10 @@ def _sum_into(seg, src, dst, c0, accumulate):
         view.index_add_(0, h["rows"], tot)  # 0 (written) or the earlier sum (accumulated) + the long lists' sums
 
 
-_deferred = []  # Segments whose longest-list word has not been read yet
+# Segments whose longest-list word has not been read yet.  Process-wide like the workspaces above: one process drives one
+# GPU from one thread (bench.py --gpus N starts N processes); the list only ever SAVES a host read -- a Segments that is
+# used before the next read fetches its own word (`Segments.sum`, `_sum_into`).
+_deferred = []
 
 
 def _read_sizes(words):
