@@ -50,8 +50,8 @@ class Segments(object):
     chunk order): the order is fixed either way, and no lane group serialises a whole launch.
 
     `longest`: None = look at the offsets now (one host sync); an int = the caller's bound (no sync); a 1-element device
-    tensor = the word mssvt_csr_transpose left (0 when no list is longer than CHUNK), read later by `resolve_all` for all
-    the index sets of a plan at once, or on first use."""
+    tensor = the word mssvt_csr_transpose left (0 when no list is longer than CHUNK), read later with the next host read of
+    sizes (`_read_sizes`), or on first use."""
 
     def __init__(self, off, idx, w, longest=None):
         self.idx, self.w, self.n_dst = idx, w, off.numel() - 1
@@ -100,14 +100,6 @@ class Segments(object):
                           c_end=torch.where(used, c_end, zero).int().contiguous(),
                           p_start=first.int().contiguous(), p_end=last.int().contiguous(),
                           p_idx=torch.arange(M2, dtype=torch.int32, device=dev), n_chunks=M2)
-
-    @staticmethod
-    def resolve_all(segs):
-        """Read the longest-list words of all pending `segs` in ONE host sync and cut the long lists."""
-        segs = [g for g in segs if g.pending is not None]
-        if segs:
-            for g, longest in zip(segs, torch.cat([g.pending for g in segs]).tolist()):
-                g._cut(longest)
 
     def sum(self, src):
         if self.idx is None or self.idx.numel() == 0:  # an empty index set: nothing to add (the C entry rejects a NULL idx)

@@ -39,9 +39,11 @@ def _grads(net, x, coords, B, w):
     return out.detach(), x.grad.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
 
 
-@pytest.mark.parametrize("C,heads,cheads,interp", [(32, [2, 2], [4], (True, False)), (64, [4, 4], [8], (True, True))])
-def test_compact_training_path_matches_the_operator_path(C, heads, cheads, interp):
-    from mssvt_amd import fused
+@pytest.mark.parametrize("C,heads,cheads,interp,tokens", [(32, [2, 2], [4], (True, False), True), (64, [4, 4], [8], (True, True), True),
+                                                         (64, [4, 4], [8], (True, False), False)])
+def test_compact_training_path_matches_the_operator_path(C, heads, cheads, interp, tokens, monkeypatch):
+    from mssvt_amd import fused, train_path
+    monkeypatch.setattr(train_path, "TOKENS", tokens)  # False: the autograd composition of the token sets (other widths' path)
     B, H = 2, 40009
     net = _net(C, _params(C, heads, cheads, interp), H)
     vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(4000, B, 31))
