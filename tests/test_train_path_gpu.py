@@ -142,7 +142,7 @@ def test_linear_weight_gradient_kernel(M, cin, cout, bias):
     torch.testing.assert_close(grads[0][2], dy @ w.detach(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("cg,hd,max_q,max_k", [(64, 16, 20, 32), (128, 16, 1, 32), (32, 8, 45, 64), (16, 4, 3, 5),
+@pytest.mark.parametrize("cg,hd,max_q,max_k", [(64, 16, 20, 32), (64, 16, 45, 100), (64, 16, 2, 17), (128, 16, 1, 32), (32, 8, 45, 64), (16, 4, 3, 5),
                                                (64, 32, 9, 12), (64, 64, 5, 7)])
 def test_pair_attention_kernels_vs_float64_autograd(cg, hd, max_q, max_k):
     """mssvt_pair_attention_fwd / _bwd against a float64 torch restatement per window (windows with no query, with no
