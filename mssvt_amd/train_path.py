@@ -220,6 +220,27 @@ class Csr(object):
         return Csr(None, idx, None, n_src, bwd_longest=bwd_longest)
 
 
+def _gather_unique(idx, n_src):
+    """Csr of a plain row gather whose rows are DISTINCT (a window's query rows when every window size is odd, the pillar
+    lists of a CompressBlock): the inverse is a partial permutation -- one scatter instead of the sort of
+    mssvt_csr_transpose; source row v sums the one entry inv[v] or nothing."""
+    c = Csr.__new__(Csr)
+    dev = idx.device
+    idx = idx.int().contiguous()
+    nnz = idx.numel()
+    c.n_src, c.n_dst = int(n_src), nnz
+    inv = torch.full((c.n_src,), -1, dtype=torch.int32, device=dev)
+    inv[idx.long()] = torch.arange(nnz, dtype=torch.int32, device=dev)
+    c.off = torch.arange(nnz + 1, dtype=torch.int32, device=dev)
+    c.idx, c.w = idx, None
+    c.fwd = Segments(c.off, idx, None, longest=1)
+    pos = torch.arange(c.n_src + 1, dtype=torch.int32, device=dev)
+    c.bwd = Segments(pos, inv.clamp(min=0), None, longest=1)
+    c.bwd.end = (pos[:-1] + (inv >= 0).int()).contiguous()  # an empty range where no entry reads the row
+    c.t_off = c.t_idx = c.t_w = None
+    return c
+
+
 class _SegmentSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, csr):
@@ -577,11 +598,14 @@ def _block_index_sets(block, sp, p):
         meta = od["row_meta"][:R]
         qs = {"q_rows": meta[:, 3].contiguous().view(torch.int32), "q_rel": meta[:, :3].contiguous(),
               "q_win": od["row_src"][:R, 0].long()}
-        qs["q_csr"] = Csr.gather(qs["q_rows"], N)
+        # (a voxel is on one window's query list when every window size is odd: ref mssvt_backbone.py:94-97)
+        distinct = all(int(wsz) % 2 == 1 for wsz in block.win1_size)
+        qs["q_csr"] = _gather_unique(qs["q_rows"], N) if distinct else Csr.gather(qs["q_rows"], N)
         qs["q_geo"] = torch.cat([qs["q_rel"], s["centre"][qs["q_win"]], common["pad2"].expand(R, 2)], dim=1).contiguous()
         qs["keys"] = [dict(k, wins=dict(q_off=od["q_off"][:nw].contiguous(), q_cnt=od["nq_valid"][:nw].contiguous(),
                                         k_off=k["k_off"], k_cnt=k["k_cnt"])) for k in common["keys"]]
-        _deferred.append(qs["q_csr"].bwd)
+        if qs["q_csr"].bwd.pending is not None:
+            _deferred.append(qs["q_csr"].bwd)
         pat["q_sets"] = qs
     s.update(qs)
     # interpolation / scatter table: 3 compact attention rows + weights per voxel (row R = the zero row)
@@ -707,7 +731,7 @@ def _compress_index_sets(block, sp, p):
     centre = _metric(p.win_ind[:nw], sp.point_cloud_range, p.win_size_m)
     wins = dict(q_off=torch.arange(nw, dtype=torch.int32, device=dev), q_cnt=torch.ones(nw, dtype=torch.int32, device=dev),
                 k_off=(torch.cumsum(cnt, 0) - cnt).int().contiguous(), k_cnt=cnt.int().contiguous())
-    vox_csr = Csr.gather(pair_vox, N, bwd_longest=1)  # windows are disjoint: a voxel is on one list, once
+    vox_csr = _gather_unique(pair_vox, N)  # windows are disjoint: a voxel is on one list, once
     return dict(pair_win=pair_win, cnt=cnt, vox_csr=vox_csr, centre=centre, wins=wins,
                 rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(), full=(cnt >= ns))
 
