@@ -335,17 +335,35 @@ def wgrad_supported(cin, cout):
     return cin % 4 == 0 and cout % 4 == 0 and ((cout + 15) // 16) * ((cin + 15) // 16 + 1) <= 160
 
 
+LINEAR_ROWS = {(64, 64)}  # (cin, cout) shapes that run on mssvt_linear_rows instead of the library GEMM (measured: the only win)
+
+
+def _linear_rows(x, w, transpose_w, b, relu, n_out):
+    M, K = x.shape
+    y = torch.empty((M, n_out), dtype=torch.float32, device=x.device)
+    if M:
+        _lib.call("mssvt_linear_rows", _i(M), _i(K), _i(n_out), _lib.ptr(x), _i(K), _lib.ptr(w), _i(1 if transpose_w else 0),
+                  _lib.ptr(b), _i(1 if relu else 0), _lib.ptr(y), _i(n_out), _lib.stream())
+    return y
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b (optionally relu'd in place) over compact rows.  y and dx are library GEMMs (tall outputs: a
-    hand-written fp32-MFMA kernel with the weight matrix in LDS was measured at 0.4 - 0.7 of the library's rate on these
-    shapes and removed); dW = dY^T X and db reduce over the ROWS into a <= 256 x 128 result, which library GEMMs do at 7 %
-    of the matrix pipe: one split-K MFMA launch here."""
+    """y = x W^T + b (optionally relu'd in place) over compact rows.  y and dx are library GEMMs on the large shapes (a
+    hand-written fp32-MFMA kernel with the weight matrix in LDS runs at 0.4 - 0.7 of the library's rate there) and
+    mssvt_linear_rows (csrc/linear_rows.hip) on 64 x 64, where the library picks poor tiles (13 vs 8 us at 33k rows, 154 vs
+    34 at 132k); dW = dY^T X and db reduce over the ROWS into a <= 256 x 128 result, which library GEMMs do at 7 % of the
+    matrix pipe: one split-K MFMA launch here."""
 
     @staticmethod
     def forward(ctx, x, w, b, relu=False):
-        y = F.linear(x, w, b)
-        if relu:
-            y = y.clamp_(min=0)
+        cout, cin = w.shape
+        if (cin, cout) in LINEAR_ROWS and x.dtype == torch.float32:
+            x = x.contiguous()
+            y = _linear_rows(x, w.detach().contiguous(), False, None if b is None else b.detach(), relu, cout)
+        else:
+            y = F.linear(x, w, b)
+            if relu:
+                y = y.clamp_(min=0)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = b is not None
         return y
@@ -356,11 +374,14 @@ class _Linear(torch.autograd.Function):
         if y is not None:
             dy = torch.ops.aten.threshold_backward(dy, y, 0.0)  # relu: the gradient where the output is positive
         dy = dy.contiguous()
-        dx = dy @ w if ctx.needs_input_grad[0] else None
+        cout, cin = w.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _linear_rows(dy, w.detach().contiguous(), True, None, False, cin) if (cout, cin) in LINEAR_ROWS else dy @ w
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x = x.contiguous()
-            M, cin, cout = x.shape[0], x.shape[1], w.shape[0]
+            M = x.shape[0]
             alloc = torch.empty if M > 0 else torch.zeros
             dw = alloc(w.shape, dtype=w.dtype, device=w.device)
             db = alloc((cout,), dtype=w.dtype, device=w.device) if ctx.has_bias else None

@@ -345,3 +345,36 @@ def test_linear_with_the_relu_epilogue_matches_the_library_composition(relu):
     assert torch.equal(out.detach(), o2.detach()) and torch.equal(xr.grad, x2.grad)
     assert float((gw - lin.weight.grad).abs().max()) <= 2e-4 * max(1.0, float(lin.weight.grad.abs().max()))
     assert float((gb - lin.bias.grad).abs().max()) <= 2e-4 * max(1.0, float(lin.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(33001, 64, 64, False), (132017, 64, 64, True), (17, 64, 64, False), (1, 64, 64, False),
+                                        (4097, 64, 128, True), (5000, 128, 64, False), (300, 128, 128, False)])
+def test_linear_rows_kernel_forward_and_input_gradient(M, K, N, relu):
+    """mssvt_linear_rows (the small weight matrices of a Block) against float64: y = x W^T + b with / without the relu
+    epilogue, dx = dy W through the transposed read of the same weight; and through train_path.linear for the shape that
+    runs on it, against the library composition."""
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    y = train_path._linear_rows(x, w, False, b, relu, N)
+    ref = x.double() @ w.double().T + b.double()
+    if relu:
+        ref = ref.clamp(min=0)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    dy = torch.randn(M, N, generator=g).to(DEV)
+    dx = train_path._linear_rows(dy, w, True, None, False, K)
+    refx = dy.double() @ w.double()
+    assert float((dx.double() - refx).abs().max()) <= 2e-5 * max(1.0, float(refx.abs().max()))
+    if (K, N) in train_path.LINEAR_ROWS:
+        lin = torch.nn.Linear(K, N).to(DEV)
+        xr = x.clone().requires_grad_(True)
+        out = train_path.linear(lin, xr, relu=relu)
+        (out * dy).sum().backward()
+        x2 = x.clone().requires_grad_(True)
+        o2 = lin(x2)
+        o2 = o2.relu() if relu else o2
+        (o2 * dy).sum().backward()
+        assert float((out.detach() - o2.detach()).abs().max()) <= 1e-4 * max(1.0, float(o2.detach().abs().max()))
+        assert float((xr.grad - x2.grad).abs().max()) <= 1e-4 * max(1.0, float(x2.grad.abs().max()))
