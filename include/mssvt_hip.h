@@ -604,6 +604,14 @@ int mssvt_segment_sum_rows_strided(int C, int n_dst, const int *seg_start, const
                                    const float *csr_w, const float *src, int src_stride, float *dst, int dst_stride,
                                    int accumulate, void *stream);
 
+/* The same sum with a residual epilogue: dst[d] = row_a[d] * res[d] + row_b[d] * sum (res, dst (n_dst,C); row_a, row_b
+ * (n_dst) f32).  The tail of a Block under autograd in one launch -- 3-NN interpolation of the attention rows, the
+ * "untouched voxels keep x_in" select, DropPath and the residual add (ref mssvt_backbone.py:298-340): row_b = the
+ * row's DropPath factor, row_a = 1 for a voxel the attention updates, 1 + row_b for one it does not.               */
+int mssvt_segment_sum_rows_residual(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
+                                    const float *csr_w, const float *src, const float *res, const float *row_a,
+                                    const float *row_b, float *dst, void *stream);
+
 /* Tokens of a Block's attention on compact rows (training path):
  *   tok[r][c] = (src ? src[rows[r]][c0+c] : 0) + relu(b[c0+c] + sum_{j<6} W6[c0+c][j] geo8[r][j]),  r < M, c < cg
  * = gathered feature + positional embedding of (offset to the window centre, window centre) (ref pos_proj,

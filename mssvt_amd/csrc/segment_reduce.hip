@@ -20,7 +20,8 @@
 template <int LPR>  // lanes per row (power of two <= 64): 64 / LPR destination rows per wavefront
 __global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, const int *seg_start, const int *seg_end,
                                                           const int *idx, const float *w, const float *src, int src_stride,
-                                                          float *dst, int dst_stride, int accumulate) {
+                                                          float *dst, int dst_stride, int accumulate, const float *res,
+                                                          const float *row_a, const float *row_b) {
     constexpr int RPW = MSSVT_WAVE / LPR;
     const int lane = lane_id(), sub = lane / LPR, l = lane % LPR;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / MSSVT_WAVE;
@@ -76,6 +77,12 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int C, int n_dst, cons
             }
         }
         float4 *out = reinterpret_cast<float4 *>(dst + (size_t)d * dst_stride + c);
+        if (res) {  // dst = row_a[d] * res[d] + row_b[d] * sum: the Block's residual / DropPath epilogue (_residual entry)
+            const float4 x = *reinterpret_cast<const float4 *>(res + (size_t)d * C + c);
+            const float ra = row_a[d], rb = row_b[d];
+            acc.x = __builtin_fmaf(rb, acc.x, ra * x.x); acc.y = __builtin_fmaf(rb, acc.y, ra * x.y);
+            acc.z = __builtin_fmaf(rb, acc.z, ra * x.z); acc.w = __builtin_fmaf(rb, acc.w, ra * x.w);
+        }
         if (accumulate) {  // dst += the list's sum (one add per element: the order stays fixed)
             const float4 o = *out;
             acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
@@ -110,9 +117,31 @@ extern "C" int mssvt_segment_sum_rows_ranges(int C, int n_dst, const int *seg_st
 // The same sum on C columns of wider rows (src / dst row strides in floats, both pointers at the first column), written
 // or ADDED to dst: the gradient of a gather of a column range lands in that range of the full-width gradient without a
 // zero-filled temporary and an add (the head groups of a Block: train_path._Tokens).
+static int seg_launch(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx, const float *csr_w,
+                      const float *src, int src_stride, float *dst, int dst_stride, int accumulate, const float *res,
+                      const float *row_a, const float *row_b, void *stream);
+
 extern "C" int mssvt_segment_sum_rows_strided(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
                                               const float *csr_w, const float *src, int src_stride, float *dst, int dst_stride,
                                               int accumulate, void *stream) {
+    return seg_launch(C, n_dst, seg_start, seg_end, csr_idx, csr_w, src, src_stride, dst, dst_stride, accumulate, nullptr, nullptr,
+                      nullptr, stream);
+}
+
+// dst[d] = row_a[d] * res[d] + row_b[d] * (the list's sum): the tail of a Block under autograd in one launch -- 3-NN
+// interpolation of the attention rows, the "untouched voxels keep x_in" select, DropPath and the residual add
+// (ref mssvt_backbone.py:298-340): row_b = the row's DropPath factor, row_a = 1 for a voxel the attention updates and
+// 1 + row_b for one it does not (whose list holds zero weights only).
+extern "C" int mssvt_segment_sum_rows_residual(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx,
+                                               const float *csr_w, const float *src, const float *res, const float *row_a,
+                                               const float *row_b, float *dst, void *stream) {
+    if (!res || !row_a || !row_b) return MSSVT_E_BADARG;
+    return seg_launch(C, n_dst, seg_start, seg_end, csr_idx, csr_w, src, C, dst, C, 0, res, row_a, row_b, stream);
+}
+
+static int seg_launch(int C, int n_dst, const int *seg_start, const int *seg_end, const int *csr_idx, const float *csr_w,
+                      const float *src, int src_stride, float *dst, int dst_stride, int accumulate, const float *res,
+                      const float *row_a, const float *row_b, void *stream) {
     const int *csr_off = seg_start;
     if (!seg_start || !seg_end || !csr_idx || !src || !dst || C <= 0 || n_dst < 0) return MSSVT_E_BADARG;
     if ((C & 3) || (src_stride & 3) || (dst_stride & 3) || src_stride < C || dst_stride < C) return MSSVT_E_BADARG;  // 16-byte row pieces
@@ -122,7 +151,7 @@ extern "C" int mssvt_segment_sum_rows_strided(int C, int n_dst, const int *seg_s
 #define SEG_LAUNCH(lpr)                                                                                    \
     {                                                                                                      \
         const int rpw = MSSVT_WAVE / lpr, waves = divup(n_dst, rpw);                                        \
-        k_segment_sum_rows<lpr><<<divup(waves, 4), 256, 0, st>>>(C, n_dst, csr_off, seg_end, csr_idx, csr_w, src, src_stride, dst, dst_stride, accumulate); \
+        k_segment_sum_rows<lpr><<<divup(waves, 4), 256, 0, st>>>(C, n_dst, csr_off, seg_end, csr_idx, csr_w, src, src_stride, dst, dst_stride, accumulate, res, row_a, row_b); \
     }
     if (q <= 4) SEG_LAUNCH(4)
     else if (q <= 8) SEG_LAUNCH(8)

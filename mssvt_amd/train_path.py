@@ -18,6 +18,7 @@ Same arithmetic as the reference up to re-association: masked key slots (additiv
 and empty query slots are dropped instead of padded; the interpolation uses the plan's 3-NN table (weights are geometry only).
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -656,6 +657,56 @@ def _block_index_sets(block, sp, p):
     return s
 
 
+BLOCK_TAIL = os.environ.get("MSSVT_TRAIN_BLOCK_TAIL", "1") != "0"  # 0: the autograd composition (gather_sum + where + DropPath + add)
+
+
+class _BlockTail(torch.autograd.Function):
+    """new = x_in + DropPath(where(owned, interpolated attention rows, x_in)) in one launch (mssvt_segment_sum_rows_residual:
+    ref mssvt_backbone.py:298-340): new[v] = row_a[v] x_in[v] + row_b[v] sum_e w_e attn[idx_e], row_b = the row's DropPath
+    factor, row_a = 1 on a voxel the attention updates and 1 + row_b elsewhere (its list holds zero weights only).
+    Backward: d attn = the inverted index's segmented sum of row_b-scaled gradient rows, d x_in = row_a-scaled rows."""
+
+    @staticmethod
+    def forward(ctx, attn_ext, x_in, csr, row_a, row_b):
+        attn_ext, x_in = attn_ext.contiguous(), x_in.contiguous()
+        N, C = x_in.shape
+        new = torch.empty_like(x_in)
+        f = csr.fwd
+        _lib.call("mssvt_segment_sum_rows_residual", _i(C), _i(N), _lib.ptr(f.start), _lib.ptr(f.end), _lib.ptr(f.idx),
+                  _lib.ptr(f.w), _lib.ptr(attn_ext), _lib.ptr(x_in), _lib.ptr(row_a), _lib.ptr(row_b), _lib.ptr(new),
+                  _lib.stream())
+        ctx.csr = csr
+        ctx.save_for_backward(row_a, row_b)
+        return new
+
+    @staticmethod
+    def backward(ctx, g):
+        row_a, row_b = ctx.saved_tensors
+        d_attn = ctx.csr.bwd.sum(g * row_b.unsqueeze(1)) if ctx.needs_input_grad[0] else None
+        d_x = g * row_a.unsqueeze(1) if ctx.needs_input_grad[1] else None
+        return d_attn, d_x, None, None, None
+
+
+def block_tail(block, attn_ext, x_in, s):
+    """The Block's update of the voxel features up to the FFN: see _BlockTail."""
+    dp = block.drop_path
+    N = x_in.shape[0]
+    p = float(getattr(dp, "drop_prob", 0.0))
+    if getattr(dp, "training", False) and p > 0.0:  # the module's own mask (DropPath.forward), kept as a row factor
+        keep = 1.0 - p
+        row_b = x_in.new_empty((N, 1)).bernoulli_(keep)
+        if keep > 0.0 and getattr(dp, "scale_by_keep", True):
+            row_b.div_(keep)
+        row_b = row_b.reshape(N)
+        row_a = torch.where(s["owned"], torch.ones_like(row_b), row_b + 1.0)
+    else:
+        if "tail_rows" not in s:  # constant per index set
+            ones = torch.ones((N,), dtype=torch.float32, device=x_in.device)
+            s["tail_rows"] = (torch.where(s["owned"], ones, ones + 1.0), ones)
+        row_a, row_b = s["tail_rows"]
+    return _BlockTail.apply(attn_ext, x_in, s["interp_csr"], row_a, row_b)
+
+
 def _pos6(conv, rel, centre, c0=None, c1=None):
     """relu(Conv1d(6 -> C, 1)([rel ; centre])) on compact rows (ref pos_proj, mssvt_backbone.py:43-47).  The six input
     columns are padded to eight so that the weight gradient (rows x 6 -> C x 6: the library's slowest shape, 370 us per
@@ -715,9 +766,12 @@ def block_forward(block, sp):
     else:
         attn = x_in.new_zeros((0, C))
     attn_ext = torch.cat([attn, attn.new_zeros((1, C))], dim=0)  # row R = zeros (empty slots, zero weights)
-    upd = gather_sum(attn_ext, s["interp_csr"])  # (N, C): interpolated / scattered update of every owned voxel
-    feats = torch.where(s["owned"].unsqueeze(1), upd, x_in)  # untouched voxels keep x_in (ref :317-338)
-    new = block.drop_path(feats) + x_in
+    if BLOCK_TAIL and s["interp_csr"].fwd.heavy is None and s["interp_csr"].fwd.pending is None:
+        new = block_tail(block, attn_ext, x_in, s)
+    else:
+        upd = gather_sum(attn_ext, s["interp_csr"])  # (N, C): interpolated / scattered update of every owned voxel
+        feats = torch.where(s["owned"].unsqueeze(1), upd, x_in)  # untouched voxels keep x_in (ref :317-338)
+        new = block.drop_path(feats) + x_in
     new = new + block.drop_path(block.dropout1(ffn(block, new)))
     if hasattr(block, "out_linear"):
         new = linear(block.out_linear, new)

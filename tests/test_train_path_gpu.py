@@ -378,3 +378,31 @@ def test_linear_rows_kernel_forward_and_input_gradient(M, K, N, relu):
         (o2 * dy).sum().backward()
         assert float((out.detach() - o2.detach()).abs().max()) <= 1e-4 * max(1.0, float(o2.detach().abs().max()))
         assert float((xr.grad - x2.grad).abs().max()) <= 1e-4 * max(1.0, float(x2.grad.abs().max()))
+
+
+def test_block_tail_in_one_launch_matches_the_composition_with_drop_path_active():
+    """train() mode (DropPath rate 0.3 on the second Block, dropout as configured): the one-launch Block tail
+    (interpolation + select + DropPath + residual, train_path._BlockTail) against the autograd composition under the same
+    random stream -- output, input gradient and every parameter gradient."""
+    from mssvt_amd import train_path
+    C, B, H = 64, 2, 40009
+    net = _net(C, _params(C, [4, 4], [8], (True, False)), H).train()
+    assert any(getattr(b.drop_path, "drop_prob", 0.0) > 0 for b in net.backbone if hasattr(b, "drop_path"))
+    vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(4000, B, 17))
+    coords = torch.from_numpy(vc).to(DEV)
+    x = torch.randn(vc.shape[0], C, device=DEV)
+    res = {}
+    for fused_tail in (True, False):
+        train_path.BLOCK_TAIL = fused_tail
+        try:
+            torch.manual_seed(123)
+            out_shape = net(dict(voxel_features=x, voxel_coords=coords, batch_size=B))["encoded_spconv_tensor"].features.shape
+            w = torch.randn(out_shape, generator=torch.Generator().manual_seed(7)).to(DEV)
+            torch.manual_seed(123)
+            res[fused_tail] = _grads(net, x, coords, B, w)
+        finally:
+            train_path.BLOCK_TAIL = True
+    (o1, gx1, gp1), (o2, gx2, gp2) = res[True], res[False]
+    for a, b, what in [(o1, o2, "output"), (gx1, gx2, "input gradient")] + [(gp1[k], gp2[k], k) for k in gp2]:
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-4 * scale, what
