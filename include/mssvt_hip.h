@@ -472,6 +472,12 @@ int mssvt_compress_ws(int C, int head_dim, float scale, int z_ws, int max_num_wi
  * (512 * 2 * C floats) added in workgroup order: deterministic.  C in {16,32,64,128,256}.                      */
 int mssvt_layer_norm_backward(const float *x, const float *dy, int num_rows, int C, const float *weight, float eps,
                               float *dx, float *dweight, float *dbias, float *workspace, void *stream);
+/* The same with dx = (LayerNorm backward of dy) + dres: dres (N,C) or NULL = the gradient that reaches x through its
+ * other uses (the residual connection around the normalised branch: ref mssvt_backbone.py:241, :339-343) -- the add
+ * autograd would run as a pass of its own.                                                                       */
+int mssvt_layer_norm_backward_residual(const float *x, const float *dy, const float *dres, int num_rows, int C,
+                                       const float *weight, float eps, float *dx, float *dweight, float *dbias,
+                                       float *workspace, void *stream);
 
 /* Rows per sample of a (N,4) [b,z,y,x] int32 index tensor -> counts (B) int32, on the device
  * (ref: the host loops with .item() of mssvt_utils.py:35-37 / mssvt_backbone.py:124-130).   */

@@ -92,7 +92,7 @@ extern "C" int mssvt_layer_norm(const float *x, int num_rows, int C, const float
 #define LNB_WG 512  // workgroups (partial rows)
 template <int LPR>
 __global__ void __launch_bounds__(256) k_layer_norm_bwd(const float *x, const float *dy, int n, const float *w, float eps,
-                                                        int rows_per_wg, float *dx, float *part) {
+                                                        int rows_per_wg, float *dx, float *part, const float *dres) {
     constexpr int C = LPR * 4, RPW = MSSVT_WAVE / LPR, RPI = 4 * RPW;  // rows per workgroup instruction
     __shared__ float red[4 * RPW][2 * C];
     const int lane = lane_id(), wv = threadIdx.x / MSSVT_WAVE;
@@ -126,9 +126,14 @@ __global__ void __launch_bounds__(256) k_layer_norm_bwd(const float *x, const fl
         }
         a *= (1.0f / C);
         b *= (1.0f / C);
-        if (live)
-            *reinterpret_cast<float4 *>(dx + off) =
-                make_float4(rs * (gx - a - hx * b), rs * (gy - a - hy * b), rs * (gz - a - hz * b), rs * (gw - a - hw * b));
+        if (live) {
+            float4 o = make_float4(rs * (gx - a - hx * b), rs * (gy - a - hy * b), rs * (gz - a - hz * b), rs * (gw - a - hw * b));
+            if (dres) {  // + the gradient that reaches x past the LayerNorm (its residual use): one add, no extra pass
+                const float4 r = *reinterpret_cast<const float4 *>(dres + off);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4 *>(dx + off) = o;
+        }
         sg.x += d.x * hx; sg.y += d.y * hy; sg.z += d.z * hz; sg.w += d.w * hw;
         sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
     }
@@ -158,8 +163,20 @@ __global__ void __launch_bounds__(256) k_layer_norm_bwd_reduce(const float *part
     }
 }
 
+extern "C" int mssvt_layer_norm_backward_residual(const float *x, const float *dy, const float *dres, int num_rows, int C,
+                                                  const float *weight, float eps, float *dx, float *dweight, float *dbias,
+                                                  float *workspace, void *stream_);
+
 extern "C" int mssvt_layer_norm_backward(const float *x, const float *dy, int num_rows, int C, const float *weight, float eps,
                                          float *dx, float *dweight, float *dbias, float *workspace, void *stream_) {
+    return mssvt_layer_norm_backward_residual(x, dy, nullptr, num_rows, C, weight, eps, dx, dweight, dbias, workspace, stream_);
+}
+
+// dx = (LayerNorm backward of dy) + dres: `dres` (num_rows, C) or NULL = the gradient that reaches x through its other
+// uses (the residual connection around the normalised branch: ref mssvt_backbone.py:241, :339-343)
+extern "C" int mssvt_layer_norm_backward_residual(const float *x, const float *dy, const float *dres, int num_rows, int C,
+                                                  const float *weight, float eps, float *dx, float *dweight, float *dbias,
+                                                  float *workspace, void *stream_) {
     if (!x || !dy || !weight || !dx || !dweight || !dbias || !workspace || num_rows < 0 || C <= 0) return MSSVT_E_BADARG;
     hipStream_t stream = (hipStream_t)stream_;
     if (num_rows == 0) {
@@ -173,7 +190,7 @@ extern "C" int mssvt_layer_norm_backward(const float *x, const float *dy, int nu
         int rows = (num_rows + LNB_WG - 1) / LNB_WG;                                                         \
         rows = (rows + rpi - 1) / rpi * rpi;                                                                 \
         const int nwg = (num_rows + rows - 1) / rows;                                                        \
-        k_layer_norm_bwd<lpr><<<nwg, 256, 0, stream>>>(x, dy, num_rows, weight, eps, rows, dx, workspace);   \
+        k_layer_norm_bwd<lpr><<<nwg, 256, 0, stream>>>(x, dy, num_rows, weight, eps, rows, dx, workspace, dres); \
         k_layer_norm_bwd_reduce<<<divup(2 * C, 4), 256, 0, stream>>>(workspace, nwg, 2 * C, dweight, dbias);  \
         return mssvt_launch_status();                                                                        \
     }

@@ -405,7 +405,9 @@ def linear(mod, x, relu=False):
 
 class _LayerNorm(torch.autograd.Function):
     """nn.LayerNorm over the channels of compact rows: forward k_layer_norm, backward k_layer_norm_bwd (csrc/rowops.hip;
-    x and dy read once, column sums in a fixed order)."""
+    x and dy read once, column sums in a fixed order).  Returns (x, y): the caller routes the OTHER uses of x (the
+    residual connection) through the returned x, so that their gradient arrives here and is added inside the backward
+    kernel instead of by an accumulation pass of autograd's."""
 
     @staticmethod
     def forward(ctx, x, w, b, eps):
@@ -415,38 +417,65 @@ class _LayerNorm(torch.autograd.Function):
                   ctypes.c_float(eps), _lib.ptr(y), _lib.stream())
         ctx.save_for_backward(x, w)
         ctx.eps = eps
-        return y
+        return x.view_as(x), y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dres, dy):
         x, w = ctx.saved_tensors
         N, C = x.shape
+        if dy is None:  # the normalised branch was not used
+            return dres, torch.zeros_like(w), torch.zeros_like(w), None
         dy = dy.contiguous()
+        dres = None if dres is None else dres.contiguous()
         dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
         ws = _wgrad_ws.get(("ln", x.device))
         if ws is None:
             ws = _wgrad_ws[("ln", x.device)] = torch.empty((512 * 2 * 256,), dtype=torch.float32, device=x.device)
-        _lib.call("mssvt_layer_norm_backward", _lib.ptr(x), _lib.ptr(dy), _i(N), _i(C), _lib.ptr(w), ctypes.c_float(ctx.eps),
-                  _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream())
+        _lib.call("mssvt_layer_norm_backward_residual", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dres), _i(N), _i(C), _lib.ptr(w),
+                  ctypes.c_float(ctx.eps), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream())
         return dx, dw, db, None
 
 
 def layer_norm(norm, x):
     """``norm(x)`` for an nn.LayerNorm over the last dimension of (N, C) rows."""
+    return layer_norm_residual(norm, x)[1]
+
+
+def layer_norm_residual(norm, x):
+    """``(x, norm(x))``: use the returned x for every other use of x (see _LayerNorm)."""
     C = x.shape[1]
     if (C not in fused.LN_WIDTHS or x.dtype != torch.float32 or not x.is_cuda or x.shape[0] == 0 or not torch.is_grad_enabled()
             or norm.weight is None or norm.bias is None):
-        return norm(x)
+        return x, norm(x)
     return _LayerNorm.apply(x, norm.weight, norm.bias, float(norm.eps))
 
 
 def ffn(block, x):
     """block._ffn with the deterministic weight gradients (ref mssvt_backbone.py:341-343)."""
+    return ffn_residual(block, x)[1]
+
+
+def ffn_residual(block, x):
+    """``(x, block._ffn(x))``: the returned x is the one to add the result to (its gradient joins norm2's backward)."""
+    x, xn = layer_norm_residual(block.norm2, x)
     if isinstance(block.activation, torch.nn.ReLU):  # the clamp rides in the first product's epilogue
-        h = linear(block.linear1, layer_norm(block.norm2, x), relu=True)
+        h = linear(block.linear1, xn, relu=True)
     else:
-        h = block.activation(linear(block.linear1, layer_norm(block.norm2, x)))
-    return linear(block.linear2, block.dropout1(h))
+        h = block.activation(linear(block.linear1, xn))
+    return x, linear(block.linear2, block.dropout1(h))
+
+
+def add_drop_path(block, x, z):
+    """``x + block.drop_path(z)`` in one launch when DropPath is active (the module's own row mask as a factor)."""
+    dp = block.drop_path
+    p = float(getattr(dp, "drop_prob", 0.0))
+    if not (getattr(dp, "training", False) and p > 0.0):
+        return x + z
+    keep = 1.0 - p
+    mask = z.new_empty((z.shape[0],) + (1,) * (z.dim() - 1)).bernoulli_(keep)
+    if keep > 0.0 and getattr(dp, "scale_by_keep", True):
+        mask.div_(keep)
+    return torch.addcmul(x, z, mask)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -724,7 +753,7 @@ def block_forward(block, sp):
         return block.forward_ops(sp)
     x_in = sp.features
     N, C = x_in.shape
-    xhat = layer_norm(block.norm1, x_in)
+    x_in, xhat = layer_norm_residual(block.norm1, x_in)  # (the later uses of x_in send their gradient through norm1's backward)
     p = fused.two_scale_plan(block, sp)
     s = _block_index_sets(block, sp, p)
     _compress_ahead(sp)
@@ -772,7 +801,8 @@ def block_forward(block, sp):
         upd = gather_sum(attn_ext, s["interp_csr"])  # (N, C): interpolated / scattered update of every owned voxel
         feats = torch.where(s["owned"].unsqueeze(1), upd, x_in)  # untouched voxels keep x_in (ref :317-338)
         new = block.drop_path(feats) + x_in
-    new = new + block.drop_path(block.dropout1(ffn(block, new)))
+    new, z = ffn_residual(block, new)
+    new = add_drop_path(block, new, block.dropout1(z))
     if hasattr(block, "out_linear"):
         new = linear(block.out_linear, new)
     sp.features = new
@@ -867,7 +897,8 @@ def compress_forward(block, sp):
     kv = linear(ma.to_kvs[0], tok_k)  # (P, 2C)
     o = pair_attention(q, kv, s["wins"], heads, hd)  # (nw, C)
     new = linear(ma.projs[0], o.reshape(-1, C))
-    new = new + block.dropout1(ffn(block, new))  # no residual to the block input (ref :383-385)
+    new, z = ffn_residual(block, new)
+    new = new + block.dropout1(z)  # no residual to the block input (ref :383-385)
     if hasattr(block, "out_linear"):
         new = linear(block.out_linear, new)
     sp.features = new
