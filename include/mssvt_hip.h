@@ -663,12 +663,13 @@ int mssvt_linear_wgrad(int M, int Cin, int Cout, const float *X, const float *dY
 /* Y = X B^T + bias over compact rows on the fp32 matrix cores (training path), for the SMALL weight matrices of a Block
  * (64 x 64 to_qs / projs of a head group: ref mssvt_utils.py:80-83, mssvt_backbone.py:25-27) and, with transpose_w, their
  * input gradient dX = dY W -- library GEMMs under autograd in the reference, which pick poor tiles on these shapes.
- *   Y[m][n] = bias[n] + sum_k X[m][k] B[n][k],  B = W (N,K) row-major, or B[n][k] = W[k][n] with W (K,N) (transpose_w != 0);
+ *   Y[m][n] = out_scale * act(bias[n] + sum_k X[m][k] B[n][k]),  B = W (N,K) row-major, or B[n][k] = W[k][n] with W (K,N)
+ * (transpose_w != 0); out_scale = 1 or the attention scale of a query projection (ref mssvt_utils.py:131-133);
  * X (M,K) f32 with row stride ldx (floats, % 4 == 0), Y (M,N) with row stride ldy, bias (N) or NULL, relu != 0 clamps Y
  * at 0.  K, N in {64,128} (mssvt_linear_rows_supported); MSSVT_E_TOOLARGE otherwise.                                  */
 int mssvt_linear_rows_supported(int K, int N);
 int mssvt_linear_rows(int M, int K, int N, const float *X, int ldx, const float *W, int transpose_w, const float *bias,
-                      int relu, float *Y, int ldy, void *stream);
+                      int relu, float out_scale, float *Y, int ldy, void *stream);
 
 /* Window attention on compact rows, forward and backward (training path; the softmax(QK^T)V of ref
  * mssvt_utils.py:131-149 for one head group, without the padded (windows, slots) layout and the -100 mask):

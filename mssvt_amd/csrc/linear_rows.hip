@@ -2,7 +2,8 @@
 // (64 x 64: to_qs and projs of a head group; training path): the forward of the nn.Linear
 // (ref mssvt_utils.py:80-83) and, with the weight read transposed, its input gradient dX = dY W.
 //
-//     Y[m][n] = bias[n] + sum_k X[m][k] * B[n][k]        B = W (N x K row-major), or B[n][k] = W[k][n] (transpose_w)
+//     Y[m][n] = s * act(bias[n] + sum_k X[m][k] * B[n][k])   B = W (N x K row-major), or B[n][k] = W[k][n] (transpose_w)
+// (s = out_scale: the attention scale of the query projection rides in the epilogue, forward and backward)
 //
 // The library GEMM the framework calls is fine on the Blocks' large shapes (128 <-> 256: 47 - 85 TFLOP/s; a kernel of
 // this form was measured at 0.4 - 0.7 of that and is not used there) but not on 64 x 64: 13 us for 33k rows, and 154 us
@@ -19,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int K, int NT>  // K columns of X, NT = N / 16 column tiles of Y
 __global__ void __launch_bounds__(LR_WAVES *MSSVT_WAVE, 1) k_linear_rows(int M, const float *X, int ldx, const float *W, int transpose_w,
-                                                                         const float *bias, int relu, float *Y, int ldy) {
+                                                                         const float *bias, int relu, float out_scale, float *Y, int ldy) {
     constexpr int N = 16 * NT, LS = K + 4, KB = K / 16;
     extern __shared__ float Wl[];  // [N][LS]
     if (!transpose_w) {
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(LR_WAVES *MSSVT_WAVE, 1) k_linear_rows(int M, 
             if (m < M) {
                 float *out = Y + (size_t)m * ldy + la;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) out[16 * t] = relu ? fmaxf(acc[t][r], 0.f) : acc[t][r];
+                for (int t = 0; t < NT; ++t) out[16 * t] = (relu ? fmaxf(acc[t][r], 0.f) : acc[t][r]) * out_scale;
             }
         }
     }
@@ -89,7 +90,7 @@ static bool lr_shape(int K, int N) { return (K == 64 || K == 128) && (N == 64 ||
 extern "C" int mssvt_linear_rows_supported(int K, int N) { return lr_shape(K, N) ? 1 : 0; }
 
 extern "C" int mssvt_linear_rows(int M, int K, int N, const float *X, int ldx, const float *W, int transpose_w, const float *bias,
-                                 int relu, float *Y, int ldy, void *stream) {
+                                 int relu, float out_scale, float *Y, int ldy, void *stream) {
     if (M < 0 || !X || !W || !Y || ldx < K || ldy < N || (ldx & 3)) return MSSVT_E_BADARG;
     if (!lr_shape(K, N)) return MSSVT_E_TOOLARGE;
     if (M == 0) return MSSVT_OK;
@@ -108,7 +109,7 @@ extern "C" int mssvt_linear_rows(int M, int K, int N, const float *X, int ldx, c
             if (e != hipSuccess) return (int)e;                                                                             \
             attr = true;                                                                                                    \
         }                                                                                                                   \
-        k_linear_rows<KK, NN / 16><<<grid, LR_WAVES * MSSVT_WAVE, lds, st>>>(M, X, ldx, W, transpose_w, bias, relu, Y, ldy);  \
+        k_linear_rows<KK, NN / 16><<<grid, LR_WAVES * MSSVT_WAVE, lds, st>>>(M, X, ldx, W, transpose_w, bias, relu, out_scale, Y, ldy); \
         return mssvt_launch_status();                                                                                       \
     }
     LR_GO(64, 64) LR_GO(64, 128) LR_GO(128, 64) LR_GO(128, 128)

@@ -339,12 +339,12 @@ def wgrad_supported(cin, cout):
 LINEAR_ROWS = {(64, 64)}  # (cin, cout) shapes that run on mssvt_linear_rows instead of the library GEMM (measured: the only win)
 
 
-def _linear_rows(x, w, transpose_w, b, relu, n_out):
+def _linear_rows(x, w, transpose_w, b, relu, n_out, scale=1.0):
     M, K = x.shape
     y = torch.empty((M, n_out), dtype=torch.float32, device=x.device)
     if M:
         _lib.call("mssvt_linear_rows", _i(M), _i(K), _i(n_out), _lib.ptr(x), _i(K), _lib.ptr(w), _i(1 if transpose_w else 0),
-                  _lib.ptr(b), _i(1 if relu else 0), _lib.ptr(y), _i(n_out), _lib.stream())
+                  _lib.ptr(b), _i(1 if relu else 0), ctypes.c_float(scale), _lib.ptr(y), _i(n_out), _lib.stream())
     return y
 
 
@@ -356,17 +356,19 @@ class _Linear(torch.autograd.Function):
     matrix pipe: one split-K MFMA launch here."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu=False):
+    def forward(ctx, x, w, b, relu=False, scale=1.0):
         cout, cin = w.shape
         if (cin, cout) in LINEAR_ROWS and x.dtype == torch.float32:
             x = x.contiguous()
-            y = _linear_rows(x, w.detach().contiguous(), False, None if b is None else b.detach(), relu, cout)
+            y = _linear_rows(x, w.detach().contiguous(), False, None if b is None else b.detach(), relu, cout, scale)
         else:
             y = F.linear(x, w, b)
             if relu:
                 y = y.clamp_(min=0)
+            if scale != 1.0:
+                y = y.mul_(scale)
         ctx.save_for_backward(x, w, y if relu else None)
-        ctx.has_bias = b is not None
+        ctx.has_bias, ctx.scale = b is not None, float(scale)
         return y
 
     @staticmethod
@@ -376,9 +378,15 @@ class _Linear(torch.autograd.Function):
             dy = torch.ops.aten.threshold_backward(dy, y, 0.0)  # relu: the gradient where the output is positive
         dy = dy.contiguous()
         cout, cin = w.shape
+        sc = ctx.scale  # y = sc * act(...): dx and dW / db carry the factor (a relu'd output is saved scaled: same sign)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _linear_rows(dy, w.detach().contiguous(), True, None, False, cin) if (cout, cin) in LINEAR_ROWS else dy @ w
+            if (cout, cin) in LINEAR_ROWS:
+                dx = _linear_rows(dy, w.detach().contiguous(), True, None, False, cin, sc)
+            else:
+                dx = dy @ w
+                if sc != 1.0:
+                    dx = dx.mul_(sc)
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x = x.contiguous()
@@ -389,18 +397,24 @@ class _Linear(torch.autograd.Function):
             if M > 0:
                 _lib.call("mssvt_linear_wgrad", _i(M), _i(cin), _i(cout), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw),
                           _lib.ptr(db), _lib.ptr(_wgrad_workspace(x.device, M, cin, cout)), _lib.stream())
-        return dx, dw, db, None
+                if sc != 1.0:  # (cout x cin and cout elements: two small launches instead of two over the rows)
+                    dw.mul_(sc)
+                    if db is not None:
+                        db.mul_(sc)
+        return dx, dw, db, None, None
 
 
-def linear(mod, x, relu=False):
-    """``mod(x)`` (``relu(mod(x))``) for an nn.Linear (or a weight / bias pair) with the deterministic weight gradient."""
+def linear(mod, x, relu=False, scale=1.0):
+    """``scale * mod(x)`` (``scale * relu(mod(x))``) for an nn.Linear (or a weight / bias pair) with the deterministic weight
+    gradient."""
     w, b = (mod.weight, mod.bias) if hasattr(mod, "weight") else mod
     if w.dim() == 3:
         w = w.squeeze(-1)  # Conv1d(k = 1)
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and wgrad_supported(w.shape[1], w.shape[0])
             and torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad))):
-        return F.relu(F.linear(x, w, b)) if relu else F.linear(x, w, b)
-    return _Linear.apply(x, w, b, relu)
+        y = F.relu(F.linear(x, w, b)) if relu else F.linear(x, w, b)
+        return y * scale if scale != 1.0 else y
+    return _Linear.apply(x, w, b, relu, float(scale))
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -786,7 +800,7 @@ def block_forward(block, sp):
                 tok_k = gather_sum(xhat[:, c0:c1].contiguous(), ks["k_csr"]) + _pos6(
                     block.pos_proj[0], ks["k_rel"], s["centre"][ks["k_win"]], c0, c1)
                 tok_qg = tok_q[:, c0:c1].contiguous()
-            q = linear(ma.to_qs[g], tok_qg) * ma.scale  # (R, cg)
+            q = linear(ma.to_qs[g], tok_qg, scale=ma.scale)  # (R, cg), scaled in the product's epilogue
             kv = linear(ma.to_kvs[g], tok_k)  # (Kg, 2 cg) = [K | V]
             o = pair_attention(q, kv, ks["wins"], heads, hd)  # (R, cg)
             outs.append(linear(ma.projs[g], o.reshape(R, cg)))
@@ -893,7 +907,7 @@ def compress_forward(block, sp):
     pos = _pos6(block.pos_proj[0], s["rel"], s["centre"][s["pair_win"]])
     pos = F.relu(linear(block.pos_proj[2], pos))
     tok_k = xk + pos
-    q = linear(ma.to_qs[0], q_tok) * ma.scale  # (nw, C)
+    q = linear(ma.to_qs[0], q_tok, scale=ma.scale)  # (nw, C)
     kv = linear(ma.to_kvs[0], tok_k)  # (P, 2C)
     o = pair_attention(q, kv, s["wins"], heads, hd)  # (nw, C)
     new = linear(ma.projs[0], o.reshape(-1, C))

@@ -370,14 +370,19 @@ def test_linear_rows_kernel_forward_and_input_gradient(M, K, N, relu):
     if (K, N) in train_path.LINEAR_ROWS:
         lin = torch.nn.Linear(K, N).to(DEV)
         xr = x.clone().requires_grad_(True)
-        out = train_path.linear(lin, xr, relu=relu)
+        out = train_path.linear(lin, xr, relu=relu, scale=0.25)
         (out * dy).sum().backward()
+        gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+        lin.weight.grad = lin.bias.grad = None
         x2 = x.clone().requires_grad_(True)
         o2 = lin(x2)
-        o2 = o2.relu() if relu else o2
+        o2 = (o2.relu() if relu else o2) * 0.25
         (o2 * dy).sum().backward()
         assert float((out.detach() - o2.detach()).abs().max()) <= 1e-4 * max(1.0, float(o2.detach().abs().max()))
         assert float((xr.grad - x2.grad).abs().max()) <= 1e-4 * max(1.0, float(x2.grad.abs().max()))
+        tol = 2e-4 * max(1.0, M ** 0.5 / 16)
+        assert float((gw - lin.weight.grad).abs().max()) <= tol * max(1.0, float(lin.weight.grad.abs().max()))
+        assert float((gb - lin.bias.grad).abs().max()) <= tol * max(1.0, float(lin.bias.grad.abs().max()))
 
 
 def test_block_tail_in_one_launch_matches_the_composition_with_drop_path_active():
