@@ -637,6 +637,18 @@ int mssvt_train_tok_backward_partial(int M, int c0, int cg, const float *geo8, c
 int mssvt_train_tok_backward_reduce(int C, int num_sets, const int *host_M, const int *host_c0, const int *host_cg,
                                     const float *const *host_slabs, float *dW, float *db, void *stream);
 
+/* Compact key sets of a window plan (index work of the training path; the padded key lists of ref
+ * mssvt_backbone.py:253-268 without their empty slots).  kmeta (cap,K,4) f32 = per key slot (offset to the window centre
+ * xyz, voxel row as int bits, < 0: empty), as mssvt_window_plan_two leaves it; K <= 64.
+ * _counts: cnt[w] = valid slots of window w (0 for w >= *num_wins_dev), *total_dev += their sum (zero it first).
+ * _compact: with off = the exclusive prefix sum of cnt, slot k of window w goes to position off[w] + (valid slots before
+ * k): k_rows (voxel row), k_win (window), k_geo8 (8 f32: offset xyz, centre xyz from wcentre (cap,4), 0, 0 -- the
+ * positional embedding's inputs for mssvt_train_tok_forward).                                                    */
+int mssvt_train_key_counts(int cap, int K, const int *num_wins_dev, const float *kmeta, int *cnt, int *total_dev,
+                           void *stream);
+int mssvt_train_key_compact(int num_wins, int K, const float *kmeta, const float *wcentre, const int *off, int *k_rows,
+                            int *k_win, float *k_geo8, void *stream);
+
 /* ========================================================================
  * Post-processing behind the backbone: rotated BEV NMS of CenterHead's boxes.
  * ref: iou3d_nms_cuda.nms_gpu, pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:90-135 (host loop) +

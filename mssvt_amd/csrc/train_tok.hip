@@ -192,3 +192,63 @@ extern "C" int mssvt_train_tok_backward_reduce(int C, int num_sets, const int *h
     k_tok_bwd_reduce<<<divup(C, 4), 256, 0, (hipStream_t)stream>>>(C, a, dW, db);
     return mssvt_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Compact key sets of a plan (index work of the training path): the valid key slots of every window, window-major, as
+// flat arrays -- what ~25 framework launches per scale (mask, nonzero, divisions, gathers, concatenations) built before.
+//   k_key_counts : cnt[w] = number of slots of window w whose row id (kmeta[w][k].w as int) is >= 0, 0 for w >= *num_wins;
+//                  *total += cnt[w] (integer atomics: the sum does not depend on the order)
+//   k_key_compact: slot k of window w goes to position off[w] + (valid slots before k): its voxel row, its window and
+//                  the 8 geometry inputs of the positional embedding (offset to the window centre, centre, 0, 0)
+// One wave per window, lane = slot (K <= 64).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_key_counts(int cap, int K, const int *num_wins, const float4 *kmeta, int *cnt, int *total) {
+    const int w = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    if (w >= cap) return;
+    int c = 0;
+    if (w < *num_wins) {
+        const bool ok = lane < K && __builtin_bit_cast(int, kmeta[(size_t)w * K + lane].w) >= 0;
+        c = __popcll(__ballot(ok));
+    }
+    if (lane == 0) {
+        cnt[w] = c;
+        if (c) atomicAdd(total, c);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_key_compact(int nw, int K, const float4 *kmeta, const float4 *wcentre, const int *off,
+                                                     int *k_rows, int *k_win, float4 *k_geo) {
+    const int w = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    if (w >= nw) return;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool ok = false;
+    if (lane < K) {
+        m = kmeta[(size_t)w * K + lane];
+        ok = __builtin_bit_cast(int, m.w) >= 0;
+    }
+    const unsigned long long mask = __ballot(ok);
+    if (!ok) return;
+    const int pos = off[w] + __popcll(mask & ((1ull << lane) - 1ull));
+    const float4 c = wcentre[w];
+    k_rows[pos] = __builtin_bit_cast(int, m.w);
+    k_win[pos] = w;
+    k_geo[2 * (size_t)pos] = make_float4(m.x, m.y, m.z, c.x);
+    k_geo[2 * (size_t)pos + 1] = make_float4(c.y, c.z, 0.f, 0.f);
+}
+
+extern "C" int mssvt_train_key_counts(int cap, int K, const int *num_wins_dev, const float *kmeta, int *cnt, int *total_dev,
+                                      void *stream) {
+    if (cap < 0 || K <= 0 || K > 64 || !num_wins_dev || !kmeta || !cnt || !total_dev) return MSSVT_E_BADARG;
+    if (cap == 0) return MSSVT_OK;
+    k_key_counts<<<divup(cap, 4), 256, 0, (hipStream_t)stream>>>(cap, K, num_wins_dev, (const float4 *)kmeta, cnt, total_dev);
+    return mssvt_launch_status();
+}
+
+extern "C" int mssvt_train_key_compact(int num_wins, int K, const float *kmeta, const float *wcentre, const int *off, int *k_rows,
+                                       int *k_win, float *k_geo8, void *stream) {
+    if (num_wins < 0 || K <= 0 || K > 64 || !kmeta || !wcentre || !off || !k_rows || !k_win || !k_geo8) return MSSVT_E_BADARG;
+    if (num_wins == 0) return MSSVT_OK;
+    k_key_compact<<<divup(num_wins, 4), 256, 0, (hipStream_t)stream>>>(num_wins, K, (const float4 *)kmeta, (const float4 *)wcentre, off,
+                                                                       k_rows, k_win, (float4 *)k_geo8);
+    return mssvt_launch_status();
+}

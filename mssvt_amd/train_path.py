@@ -497,6 +497,7 @@ def add_drop_path(block, x, z):
 # ---------------------------------------------------------------------------------------------------------
 
 TOK_WIDTHS = (16, 32, 64, 128, 256)
+KEY_SETS = True  # False: the key sets of a plan from framework ops (mask / nonzero / gathers), kept for A/B and K > 64
 TOKENS = True  # False: the autograd composition (gather_sum + _pos6), kept for A/B and for widths outside TOK_WIDTHS
 
 
@@ -611,16 +612,25 @@ def _plan_index_sets(block, sp, p):
             q_ind, nq, owner_q = fused._query(b, p)
             pats[b.cbs_pattern] = dict(q_ind=q_ind, nq=nq, owner_q=owner_q, od=fused._work_order(b, p, nq, N))
     order = sorted(pats)
-    # valid key slots of each scale (windows past num_wins hold stale memory: masked on the device)
-    in_use = torch.arange(p.cap, device=dev).unsqueeze(1) < p.num_wins
-    valid_g, rows_g = [], []
-    for g in range(2):
-        rows = p.kmeta[g][..., 3].contiguous().view(torch.int32)  # (cap, K)
-        rows_g.append(rows)
-        valid_g.append(((rows >= 0) & in_use).reshape(-1))
-    words = [p.num_wins.reshape(1)] + [v.sum().int().reshape(1) for v in valid_g] + [pats[k]["od"]["n_rows"].reshape(1)
-                                                                                     for k in order]
-    host = _read_sizes(torch.cat(words))
+    # valid key slots of each scale: counted per window on the device (windows past num_wins hold stale memory and count 0)
+    kdim = [int(p.kmeta[g].shape[1]) for g in range(2)]
+    fast = KEY_SETS and all(K <= 64 for K in kdim)
+    if fast:
+        totals = torch.zeros(2, dtype=torch.int32, device=dev)
+        cnts = [torch.empty(p.cap, dtype=torch.int32, device=dev) for _ in range(2)]
+        for g in range(2):
+            _lib.call("mssvt_train_key_counts", _i(p.cap), _i(kdim[g]), _lib.ptr(p.num_wins), _lib.ptr(p.kmeta[g]), _lib.ptr(cnts[g]),
+                      ctypes.c_void_p(totals.data_ptr() + 4 * g), _lib.stream())
+        words = [p.num_wins.reshape(1), totals]
+    else:
+        in_use = torch.arange(p.cap, device=dev).unsqueeze(1) < p.num_wins
+        valid_g, rows_g = [], []
+        for g in range(2):
+            rows = p.kmeta[g][..., 3].contiguous().view(torch.int32)  # (cap, K)
+            rows_g.append(rows)
+            valid_g.append(((rows >= 0) & in_use).reshape(-1))
+        words = [p.num_wins.reshape(1)] + [v.sum().int().reshape(1) for v in valid_g]
+    host = _read_sizes(torch.cat(words + [pats[k]["od"]["n_rows"].reshape(1) for k in order]))
     nw = host[0]
     for k, R in zip(order, host[3:]):
         pats[k]["R"] = R
@@ -629,7 +639,19 @@ def _plan_index_sets(block, sp, p):
     keys = []  # valid key slots of each scale, window-major (FPS pick order inside a window)
     for g, Kg in enumerate(host[1:3]):
         km = p.kmeta[g]
-        K = km.shape[1]
+        K = kdim[g]
+        if fast:  # two launches: prefix of the counts, then every valid slot to its place (csrc/train_tok.hip)
+            nk = cnts[g][:nw]
+            koff = (torch.cumsum(nk, 0, dtype=torch.int32) - nk).contiguous()
+            k_rows = torch.empty(Kg, dtype=torch.int32, device=dev)
+            k_win = torch.empty(Kg, dtype=torch.int32, device=dev)
+            k_geo = torch.empty((Kg, 8), dtype=torch.float32, device=dev)
+            if nw and Kg:
+                _lib.call("mssvt_train_key_compact", _i(nw), _i(K), _lib.ptr(km), _lib.ptr(p.wcentre), _lib.ptr(koff),
+                          _lib.ptr(k_rows), _lib.ptr(k_win), _lib.ptr(k_geo), _lib.stream())
+            keys.append(dict(k_rows=k_rows, k_win=k_win, k_geo=k_geo, k_csr=Csr.gather(k_rows, N), k_off=koff,
+                             k_cnt=nk.contiguous()))
+            continue
         flat = _nonzero_known(valid_g[g], Kg)
         k_win = flat // K
         nk = valid_g[g].reshape(p.cap, K)[:nw].sum(1)  # keys per window
@@ -637,7 +659,7 @@ def _plan_index_sets(block, sp, p):
         k_rows = rows_g[g].reshape(-1)[flat].contiguous()
         k_rel = km[..., :3].reshape(-1, 3)[flat].contiguous()
         k_geo = torch.cat([k_rel, centre[k_win], pad2.expand(k_rel.shape[0], 2)], dim=1).contiguous()
-        keys.append(dict(k_rows=k_rows, k_rel=k_rel, k_win=k_win, k_geo=k_geo, k_csr=Csr.gather(k_rows, N),
+        keys.append(dict(k_rows=k_rows, k_win=k_win, k_geo=k_geo, k_csr=Csr.gather(k_rows, N),
                          k_off=koff.int().contiguous(), k_cnt=nk.int().contiguous()))
     _deferred.extend(k["k_csr"].bwd for k in keys)
     common = p.train_common = dict(nw=nw, centre=centre, keys=keys, pats=pats, pad2=pad2)
@@ -798,7 +820,7 @@ def block_forward(block, sp):
                 tok_qg, tok_k = toks[g], toks[ng + g]
             else:
                 tok_k = gather_sum(xhat[:, c0:c1].contiguous(), ks["k_csr"]) + _pos6(
-                    block.pos_proj[0], ks["k_rel"], s["centre"][ks["k_win"]], c0, c1)
+                    block.pos_proj[0], ks["k_geo"][:, :3], ks["k_geo"][:, 3:6], c0, c1)
                 tok_qg = tok_q[:, c0:c1].contiguous()
             q = linear(ma.to_qs[g], tok_qg, scale=ma.scale)  # (R, cg), scaled in the product's epilogue
             kv = linear(ma.to_kvs[g], tok_k)  # (Kg, 2 cg) = [K | V]

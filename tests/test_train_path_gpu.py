@@ -411,3 +411,37 @@ def test_block_tail_in_one_launch_matches_the_composition_with_drop_path_active(
     for a, b, what in [(o1, o2, "output"), (gx1, gx2, "input gradient")] + [(gp1[k], gp2[k], k) for k in gp2]:
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 1e-4 * scale, what
+
+
+@pytest.mark.parametrize("cap,nw,K", [(5000, 3777, 32), (300, 300, 64), (64, 1, 8), (1000, 0, 16)])
+def test_key_set_kernels_match_the_framework_composition(cap, nw, K):
+    """mssvt_train_key_counts / _compact (the compact key sets of a plan) against mask + nonzero + gathers."""
+    import ctypes
+    from mssvt_amd import _lib
+    g = torch.Generator().manual_seed(cap + K)
+    kmeta = torch.randn(cap, K, 4, generator=g)
+    rows = torch.randint(-1, 900, (cap, K), generator=g).int()
+    rows[torch.rand(cap, K, generator=g) < 0.4] = -1
+    kmeta[..., 3] = rows.view(torch.float32)
+    wcentre = torch.randn(cap, 4, generator=g)
+    kmeta, wcentre = kmeta.to(DEV).contiguous(), wcentre.to(DEV)
+    num_wins = torch.tensor([nw], dtype=torch.int32, device=DEV)
+    cnt = torch.full((cap,), -7, dtype=torch.int32, device=DEV)
+    total = torch.zeros(1, dtype=torch.int32, device=DEV)
+    i = ctypes.c_int
+    _lib.call("mssvt_train_key_counts", i(cap), i(K), _lib.ptr(num_wins), _lib.ptr(kmeta), _lib.ptr(cnt), _lib.ptr(total), _lib.stream())
+    valid = (rows.to(DEV) >= 0) & (torch.arange(cap, device=DEV).unsqueeze(1) < nw)
+    assert torch.equal(cnt.long(), valid.sum(1)) and int(total.item()) == int(valid.sum())
+    n = int(total.item())
+    off = (torch.cumsum(cnt[:nw], 0, dtype=torch.int32) - cnt[:nw]).contiguous()
+    k_rows = torch.empty(n, dtype=torch.int32, device=DEV)
+    k_win = torch.empty(n, dtype=torch.int32, device=DEV)
+    k_geo = torch.empty((n, 8), dtype=torch.float32, device=DEV)
+    if nw and n:
+        _lib.call("mssvt_train_key_compact", i(nw), i(K), _lib.ptr(kmeta), _lib.ptr(wcentre), _lib.ptr(off), _lib.ptr(k_rows),
+                  _lib.ptr(k_win), _lib.ptr(k_geo), _lib.stream())
+    flat = torch.nonzero(valid.reshape(-1), as_tuple=True)[0]
+    win = flat // K
+    assert torch.equal(k_rows.long(), rows.to(DEV).reshape(-1)[flat].long()) and torch.equal(k_win.long(), win)
+    want = torch.cat([kmeta[..., :3].reshape(-1, 3)[flat], wcentre[win, :3], torch.zeros(n, 2, device=DEV)], 1)
+    assert torch.equal(k_geo, want)
