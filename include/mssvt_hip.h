@@ -649,6 +649,13 @@ int mssvt_train_key_counts(int cap, int K, const int *num_wins_dev, const float 
 int mssvt_train_key_compact(int num_wins, int K, const float *kmeta, const float *wcentre, const int *off, int *k_rows,
                             int *k_win, float *k_geo8, void *stream);
 
+/* The table of mssvt_block_interp_table (tab_row4 / tab_w4 (N,4): three rows of the padded attention buffer + weights per
+ * voxel, row < 0 in .x: a voxel the attention does not update) in compact form for the training path: idx3 / w3 (3 per
+ * voxel) name compact attention rows through inv (padded row -> compact row); an untouched voxel gets row R (the zero
+ * row) with weight 0; owned (N) bytes = 1 where the attention updates the voxel (ref mssvt_backbone.py:298-338).   */
+int mssvt_train_interp_compact(int N, int R, const int *inv, const int *tab_row4, const float *tab_w4, int *idx3, float *w3,
+                               unsigned char *owned, void *stream);
+
 /* ========================================================================
  * Post-processing behind the backbone: rotated BEV NMS of CenterHead's boxes.
  * ref: iou3d_nms_cuda.nms_gpu, pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:90-135 (host loop) +

@@ -252,3 +252,27 @@ extern "C" int mssvt_train_key_compact(int num_wins, int K, const float *kmeta, 
                                                                        k_rows, k_win, (float4 *)k_geo8);
     return mssvt_launch_status();
 }
+
+// The interpolation / scatter table of a Block (mssvt_block_interp_table: per voxel three rows of the padded attention
+// buffer + weights) in compact form: idx3 / w3 (3 per voxel) name compact attention rows through `inv` (padded row ->
+// compact row); a voxel the attention does not update (tab_row[v].x < 0) gets the zero row R with weight 0.
+__global__ void __launch_bounds__(256) k_interp_compact(int N, int R, const int *inv, const int4 *tab_row, const float4 *tab_w, int *idx3,
+                                                        float *w3, unsigned char *owned) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const int4 t = tab_row[v];
+    const float4 w = tab_w[v];
+    const bool own = t.x >= 0;
+    owned[v] = own ? 1 : 0;
+    idx3[3 * v + 0] = own ? inv[max(t.x, 0)] : R; idx3[3 * v + 1] = own ? inv[max(t.y, 0)] : R; idx3[3 * v + 2] = own ? inv[max(t.z, 0)] : R;
+    w3[3 * v + 0] = own ? w.x : 0.f; w3[3 * v + 1] = own ? w.y : 0.f; w3[3 * v + 2] = own ? w.z : 0.f;
+}
+
+extern "C" int mssvt_train_interp_compact(int N, int R, const int *inv, const int *tab_row4, const float *tab_w4, int *idx3, float *w3,
+                                          unsigned char *owned, void *stream) {
+    if (N < 0 || R < 0 || !inv || !tab_row4 || !tab_w4 || !idx3 || !w3 || !owned) return MSSVT_E_BADARG;
+    if (N == 0) return MSSVT_OK;
+    k_interp_compact<<<divup(N, 256), 256, 0, (hipStream_t)stream>>>(N, R, inv, (const int4 *)tab_row4, (const float4 *)tab_w4, idx3, w3,
+                                                                     owned);
+    return mssvt_launch_status();
+}

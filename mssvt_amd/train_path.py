@@ -707,13 +707,13 @@ def _block_index_sets(block, sp, p):
               _lib.ptr(tab_row), _lib.ptr(tab_w), _lib.stream())
     inv = torch.full((zero_row + 1,), R, dtype=torch.int32, device=dev)  # padded attention row -> compact row
     inv[od["row_src"][:R, 1].long()] = torch.arange(R, dtype=torch.int32, device=dev)
-    owned = tab_row[:N, 0] >= 0
-    idx3 = inv[tab_row[:N, :3].clamp(min=0).long()]
-    idx3 = torch.where(owned.unsqueeze(1), idx3, torch.full_like(idx3, R))
-    w3 = torch.where(owned.unsqueeze(1), tab_w[:N, :3], torch.zeros_like(tab_w[:N, :3]))
+    owned = torch.empty(N, dtype=torch.bool, device=dev)
+    idx3 = torch.empty(3 * N, dtype=torch.int32, device=dev)
+    w3 = torch.empty(3 * N, dtype=torch.float32, device=dev)
+    _lib.call("mssvt_train_interp_compact", _i(N), _i(R), _lib.ptr(inv), _lib.ptr(tab_row), _lib.ptr(tab_w), _lib.ptr(idx3),
+              _lib.ptr(w3), ctypes.c_void_p(owned.data_ptr()), _lib.stream())
     off3 = torch.arange(0, 3 * N + 1, 3, dtype=torch.int32, device=dev)
-    s["interp_csr"] = Csr(off3, idx3.reshape(-1).contiguous(), w3.reshape(-1).contiguous(), R + 1, drop_src=R,
-                          fwd_longest=3)
+    s["interp_csr"] = Csr(off3, idx3, w3, R + 1, drop_src=R, fwd_longest=3)
     s["owned"] = owned
     # the longest-list words of the four inverted indices ride with the next host read (_read_sizes), or are read on
     # first use: no host wait of their own
