@@ -656,6 +656,18 @@ int mssvt_train_key_compact(int num_wins, int K, const float *kmeta, const float
 int mssvt_train_interp_compact(int N, int R, const int *inv, const int *tab_row4, const float *tab_w4, int *idx3, float *w3,
                                unsigned char *owned, void *stream);
 
+/* Compact (window, voxel) pairs of a CompressBlock's window lists (training path; index work): k_ind (num_wins,ns) int32 =
+ * positions inside the window's run of voxel rows, < 0: empty (mssvt_window_plan_one), ns <= 64.  _counts: cnt[w] = valid
+ * slots, *total_dev += their sum (zero it first).  _compact, with off = the exclusive prefix sum of cnt: pair_vox (voxel
+ * row win_vstart[w] + k), pair_win, geo8 (8 f32: voxel centre - window centre, window centre, 0, 0; centres as
+ * (index + 0.5) * cell + min in three rounded fp32 operations, ref with_coords mssvt_backbone.py:132-137) at the prefix
+ * position of the slot.  indices (N,4) / win_ind (num_wins,4) int32 (b,z,y,x).                                    */
+int mssvt_train_list_counts(int num_wins, int ns, const int *k_ind, int *cnt, int *total_dev, void *stream);
+int mssvt_train_pairs_compact(int num_wins, int ns, const int *k_ind, const int *win_vstart, const int *off,
+                              const int *indices, const int *win_ind, const float *host_voxel_size3,
+                              const float *host_range_min3, const float *host_win_size3, int *pair_vox, int *pair_win,
+                              float *geo8, void *stream);
+
 /* ========================================================================
  * Post-processing behind the backbone: rotated BEV NMS of CenterHead's boxes.
  * ref: iou3d_nms_cuda.nms_gpu, pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:90-135 (host loop) +

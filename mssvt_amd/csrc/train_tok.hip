@@ -276,3 +276,70 @@ extern "C" int mssvt_train_interp_compact(int N, int R, const int *inv, const in
                                                                      owned);
     return mssvt_launch_status();
 }
+
+// Compact (window, voxel) pairs of a CompressBlock's window lists (index work of the training path): k_ind (nw, ns) int32
+// = positions inside the window's run of voxel rows, < 0: empty (mssvt_window_plan_one).  _counts as for the key sets;
+// _compact writes, at the prefix position, the voxel row win_vstart[w] + k, the window, and the geometry inputs of the
+// positional embedding: voxel centre - window centre, window centre ((index + 0.5) * cell + min, three separately rounded
+// fp32 operations as in ref with_coords, mssvt_backbone.py:132-137), 0, 0.
+__global__ void __launch_bounds__(256) k_list_counts(int nw, int ns, const int *k_ind, int *cnt, int *total) {
+    const int w = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    if (w >= nw) return;
+    const bool ok = lane < ns && k_ind[(size_t)w * ns + lane] >= 0;
+    const int c = __popcll(__ballot(ok));
+    if (lane == 0) {
+        cnt[w] = c;
+        if (c) atomicAdd(total, c);
+    }
+}
+
+struct PairGeo {
+    float vs[3], mn[3], ws[3];
+};
+__global__ void __launch_bounds__(256) k_pairs_compact(int nw, int ns, const int *k_ind, const int *win_vstart, const int *off,
+                                                       const int4 *indices, const int4 *win_ind, PairGeo gq, int *pair_vox, int *pair_win,
+                                                       float4 *geo) {
+    const int w = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE, lane = lane_id();
+    if (w >= nw) return;
+    const int k = lane < ns ? k_ind[(size_t)w * ns + lane] : -1;
+    const bool ok = k >= 0;
+    const unsigned long long mask = __ballot(ok);
+    if (!ok) return;
+    const int pos = off[w] + __popcll(mask & ((1ull << lane) - 1ull));
+    const int v = win_vstart[w] + k;
+    const int4 vi = indices[v], wi = win_ind[w];  // (b, z, y, x)
+    const float vx = ((float)vi.w + 0.5f) * gq.vs[0] + gq.mn[0], vy = ((float)vi.z + 0.5f) * gq.vs[1] + gq.mn[1],
+                vz = ((float)vi.y + 0.5f) * gq.vs[2] + gq.mn[2];
+    const float cx = ((float)wi.w + 0.5f) * gq.ws[0] + gq.mn[0], cy = ((float)wi.z + 0.5f) * gq.ws[1] + gq.mn[1],
+                cz = ((float)wi.y + 0.5f) * gq.ws[2] + gq.mn[2];
+    pair_vox[pos] = v;
+    pair_win[pos] = w;
+    geo[2 * (size_t)pos] = make_float4(vx - cx, vy - cy, vz - cz, cx);
+    geo[2 * (size_t)pos + 1] = make_float4(cy, cz, 0.f, 0.f);
+}
+
+extern "C" int mssvt_train_list_counts(int num_wins, int ns, const int *k_ind, int *cnt, int *total_dev, void *stream) {
+    if (num_wins < 0 || ns <= 0 || ns > 64 || !k_ind || !cnt || !total_dev) return MSSVT_E_BADARG;
+    if (num_wins == 0) return MSSVT_OK;
+    k_list_counts<<<divup(num_wins, 4), 256, 0, (hipStream_t)stream>>>(num_wins, ns, k_ind, cnt, total_dev);
+    return mssvt_launch_status();
+}
+
+extern "C" int mssvt_train_pairs_compact(int num_wins, int ns, const int *k_ind, const int *win_vstart, const int *off,
+                                         const int *indices, const int *win_ind, const float *host_voxel_size3,
+                                         const float *host_range_min3, const float *host_win_size3, int *pair_vox, int *pair_win,
+                                         float *geo8, void *stream) {
+    if (num_wins < 0 || ns <= 0 || ns > 64 || !k_ind || !win_vstart || !off || !indices || !win_ind || !host_voxel_size3 ||
+        !host_range_min3 || !host_win_size3 || !pair_vox || !pair_win || !geo8)
+        return MSSVT_E_BADARG;
+    if (num_wins == 0) return MSSVT_OK;
+    PairGeo gq;
+    for (int i = 0; i < 3; ++i) {
+        gq.vs[i] = host_voxel_size3[i];
+        gq.mn[i] = host_range_min3[i];
+        gq.ws[i] = host_win_size3[i];
+    }
+    k_pairs_compact<<<divup(num_wins, 4), 256, 0, (hipStream_t)stream>>>(num_wins, ns, k_ind, win_vstart, off, (const int4 *)indices,
+                                                                         (const int4 *)win_ind, gq, pair_vox, pair_win, (float4 *)geo8);
+    return mssvt_launch_status();
+}

@@ -861,6 +861,23 @@ def compress_supported(block, sp):
 def _compress_index_sets(block, sp, p):
     dev = sp.indices.device
     N, nw, ns = sp.indices.shape[0], p.nw, block.max_num_win1
+    if KEY_SETS and ns <= 64 and nw > 0:  # two launches (csrc/train_tok.hip) instead of ~35 framework ones
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        cnt = torch.empty(nw, dtype=torch.int32, device=dev)
+        _lib.call("mssvt_train_list_counts", _i(nw), _i(ns), _lib.ptr(p.k_ind), _lib.ptr(cnt), _lib.ptr(total), _lib.stream())
+        P, = _read_sizes(total)  # one sync: the pair count (+ the pending words of the Blocks' index sets)
+        koff = (torch.cumsum(cnt, 0, dtype=torch.int32) - cnt).contiguous()
+        pair_vox = torch.empty(P, dtype=torch.int32, device=dev)
+        pair_win = torch.empty(P, dtype=torch.int32, device=dev)
+        geo = torch.empty((P, 8), dtype=torch.float32, device=dev)
+        if P:
+            _lib.call("mssvt_train_pairs_compact", _i(nw), _i(ns), _lib.ptr(p.k_ind), _lib.ptr(p.win_vstart), _lib.ptr(koff),
+                      _lib.ptr(sp.indices), _lib.ptr(p.win_ind), fused._f3(sp.voxel_size), fused._f3(sp.point_cloud_range[0:3]),
+                      fused._f3(p.win_size_m), _lib.ptr(pair_vox), _lib.ptr(pair_win), _lib.ptr(geo), _lib.stream())
+        wins = dict(q_off=torch.arange(nw, dtype=torch.int32, device=dev), q_cnt=torch.ones(nw, dtype=torch.int32, device=dev),
+                    k_off=koff, k_cnt=cnt)
+        return dict(cnt=cnt.long(), vox_csr=_gather_unique(pair_vox, N), wins=wins, rel=geo[:, :3], pair_centre=geo[:, 3:6],
+                    full=(cnt >= ns))
     k = p.k_ind[:nw]
     valid = k >= 0
     P, = _read_sizes(valid.sum().reshape(1))  # one sync: the pair count (+ the pending words of the Blocks' index sets)
@@ -873,8 +890,8 @@ def _compress_index_sets(block, sp, p):
     wins = dict(q_off=torch.arange(nw, dtype=torch.int32, device=dev), q_cnt=torch.ones(nw, dtype=torch.int32, device=dev),
                 k_off=(torch.cumsum(cnt, 0) - cnt).int().contiguous(), k_cnt=cnt.int().contiguous())
     vox_csr = _gather_unique(pair_vox, N)  # windows are disjoint: a voxel is on one list, once
-    return dict(pair_win=pair_win, cnt=cnt, vox_csr=vox_csr, centre=centre, wins=wins,
-                rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(), full=(cnt >= ns))
+    return dict(cnt=cnt, vox_csr=vox_csr, wins=wins, rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(),
+                pair_centre=centre[pair_win], full=(cnt >= ns))
 
 
 def _compress_sets(block, sp):
@@ -926,7 +943,7 @@ def compress_forward(block, sp):
     # query = channel-wise max over the zero padded list (ref :370): the zeros take part unless the list is full
     q_tok = torch.segment_reduce(xk, "max", lengths=s["cnt"], unsafe=True)
     q_tok = torch.where(s["full"].unsqueeze(1), q_tok, torch.clamp(q_tok, min=0.0))
-    pos = _pos6(block.pos_proj[0], s["rel"], s["centre"][s["pair_win"]])
+    pos = _pos6(block.pos_proj[0], s["rel"], s["pair_centre"])
     pos = F.relu(linear(block.pos_proj[2], pos))
     tok_k = xk + pos
     q = linear(ma.to_qs[0], q_tok, scale=ma.scale)  # (nw, C)
