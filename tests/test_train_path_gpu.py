@@ -445,3 +445,42 @@ def test_key_set_kernels_match_the_framework_composition(cap, nw, K):
     assert torch.equal(k_rows.long(), rows.to(DEV).reshape(-1)[flat].long()) and torch.equal(k_win.long(), win)
     want = torch.cat([kmeta[..., :3].reshape(-1, 3)[flat], wcentre[win, :3], torch.zeros(n, 2, device=DEV)], 1)
     assert torch.equal(k_geo, want)
+
+
+@pytest.mark.parametrize("nw,ns,N", [(3000, 32, 9000), (50, 64, 400), (1, 8, 5)])
+def test_pair_set_kernels_match_the_framework_composition(nw, ns, N):
+    """mssvt_train_list_counts / _pairs_compact (the CompressBlock's (window, voxel) pairs and their geometry) against
+    mask + nonzero + gathers + metric_centres."""
+    import ctypes
+    from mssvt_amd import _lib, fused
+    from mssvt_amd.mssvt_backbone import metric_centres
+    g = torch.Generator().manual_seed(nw + ns)
+    k_ind = torch.randint(0, 3, (nw, ns), generator=g).int()
+    k_ind[torch.rand(nw, ns, generator=g) < 0.5] = -1
+    vstart = torch.randint(0, N - 3, (nw,), generator=g).int()
+    indices = torch.randint(0, 40, (N, 4), generator=g).int()
+    win_ind = torch.randint(0, 12, (nw, 4), generator=g).int()
+    vs, rng, wsz = [0.32, 0.32, 0.1875], [-74.88, -74.88, -2.0, 74.88, 74.88, 4.0], [0.32, 0.32, 6.0]
+    k_ind, vstart, indices, win_ind = (t.to(DEV).contiguous() for t in (k_ind, vstart, indices, win_ind))
+    i = ctypes.c_int
+    cnt = torch.empty(nw, dtype=torch.int32, device=DEV)
+    total = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.call("mssvt_train_list_counts", i(nw), i(ns), _lib.ptr(k_ind), _lib.ptr(cnt), _lib.ptr(total), _lib.stream())
+    valid = k_ind >= 0
+    assert torch.equal(cnt.long(), valid.sum(1)) and int(total.item()) == int(valid.sum())
+    P = int(total.item())
+    off = (torch.cumsum(cnt, 0, dtype=torch.int32) - cnt).contiguous()
+    pair_vox = torch.empty(P, dtype=torch.int32, device=DEV)
+    pair_win = torch.empty(P, dtype=torch.int32, device=DEV)
+    geo = torch.empty((P, 8), dtype=torch.float32, device=DEV)
+    if P:
+        _lib.call("mssvt_train_pairs_compact", i(nw), i(ns), _lib.ptr(k_ind), _lib.ptr(vstart), _lib.ptr(off), _lib.ptr(indices),
+                  _lib.ptr(win_ind), fused._f3(vs), fused._f3(rng[:3]), fused._f3(wsz), _lib.ptr(pair_vox), _lib.ptr(pair_win),
+                  _lib.ptr(geo), _lib.stream())
+    flat = torch.nonzero(valid.reshape(-1), as_tuple=True)[0]
+    win = flat // ns
+    vox = k_ind.reshape(-1)[flat].long() + vstart.long()[win]
+    assert torch.equal(pair_vox.long(), vox) and torch.equal(pair_win.long(), win)
+    centre = metric_centres(win_ind, rng, wsz)[win]
+    rel = metric_centres(indices, rng, vs)[vox] - centre
+    assert torch.equal(geo[:, :3], rel) and torch.equal(geo[:, 3:6], centre) and bool((geo[:, 6:] == 0).all())
