@@ -668,6 +668,20 @@ int mssvt_train_pairs_compact(int num_wins, int ns, const int *k_ind, const int 
                               const float *host_range_min3, const float *host_win_size3, int *pair_vox, int *pair_win,
                               float *geo8, void *stream);
 
+/* Compact query rows of a query pattern of a window plan (training path; index work): from what mssvt_plan_order leaves
+ * (row_meta (rows,4) f32 = offset to the window centre xyz + voxel row as int bits; row_src (rows,2) int32 = window,
+ * padded attention row) the voxel rows q_rows (R) and the positional embedding's inputs q_geo8 (R,8: offset, centre from
+ * wcentre (cap,4), 0, 0) of the first R rows.                                                                    */
+int mssvt_train_query_sets(int R, const float *row_meta, const int *row_src, const float *wcentre, int *q_rows,
+                           float *q_geo8, void *stream);
+
+/* Inverse of a gather of DISTINCT rows (dst[i] = src[idx[i]], every source row named at most once: a window's query rows
+ * when every window size is odd, the voxels of disjoint windows) as ranges for mssvt_segment_sum_rows_ranges over the
+ * n_src source rows: seg_start[v] = v, seg_end[v] = bwd_end[v] (v + 1 or v), csr_idx = bwd_idx.  inv_scratch: n_src ints.
+ * Replaces the sort of mssvt_csr_transpose for such gathers (the reference's atomicAdd backward needs no order there). */
+int mssvt_train_unique_inverse(int nnz, int n_src, const int *idx, int *inv_scratch, int *bwd_idx, int *bwd_end,
+                               void *stream);
+
 /* ========================================================================
  * Post-processing behind the backbone: rotated BEV NMS of CenterHead's boxes.
  * ref: iou3d_nms_cuda.nms_gpu, pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:90-135 (host loop) +

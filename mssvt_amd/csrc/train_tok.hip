@@ -343,3 +343,51 @@ extern "C" int mssvt_train_pairs_compact(int num_wins, int ns, const int *k_ind,
                                                                          (const int4 *)win_ind, gq, pair_vox, pair_win, (float4 *)geo8);
     return mssvt_launch_status();
 }
+
+// Compact query rows of a window plan's query pattern (mssvt_plan_order leaves row_meta (rows,4) f32 = offset to the window
+// centre xyz + voxel row as int bits, row_src (rows,2) int32 = window, padded attention row): the voxel rows and the eight
+// geometry inputs of the positional embedding for the first R rows.
+__global__ void __launch_bounds__(256) k_query_sets(int R, const float4 *row_meta, const int2 *row_src, const float4 *wcentre, int *q_rows,
+                                                    float4 *q_geo) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float4 m = row_meta[r];
+    const float4 c = wcentre[row_src[r].x];
+    q_rows[r] = __builtin_bit_cast(int, m.w);
+    q_geo[2 * (size_t)r] = make_float4(m.x, m.y, m.z, c.x);
+    q_geo[2 * (size_t)r + 1] = make_float4(c.y, c.z, 0.f, 0.f);
+}
+
+extern "C" int mssvt_train_query_sets(int R, const float *row_meta, const int *row_src, const float *wcentre, int *q_rows,
+                                      float *q_geo8, void *stream) {
+    if (R < 0 || !row_meta || !row_src || !wcentre || !q_rows || !q_geo8) return MSSVT_E_BADARG;
+    if (R == 0) return MSSVT_OK;
+    k_query_sets<<<divup(R, 256), 256, 0, (hipStream_t)stream>>>(R, (const float4 *)row_meta, (const int2 *)row_src,
+                                                                 (const float4 *)wcentre, q_rows, (float4 *)q_geo8);
+    return mssvt_launch_status();
+}
+
+// Inverse of a gather of DISTINCT rows (dst[i] = src[idx[i]], every source row named at most once) as the ranges of a
+// segmented sum over the source rows: source row v sums entry bwd_idx[v] if bwd_end[v] == v + 1, nothing if == v.
+__global__ void __launch_bounds__(256) k_inverse_scatter(int nnz, const int *idx, int *inv) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) inv[idx[e]] = e;
+}
+__global__ void __launch_bounds__(256) k_inverse_ranges(int n_src, const int *inv, int *bwd_idx, int *bwd_end) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_src) return;
+    const int e = inv[v];
+    bwd_idx[v] = e > 0 ? e : 0;
+    bwd_end[v] = v + (e >= 0 ? 1 : 0);
+}
+
+extern "C" int mssvt_train_unique_inverse(int nnz, int n_src, const int *idx, int *inv_scratch, int *bwd_idx, int *bwd_end, void *stream) {
+    if (nnz < 0 || n_src < 0 || (nnz && !idx) || (n_src && (!inv_scratch || !bwd_idx || !bwd_end))) return MSSVT_E_BADARG;
+    if (n_src == 0) return MSSVT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(inv_scratch, 0xFF, (size_t)n_src * 4, st);  // -1: no entry reads the row
+    if (e != hipSuccess) return (int)e;
+    if (nnz) k_inverse_scatter<<<divup(nnz, 256), 256, 0, st>>>(nnz, idx, inv_scratch);
+    k_inverse_ranges<<<divup(n_src, 256), 256, 0, st>>>(n_src, inv_scratch, bwd_idx, bwd_end);
+    return mssvt_launch_status();
+}

@@ -230,14 +230,16 @@ def _gather_unique(idx, n_src):
     idx = idx.int().contiguous()
     nnz = idx.numel()
     c.n_src, c.n_dst = int(n_src), nnz
-    inv = torch.full((c.n_src,), -1, dtype=torch.int32, device=dev)
-    inv[idx.long()] = torch.arange(nnz, dtype=torch.int32, device=dev)
+    inv = torch.empty(c.n_src, dtype=torch.int32, device=dev)
+    bwd_idx = torch.empty(c.n_src, dtype=torch.int32, device=dev)
+    bwd_end = torch.empty(c.n_src, dtype=torch.int32, device=dev)
+    _lib.call("mssvt_train_unique_inverse", _i(nnz), _i(c.n_src), _lib.ptr(idx) if nnz else None, _lib.ptr(inv), _lib.ptr(bwd_idx),
+              _lib.ptr(bwd_end), _lib.stream())
     c.off = torch.arange(nnz + 1, dtype=torch.int32, device=dev)
     c.idx, c.w = idx, None
     c.fwd = Segments(c.off, idx, None, longest=1)
-    pos = torch.arange(c.n_src + 1, dtype=torch.int32, device=dev)
-    c.bwd = Segments(pos, inv.clamp(min=0), None, longest=1)
-    c.bwd.end = (pos[:-1] + (inv >= 0).int()).contiguous()  # an empty range where no entry reads the row
+    c.bwd = Segments(torch.arange(c.n_src + 1, dtype=torch.int32, device=dev), bwd_idx, None, longest=1)
+    c.bwd.end = bwd_end  # an empty range where no entry reads the row
     c.t_off = c.t_idx = c.t_w = None
     return c
 
@@ -682,17 +684,19 @@ def _block_index_sets(block, sp, p):
     s = {"nw": nw, "R": R, "nq": nq, "centre": common["centre"]}
     qs = pat.get("q_sets")
     if qs is None:  # the query rows of this pattern (shared by its with / without interpolation variants)
-        meta = od["row_meta"][:R]
-        qs = {"q_rows": meta[:, 3].contiguous().view(torch.int32), "q_rel": meta[:, :3].contiguous(),
-              "q_win": od["row_src"][:R, 0].long()}
+        q_rows = torch.empty(R, dtype=torch.int32, device=dev)
+        q_geo = torch.empty((R, 8), dtype=torch.float32, device=dev)
+        if R:
+            _lib.call("mssvt_train_query_sets", _i(R), _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]), _lib.ptr(p.wcentre),
+                      _lib.ptr(q_rows), _lib.ptr(q_geo), _lib.stream())
+        qs = {"q_rows": q_rows, "q_geo": q_geo, "q_rel": q_geo[:, :3], "q_centre": q_geo[:, 3:6]}
         # (a voxel is on one window's query list when every window size is odd: ref mssvt_backbone.py:94-97)
         distinct = all(int(wsz) % 2 == 1 for wsz in block.win1_size)
-        qs["q_csr"] = _gather_unique(qs["q_rows"], N) if distinct else Csr.gather(qs["q_rows"], N)
-        qs["q_geo"] = torch.cat([qs["q_rel"], s["centre"][qs["q_win"]], common["pad2"].expand(R, 2)], dim=1).contiguous()
-        qs["keys"] = [dict(k, wins=dict(q_off=od["q_off"][:nw].contiguous(), q_cnt=od["nq_valid"][:nw].contiguous(),
-                                        k_off=k["k_off"], k_cnt=k["k_cnt"])) for k in common["keys"]]
+        qs["q_csr"] = _gather_unique(q_rows, N) if distinct else Csr.gather(q_rows, N)
         if qs["q_csr"].bwd.pending is not None:
             _deferred.append(qs["q_csr"].bwd)
+        qs["keys"] = [dict(k, wins=dict(q_off=od["q_off"][:nw].contiguous(), q_cnt=od["nq_valid"][:nw].contiguous(),
+                                        k_off=k["k_off"], k_cnt=k["k_cnt"])) for k in common["keys"]]
         pat["q_sets"] = qs
     s.update(qs)
     # interpolation / scatter table: 3 compact attention rows + weights per voxel (row R = the zero row)
@@ -809,8 +813,7 @@ def block_forward(block, sp):
                 c0 += cg
             toks = tokens(xhat, block.pos_proj[0], parts)
         else:
-            cq = s["centre"][s["q_win"]]
-            tok_q = gather_sum(xhat, s["q_csr"]) + _pos6(block.pos_proj[0], s["q_rel"], cq)
+            tok_q = gather_sum(xhat, s["q_csr"]) + _pos6(block.pos_proj[0], s["q_rel"], s["q_centre"])
         outs, c0 = [], 0
         ng = len(ma.scale_dims)
         for g, (heads, cg) in enumerate(zip(ma.num_heads, ma.scale_dims)):
