@@ -43,6 +43,11 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    # objects (and compiler temporaries) whose source is gone must not linger beside the library
+    keep = {os.path.basename(s) + ".o" for s in sources()} | {os.path.basename(LIB_PATH)}
+    for name in os.listdir(LIB_DIR):
+        if name not in keep and (".hip.o" in name):
+            os.remove(os.path.join(LIB_DIR, name))
     objs = []
     procs = []
     for src in sources():

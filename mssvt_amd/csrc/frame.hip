@@ -74,7 +74,7 @@ struct Frame {
     hipEvent_t ready = nullptr;
     int *host_words = nullptr;  // pinned
     int words = 0;
-    // optional: the two launches that neither need nor feed the index chain (first norm1, the CompressBlock's pillar plan)
+    // optional: the launch that neither needs nor feeds the index chain (first norm1)
     // on a second stream, under the Blocks' plan kernel (VALU / latency bound; the LayerNorm is HBM bound)
     int overlap = 0;
     hipStream_t side = nullptr;
@@ -524,19 +524,34 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
         if (e == hipSuccess) e = hipEventRecord(f->ready, stream);
         if (e != hipSuccess) return (int)e;
     }
-    // ---- first norm1 (+ the CompressBlock's pillar plan): on the side stream under the plan kernel when asked to
+    // ---- first norm1: on the side stream under the plan kernel when asked to.  Between the fork and the join every error
+    // return goes through `unfork` (the side stream may still be writing L.xhat0 of the caller's workspace)
     hipStream_t s2 = stream;
+    int forked = 0;  // 1: side stream has work, join not recorded; 2: join recorded, not yet waited for
+    auto unfork = [&](int rc) {
+        if (forked == 2 && hipStreamWaitEvent(stream, f->join, 0) == hipSuccess) forked = 0;
+        if (forked) (void)hipStreamSynchronize(f->side);
+        forked = 0;
+        return rc;
+    };
+#define FR_TRY_FORKED(call_)                          \
+    {                                                 \
+        const int st_ = (call_);                      \
+        if (st_ != MSSVT_OK) return unfork(st_);      \
+    }
     if (f->overlap) {
         hipError_t e = hipEventRecord(f->fork, stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(f->side, f->fork, 0);
         if (e != hipSuccess) return (int)e;
         s2 = f->side;
+        forked = 1;
     }
     if (!ln_in_fill)
-        FR_TRY(mssvt_layer_norm(features, n, C, f->blocks[0].n1w, f->blocks[0].n1b, f->blocks[0].n1eps, L.xhat0, s2));
+        FR_TRY_FORKED(mssvt_layer_norm(features, n, C, f->blocks[0].n1w, f->blocks[0].n1b, f->blocks[0].n1eps, L.xhat0, s2));
     if (f->overlap) {
         const hipError_t e = hipEventRecord(f->join, s2);
-        if (e != hipSuccess) return (int)e;
+        if (e != hipSuccess) return unfork((int)e);
+        forked = 2;
     }
     // ---- window plan of the Blocks, with the interpolation tables of every (pattern, interpolation) variant
     const float mn3[3] = {f->range[0], f->range[1], f->range[2]};
@@ -551,7 +566,7 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
             tab_row[t] = L.tab_rows + (size_t)t * n * 4;
             tab_w[t] = L.tab_w + (size_t)t * n * 4;
         }
-        FR_TRY(mssvt_window_plan_two(
+        FR_TRY_FORKED(mssvt_window_plan_two(
             X, Y, Z, p.ws[0], p.ws[1], p.ws[2], p.n_o, p.n_e, p.n1, p.n2, H, B, p.num_o, p.num_e, p.num_1, p.num_2, p.t_o, p.t_e,
             p.t_1, p.t_2, p.K, L.win_blk, L.hdr[0] + 1, cap, nullptr, L.cnt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
             nullptr, L.win_vstart, nullptr, nullptr, nullptr, indices, f->vs, mn3, wsm,  // (lists / key indices / owners: nobody reads them here)
@@ -571,13 +586,15 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
         }
         // (counting the order histograms inside the plan kernel with atomics was measured: the plan kernel +16.7 us for the
         // 4.9 us launch it saves)
-        FR_TRY(mssvt_plan_order_multi(L.n_pat, L.hdr[0] + 1, nqv, nq, qm, cap, (int)L.row_cap, L.perm, L.n_act, L.q_off, L.row_meta,
+        FR_TRY_FORKED(mssvt_plan_order_multi(L.n_pat, L.hdr[0] + 1, nqv, nq, qm, cap, (int)L.row_cap, L.perm, L.n_act, L.q_off, L.row_meta,
                                       L.row_src, L.n_rows, stream));
     }
     if (f->overlap) {
         const hipError_t e = hipStreamWaitEvent(stream, f->join, 0);
-        if (e != hipSuccess) return (int)e;
+        if (e != hipSuccess) return unfork((int)e);
+        forked = 0;
     }
+#undef FR_TRY_FORKED
     // ---- the Blocks
     const float *x = features, *xhat = L.xhat0;
     const int nb = (int)f->blocks.size();
@@ -612,7 +629,7 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
         x = y;
         xhat = yn;
     }
-    // ---- CompressBlock: pillar plan, attention (three launches), FFN tail over the live windows
+    // ---- CompressBlock: attention (one launch on a sorted pillar level, else three), FFN tail over the live windows
     const float cwsm[3] = {f->vs[0] * c.ws[0], f->vs[1] * c.ws[1], f->vs[2] * c.ws[2]};
     if (c.ws_packed) {
         FR_TRY(mssvt_compress_ws(C, c.head_dim, c.scale, c.ws[2], c.ns, n, L.hdr[1] + 1, cap, indices, L.c_win_cnt, L.pair_win,

@@ -202,18 +202,31 @@ extern "C" int mssvt_train_tok_backward_reduce(int C, int num_sets, const int *h
 //                  the 8 geometry inputs of the positional embedding (offset to the window centre, centre, 0, 0)
 // One wave per window, lane = slot (K <= 64).
 // ---------------------------------------------------------------------------------------------------------------------
+// (the total: one atomicAdd per WORKGROUP of a grid of at most 512 -- an add per window on one address serialises at ~88 per
+// microsecond chip-wide: 223 / 373 us per launch at 19k / 33k windows, DESIGN 4 "design rules")
+__device__ __forceinline__ void add_block_total(int wave_sum, int *total) {
+    __shared__ int part[4];
+    if (lane_id() == 0) part[threadIdx.x / MSSVT_WAVE] = wave_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int s = part[0] + part[1] + part[2] + part[3];
+        if (s) atomicAdd(total, s);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_key_counts(int cap, int K, const int *num_wins, const float4 *kmeta, int *cnt, int *total) {
-    const int w = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE, lane = lane_id();
-    if (w >= cap) return;
-    int c = 0;
-    if (w < *num_wins) {
-        const bool ok = lane < K && __builtin_bit_cast(int, kmeta[(size_t)w * K + lane].w) >= 0;
-        c = __popcll(__ballot(ok));
+    const int lane = lane_id(), nw = *num_wins;
+    int sum = 0;
+    for (int w = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE; w < cap; w += gridDim.x * 4) {
+        int c = 0;
+        if (w < nw) {
+            const bool ok = lane < K && __builtin_bit_cast(int, kmeta[(size_t)w * K + lane].w) >= 0;
+            c = __popcll(__ballot(ok));
+        }
+        if (lane == 0) cnt[w] = c;
+        sum += c;
     }
-    if (lane == 0) {
-        cnt[w] = c;
-        if (c) atomicAdd(total, c);
-    }
+    add_block_total(sum, total);
 }
 
 __global__ void __launch_bounds__(256) k_key_compact(int nw, int K, const float4 *kmeta, const float4 *wcentre, const int *off,
@@ -240,7 +253,7 @@ extern "C" int mssvt_train_key_counts(int cap, int K, const int *num_wins_dev, c
                                       void *stream) {
     if (cap < 0 || K <= 0 || K > 64 || !num_wins_dev || !kmeta || !cnt || !total_dev) return MSSVT_E_BADARG;
     if (cap == 0) return MSSVT_OK;
-    k_key_counts<<<divup(cap, 4), 256, 0, (hipStream_t)stream>>>(cap, K, num_wins_dev, (const float4 *)kmeta, cnt, total_dev);
+    k_key_counts<<<min(divup(cap, 4), 512), 256, 0, (hipStream_t)stream>>>(cap, K, num_wins_dev, (const float4 *)kmeta, cnt, total_dev);
     return mssvt_launch_status();
 }
 
@@ -283,14 +296,15 @@ extern "C" int mssvt_train_interp_compact(int N, int R, const int *inv, const in
 // positional embedding: voxel centre - window centre, window centre ((index + 0.5) * cell + min, three separately rounded
 // fp32 operations as in ref with_coords, mssvt_backbone.py:132-137), 0, 0.
 __global__ void __launch_bounds__(256) k_list_counts(int nw, int ns, const int *k_ind, int *cnt, int *total) {
-    const int w = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE, lane = lane_id();
-    if (w >= nw) return;
-    const bool ok = lane < ns && k_ind[(size_t)w * ns + lane] >= 0;
-    const int c = __popcll(__ballot(ok));
-    if (lane == 0) {
-        cnt[w] = c;
-        if (c) atomicAdd(total, c);
+    const int lane = lane_id();
+    int sum = 0;
+    for (int w = blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE; w < nw; w += gridDim.x * 4) {
+        const bool ok = lane < ns && k_ind[(size_t)w * ns + lane] >= 0;
+        const int c = __popcll(__ballot(ok));
+        if (lane == 0) cnt[w] = c;
+        sum += c;
     }
+    add_block_total(sum, total);
 }
 
 struct PairGeo {
@@ -321,7 +335,7 @@ __global__ void __launch_bounds__(256) k_pairs_compact(int nw, int ns, const int
 extern "C" int mssvt_train_list_counts(int num_wins, int ns, const int *k_ind, int *cnt, int *total_dev, void *stream) {
     if (num_wins < 0 || ns <= 0 || ns > 64 || !k_ind || !cnt || !total_dev) return MSSVT_E_BADARG;
     if (num_wins == 0) return MSSVT_OK;
-    k_list_counts<<<divup(num_wins, 4), 256, 0, (hipStream_t)stream>>>(num_wins, ns, k_ind, cnt, total_dev);
+    k_list_counts<<<min(divup(num_wins, 4), 512), 256, 0, (hipStream_t)stream>>>(num_wins, ns, k_ind, cnt, total_dev);
     return mssvt_launch_status();
 }
 

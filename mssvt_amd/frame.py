@@ -12,6 +12,7 @@ FFN, custom tables whose lists overlap, ...) returns ``None`` from :func:`forwar
 ref: MixedScaleSparseTransformer.forward, pcdet/models/backbones_3d/mssvt_backbone.py:450-472.
 """
 import ctypes
+import logging
 import os
 
 import torch
@@ -21,7 +22,7 @@ from .mssvt_utils import SparseTensor
 
 ENABLED = os.environ.get("MSSVT_FRAME", "1") != "0"
 _WORDS = 192
-# the first norm1 and the CompressBlock's pillar plan on a second stream, under the Blocks' plan kernel: "auto" = from
+# the first norm1 on a second stream, under the Blocks' plan kernel (the pillar lists come out of the level set-up): "auto" = from
 # OVERLAP_MIN_VOXELS up (measured with the frame call: one scene 1 432 -> 1 422 frames/s, batch 4 1 739 -> 1 782, batch 8
 # 1 828 -> 1 853: the plan kernel slows down when it shares the chip, large frames gain more than that costs)
 OVERLAP = os.environ.get("MSSVT_FRAME_OVERLAP", "auto")
@@ -43,6 +44,7 @@ class _Frame(object):
         self.handle = h.value
         self.keep = []  # tensors / ctypes arrays whose addresses the frame object holds
         self.workspace = None
+        self.last_stream = None
         self.words = (ctypes.c_int * _WORDS)()
 
     def __del__(self):
@@ -61,42 +63,62 @@ def _params(net):
     return out
 
 
+_why = [None]  # why the last eligibility check said no (read by `_declined`)
+
+
+def _no(reason, value=False):
+    _why[0] = reason
+    return value
+
+
+def _declined(net, reason):
+    """Log ONCE per network (and reason) that the whole-frame call is not taking it: the Python-driven path issues the same
+    kernels but needs ~3.5x the host time per frame, which should not go unnoticed in production."""
+    seen = net.__dict__.setdefault("_frame_declined", set())
+    if reason not in seen:
+        seen.add(reason)
+        logging.getLogger("mssvt_amd.frame").warning(
+            "mssvt_frame_forward declined this network (%s): running the Python-driven fused path "
+            "(same kernels, ~3.5x the host time per frame)", reason)
+    return None
+
+
 def _structure_ok(net):
     """The constructor-time half of the eligibility: block layout and shapes (cached per network)."""
     from .mssvt_backbone import MixedScaleSparseTransformerBlock as Block, MixedScaleSparseTransformerCompressBlock as Compress
     blocks = list(net.backbone)
     if len(blocks) < 2 or len(blocks) > 17 or not isinstance(blocks[-1], Compress):
-        return False
+        return _no("block layout (Blocks closed by one CompressBlock)")
     body, cmp_blk = blocks[:-1], blocks[-1]
     if any(isinstance(b, Compress) or not isinstance(b, Block) for b in body):
-        return False
+        return _no("a CompressBlock or foreign module among the Blocks")
     if any(hasattr(b, "out_linear") for b in blocks):
-        return False
+        return _no("out_linear")
     C, FF = body[0].linear1.in_features, body[0].linear1.out_features
     if (C, FF) not in fused.FFN_SHAPES or any((b.linear1.in_features, b.linear1.out_features) != (C, FF) for b in blocks):
-        return False
+        return _no("FFN shape outside fused.FFN_SHAPES or not uniform")
     if any(b.plan_key() != body[0].plan_key() or b.max_num_wins != body[0].max_num_wins for b in body):
-        return False
+        return _no("Blocks with different window configurations")
     if not all(fused._supported_static(b) and fused._lists_disjoint(b) for b in body):
-        return False
+        return _no("a Block the fused kernels do not cover, or custom tables with overlapping lists")
     ma0 = body[0].ms_attn
     if any(tuple(b.ms_attn.num_heads) != tuple(ma0.num_heads) or tuple(b.ms_attn.scale_dims) != tuple(ma0.scale_dims) or
            b.ms_attn.per_head_dim != ma0.per_head_dim for b in body):
-        return False
+        return _no("Blocks with different head layouts")
     if len({(b.cbs_pattern, bool(b.use_feature_interpolation)) for b in body}) > 4:
-        return False
+        return _no("more than four (pattern, interpolation) variants")
     # CompressBlock: pillar windows, one head group, every table offset inside the window's own column
     hd = cmp_blk.ms_attn.per_head_dim
     if not (hd <= 64 and (hd & (hd - 1)) == 0 and max(cmp_blk.ms_attn.scale_dims) <= 128):
-        return False
+        return _no("CompressBlock head dimension")
     if not fused._compress_fused_ok(cmp_blk, None, C) or cmp_blk.win2_size is not None:
-        return False
+        return _no("CompressBlock not covered by the fused kernels")
     w = cmp_blk.win1_size
     t = cmp_blk.vox_query_table['win1'].cpu()
     lo = torch.tensor([-(v // 2) for v in w])
     hi = torch.tensor([v - v // 2 - 1 for v in w])
     if not (bool(((t >= lo) & (t <= hi)).all()) and bool((t[:, :2] == 0).all()) and w[0] == 1 and w[1] == 1 and 1 <= t.shape[0] <= 64):
-        return False
+        return _no("CompressBlock window / table is not a pillar")
     return True
 
 
@@ -106,7 +128,7 @@ def _build(net, dev, batch_size):
     body, cmp_blk = blocks[:-1], blocks[-1]
     X, Y, Z = (int(v) for v in net.grid_size)
     if Z > 64:
-        return None
+        return _no("grid taller than 64 cells", None)
     C, FF = body[0].linear1.in_features, body[0].linear1.out_features
     stub = _Stub(net.point_cloud_range)
     fr = _Frame()
@@ -117,11 +139,11 @@ def _build(net, dev, batch_size):
     P = fused._P
     for blk in body:
         if getattr(blk, "impl", None) != "fused" or getattr(blk, "ffn_arith", fused.FFN_ARITH) != "f16x3":
-            return None
+            return _no("a Block with impl != 'fused' or ffn_arith != 'f16x3'", None)
         t = blk._tables_on(dev)
         fp4, packed_offsets = fused._table_footprint(blk, t)
         if fp4[2] * fp4[3] > 1024:
-            return None
+            return _no("table footprint wider than 1024 words", None)
         r = fused._attn_refs(blk, None)
         n = r["n"]
         pa = lambda ts: (ctypes.c_void_p * n)(*[x.data_ptr() for x in ts])  # noqa: E731
@@ -134,7 +156,7 @@ def _build(net, dev, batch_size):
         ffr = fused._ffn_refs(blk)
         ffn_packed = fused._ffn_f16_weights(ffr)
         if ffn_packed is None:
-            return None
+            return _no("FFN weights outside the fp16 range of the split products", None)
         arrays = (pa(r["Wq"]), pa(r["bq"]), pa(r["Wkv"]), pa(r["bkv"]), pa(r["Wo"]), pa(r["bo"]))
         fr.keep += [t, packed_offsets, fp4, r, ffr, ffn_packed, arrays, packed]
         _lib.call("mssvt_frame_add_block", fr.handle, i3(blk.win1_size), int(blk.max_num_odd), int(blk.max_num_even),
@@ -147,12 +169,12 @@ def _build(net, dev, batch_size):
                   P(ffn_packed))
     blk = cmp_blk
     if getattr(blk, "impl", None) != "fused" or getattr(blk, "ffn_arith", fused.FFN_ARITH) != "f16x3":
-        return None
+        return _no("the CompressBlock has impl != 'fused' or ffn_arith != 'f16x3'", None)
     ma = blk.ms_attn
     ffr = fused._ffn_refs(blk)
     ffn_packed = fused._ffn_f16_weights(ffr)
     if ffn_packed is None:
-        return None
+        return _no("CompressBlock FFN weights outside the fp16 range", None)
     t = blk._tables_on(dev)
     split = 1 if fused._compress_f16_ok(blk, stub) else 0
     # the one-launch attention of a sorted pillar level (csrc/compress_ws.hip): the table must list every cell of the slab
@@ -179,6 +201,7 @@ def _state(net, feats, batch_size):
                  for b in net.backbone)
     if st is None or st["skey"] != skey:
         st = net.__dict__["_frame_state"] = dict(skey=skey, ok=_structure_ok(net), params=_params(net), key=None, frame=None)
+        st["why"] = None if st["ok"] else _why[0]
     if not st["ok"]:
         return None
     ps = st["params"]
@@ -195,7 +218,8 @@ def _state(net, feats, batch_size):
             except _lib.MssvtHipError as e:
                 if "status -2" not in str(e):  # MSSVT_E_TOOLARGE: a shape the frame call does not cover -> Python path
                     raise
-                st["frame"] = None
+                st["frame"] = _no("a shape the frame call does not cover (MSSVT_E_TOOLARGE)", None)
+        st["why"] = None if st["frame"] is not None else _why[0]
         st["key"] = key
     return st["frame"]
 
@@ -218,9 +242,16 @@ def forward(net, feats, coords, batch_size):
         return None
     fr = _state(net, feats, batch_size)
     if fr is None:
-        return None
+        return _declined(net, net.__dict__["_frame_state"].get("why") or "not eligible")
     if feats.shape[1] != net.backbone[0].linear1.in_features:
-        return None
+        return _declined(net, "feature width differs from the first Block's")
+    # one persistent workspace + one pinned words buffer per network: frames are kept apart by STREAM ORDER.  A call on
+    # another stream first waits for everything queued before (rare; one caller thread per network, as in the reference)
+    cur = _lib.stream()
+    cur = getattr(cur, "value", cur)
+    if fr.last_stream is not None and fr.last_stream != cur:
+        torch.cuda.synchronize(feats.device)
+    fr.last_stream = cur
     indices = coords if coords.dtype == torch.int32 and coords.is_contiguous() else coords.int().contiguous()
     dev = feats.device
     C = feats.shape[1]

@@ -690,8 +690,9 @@ def _block_index_sets(block, sp, p):
             _lib.call("mssvt_train_query_sets", _i(R), _lib.ptr(od["row_meta"]), _lib.ptr(od["row_src"]), _lib.ptr(p.wcentre),
                       _lib.ptr(q_rows), _lib.ptr(q_geo), _lib.stream())
         qs = {"q_rows": q_rows, "q_geo": q_geo, "q_rel": q_geo[:, :3], "q_centre": q_geo[:, 3:6]}
-        # (a voxel is on one window's query list when every window size is odd: ref mssvt_backbone.py:94-97)
-        distinct = all(int(wsz) % 2 == 1 for wsz in block.win1_size)
+        # (a voxel is on one window's query list when every window size is odd, ref mssvt_backbone.py:94-97, AND no
+        # offset of a custom table leaves the window: then the inverse of the gather is one scatter, else a sort)
+        distinct = all(int(wsz) % 2 == 1 for wsz in block.win1_size) and fused._lists_disjoint(block)
         qs["q_csr"] = _gather_unique(q_rows, N) if distinct else Csr.gather(q_rows, N)
         if qs["q_csr"].bwd.pending is not None:
             _deferred.append(qs["q_csr"].bwd)
@@ -879,7 +880,8 @@ def _compress_index_sets(block, sp, p):
                       fused._f3(p.win_size_m), _lib.ptr(pair_vox), _lib.ptr(pair_win), _lib.ptr(geo), _lib.stream())
         wins = dict(q_off=torch.arange(nw, dtype=torch.int32, device=dev), q_cnt=torch.ones(nw, dtype=torch.int32, device=dev),
                     k_off=koff, k_cnt=cnt)
-        return dict(cnt=cnt.long(), vox_csr=_gather_unique(pair_vox, N), wins=wins, rel=geo[:, :3], pair_centre=geo[:, 3:6],
+        vox_csr = _gather_unique(pair_vox, N) if p.disjoint else Csr.gather(pair_vox, N)
+        return dict(cnt=cnt.long(), vox_csr=vox_csr, wins=wins, rel=geo[:, :3], pair_centre=geo[:, 3:6],
                     full=(cnt >= ns))
     k = p.k_ind[:nw]
     valid = k >= 0
@@ -892,7 +894,9 @@ def _compress_index_sets(block, sp, p):
     centre = _metric(p.win_ind[:nw], sp.point_cloud_range, p.win_size_m)
     wins = dict(q_off=torch.arange(nw, dtype=torch.int32, device=dev), q_cnt=torch.ones(nw, dtype=torch.int32, device=dev),
                 k_off=(torch.cumsum(cnt, 0) - cnt).int().contiguous(), k_cnt=cnt.int().contiguous())
-    vox_csr = _gather_unique(pair_vox, N)  # windows are disjoint: a voxel is on one list, once
+    # disjoint windows: a voxel is on one list, once -> the inverse is one scatter; a custom table whose offsets leave
+    # the window puts a voxel on several lists -> the general inverted index (every contribution kept)
+    vox_csr = _gather_unique(pair_vox, N) if p.disjoint else Csr.gather(pair_vox, N)
     return dict(cnt=cnt, vox_csr=vox_csr, wins=wins, rel=(vox_xyz[pair_vox.long()] - centre[pair_win]).contiguous(),
                 pair_centre=centre[pair_win], full=(cnt >= ns))
 

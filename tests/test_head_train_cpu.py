@@ -64,5 +64,6 @@ def test_objects_without_size_or_padding_rows_get_no_target(golden_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs the MI355X")
 def test_training_step_matches_the_reference_run_on_the_gpu(golden_dir):
     _check(*_step(golden_dir, "cuda"))

@@ -72,6 +72,44 @@ def test_compact_training_path_matches_the_operator_path(C, heads, cheads, inter
         close(gp1[k], gp2[k], k)
 
 
+@pytest.mark.parametrize("which", ["block", "compress"])
+def test_compact_training_path_with_overlapping_custom_tables(which):
+    """A custom table whose offsets leave the window puts a voxel on the lists of several windows: the inverse of the
+    gather is then the general inverted index, not one scatter (every contribution of the backward kept)."""
+    from mssvt_amd import fused
+    C, B, H = 32, 2, 40009
+    net = _net(C, _params(C, [2, 2], [4]), H)
+    if which == "block":
+        for blk in net.backbone[:2]:
+            t = {k: v.clone().cpu() for k, v in blk.vox_query_table.items()}
+            far = int((t["win2"][:, 0].abs() == 2).nonzero()[0])  # a cell of the 7x7x7 surround, outside the 3x3x5 window
+            t["odd"][-1], t["win2"][far] = t["win2"][far].clone(), t["odd"][-1].clone()
+            t["even"][-1, 0] += 2  # stays even, leaves the window
+            blk.set_vox_query_table(t)
+            assert not fused._lists_disjoint(blk)
+    else:
+        blk = net.backbone[2]
+        t = {k: v.clone().cpu() for k, v in blk.vox_query_table.items()}
+        t["win1"][::4, 0] = 1  # every fourth cell of the pillar comes from the neighbouring column
+        blk.set_vox_query_table(t)
+    vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(4000, B, 11))
+    coords = torch.from_numpy(vc).to(DEV)
+    x = torch.randn(vc.shape[0], C, device=DEV)
+    res = {}
+    for compact in (True, False):
+        fused.TRAIN_COMPACT = compact
+        try:
+            shape = net(dict(voxel_features=x, voxel_coords=coords, batch_size=B))["encoded_spconv_tensor"].features.shape
+            w = torch.randn(shape, generator=torch.Generator().manual_seed(7)).to(DEV)
+            res[compact] = _grads(net, x, coords, B, w)
+        finally:
+            fused.TRAIN_COMPACT = True
+    (o1, gx1, gp1), (o2, gx2, gp2) = res[True], res[False]
+    for a, b, what in [(o1, o2, "output"), (gx1, gx2, "input gradient")] + [(gp1[k], gp2[k], k) for k in gp2]:
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-4 * scale, what
+
+
 def test_training_gradients_are_bit_identical_run_to_run():
     """Segmented sums in a fixed order instead of atomics: two backward passes of the same step agree bit for bit
     (input gradient and every parameter gradient), at a size where atomics would reorder (20k points x 2)."""

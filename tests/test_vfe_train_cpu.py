@@ -53,5 +53,6 @@ def test_eval_mode_stays_forward_only_and_train_mode_moves_the_statistics(golden
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs the MI355X")
 def test_training_step_matches_the_reference_run_on_the_gpu(golden_dir):
     _check(*_step(golden_dir, "cuda"))
