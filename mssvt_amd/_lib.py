@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmssvt_hip.so")
+# MSSVT_LIB: another build of the same library (the schedule variants of mssvt_amd/build.py, for the hazard test)
+LIB_PATH = os.environ.get("MSSVT_LIB") or os.path.join(_HERE, "lib", "libmssvt_hip.so")
 
 _lib = None
 

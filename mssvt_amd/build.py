@@ -25,6 +25,20 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
+# Schedule variants of the translation units that issue matrix instructions (tests/test_mfma_schedules_gpu.py): the same
+# sources under another optimisation level / without the post-RA scheduler.  A result that is "right by the luck of the
+# schedule" (a sum read before its last matrix instruction has landed) differs between them; every
+# variant must reproduce the default library's outputs.  Only the listed files are recompiled, the rest is re-linked.
+MFMA_SOURCES = ("block_attn.hip", "block_attn_bf16.hip", "compress_fused.hip", "compress_ws.hip", "ffn.hip",
+                "linear_rows.hip", "linear_wgrad.hip")
+VARIANTS = {"O2": ["-O2"], "nopost": ["-mllvm", "-enable-post-misched=false"]}
+VARIANT_DIR = os.path.join(LIB_DIR, "variants")
+
+
+def variant_path(tag):
+    return os.path.join(VARIANT_DIR, "libmssvt_hip_%s.so" % tag)
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -46,7 +60,7 @@ def build(force=False, verbose=False):
     # objects (and compiler temporaries) whose source is gone must not linger beside the library
     keep = {os.path.basename(s) + ".o" for s in sources()} | {os.path.basename(LIB_PATH)}
     for name in os.listdir(LIB_DIR):
-        if name not in keep and (".hip.o" in name):
+        if name not in keep and (".hip.o" in name) and os.path.isfile(os.path.join(LIB_DIR, name)):
             os.remove(os.path.join(LIB_DIR, name))
     objs = []
     procs = []
@@ -71,5 +85,35 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_variants(force=False):
+    """The schedule-variant libraries {tag: path} (built after `build()`, whose objects the other sources reuse)."""
+    build()
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    out = {}
+    for tag, extra in VARIANTS.items():
+        path = variant_path(tag)
+        out[tag] = path
+        if not force and os.path.exists(path) and os.path.getmtime(path) >= os.path.getmtime(LIB_PATH):
+            continue
+        procs, objs = [], []
+        for src in sources():
+            base = os.path.basename(src)
+            if base not in MFMA_SOURCES:
+                objs.append(os.path.join(LIB_DIR, base + ".o"))
+                continue
+            obj = os.path.join(VARIANT_DIR, "%s.%s.o" % (base, tag))
+            objs.append(obj)
+            procs.append((src, subprocess.Popen([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj], stdout=subprocess.PIPE,
+                                                stderr=subprocess.STDOUT)))
+        for src, p in procs:
+            o, _ = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError("hipcc failed for %s (%s):\n%s" % (src, tag, o.decode()))
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", path] + objs)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--variants" in sys.argv:
+        print(build_variants(force="--force" in sys.argv))

@@ -905,9 +905,12 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
             f32x4 sc[KT], sc2[KT];
 #pragma unroll
             for (int t = 0; t < KT; ++t) sc[t] = sc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // Tiles in DESCENDING order, tile 0 (never empty: slot 0 of a list is never masked) unconditionally and
+            // last: the reads below then follow a chain in straight-line code -- behind a branch that skips the tail
+            // of the chain the compiler's padding came out one wait state short (tools/mfma_hazard_check.py)
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                if (!(used >> t & 1)) continue;
+            for (int t = KT - 1; t >= 0; --t) {
+                if (t > 0 && !(used >> t & 1)) continue;
 #pragma unroll
                 for (int S = 0; S < NT; S += 2) {
 #pragma unroll
@@ -949,8 +952,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, 2) k_attn_kv(AttnP
 #pragma unroll
             for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                if (!(used >> t & 1)) continue;
+            for (int t = KT - 1; t >= 0; --t) {  // (descending, tile 0 unconditionally: as for the scores)
+                if (t > 0 && !(used >> t & 1)) continue;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float pv = sc[t][i] * inv;

@@ -266,12 +266,15 @@ __device__ __forceinline__ void cmp_query_body(const CmpArgs &a, int block_id, i
             acc[u] = f32x4{b.x, b.y, b.z, b.w};
         }
         cf_gemm_x<H, NT, LS>(acc, Wq_l, m, la, g);
+        // the first read of the sums in straight-line code BEHIND the chain, not inside the predicated store region
+        // (tools/mfma_hazard_check.py: a wave that skips the region reaches the next tile's register writes early)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[u] = acc[u] * a.scale;
         if (live) {
             float *dst = a.qp + (size_t)w * C + 4 * g;
 #pragma unroll
             for (int u = 0; u < NT; ++u)
-                *reinterpret_cast<float4 *>(dst + 16 * u) =
-                    make_float4(acc[u][0] * a.scale, acc[u][1] * a.scale, acc[u][2] * a.scale, acc[u][3] * a.scale);
+                *reinterpret_cast<float4 *>(dst + 16 * u) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
         }
     }
 }
@@ -508,11 +511,15 @@ __global__ void __launch_bounds__(CFO_NW *MSSVT_WAVE) k_cmp_out(CmpArgs a) {
         }
         f32x4 acc[NT];
 #pragma unroll
+        for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cf_gemm_x<H, NT, LS>(acc, Wo_l, o, la, g);
+        // bias BEHIND the product: the first read of the sums is straight-line code, not the predicated store region
+        // (tools/mfma_hazard_check.py: a wave that skips the region reaches the next tile's register writes early)
+#pragma unroll
         for (int u = 0; u < NT; ++u) {
             const float4 b = *reinterpret_cast<const float4 *>(bo_l + 16 * u + 4 * g);
-            acc[u] = f32x4{b.x, b.y, b.z, b.w};
+            acc[u] = acc[u] + f32x4{b.x, b.y, b.z, b.w};
         }
-        cf_gemm_x<H, NT, LS>(acc, Wo_l, o, la, g);
         if (live) {
             float *dst = a.out + (size_t)w * C + 4 * g;
 #pragma unroll
