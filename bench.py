@@ -58,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--ffn-arith", choices=["f16x3", "f32"], default=None,
                     help="matrix products of the FFN / CompressBlock: split-fp16 operands (default) or the fp32 MFMA")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="frames in flight (mssvt_amd/pipeline.py: consecutive frames are independent; each runs on its own HIP "
+                         "stream with its own workspace); 1: one frame at a time on one stream, as every round before round 5")
     ap.add_argument("--frames", type=int, default=4,
                     help="distinct resident frames the steps rotate over (1: the same frame from the same addresses every step)")
     return ap.parse_args(argv)
@@ -275,6 +278,7 @@ def main():
         turn[0] += 1
         return f[2], f[3]
 
+    step_alone = None
     if args.train:
         net.train()
         ddp = net
@@ -292,10 +296,21 @@ def main():
     else:
         net.eval()
 
-        def step():
+        def step_alone():
             vc_, feats_ = next_frame()
             with torch.no_grad():
                 return net(dict(voxel_features=feats_, voxel_coords=vc_, batch_size=args.batch))
+        step = step_alone
+        if args.in_flight > 1:
+            from mssvt_amd.pipeline import FramePipeline
+            pipe = FramePipeline(net, depth=args.in_flight, device=dev)
+
+            def step():
+                vc_, feats_ = next_frame()
+                return pipe(dict(voxel_features=feats_, voxel_coords=vc_, batch_size=args.batch))
+            for _ in range(args.in_flight):  # every stream's frame object and workspace exist before anything is timed
+                step()
+            torch.cuda.synchronize()
     impl = net.backbone[0].impl
     # which host path issued the timed frames: the whole-frame C call (mssvt_amd/frame.py) or the Python-driven path
     from mssvt_amd import frame as _frame
@@ -317,7 +332,14 @@ def main():
     elapsed, out = mdist.timed_steps(step, args.steps, dist, dev)
     # SURVEY 8(d) protocol beside the driver's K-step clock: every step between two HIP events
     # (a training step is collective -- every rank takes part; the forward is not, rank 0 measures alone)
-    times = per_step_times_ms(step, max(50, args.steps)) if (rank == 0 or args.train) else None
+    # (one frame at a time on one stream: a step's duration = its latency; the pipelined steps overlap)
+    one = step_alone or step
+    times = per_step_times_ms(one, max(50, args.steps)) if (rank == 0 or args.train) else None
+    alone = None
+    if step_alone is not None and step is not step_alone and rank == 0:
+        for _ in range(3):
+            step_alone()
+        alone, _ = mdist.timed_steps(step_alone, args.steps, None, dev)
     # live roofline: the same K steps once more on rank 0 with HIP events around every launch of the
     # dominant kernel (kept out of the timed region above: the event markers cost ~3 % of the frame rate)
     live = None
@@ -326,7 +348,7 @@ def main():
         from mssvt_amd import fused
         fused.FFN_TIMER = []
         for _ in range(args.steps):
-            step()
+            one()
         torch.cuda.synchronize()
         live = fused.ffn_timer_summary(fused.FFN_TIMER)
         fused.FFN_TIMER = None
@@ -334,7 +356,8 @@ def main():
     if rank == 0:
         if not args.train:  # frame 0 once more (outside every timed region): the output cpu_baseline checks against the oracle
             turn[0] = 0
-            out = step()
+            out = one()
+            torch.cuda.synchronize()
         sp_out = out["encoded_spconv_tensor"]
         ms = 1e3 * elapsed / args.steps
         res = {
@@ -350,6 +373,7 @@ def main():
                        "impl": impl, "attn_dtype": args.attn_dtype, "attn_arith": attn_arith_name(net, args.attn_dtype),
                        "ffn_arith": ffn_arith_name(net), "host_path": host_path(),
                        "voxels_per_gpu": int(vc.shape[0]),
+                       "frames_in_flight": 1 if (args.train or args.in_flight <= 1) else args.in_flight,
                        "frames_rotated": len(frames), "voxels_per_frame": [int(f[2].shape[0]) for f in frames],
                        "output_voxels": int(sp_out.features.shape[0]),
                        "parallelism": "scenes sharded over %d GPU(s), %s" % (
@@ -360,6 +384,12 @@ def main():
                        "p90_ms": times[(len(times) * 9) // 10], "frames_per_s_at_median":
                            args.batch / (times[len(times) // 2] * 1e-3)},
         }
+        if alone is not None:
+            res["one_frame_in_flight"] = {
+                "value": args.batch * args.steps / alone, "ms_per_step": 1e3 * alone / args.steps,
+                "note": "the same %d steps one at a time on one stream (what rounds 1-4 reported as value); the headline keeps %d "
+                        "independent frames in flight, each on its own HIP stream and workspace (mssvt_amd/pipeline.py; every "
+                        "frame bit-identical to the frame run alone: tests/test_pipeline_gpu.py)" % (args.steps, args.in_flight)}
         if std and not args.no_roofline:
             res["roofline"] = roofline.measure(net, vc, feats, args.batch, event_time_ms, HBM_PEAK_GBS, live=live,
                                                ms_per_step=ms)

@@ -44,7 +44,6 @@ class _Frame(object):
         self.handle = h.value
         self.keep = []  # tensors / ctypes arrays whose addresses the frame object holds
         self.workspace = None
-        self.last_stream = None
         self.words = (ctypes.c_int * _WORDS)()
 
     def __del__(self):
@@ -111,7 +110,7 @@ def _structure_ok(net):
     hd = cmp_blk.ms_attn.per_head_dim
     if not (hd <= 64 and (hd & (hd - 1)) == 0 and max(cmp_blk.ms_attn.scale_dims) <= 128):
         return _no("CompressBlock head dimension")
-    if not fused._compress_fused_ok(cmp_blk, None, C) or cmp_blk.win2_size is not None:
+    if not fused._compress_fused_ok(cmp_blk, None, C) or cmp_blk.win2_size is not None or not fused._table_covers_window(cmp_blk):
         return _no("CompressBlock not covered by the fused kernels")
     w = cmp_blk.win1_size
     t = cmp_blk.vox_query_table['win1'].cpu()
@@ -194,13 +193,15 @@ def _build(net, dev, batch_size):
     return fr
 
 
-def _state(net, feats, batch_size):
-    """(frame object or None) for this network / device / batch size, rebuilt when a parameter moved or changed."""
+def _state(net, feats, batch_size, stream=0):
+    """(frame object or None) for this network / device / batch size AND HIP stream, rebuilt when a parameter moved or
+    changed.  One frame object -- persistent workspace, pinned status words, events -- per stream: forwards of the same
+    network on different streams (several frames in flight, mssvt_amd/pipeline.py) share nothing they write."""
     st = net.__dict__.get("_frame_state")
     skey = tuple((b.__class__, b.cbs_pattern, b.use_feature_interpolation, b.plan_key(), b.max_num_wins, b.key_num_sample)
                  for b in net.backbone)
     if st is None or st["skey"] != skey:
-        st = net.__dict__["_frame_state"] = dict(skey=skey, ok=_structure_ok(net), params=_params(net), key=None, frame=None)
+        st = net.__dict__["_frame_state"] = dict(skey=skey, ok=_structure_ok(net), params=_params(net), key=None, frames={})
         st["why"] = None if st["ok"] else _why[0]
     if not st["ok"]:
         return None
@@ -212,16 +213,21 @@ def _state(net, feats, batch_size):
                   getattr(b, "attn_kv16", None), getattr(b, "attn_qo16", None), b._table_sig,
                   b.vox_query_table['win1'].data_ptr()) for b in net.backbone)) + fused._content_key(ps)
     if st["key"] != key:
+        st["frames"] = {}
+        st["key"] = key
+    if stream not in st["frames"]:
+        if len(st["frames"]) >= 8:  # streams come and go: do not keep a workspace for each one ever seen
+            st["frames"].pop(next(iter(st["frames"])))
         with torch.no_grad():
             try:
-                st["frame"] = _build(net, feats.device, batch_size)
+                fr = _build(net, feats.device, batch_size)
             except _lib.MssvtHipError as e:
                 if "status -2" not in str(e):  # MSSVT_E_TOOLARGE: a shape the frame call does not cover -> Python path
                     raise
-                st["frame"] = _no("a shape the frame call does not cover (MSSVT_E_TOOLARGE)", None)
-        st["why"] = None if st["frame"] is not None else _why[0]
-        st["key"] = key
-    return st["frame"]
+                fr = _no("a shape the frame call does not cover (MSSVT_E_TOOLARGE)", None)
+        st["frames"][stream] = fr
+        st["why"] = None if fr is not None else _why[0]
+    return st["frames"][stream]
 
 
 def invalidate(net):
@@ -240,18 +246,13 @@ def forward(net, feats, coords, batch_size):
     n = feats.shape[0]
     if n <= 0 or coords.shape[0] != n:
         return None
-    fr = _state(net, feats, batch_size)
+    cur = _lib.stream()
+    cur = getattr(cur, "value", cur) or 0
+    fr = _state(net, feats, batch_size, cur)
     if fr is None:
         return _declined(net, net.__dict__["_frame_state"].get("why") or "not eligible")
     if feats.shape[1] != net.backbone[0].linear1.in_features:
         return _declined(net, "feature width differs from the first Block's")
-    # one persistent workspace + one pinned words buffer per network: frames are kept apart by STREAM ORDER.  A call on
-    # another stream first waits for everything queued before (rare; one caller thread per network, as in the reference)
-    cur = _lib.stream()
-    cur = getattr(cur, "value", cur)
-    if fr.last_stream is not None and fr.last_stream != cur:
-        torch.cuda.synchronize(feats.device)
-    fr.last_stream = cur
     indices = coords if coords.dtype == torch.int32 and coords.is_contiguous() else coords.int().contiguous()
     dev = feats.device
     C = feats.shape[1]

@@ -1085,7 +1085,25 @@ def _interp_table(block, sp, p, q_ind, nq, upd_ind, n_upd, owner, interp, vs3, m
     return tabs[key]
 
 
+def _table_covers_window(block):
+    """True when the win1 table lists every cell of the window itself (what the generated tables do).  A custom table that
+    omits cells can leave a non-empty window with an EMPTY key list; the reference then averages the 32 padded slots
+    (uniform softmax over -100-masked scores, ref mssvt_utils.py:129-134) -- the compact kernels here do not restate that
+    corner: such a block runs the operator path (which does)."""
+    t = block.vox_query_table['win1']
+    c = block.__dict__.get("_cover_cache")
+    if c is None or c[0] is not t:
+        have = set(map(tuple, t.cpu().tolist()))
+        w = [int(v) for v in block.win1_size]
+        need = ((x, y, z) for x in range(-(w[0] // 2), w[0] - w[0] // 2) for y in range(-(w[1] // 2), w[1] - w[1] // 2)
+                for z in range(-(w[2] // 2), w[2] - w[2] // 2))
+        c = block.__dict__["_cover_cache"] = (t, all(cell in have for cell in need))
+    return c[1]
+
+
 def compress_supported(block, sp):
+    if not _table_covers_window(block):
+        return False
     if torch.is_grad_enabled() and (sp.features.requires_grad or any(p.requires_grad for p in block.parameters())):
         return False
     if sp.features.dtype != torch.float32 or not sp.features.is_cuda:

@@ -858,7 +858,8 @@ def block_forward(block, sp):
 def compress_supported(block, sp):
     ma = block.ms_attn
     return (sp.features.is_cuda and sp.features.dtype == torch.float32 and ma.num_head_groups == 1
-            and sp.features.shape[1] % 4 == 0 and len(block.pos_proj) >= 3 and _pair_attention_covers(ma))
+            and sp.features.shape[1] % 4 == 0 and len(block.pos_proj) >= 3 and _pair_attention_covers(ma)
+            and fused._table_covers_window(block))
 
 
 @torch.no_grad()

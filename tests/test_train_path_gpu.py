@@ -90,8 +90,11 @@ def test_compact_training_path_with_overlapping_custom_tables(which):
     else:
         blk = net.backbone[2]
         t = {k: v.clone().cpu() for k, v in blk.vox_query_table.items()}
-        t["win1"][::4, 0] = 1  # every fourth cell of the pillar comes from the neighbouring column
+        # the pillar's own cells + eight cells of the neighbouring column: a voxel there is on two windows' lists
+        extra = torch.tensor([[1, 0, z] for z in range(-4, 4)], dtype=t["win1"].dtype)
+        t["win1"] = torch.cat([t["win1"][:12], extra, t["win1"][12:]], 0)
         blk.set_vox_query_table(t)
+        assert fused._table_covers_window(blk)
     vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(4000, B, 11))
     coords = torch.from_numpy(vc).to(DEV)
     x = torch.randn(vc.shape[0], C, device=DEV)
@@ -108,6 +111,32 @@ def test_compact_training_path_with_overlapping_custom_tables(which):
     for a, b, what in [(o1, o2, "output"), (gx1, gx2, "input gradient")] + [(gp1[k], gp2[k], k) for k in gp2]:
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 2e-4 * scale, what
+
+
+def test_a_table_that_leaves_windows_without_keys_takes_the_operator_path():
+    """A custom win1 table that omits cells of the window can leave a non-empty window with an empty key list: the reference
+    averages the padded slots there (uniform softmax over -100-masked scores), which only the operator path restates --
+    the compact kernels must decline such a block, with and without autograd."""
+    from mssvt_amd import fused
+    C, B, H = 32, 2, 40009
+    net = _net(C, _params(C, [2, 2], [4]), H)
+    blk = net.backbone[2]
+    t = {k: v.clone().cpu() for k, v in blk.vox_query_table.items()}
+    t["win1"][::4, 0] = 1  # every fourth cell of the pillar is looked up in the neighbouring column instead
+    blk.set_vox_query_table(t)
+    assert not fused._table_covers_window(blk)
+    vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(4000, B, 11))
+    coords = torch.from_numpy(vc).to(DEV)
+    x = torch.randn(vc.shape[0], C, device=DEV)
+    with torch.no_grad():
+        got = net(dict(voxel_features=x, voxel_coords=coords, batch_size=B))["encoded_spconv_tensor"].features
+    xg = x.clone().requires_grad_(True)
+    got_g = net(dict(voxel_features=xg, voxel_coords=coords, batch_size=B))["encoded_spconv_tensor"].features
+    net.set_impl("ops")
+    with torch.no_grad():
+        want = net(dict(voxel_features=x, voxel_coords=coords, batch_size=B))["encoded_spconv_tensor"].features
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= 2e-4 * scale and float((got_g.detach() - want).abs().max()) <= 2e-4 * scale
 
 
 def test_training_gradients_are_bit_identical_run_to_run():

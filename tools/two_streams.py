@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Frames of a stream of scenes are independent: how much throughput do two frames in flight (two HIP streams, one
+persistent workspace each) buy over one?  python tools/two_streams.py [--batch 1] [--steps 100]"""
+import argparse
+import copy
+import os
+import sys
+import time
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from mssvt_amd import config  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--streams", type=int, default=2)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    cfg = config.load_yaml(config.DEFAULT_CFG)
+    net = config.build_backbone_from_cfg(cfg).to(dev).eval()
+    nets = [net] + [copy.deepcopy(net) for _ in range(a.streams - 1)]
+    streams = [torch.cuda.Stream() for _ in range(a.streams)]
+    frames = [bench.make_inputs(160000, a.batch, 0, dev, frame=f) for f in range(4)]
+
+    def run(n_streams, steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            f = frames[i % len(frames)]
+            k = i % n_streams
+            with torch.cuda.stream(streams[k]), torch.no_grad():
+                nets[k](dict(voxel_features=f[3], voxel_coords=f[2], batch_size=a.batch))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    for n in range(1, a.streams + 1):
+        run(n, 20)
+        t = min(run(n, a.steps) for _ in range(3))
+        print("%d stream(s): %.3f ms per step, %.0f frames/s" % (n, t * 1e3, a.batch / t))
+
+
+if __name__ == "__main__":
+    main()
