@@ -307,7 +307,8 @@ def main():
 
             def step():
                 vc_, feats_ = next_frame()
-                return pipe(dict(voxel_features=feats_, voxel_coords=vc_, batch_size=args.batch))
+                # (the frames are resident and complete before the timed region: nothing on this stream to wait for)
+                return pipe(dict(voxel_features=feats_, voxel_coords=vc_, batch_size=args.batch), inputs_ready=True)
             for _ in range(args.in_flight):  # every stream's frame object and workspace exist before anything is timed
                 step()
             torch.cuda.synchronize()

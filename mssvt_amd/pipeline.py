@@ -26,13 +26,16 @@ class FramePipeline(object):
     def depth(self):
         return len(self.streams)
 
-    def __call__(self, batch_dict):
+    def __call__(self, batch_dict, inputs_ready=False):
         """Enqueue one forward on the next stream and return its output dict (as `net(batch_dict)`, plus "stream": the
         stream its tensors are produced on -- a consumer on another stream waits for it: `cur.wait_stream(out["stream"])`).
-        The inputs may come from the caller's current stream: the frame's stream waits for what is queued there now."""
+        The inputs may come from the caller's current stream: the frame's stream first waits for what is queued there now,
+        unless `inputs_ready` says they are complete already (resident frames: the event pair on the default stream costs
+        4 % of the frame rate at two frames in flight, tools/two_streams.py)."""
         s = self.streams[self.turn % len(self.streams)]
         self.turn += 1
-        s.wait_stream(torch.cuda.current_stream(self.device))
+        if not inputs_ready:
+            s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s), torch.no_grad():
             out = self.net(batch_dict)
         out["stream"] = s

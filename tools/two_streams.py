@@ -44,7 +44,30 @@ def main():
     for n in range(1, a.streams + 1):
         run(n, 20)
         t = min(run(n, a.steps) for _ in range(3))
-        print("%d stream(s): %.3f ms per step, %.0f frames/s" % (n, t * 1e3, a.batch / t))
+        print("%d stream(s), one network copy each: %.3f ms per step, %.0f frames/s" % (n, t * 1e3, a.batch / t))
+    from mssvt_amd.pipeline import FramePipeline
+
+    def run_pipe(pipe, steps, wait=True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            f = frames[i % len(frames)]
+            if wait:
+                pipe(dict(voxel_features=f[3], voxel_coords=f[2], batch_size=a.batch))
+            else:
+                s = pipe.streams[i % pipe.depth]
+                with torch.cuda.stream(s), torch.no_grad():
+                    net(dict(voxel_features=f[3], voxel_coords=f[2], batch_size=a.batch))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    for n in range(1, a.streams + 1):
+        pipe = FramePipeline(net, depth=n)
+        for wait in (True, False):
+            run_pipe(pipe, 20, wait)
+            t = min(run_pipe(pipe, a.steps, wait) for _ in range(3))
+            print("FramePipeline depth %d (%s): %.3f ms per step, %.0f frames/s" %
+                  (n, "wait_stream" if wait else "no wait_stream", t * 1e3, a.batch / t))
 
 
 if __name__ == "__main__":
