@@ -52,11 +52,23 @@ def parse(argv=None):
     ap.add_argument("--attn-dtype", default="f32", choices=["f32", "bf16"],
                     help="operand type of the window-attention matrix products (accumulation and softmax stay fp32)")
     ap.add_argument("--train", action="store_true", help="DDP training step instead of the inference forward")
+    ap.add_argument("--detector", action="store_true",
+                    help="with --train: the whole CenterPoint detector (DynamicVFE -> backbone -> HeightCompression -> BEV backbone -> "
+                         "CenterHead losses) under DistributedDataParallel, points + synthetic boxes in (ref tools/train.py:143-144)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="with --detector: BatchNorm layers -> SyncBatchNorm before the DDP wrap (ref tools/train.py:118-119)")
     ap.add_argument("--cfg", default=None, help="backbone yaml (default: mssvt_amd/cfgs/mssvt.yaml = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ffn-arith", choices=["f16x3", "f32"], default=None,
                     help="matrix products of the FFN / CompressBlock: split-fp16 operands (default) or the fp32 MFMA")
+    ap.add_argument("--arith", choices=["split16", "f32"], default="split16",
+                    help="every matrix product of the fp32 path: fp32 operands as two fp16 halves on the 16-bit MFMA (default), "
+                         "or f32 = the native v_mfma_f32_16x16x4_f32 in the FFN, the CompressBlock AND the three attention "
+                         "launches (the reference's own operand width; the comparator line kept beside the headline)")
+    ap.add_argument("--from-points", action="store_true",
+                    help="a step = points -> voxelizer + DynamicVFE -> backbone -> dense() / HeightCompression view (SURVEY 8 f1, "
+                         "f2: the neighbours either side of the path), with its own algorithmic bytes; not the BASELINE metric")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="frames in flight (mssvt_amd/pipeline.py: consecutive frames are independent; each runs on its own HIP "
@@ -223,6 +235,10 @@ def attn_arith_name(net, attn_dtype):
 
 
 def workload_name(args, cfg_given):
+    if args.train and getattr(args, "detector", False):
+        return ("CenterPoint detector training step (mssvt.yaml: DynamicVFE + MsSVT backbone + BEV backbone + CenterHead), %d-point "
+                "scenes x batch %d per GPU with 12 synthetic boxes each, fp32, forward + loss + backward + all-reduce + SGD%s"
+                % (args.points, args.batch, ", SyncBatchNorm" if args.sync_bn else ""))
     if cfg_given:
         return "%s: %d-point scene x batch %d per GPU" % (os.path.basename(args.cfg), args.points, args.batch)
     base = ("%d-point Waymo-shaped scene x batch %d per GPU, full mssvt.yaml backbone (4 Blocks [3,3,5]/[7,7,7] cbs "
@@ -267,6 +283,10 @@ def main():
     if args.ffn_arith:
         from mssvt_amd import fused as _fused
         _fused.FFN_ARITH = args.ffn_arith
+    if args.arith == "f32":
+        from mssvt_amd import fused as _fused
+        _fused.FFN_ARITH = "f32"  # FFN tails + CompressBlock products
+        _fused.ATTN_KV16 = _fused.ATTN_QO16 = False  # k_attn_q / k_attn_kv / k_attn_o on v_mfma_f32_16x16x4_f32
     # the steps rotate over `--frames` different frames, all resident in HBM before the timed region: replaying ONE frame
     # from the same addresses would keep its 38 MB of input in the Infinity Cache, which a stream of frames does not
     frames = [make_inputs(args.points, args.batch, rank, dev, frame=f) for f in range(max(args.frames, 1))]
@@ -279,7 +299,35 @@ def main():
         return f[2], f[3]
 
     step_alone = None
-    if args.train:
+    det = None
+    if args.train and args.detector:
+        # the reference's training wrap (tools/train.py:118-119,143-144): SyncBatchNorm conversion of EVERY BatchNorm layer
+        # (DynamicVFE's BatchNorm1d, the BEV backbone's and the head's BatchNorm2d), then DDP around the whole model
+        from mssvt_amd import centerpoint, detector_data
+        torch.manual_seed(0)
+        det = centerpoint.build_detector(cfg).to(dev)
+        det.backbone_3d.load_state_dict(net.state_dict())
+        if args.impl:
+            det.backbone_3d.set_impl(args.impl)
+        if args.sync_bn:
+            det = torch.nn.SyncBatchNorm.convert_sync_batchnorm(det)
+        det.train()
+        ddp = det
+        if dist:
+            ddp = torch.nn.parallel.DistributedDataParallel(det, device_ids=None if one_dev else [dev.index])
+        opt = torch.optim.SGD(det.parameters(), lr=1e-4)
+        scenes = [detector_data.make_scene(args.points, args.batch, rank, dev, frame=f) for f in range(max(args.frames, 1))]
+        net = det.backbone_3d
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            pts_, gt_ = scenes[turn[0] % len(scenes)]
+            turn[0] += 1
+            ret, tb, _ = ddp(dict(points=pts_, batch_size=args.batch, gt_boxes=gt_))
+            ret["loss"].backward()  # gradients all-reduced here
+            opt.step()
+            return dict(ret, encoded_spconv_tensor=None)
+    elif args.train:
         net.train()
         ddp = net
         if dist:
@@ -312,6 +360,38 @@ def main():
             for _ in range(args.in_flight):  # every stream's frame object and workspace exist before anything is timed
                 step()
             torch.cuda.synchronize()
+    points_line = None
+    if args.from_points and not args.train:
+        import numpy as np
+        from mssvt_amd import synthetic
+        from mssvt_amd.dist import scene_seeds
+        from mssvt_amd.dynamic_vfe import DynamicVFE
+        from mssvt_amd.height_compression import HeightCompression
+        torch.manual_seed(1)
+        vfe = DynamicVFE(cfg.MODEL.VFE, 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.POINT_CLOUD_RANGE).to(dev).eval()
+        to_bev = HeightCompression(config.Config.wrap(dict(NUM_BEV_FEATURES=128, COMPRESS_LAYER_NUMS=0))).to(dev).eval()
+        clouds = [torch.from_numpy(synthetic.make_batch_points(
+            args.points, args.batch, seed0=scene_seeds(rank, args.batch)[0] + 7919 * f)).to(dev) for f in range(len(frames))]
+
+        def step_points():
+            pts = clouds[turn[0] % len(clouds)]
+            turn[0] += 1
+            with torch.no_grad():
+                bd = vfe(dict(points=pts, batch_size=args.batch))
+                bd = net(bd)
+                return to_bev(bd)
+        step = step_alone = step_points
+        args.in_flight = 1  # (one stream: the framework ops of the PFN layers run on the current stream)
+        with torch.no_grad():
+            bd0 = vfe(dict(points=clouds[0], batch_size=args.batch))
+        n_vox, n_pts = int(bd0["voxel_coords"].shape[0]), int(clouds[0].shape[0])
+        # SURVEY 8(d)-style algorithmic bytes of the two neighbours: the point rows read once + the point -> voxel index
+        # written; per PFN layer its per-point output read once by the max reduction + the reduced rows written; the dense
+        # (B, C, Z, Y, X) grid written once + the output rows read
+        f_out = list(cfg.MODEL.VFE.NUM_FILTERS)
+        vfe_bytes = n_pts * (4.0 * clouds[0].shape[1] + 4.0) + sum(4.0 * f * (n_pts + n_vox) for f in f_out)
+        by_bb, _, _ = roofline.frame_algorithmic(net, bd0["voxel_coords"], bd0["voxel_features"], args.batch)
+        points_line = dict(points=n_pts, voxels=n_vox, vfe_bytes=vfe_bytes, backbone_bytes=by_bb)
     impl = net.backbone[0].impl
     # which host path issued the timed frames: the whole-frame C call (mssvt_amd/frame.py) or the Python-driven path
     from mssvt_amd import frame as _frame
@@ -344,7 +424,7 @@ def main():
     # live roofline: the same K steps once more on rank 0 with HIP events around every launch of the
     # dominant kernel (kept out of the timed region above: the event markers cost ~3 % of the frame rate)
     live = None
-    std = rank == 0 and impl == "fused" and not args.cfg and not args.train
+    std = rank == 0 and impl == "fused" and not args.cfg and not args.train and not args.from_points
     if std and not args.no_roofline:
         from mssvt_amd import fused
         fused.FFN_TIMER = []
@@ -356,11 +436,14 @@ def main():
 
     if rank == 0:
         if not args.train:  # frame 0 once more (outside every timed region): the output cpu_baseline checks against the oracle
+            one = step_alone or step
             turn[0] = 0
             out = one()
             torch.cuda.synchronize()
         sp_out = out["encoded_spconv_tensor"]
         ms = 1e3 * elapsed / args.steps
+        n_bn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in det.modules()) if det is not None else 0
+        n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in det.modules()) if det is not None else 0
         res = {
             "metric": "frames/sec (MsSVT backbone %s, synthetic Waymo-shaped scenes)"
                       % ("DDP training step" if args.train else "forward"),
@@ -372,11 +455,15 @@ def main():
             "dtype": "bf16" if args.attn_dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": workload_name(args, bool(args.cfg)),
                        "impl": impl, "attn_dtype": args.attn_dtype, "attn_arith": attn_arith_name(net, args.attn_dtype),
-                       "ffn_arith": ffn_arith_name(net), "host_path": host_path(),
+                       "ffn_arith": ffn_arith_name(net), "arith": args.arith, "host_path": host_path(),
                        "voxels_per_gpu": int(vc.shape[0]),
                        "frames_in_flight": 1 if (args.train or args.in_flight <= 1) else args.in_flight,
                        "frames_rotated": len(frames), "voxels_per_frame": [int(f[2].shape[0]) for f in frames],
-                       "output_voxels": int(sp_out.features.shape[0]),
+                       "output_voxels": int(sp_out.features.shape[0]) if sp_out is not None else None,
+                       "detector": None if det is None else {
+                           "model": "CenterPoint: DynamicVFE -> MixedScaleSparseTransformer -> HeightCompression -> BaseBEVBackbone -> "
+                                    "CenterHead (targets + losses), the whole model under DDP", "loss": float(out["loss"]),
+                           "batch_norm_layers": n_bn, "sync_batch_norm_layers": n_sync},
                        "parallelism": "scenes sharded over %d GPU(s), %s" % (
                            world, "DDP gradient all-reduce (%s)" % backend if args.train else "no data-path collective"),
                        "process_group": {"backend": backend if dist else None, "world_size": seen_world}},
@@ -385,6 +472,19 @@ def main():
                        "p90_ms": times[(len(times) * 9) // 10], "frames_per_s_at_median":
                            args.batch / (times[len(times) // 2] * 1e-3)},
         }
+        if points_line is not None:
+            bev = out["spatial_features"]
+            dense_bytes = 4.0 * bev.numel() + 4.0 * sp_out.features.numel()
+            tot = points_line["vfe_bytes"] + points_line["backbone_bytes"] + dense_bytes
+            res["metric"] = "frames/sec (points -> voxelizer + DynamicVFE -> MsSVT backbone -> dense BEV, synthetic Waymo-shaped scenes)"
+            res["config"]["workload"] = "points -> BEV (SURVEY 8 f1 + path + f2): " + res["config"]["workload"]
+            res["from_points"] = dict(points_line, dense_bytes=dense_bytes, algorithmic_bytes=tot,
+                                      hbm_floor_us=tot / (HBM_PEAK_GBS * 1e9) * 1e6,
+                                      frac=tot / (HBM_PEAK_GBS * 1e9) * 1e3 / ms, bev_shape=list(bev.shape),
+                                      note="DynamicVFE: device voxelizer (bitmap + popcount rank) + HIP reductions, PFN Linear / "
+                                           "BatchNorm1d through the framework (ref dynamic_vfe.py:71-131); dense(): k_dense_bev "
+                                           "(ref mssvt_utils.py:50-62, height_compression.py:41-50); frac = algorithmic bytes of "
+                                           "VFE + backbone + dense at 8 TB/s against ms_per_step")
         if alone is not None:
             res["one_frame_in_flight"] = {
                 "value": args.batch * args.steps / alone, "ms_per_step": 1e3 * alone / args.steps,

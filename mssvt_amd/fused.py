@@ -1476,6 +1476,11 @@ def ffn_timer_summary(samples):
     return out
 
 
+def kv16_early(blk, p):
+    return getattr(blk, "attn_dtype", "f32") != "bf16" and getattr(blk, "attn_kv16", ATTN_KV16) and \
+        _attn_kv16_ok(blk, _attn_refs(blk, None), p)
+
+
 def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
     """One Block's window attention on the bench frame against both roofs: algorithmic bytes (window metadata, valid key
     rows Cg wide, query rows in + attention rows out C wide -- the Q~ / Xbar hand-off of the fp32 launches is this
@@ -1504,7 +1509,9 @@ def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
     bf16 = getattr(blk, "attn_dtype", "f32") == "bf16" and _attn_refs(blk, None)["bf16_ok"]
     kv16 = not bf16 and getattr(blk, "attn_kv16", ATTN_KV16) and _attn_kv16_ok(blk, _attn_refs(blk, None), p)
     names = ["k_attn_bf16"] if bf16 else ["k_attn_q", "k_attn_kv", "k_attn_o"]  # prefixes: k_attn_q16 / k_attn_kvh / k_attn_o16 too
-    peak_tf = MFMA_F16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+    # priced against the pipe the products RUN on: bf16 operands -> one 16-bit MFMA per product; split-fp16 operands ->
+    # three 16-bit MFMAs per fp32 product (3 x FLOP against the 16-bit peak); fp32 instruction -> the fp32 matrix peak
+    peak_tf = MFMA_F16_PEAK_TFLOPS if (bf16 or kv16_early(blk, p)) else MFMA_F32_PEAK_TFLOPS
     gbs = alg / (ms * 1e-3) / 1e9
     counters = {k: {kk: v.get(kk) for kk in ("hbm_bytes_per_launch", "mfma_busy_frac", "valu_issue_frac", "cycles_per_launch")}
                 for k, v in (pmc or {}).items() if isinstance(v, dict) and any(k.startswith(n) for n in names)}
@@ -1516,8 +1523,12 @@ def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
             "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs, "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": ms * 1e3, "units_per_launch": {"windows": nw, "valid_key_rows": sum(keys), "valid_query_rows": n_q},
             "matrix": {"algorithmic_flop_per_launch": flop, "tflops": flop / (ms * 1e-3) / 1e12, "peak_tflops": peak_tf,
-                       "frac": flop / (ms * 1e-3) / 1e12 / peak_tf,
-                       "operands": "bf16" if bf16 else "f32 as hi + 2^-11 lo fp16 halves, 3 x v_mfma_f32_16x16x32_f16 (priced against the fp32 matrix peak)" if kv16 else "f32"},
+                       "issued_over_algorithmic": 3.0 if kv16 else 1.0,
+                       "frac": (3.0 if kv16 else 1.0) * flop / (ms * 1e-3) / 1e12 / peak_tf,
+                       "frac_vs_f32_matrix_peak": flop / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                       "operands": "bf16" if bf16 else "f32 as hi + 2^-11 lo fp16 halves, 3 x v_mfma_f32_16x16x32_f16: frac = 3 x FLOP "
+                                   "against the 16-bit matrix peak (the pipe it runs on); frac_vs_f32_matrix_peak = the same FLOP "
+                                   "against the fp32 instruction's peak (what rounds 3-4 reported as frac)" if kv16 else "f32"},
             "pmc": counters or None,
             "note": "algorithmic bytes exclude the Q' / Xbar hand-off between the launches; pmc = per-launch means of "
                     "profiles/pmc_frame.json (HBM bytes = 2 FETCH + WRITE, MFMA-pipe and VALU-issue busy fractions)"}

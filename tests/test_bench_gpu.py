@@ -62,3 +62,29 @@ def test_bench_ffn_arith_flag_and_roofline_object():
     assert rf["bound"] == "hbm" and "k_ffn_ws" in rf["kernel"] and 0 < rf["frac"] < 1 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["frame"]["frac"] > 0
     assert any("mssvt_block_attention" in o["kernel"] for o in rf["other_kernels"])
+
+
+def test_bench_detector_training_two_ranks_and_sync_bn():
+    """ref tools/train.py:118-119,143-144: the WHOLE detector under DDP (two ranks, one device, gloo), and the SyncBatchNorm
+    conversion of every BatchNorm layer before the wrap (one rank here: gloo cannot gather device tensors, and two RCCL ranks
+    cannot share a device -- the driver's 8-GPU node runs the synchronised statistics)."""
+    res = _bench("--gpus", "2", "--train", "--detector", "--batch", "1", env={"MSSVT_BENCH_ONE_DEVICE": "1"})
+    d = res["config"]["detector"]
+    assert res["n_gpus"] == 2 and d["batch_norm_layers"] > 20 and d["sync_batch_norm_layers"] == 0 and d["loss"] > 0
+    assert "CenterPoint" in res["config"]["workload"] and "DDP" in res["config"]["parallelism"]
+    res = _bench("--train", "--detector", "--sync-bn", "--batch", "2")
+    d = res["config"]["detector"]
+    assert d["sync_batch_norm_layers"] == d["batch_norm_layers"] > 20 and d["loss"] > 0 and res["value"] > 0
+
+
+def test_bench_arith_f32_in_flight_and_from_points():
+    res = _bench("--arith", "f32", "--in-flight", "1")
+    assert res["config"]["arith"] == "f32" and "v_mfma_f32_16x16x4_f32" in res["config"]["ffn_arith"]
+    assert res["config"]["attn_arith"] == "v_mfma_f32_16x16x4_f32" and res["config"]["frames_in_flight"] == 1
+    res = _bench("--in-flight", "3")
+    assert res["config"]["frames_in_flight"] == 3 and res["one_frame_in_flight"]["value"] > 0
+    assert "mssvt_frame_forward" in res["config"]["host_path"]
+    res = _bench("--from-points")
+    fp = res["from_points"]
+    assert fp["points"] == 20000 and fp["voxels"] > 5000 and fp["bev_shape"][1] == 128 and 0 < fp["frac"] < 1
+    assert fp["algorithmic_bytes"] == fp["vfe_bytes"] + fp["backbone_bytes"] + fp["dense_bytes"]

@@ -24,8 +24,19 @@ def _worker(rank, world, port, q):
     seeds = mdist.scene_seeds(rank, 2)
     vc, _, _ = synthetic.voxelize_numpy(synthetic.make_batch_points(500, 2, seeds[0]))
 
+    net = None
+    if torch.cuda.is_available():  # the real (small) model where a device exists; the CPU box keeps the sleep below
+        from mssvt_amd import config
+        torch.manual_seed(0)
+        net = config.build_backbone_from_cfg().cuda().eval()
+        feats = torch.randn(vc.shape[0], 128).cuda()
+        coords = torch.from_numpy(vc).cuda()
+
     def step():  # rank 1 is slower: the reported time must be ITS time on both ranks
         time.sleep(0.02 * (rank + 1))
+        if net is not None:
+            with torch.no_grad():
+                return int(net(dict(voxel_features=feats, voxel_coords=coords, batch_size=2))["encoded_spconv_tensor"].features.shape[0])
         return vc.shape[0]
 
     elapsed, out = mdist.timed_steps(step, 3, d, torch.device("cpu"), sync=lambda: None)
