@@ -808,6 +808,26 @@ int mssvt_frame_forward(void *frame, int num_voxels, const float *features, cons
                         int *out_counts, void *stream);
 int mssvt_frame_wait_words(void *frame, int *host_out, int num_words);
 
+/* Y = out_scale * act(X B^T + bias) over compact rows with split-fp16 matrix operands (csrc/linear_rows_h.hip; the
+ * training path's nn.Linear forward and, with transpose_w, its input gradient dX = dY W -- ref mssvt_backbone.py:339-343,
+ * mssvt_utils.py:80-83 through autograd): B = W (N, K) row-major, or B[n][k] = W[k][n] with transpose_w (W then (K, N)).
+ * (K, N) in {(128,256), (256,128), (64,128), (128,64), (128,128), (64,64)}; ldx >= K, ldy >= N, multiples of 4.  Rows of X
+ * and the weight matrix are normalised by powers of two inside the kernel: no range precondition.                    */
+int mssvt_linear_rows_h_supported(int K, int N);
+int mssvt_linear_rows_h(int M, int K, int N, const float *X, int ldx, const float *W, int transpose_w, const float *bias,
+                        int relu, float out_scale, float *Y, int ldy, void *stream);
+
+/* ======================================================================== *
+ * Part 6 -- timing-only launches (csrc/ceiling.hip; no reference counterpart, nothing reads their output): the byte and
+ *           instruction mix of k_ffn_ws / k_attn_kvh on the frame's real tables with every dependency between the
+ *           phases removed -- the ceiling of the structure, reported by bench.py as roofline.ceiling_us.
+ * ======================================================================== */
+int mssvt_ceiling_ffn_ws(int n_rows, const float *x_in, const int *tab_row, const float *tab_w, const float *attn,
+                         const void *fragments_256k, float *y, float *y_norm, void *stream);
+int mssvt_ceiling_attn_kvh(int C, int c0_group0, int c0_group1, int K, const float *xhat, const float *kmeta0,
+                           const float *kmeta1, const int *perm, const int *num_active_dev, const int *q_off,
+                           const int *nq_valid, int row_capacity, int win_capacity, float *qbuf, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,150 @@
+// ceiling.hip -- TIMING-ONLY launches (never on the product path; results are not read by anything).
+//
+// "What can a launch of this shape reach?"  For the two kernels that own most of a frame -- k_ffn_ws (ffn.hip) and
+// k_attn_kvh (block_attn.hip) -- these kernels move the SAME bytes from and to the SAME addresses (the real tables,
+// work order and metadata of the frame), issue the SAME number of matrix instructions of the same type and the same
+// number of vector instructions per unit of work, in workgroups of the same shape and register footprint -- and remove
+// every dependency between them: no LDS hand-off, no barrier, no phase that waits for another phase's values; loads are
+// consumed by the vector filler of the SAME iteration only through one add.  The measured duration is the ceiling of the
+// structure "this instruction and byte mix on this many waves", the number bench.py reports as `roofline.ceiling_us`
+// beside the kernel's own time: the gap between the two is what the dependency chain (rows -> LDS -> product -> LDS ->
+// product -> rows; tokens -> image -> scores -> softmax -> second product) costs, the gap to the HBM roof is what the mix
+// itself costs.  ("Next round" item 1.)
+#include "common.hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+// NV independent fused multiply-adds per lane, eight chains (a chain's dependent latency is hidden by the others)
+template <int NV>
+__device__ __forceinline__ float valu_filler(float seed, float c) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = seed + (float)i;
+#pragma unroll
+    for (int k = 0; k < NV / 8; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaf(v[i], c, 1.0f);
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
+// ---- the FFN tail's mix: per 16-row tile and wave 48 v_mfma_f32_16x16x32_f16 on 128 resident fragment registers,
+// ~260 vector instructions, per row 512 B in + 3 gathered 512-B rows + 32 B of table + 2 x 512 B out ------------------
+__global__ void __launch_bounds__(512, 2) k_ceiling_ffn_ws(int n_rows, const float4 *x_in, const int4 *tab_row, const float4 *tab_w,
+                                                           const float4 *attn, const h16x8 *frags, float4 *y, float4 *yn) {
+    const int lane = lane_id(), wv = threadIdx.x / MSSVT_WAVE;
+    // the stationary fragments of k_ffn_ws: 2 x 16 h16x8 per lane (128 VGPRs), loaded once
+    h16x8 w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = frags[((size_t)wv * 32 + i) * 64 + lane];
+    const int tiles = (n_rows + 15) >> 4;
+    const int r_in_tile = threadIdx.x >> 5, piece = threadIdx.x & 31;  // lane = 4 channels of a row (32 lanes per row)
+    f32x4 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sink = 0.f;
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int row = min(t * 16 + r_in_tile, n_rows - 1);
+        const float4 x = x_in[(size_t)row * 32 + piece];
+        const int4 tr = tab_row[row];
+        const float4 tw = tab_w[row];
+        const float4 a0 = attn[(size_t)max(tr.x, 0) * 32 + piece], a1 = attn[(size_t)max(tr.y, 0) * 32 + piece],
+                     a2 = attn[(size_t)max(tr.z, 0) * 32 + piece];
+        const h16x8 bfrag = h16x8{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
+#pragma unroll
+        for (int k = 0; k < 48; ++k)
+            acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[k % 32], bfrag, acc[k % 6], 0, 0, 0);
+        const float in = ((x.x + a0.x * tw.x) + (a1.y * tw.y + a2.z * tw.z)) + (x.w + x.y);
+        const float f = valu_filler<248>(in, 0.999f);
+        sink += f;
+        y[(size_t)row * 32 + piece] = make_float4(f, in, x.z, a0.w);
+        yn[(size_t)row * 32 + piece] = make_float4(in, f, a1.w, a2.w);
+    }
+    float s = sink;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456f) y[0] = make_float4(s, s, s, s);  // (keeps the matrix results alive)
+}
+
+extern "C" int mssvt_ceiling_ffn_ws(int n_rows, const float *x_in, const int *tab_row, const float *tab_w, const float *attn,
+                                    const void *fragments_256k, float *y, float *y_norm, void *stream) {
+    if (n_rows <= 0 || !x_in || !tab_row || !tab_w || !attn || !fragments_256k || !y || !y_norm) return MSSVT_E_BADARG;
+    k_ceiling_ffn_ws<<<256, 512, 0, (hipStream_t)stream>>>(n_rows, (const float4 *)x_in, (const int4 *)tab_row, (const float4 *)tab_w,
+                                                           (const float4 *)attn, (const h16x8 *)fragments_256k, (float4 *)y,
+                                                           (float4 *)y_norm);
+    return mssvt_launch_status();
+}
+
+// ---- the window attention's mix (k_attn_kvh<64, 16, 4, 2, true>): one wave per (window, head group) of the real work
+// order; per window 32 key rows x 256 B gathered through the real metadata, 8 fp32 + 48 split-fp16 matrix instructions
+// and ~200 vector instructions per pass of 4 queries (+ ~250 per window), 16 B of Q' in and 4 x 16 B of Xbar out per lane
+// and pass ------------------------------------------------------------------------------------------------------------
+struct CeilKvh {
+    const float *xhat;
+    const float4 *kmeta[2];
+    const int *perm, *num_act, *q_off, *nq_valid;
+    float *qbuf;
+    int C, c0[2], K, row_capacity;
+};
+__global__ void __launch_bounds__(256, 3) k_ceiling_attn_kvh(CeilKvh a) {
+    const int g = blockIdx.y, lane = lane_id(), la = lane & 15, gq = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
+    const int n_act = *a.num_act, wstep = gridDim.x * 4;
+    f32x4 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sink = 0.f;
+    const h16x8 one = h16x8{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
+    for (int wi = blockIdx.x * 4 + wv; wi < n_act; wi += wstep) {
+        const int w = a.perm[wi];
+        const int nqv = a.q_off[w] + a.nq_valid[w] <= a.row_capacity ? a.nq_valid[w] : 0;
+        const size_t qbase = (size_t)a.q_off[w];
+        float4 rows[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 km = a.kmeta[g][(size_t)w * a.K + min(16 * t + la, a.K - 1)];
+            const int r = max(__builtin_bit_cast(int, km.w), 0);
+            const float4 *src = reinterpret_cast<const float4 *>(a.xhat + (size_t)r * a.C + a.c0[g]) + gq;
+#pragma unroll
+            for (int S = 0; S < 4; ++S) rows[t][S] = src[4 * S];
+        }
+        float tok = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int S = 0; S < 4; ++S) tok += rows[t][S].x + rows[t][S].w;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x4f32(tok, 1.0f, acc[k % 6], 0, 0, 0);
+        sink += valu_filler<240>(tok, 0.999f);
+        for (int q0 = 0; q0 < nqv; q0 += 4) {
+            const int q = min(q0 + la / 4, nqv - 1);
+            float4 *xrow = reinterpret_cast<float4 *>(a.qbuf + (size_t)g * a.row_capacity * 256 + (qbase + q) * 256 + (la % 4) * 64) + gq;
+            const float4 qp = xrow[0];
+#pragma unroll
+            for (int k = 0; k < 48; ++k) acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(one, one, acc[k % 6], 0, 0, 0);
+            const float f = valu_filler<200>(qp.x + qp.w, 0.999f);
+            sink += f;
+            if (q0 + la / 4 < nqv) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xrow[4 * u] = make_float4(f, qp.y, qp.z, qp.x);
+            }
+        }
+    }
+    float s = sink;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456f) a.qbuf[0] = s;
+}
+
+extern "C" int mssvt_ceiling_attn_kvh(int C, int c0_group0, int c0_group1, int K, const float *xhat, const float *kmeta0,
+                                      const float *kmeta1, const int *perm, const int *num_active_dev, const int *q_off,
+                                      const int *nq_valid, int row_capacity, int win_capacity, float *qbuf, void *stream) {
+    if (C <= 0 || K <= 0 || !xhat || !kmeta0 || !kmeta1 || !perm || !num_active_dev || !q_off || !nq_valid || !qbuf || win_capacity <= 0)
+        return MSSVT_E_BADARG;
+    CeilKvh a;
+    a.xhat = xhat; a.kmeta[0] = (const float4 *)kmeta0; a.kmeta[1] = (const float4 *)kmeta1;
+    a.perm = perm; a.num_act = num_active_dev; a.q_off = q_off; a.nq_valid = nq_valid; a.qbuf = qbuf;
+    a.C = C; a.c0[0] = c0_group0; a.c0[1] = c0_group1; a.K = K; a.row_capacity = row_capacity;
+    const int grid = min(divup(win_capacity, 4), 512);  // the product launch: (256 CUs x 4 workgroups / 2 groups, 2) at 3 waves per SIMD
+    k_ceiling_attn_kvh<<<dim3(grid, 2), 256, 0, (hipStream_t)stream>>>(a);
+    return mssvt_launch_status();
+}

@@ -1495,6 +1495,14 @@ def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
     ma = blk.ms_attn
     qbuf = _query_scratch(p, od["row_cap"], ma, x_in.device)
     ms = event_time_ms(lambda: _attention_call(blk, p, od, C, nq, xhat, qbuf, attn), 20)
+    ms_ceil = None
+    r_ = _attn_refs(blk, None)
+    if r_["n"] == 2 and tuple(ma.scale_dims) == (64, 64) and blk.key_num_sample == 32 and ma.per_head_dim == 16:
+        # csrc/ceiling.hip: k_attn_kvh's bytes through the real work order and key metadata, its instruction counts per
+        # window and pass, no dependency between them (the two row-tiled launches either side are not part of it)
+        ms_ceil = event_time_ms(lambda: _lib.call(
+            "mssvt_ceiling_attn_kvh", _i(C), _i(0), _i(64), _i(32), _P(xhat), _P(p.kmeta[0]), _P(p.kmeta[1]), _P(od["perm"]),
+            _P(od["n_act"]), _P(od["q_off"]), _P(od["nq_valid"]), _i(od["row_cap"]), _i(p.cap), _P(qbuf), _lib.stream()), 20)
     nw = int(p.num_wins.item())
     K = blk.key_num_sample
     keys = [int((p.k_mask[g][:nw] == 0).sum()) for g in range(2)]
@@ -1529,8 +1537,11 @@ def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
                        "operands": "bf16" if bf16 else "f32 as hi + 2^-11 lo fp16 halves, 3 x v_mfma_f32_16x16x32_f16: frac = 3 x FLOP "
                                    "against the 16-bit matrix peak (the pipe it runs on); frac_vs_f32_matrix_peak = the same FLOP "
                                    "against the fp32 instruction's peak (what rounds 3-4 reported as frac)" if kv16 else "f32"},
+            "ceiling_us_window_launch": None if ms_ceil is None else ms_ceil * 1e3,
             "pmc": counters or None,
-            "note": "algorithmic bytes exclude the Q' / Xbar hand-off between the launches; pmc = per-launch means of "
+            "note": "ceiling_us_window_launch = k_ceiling_attn_kvh (csrc/ceiling.hip, timing only): the bytes and instruction "
+                    "counts of the per-window launch k_attn_kvh (its own time: profiles/r05_*_kernel_stats.csv) with no dependency "
+                    "between tokens, scores, softmax and the second product; algorithmic bytes exclude the Q' / Xbar hand-off between the launches; pmc = per-launch means of "
                     "profiles/pmc_frame.json (HBM bytes = 2 FETCH + WRITE, MFMA-pipe and VALU-issue busy fractions)"}
 
 
@@ -1575,9 +1586,18 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
         abuf.zero_()
         sp._next_norm1 = net.backbone[1].norm1
         split16 = getattr(blk, "ffn_arith", FFN_ARITH) == "f16x3" and _ffn_f16_weights(_ffn_refs(blk)) is not None
+        ms_ceil = None
         if split16:
             ms_ws = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf)), 20)
             ms_up = ms_down = None
+            if C == 128 and blk.linear1.out_features == 256:
+                # csrc/ceiling.hip: the same bytes from the same tables, the same matrix / vector instruction counts in
+                # workgroups of the same shape, NO dependency between the phases: what the structure could reach
+                frag = _ffn_f16_weights(_ffn_refs(blk))
+                yc, ync = torch.empty_like(x_in), torch.empty_like(x_in)
+                ms_ceil = event_time_ms(lambda: _lib.call(
+                    "mssvt_ceiling_ffn_ws", _i(x_in.shape[0]), _P(x_in), _P(tab[0]), _P(tab[1]), _P(abuf), _P(frag), _P(yc), _P(ync),
+                    _lib.stream()), 20)
         else:
             ms_ws = None
             ms_up = event_time_ms(lambda: _ffn_tail(blk, sp, None, x_in, None, table=(tab, abuf), phases=1), 20)
@@ -1631,6 +1651,15 @@ def roofline(net, vc, feats, batch, event_time_ms, peak_gbs, live=None):
                           "frac_of_f16_peak_incl_3x": 3 * 2.0 * flop / (ms_ws * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}}
         if "isolated_launch_us_full_frame_rows" in head:
             res["isolated_launch_us_full_frame_rows"] = head["isolated_launch_us_full_frame_rows"]
+        if ms_ceil is not None:
+            res["ceiling_us"] = ms_ceil * 1e3
+            res["ceiling"] = {"us": ms_ceil * 1e3, "kernel_us_same_rows": ms_ws * 1e3, "frac_of_ceiling": ms_ceil / ms_ws,
+                              "hbm_frac_at_ceiling": alg_b / (ms_ceil * 1e-3) / 1e9 / peak_gbs,
+                              "what": "k_ceiling_ffn_ws (csrc/ceiling.hip, timing only): the launch's byte traffic on the frame's "
+                                      "real tables, 48 v_mfma_f32_16x16x32_f16 and ~260 vector instructions per wave and 16-row "
+                                      "tile on 128 resident fragment registers, 8-wave workgroups, two waves per SIMD -- with no LDS "
+                                      "hand-off, no barrier and no dependency between the phases; kernel_us - us = the price of "
+                                      "the chain rows -> LDS -> product -> LDS -> product -> rows"}
     else:
         tf_up = flop / (ms_up * 1e-3) / 1e12
         tf_down = flop / (ms_down * 1e-3) / 1e12

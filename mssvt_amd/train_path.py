@@ -341,12 +341,19 @@ def wgrad_supported(cin, cout):
 LINEAR_ROWS = {(64, 64)}  # (cin, cout) shapes that run on mssvt_linear_rows instead of the library GEMM (measured: the only win)
 
 
-def _linear_rows(x, w, transpose_w, b, relu, n_out, scale=1.0):
+# ... and the (cin, cout) shapes that run on mssvt_linear_rows_h (csrc/linear_rows_h.hip: split-fp16 operands, rows and weight
+# matrix normalised by powers of two inside the kernel): the Blocks' 128 <-> 256 FFN, 64 <-> 128 to_kvs, 128 x 128 pos_proj.2 --
+# the library GEMMs that were 24 % of the training step's GPU time (profiles/r04_f_train_step_kernel_stats.csv)
+LINEAR_ROWS_H = {(128, 256), (256, 128), (64, 128), (128, 64), (128, 128)} if os.environ.get("MSSVT_LINEAR_ROWS_H", "1") != "0" else set()
+
+
+def _linear_rows(x, w, transpose_w, b, relu, n_out, scale=1.0, split16=False):
     M, K = x.shape
     y = torch.empty((M, n_out), dtype=torch.float32, device=x.device)
     if M:
-        _lib.call("mssvt_linear_rows", _i(M), _i(K), _i(n_out), _lib.ptr(x), _i(K), _lib.ptr(w), _i(1 if transpose_w else 0),
-                  _lib.ptr(b), _i(1 if relu else 0), ctypes.c_float(scale), _lib.ptr(y), _i(n_out), _lib.stream())
+        _lib.call("mssvt_linear_rows_h" if split16 else "mssvt_linear_rows", _i(M), _i(K), _i(n_out), _lib.ptr(x), _i(K), _lib.ptr(w),
+                  _i(1 if transpose_w else 0), _lib.ptr(b), _i(1 if relu else 0), ctypes.c_float(scale), _lib.ptr(y), _i(n_out),
+                  _lib.stream())
     return y
 
 
@@ -360,9 +367,10 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, relu=False, scale=1.0):
         cout, cin = w.shape
-        if (cin, cout) in LINEAR_ROWS and x.dtype == torch.float32:
+        if ((cin, cout) in LINEAR_ROWS or (cin, cout) in LINEAR_ROWS_H) and x.dtype == torch.float32:
             x = x.contiguous()
-            y = _linear_rows(x, w.detach().contiguous(), False, None if b is None else b.detach(), relu, cout, scale)
+            y = _linear_rows(x, w.detach().contiguous(), False, None if b is None else b.detach(), relu, cout, scale,
+                             split16=(cin, cout) in LINEAR_ROWS_H)
         else:
             y = F.linear(x, w, b)
             if relu:
@@ -383,8 +391,8 @@ class _Linear(torch.autograd.Function):
         sc = ctx.scale  # y = sc * act(...): dx and dW / db carry the factor (a relu'd output is saved scaled: same sign)
         dx = None
         if ctx.needs_input_grad[0]:
-            if (cout, cin) in LINEAR_ROWS:
-                dx = _linear_rows(dy, w.detach().contiguous(), True, None, False, cin, sc)
+            if (cout, cin) in LINEAR_ROWS or (cout, cin) in LINEAR_ROWS_H:
+                dx = _linear_rows(dy, w.detach().contiguous(), True, None, False, cin, sc, split16=(cout, cin) in LINEAR_ROWS_H)
             else:
                 dx = dy @ w
                 if sc != 1.0:

@@ -452,6 +452,49 @@ def test_linear_rows_kernel_forward_and_input_gradient(M, K, N, relu):
         assert float((gb - lin.bias.grad).abs().max()) <= tol * max(1.0, float(lin.bias.grad.abs().max()))
 
 
+@pytest.mark.parametrize("M,K,N,relu", [(74270, 128, 256, True), (74270, 256, 128, False), (300011, 64, 128, False), (5000, 128, 64, False),
+                                        (19307, 128, 128, True), (17, 128, 256, False), (1, 64, 64, False)])
+def test_split_fp16_linear_rows_kernel_vs_float64_at_any_scale(M, K, N, relu):
+    """mssvt_linear_rows_h (the large weight matrices of the training path on split-fp16 operands) against float64: forward
+    with bias / relu / output scale and the transposed-weight form (dx = dy W) -- on rows whose scales span 2^-60 .. 2^60
+    (gradients do not respect the fp16 range: the kernel normalises every row and the matrix by powers of two) and a weight
+    matrix far outside it.  Error bound per ROW: relative to that row's own |x| |W| scale, the fp32 instruction's class."""
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    x *= torch.exp2(torch.randint(-60, 61, (M, 1), generator=g).float())  # every row at its own scale
+    x[M // 2] = 0.0  # an all-zero row stays zero
+    for wscale in (1.0, 3.0e7, 2.0e-9):
+        w = torch.randn(N, K, generator=g) / K ** 0.5 * wscale
+        b = torch.randn(N, generator=g) * wscale
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        y = train_path._linear_rows(xd, wd, False, bd, relu, N, 0.25, split16=True)
+        ref = x.double() @ w.double().T + b.double()
+        ref = (ref.clamp(min=0) if relu else ref) * 0.25
+        row_scale = (x.double().abs().max(1, keepdim=True).values * w.double().abs().max() * K ** 0.5 + b.double().abs().max()).clamp(min=1e-300)
+        assert float(((y.cpu().double() - ref).abs() / row_scale).max()) <= 2e-6, wscale
+        assert bool((y[M // 2] == ((bd.clamp(min=0) if relu else bd) * 0.25)).all())
+        dy = x[:, :N] if N <= K else torch.cat([x, x], 1)[:, :N]
+        dy = dy.contiguous()
+        dx = train_path._linear_rows(dy.to(DEV), wd, True, None, False, K, 1.0, split16=True)
+        refx = dy.double() @ w.double()
+        row_scale = (dy.double().abs().max(1, keepdim=True).values * w.double().abs().max() * N ** 0.5).clamp(min=1e-300)
+        assert float(((dx.cpu().double() - refx).abs() / row_scale).max()) <= 2e-6, wscale
+    if (K, N) in train_path.LINEAR_ROWS_H:  # through the autograd function, against the library composition
+        lin = torch.nn.Linear(K, N).to(DEV)
+        xs = torch.randn(M, K, generator=g).to(DEV)
+        dys = torch.randn(M, N, generator=g).to(DEV)
+        xr = xs.clone().requires_grad_(True)
+        out = train_path.linear(lin, xr, relu=relu)
+        (out * dys).sum().backward()
+        x2 = xs.clone().requires_grad_(True)
+        o2 = lin(x2)
+        o2 = o2.relu() if relu else o2
+        (o2 * dys).sum().backward()
+        assert float((out.detach() - o2.detach()).abs().max()) <= 2e-5 * max(1.0, float(o2.detach().abs().max()))
+        assert float((xr.grad - x2.grad).abs().max()) <= 2e-5 * max(1.0, float(x2.grad.abs().max()))
+
+
 def test_block_tail_in_one_launch_matches_the_composition_with_drop_path_active():
     """train() mode (DropPath rate 0.3 on the second Block, dropout as configured): the one-launch Block tail
     (interpolation + select + DropPath + residual, train_path._BlockTail) against the autograd composition under the same
