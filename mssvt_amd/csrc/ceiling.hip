@@ -43,13 +43,23 @@ __global__ void __launch_bounds__(512, 2) k_ceiling_ffn_ws(int n_rows, const flo
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float sink = 0.f;
+    // the next tile's rows are requested before this tile's work (as every streaming kernel of the library does)
+    float4 x_n, tw_n, a0_n, a1_n, a2_n;
+#define CEIL_LOAD(t_)                                                                  \
+    {                                                                                  \
+        const int row_ = min((t_) * 16 + r_in_tile, n_rows - 1);                       \
+        x_n = x_in[(size_t)row_ * 32 + piece];                                         \
+        const int4 tr_ = tab_row[row_];                                                \
+        tw_n = tab_w[row_];                                                            \
+        a0_n = attn[(size_t)max(tr_.x, 0) * 32 + piece];                               \
+        a1_n = attn[(size_t)max(tr_.y, 0) * 32 + piece];                               \
+        a2_n = attn[(size_t)max(tr_.z, 0) * 32 + piece];                               \
+    }
+    if ((int)blockIdx.x < tiles) CEIL_LOAD(blockIdx.x)
     for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int row = min(t * 16 + r_in_tile, n_rows - 1);
-        const float4 x = x_in[(size_t)row * 32 + piece];
-        const int4 tr = tab_row[row];
-        const float4 tw = tab_w[row];
-        const float4 a0 = attn[(size_t)max(tr.x, 0) * 32 + piece], a1 = attn[(size_t)max(tr.y, 0) * 32 + piece],
-                     a2 = attn[(size_t)max(tr.z, 0) * 32 + piece];
+        const float4 x = x_n, tw = tw_n, a0 = a0_n, a1 = a1_n, a2 = a2_n;
+        CEIL_LOAD(min(t + (int)gridDim.x, tiles - 1))
         const h16x8 bfrag = h16x8{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
 #pragma unroll
         for (int k = 0; k < 48; ++k)
@@ -60,6 +70,7 @@ __global__ void __launch_bounds__(512, 2) k_ceiling_ffn_ws(int n_rows, const flo
         y[(size_t)row * 32 + piece] = make_float4(f, in, x.z, a0.w);
         yn[(size_t)row * 32 + piece] = make_float4(in, f, a1.w, a2.w);
     }
+#undef CEIL_LOAD
     float s = sink;
 #pragma unroll
     for (int i = 0; i < 6; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -94,19 +105,30 @@ __global__ void __launch_bounds__(256, 3) k_ceiling_attn_kvh(CeilKvh a) {
     for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float sink = 0.f;
     const h16x8 one = h16x8{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
+    // the next window's key rows are requested before this window's work (k_attn_kvh runs its rows one window ahead too)
+    float4 rows_n[2][4];
+    int w_n = 0;
+#define CEIL_ROWS(wi_)                                                                                   \
+    {                                                                                                    \
+        w_n = a.perm[min((wi_), n_act - 1)];                                                             \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                  \
+            const float4 km = a.kmeta[g][(size_t)w_n * a.K + min(16 * t + la, a.K - 1)];                 \
+            const int r = max(__builtin_bit_cast(int, km.w), 0);                                         \
+            const float4 *src = reinterpret_cast<const float4 *>(a.xhat + (size_t)r * a.C + a.c0[g]) + gq; \
+            _Pragma("unroll") for (int S = 0; S < 4; ++S) rows_n[t][S] = src[4 * S];                     \
+        }                                                                                                \
+    }
+    if ((int)(blockIdx.x * 4 + wv) < n_act) CEIL_ROWS(blockIdx.x * 4 + wv)
     for (int wi = blockIdx.x * 4 + wv; wi < n_act; wi += wstep) {
-        const int w = a.perm[wi];
+        const int w = w_n;
         const int nqv = a.q_off[w] + a.nq_valid[w] <= a.row_capacity ? a.nq_valid[w] : 0;
         const size_t qbase = (size_t)a.q_off[w];
         float4 rows[2][4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float4 km = a.kmeta[g][(size_t)w * a.K + min(16 * t + la, a.K - 1)];
-            const int r = max(__builtin_bit_cast(int, km.w), 0);
-            const float4 *src = reinterpret_cast<const float4 *>(a.xhat + (size_t)r * a.C + a.c0[g]) + gq;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int S = 0; S < 4; ++S) rows[t][S] = src[4 * S];
-        }
+            for (int S = 0; S < 4; ++S) rows[t][S] = rows_n[t][S];
+        CEIL_ROWS(wi + wstep)
         float tok = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)

@@ -409,7 +409,11 @@ def test_linear_with_the_relu_epilogue_matches_the_library_composition(relu):
     o2 = lin(x2)
     o2 = o2.relu() if relu else o2
     (o2 * dy).sum().backward()
-    assert torch.equal(out.detach(), o2.detach()) and torch.equal(xr.grad, x2.grad)
+    # (64 -> 128 runs on mssvt_linear_rows_h since round 5: the fp32 instruction's error class, not the library's bits)
+    assert float((out.detach() - o2.detach()).abs().max()) <= 1e-5 * max(1.0, float(o2.detach().abs().max()))
+    assert float((xr.grad - x2.grad).abs().max()) <= 1e-5 * max(1.0, float(x2.grad.abs().max()))
+    if relu:
+        assert torch.equal(out.detach() > 0, o2.detach() > 0) or float(o2.detach().abs()[(out.detach() > 0) != (o2.detach() > 0)].max()) < 1e-5
     assert float((gw - lin.weight.grad).abs().max()) <= 2e-4 * max(1.0, float(lin.weight.grad.abs().max()))
     assert float((gb - lin.bias.grad).abs().max()) <= 2e-4 * max(1.0, float(lin.bias.grad.abs().max()))
 
