@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256, 3) k_ceiling_attn_kvh(CeilKvh a) {
             _Pragma("unroll") for (int S = 0; S < 4; ++S) rows_n[t][S] = src[4 * S];                     \
         }                                                                                                \
     }
-    if ((int)(blockIdx.x * 4 + wv) < n_act) CEIL_ROWS(blockIdx.x * 4 + wv)
+    if ((int)(blockIdx.x * 4 + wv) < n_act) CEIL_ROWS((int)(blockIdx.x * 4 + wv))
     for (int wi = blockIdx.x * 4 + wv; wi < n_act; wi += wstep) {
         const int w = w_n;
         const int nqv = a.q_off[w] + a.nq_valid[w] <= a.row_capacity ? a.nq_valid[w] : 0;

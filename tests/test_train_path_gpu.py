@@ -409,11 +409,12 @@ def test_linear_with_the_relu_epilogue_matches_the_library_composition(relu):
     o2 = lin(x2)
     o2 = o2.relu() if relu else o2
     (o2 * dy).sum().backward()
-    # (64 -> 128 runs on mssvt_linear_rows_h since round 5: the fp32 instruction's error class, not the library's bits)
+    # (64 -> 128 runs on mssvt_linear_rows_h since round 5: the fp32 instruction's error class, not the library's bits;
+    # an output within rounding of 0 may fall on either side of the relu: those elements' gradients are not compared)
     assert float((out.detach() - o2.detach()).abs().max()) <= 1e-5 * max(1.0, float(o2.detach().abs().max()))
-    assert float((xr.grad - x2.grad).abs().max()) <= 1e-5 * max(1.0, float(x2.grad.abs().max()))
-    if relu:
-        assert torch.equal(out.detach() > 0, o2.detach() > 0) or float(o2.detach().abs()[(out.detach() > 0) != (o2.detach() > 0)].max()) < 1e-5
+    same = ((out.detach() > 0) == (o2.detach() > 0)).all(1)
+    assert int((~same).sum()) <= 5
+    assert float((xr.grad - x2.grad)[same].abs().max()) <= 1e-5 * max(1.0, float(x2.grad.abs().max()))
     assert float((gw - lin.weight.grad).abs().max()) <= 2e-4 * max(1.0, float(lin.weight.grad.abs().max()))
     assert float((gb - lin.bias.grad).abs().max()) <= 2e-4 * max(1.0, float(lin.bias.grad.abs().max()))
 
@@ -491,12 +492,13 @@ def test_split_fp16_linear_rows_kernel_vs_float64_at_any_scale(M, K, N, relu):
         xr = xs.clone().requires_grad_(True)
         out = train_path.linear(lin, xr, relu=relu)
         (out * dys).sum().backward()
-        x2 = xs.clone().requires_grad_(True)
-        o2 = lin(x2)
+        o2 = xs.double() @ lin.weight.detach().double().T + lin.bias.detach().double()
         o2 = o2.relu() if relu else o2
-        (o2 * dys).sum().backward()
-        assert float((out.detach() - o2.detach()).abs().max()) <= 2e-5 * max(1.0, float(o2.detach().abs().max()))
-        assert float((xr.grad - x2.grad).abs().max()) <= 2e-5 * max(1.0, float(x2.grad.abs().max()))
+        assert float((out.detach().double() - o2).abs().max()) <= 2e-5 * max(1.0, float(o2.abs().max()))
+        # the relu's gradient mask is the KERNEL's output sign (an output within rounding of 0 may fall either side)
+        gate = (out.detach() > 0).double() if relu else 1.0
+        want = (dys.double() * gate) @ lin.weight.detach().double()
+        assert float((xr.grad.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
 
 
 def test_block_tail_in_one_launch_matches_the_composition_with_drop_path_active():
