@@ -51,6 +51,9 @@ __global__ void __launch_bounds__(LH_WAVES *MSSVT_WAVE, 1) k_linear_rows_h(int M
     // the whole matrix normalised by ONE power of two (2^-e(max |W|), undone in the epilogue): any finite weight scale works
     constexpr int FR = (IMG + LH_WAVES * MSSVT_WAVE - 1) / (LH_WAVES * MSSVT_WAVE);
     __shared__ float wmax_l[LH_WAVES];
+    __shared__ float4 bias_l[N / 4];  // (a global load per column tile inside the row loop is a dependent round trip per tile)
+    for (int e = threadIdx.x; e < N / 4; e += blockDim.x)
+        bias_l[e] = bias ? reinterpret_cast<const float4 *>(bias)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 wv0[FR], wv1[FR];
     float wmx = 0.f;
 #pragma unroll
@@ -143,8 +146,7 @@ __global__ void __launch_bounds__(LH_WAVES *MSSVT_WAVE, 1) k_linear_rows_h(int M
                 LH_MFMA(cr, bl, ah[P]);
             }
             // lane (m = la, g) holds Y[m][16 t + 4 g + i]
-            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias) b4 = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * g);
+            const float4 b4 = bias_l[4 * t + g];
             float r[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(cr[i], LH_INV, mm[i]);
