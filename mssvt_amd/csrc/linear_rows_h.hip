@@ -23,7 +23,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-#define LH_WAVES 16
+// waves per workgroup: 16 (4 per SIMD, <= 128 registers each) for K <= 128; 8 for K = 256 (the row's 64 prefetch registers +
+// 64 accumulator registers do not fit 128: the 16-wave form spilled 742 registers)
+#define LH_WAVES_OF(K) ((K) > 128 ? 8 : 16)
 #define LH_SCALE 2048.0f
 #define LH_INV (1.0f / 2048.0f)
 #define LH_MFMA(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16((av), (bv), acc, 0, 0, 0)
@@ -41,10 +43,11 @@ __device__ __forceinline__ void lh_split8(const float4 v0, const float4 v1, floa
 }
 
 template <int K, int N>
-__global__ void __launch_bounds__(LH_WAVES *MSSVT_WAVE, 1) k_linear_rows_h(int M, const float *X, int ldx, const float *W, int transpose_w,
+__global__ void __launch_bounds__(LH_WAVES_OF(K) *MSSVT_WAVE, 1) k_linear_rows_h(int M, const float *X, int ldx, const float *W, int transpose_w,
                                                                            const float *bias, int relu, float out_scale, float *Y,
                                                                            int ldy) {
     constexpr int KS = K / 32, NT = N / 16, IMG = KS * NT * 64;  // h16x8 fragments per (hi or lo) image
+    constexpr int LH_WAVES = LH_WAVES_OF(K);
     extern __shared__ float4 lds4[];
     h16x8 *Bh = reinterpret_cast<h16x8 *>(lds4), *Bl = Bh + IMG;
     // stage + split the weights: fragment (P, t, lane = 16 g + n % 16) = B[n = 16 t + lane % 16][k = 32 P + 8 g .. + 8),
@@ -122,30 +125,10 @@ __global__ void __launch_bounds__(LH_WAVES *MSSVT_WAVE, 1) k_linear_rows_h(int M
         const bool norm = eb != 0 && eb < 0x7F000000;  // zero / denormal rows and inf / nan rows pass through unscaled
         const float s_in = norm ? __builtin_bit_cast(float, 0x7F000000 - eb) : 1.0f;
         const float un = (norm ? __builtin_bit_cast(float, eb) : 1.0f) * w_un;  // both normalisations undone: exact powers of two
-        h16x8 ah[KS], al[KS];
-#pragma unroll
-        for (int P = 0; P < KS; ++P) lh_split8(xn[P][0], xn[P][1], s_in, ah[P], al[P]);
-        if (tile + step < tiles) {
-            const float *row = X + (size_t)min((tile + step) * 16 + la, M - 1) * ldx + 8 * g;
-#pragma unroll
-            for (int P = 0; P < KS; ++P) {
-                xn[P][0] = *reinterpret_cast<const float4 *>(row + 32 * P);
-                xn[P][1] = *reinterpret_cast<const float4 *>(row + 32 * P + 4);
-            }
-        }
         const int m = tile * 16 + la;
         float *out = Y + (size_t)min(m, M - 1) * ldy + 4 * g;
-#pragma unroll 2
-        for (int t = 0; t < NT; ++t) {
-            f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
-#pragma unroll
-            for (int P = 0; P < KS; ++P) {
-                const h16x8 bh = Bh[(P * NT + t) * 64 + lane], bl = Bl[(P * NT + t) * 64 + lane];
-                LH_MFMA(mm, bh, ah[P]);  // Y^T tile: A = the weights' rows n, B = the tile's rows m
-                LH_MFMA(cr, bh, al[P]);
-                LH_MFMA(cr, bl, ah[P]);
-            }
-            // lane (m = la, g) holds Y[m][16 t + 4 g + i]
+        // epilogue of column tile t: lane (m = la, g) holds Y[m][16 t + 4 g + i]
+        auto finish = [&](int t, const f32x4 &mm, const f32x4 &cr) {
             const float4 b4 = bias_l[4 * t + g];
             float r[4];
 #pragma unroll
@@ -156,6 +139,62 @@ __global__ void __launch_bounds__(LH_WAVES *MSSVT_WAVE, 1) k_linear_rows_h(int M
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             o.x *= out_scale; o.y *= out_scale; o.z *= out_scale; o.w *= out_scale;
             if (m < M) *reinterpret_cast<float4 *>(out + 16 * t) = o;
+        };
+        if constexpr (KS <= 4) {
+            // few k steps: the row's fragments stay in registers (8 KS), column tiles one after the other
+            h16x8 ah[KS], al[KS];
+#pragma unroll
+            for (int P = 0; P < KS; ++P) lh_split8(xn[P][0], xn[P][1], s_in, ah[P], al[P]);
+            if (tile + step < tiles) {
+                const float *row = X + (size_t)min((tile + step) * 16 + la, M - 1) * ldx + 8 * g;
+#pragma unroll
+                for (int P = 0; P < KS; ++P) {
+                    xn[P][0] = *reinterpret_cast<const float4 *>(row + 32 * P);
+                    xn[P][1] = *reinterpret_cast<const float4 *>(row + 32 * P + 4);
+                }
+            }
+#pragma unroll 2
+            for (int t = 0; t < NT; ++t) {
+                f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
+#pragma unroll
+                for (int P = 0; P < KS; ++P) {
+                    const h16x8 bh = Bh[(P * NT + t) * 64 + lane], bl = Bl[(P * NT + t) * 64 + lane];
+                    LH_MFMA(mm, bh, ah[P]);  // Y^T tile: A = the weights' rows n, B = the tile's rows m
+                    LH_MFMA(cr, bh, al[P]);
+                    LH_MFMA(cr, bl, ah[P]);
+                }
+                finish(t, mm, cr);
+            }
+        } else {
+            // many k steps, few column tiles (256 -> 128): every column tile's sums stay in registers (8 NT), the row's
+            // fragments are split one k step at a time (8 live registers instead of 8 KS)
+            static_assert(NT <= 8, "accumulators of all column tiles in registers");
+            f32x4 mm[NT], cr[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mm[t] = cr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int P = 0; P < KS; ++P) {
+                h16x8 ah, al;
+                lh_split8(xn[P][0], xn[P][1], s_in, ah, al);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const h16x8 bh = Bh[(P * NT + t) * 64 + lane], bl = Bl[(P * NT + t) * 64 + lane];
+                    LH_MFMA(mm[t], bh, ah);
+                    LH_MFMA(cr[t], bh, al);
+                    LH_MFMA(cr[t], bl, ah);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist every fragment read of the unrolled loop: spills)
+            }
+            if (tile + step < tiles) {
+                const float *row = X + (size_t)min((tile + step) * 16 + la, M - 1) * ldx + 8 * g;
+#pragma unroll
+                for (int P = 0; P < KS; ++P) {
+                    xn[P][0] = *reinterpret_cast<const float4 *>(row + 32 * P);
+                    xn[P][1] = *reinterpret_cast<const float4 *>(row + 32 * P + 4);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) finish(t, mm[t], cr[t]);
         }
     }
 }
@@ -178,7 +217,7 @@ extern "C" int mssvt_linear_rows_h(int M, int K, int N, const float *X, int ldx,
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    const int grid = min(cus, divup(M, 16 * LH_WAVES));
+    const int grid = min(cus, divup(M, 16 * LH_WAVES_OF(K)));
     const size_t lds = (size_t)K * N * 4;  // two fp16 images
 #define LH_GO(KK, NN)                                                                                                    \
     if (K == KK && N == NN) {                                                                                            \
@@ -189,7 +228,7 @@ extern "C" int mssvt_linear_rows_h(int M, int K, int N, const float *X, int ldx,
             if (e != hipSuccess) return (int)e;                                                                          \
             attr = true;                                                                                                 \
         }                                                                                                                \
-        k_linear_rows_h<KK, NN><<<grid, LH_WAVES * MSSVT_WAVE, lds, st>>>(M, X, ldx, W, transpose_w, bias, relu, out_scale, Y, ldy); \
+        k_linear_rows_h<KK, NN><<<grid, LH_WAVES_OF(KK) * MSSVT_WAVE, lds, st>>>(M, X, ldx, W, transpose_w, bias, relu, out_scale, Y, ldy); \
         return mssvt_launch_status();                                                                                    \
     }
     LH_GO(128, 256) LH_GO(256, 128) LH_GO(64, 128) LH_GO(128, 64) LH_GO(128, 128) LH_GO(64, 64)
