@@ -70,7 +70,7 @@ def parse(argv=None):
                     help="a step = points -> voxelizer + DynamicVFE -> backbone -> dense() / HeightCompression view (SURVEY 8 f1, "
                          "f2: the neighbours either side of the path), with its own algorithmic bytes; not the BASELINE metric")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="frames in flight (mssvt_amd/pipeline.py: consecutive frames are independent; each runs on its own HIP "
                          "stream with its own workspace); 1: one frame at a time on one stream, as every round before round 5")
     ap.add_argument("--frames", type=int, default=4,
@@ -298,7 +298,7 @@ def main():
         turn[0] += 1
         return f[2], f[3]
 
-    step_alone = None
+    step_alone = pipe = None
     det = None
     if args.train and args.detector:
         # the reference's training wrap (tools/train.py:118-119,143-144): SyncBatchNorm conversion of EVERY BatchNorm layer
@@ -458,6 +458,9 @@ def main():
                        "ffn_arith": ffn_arith_name(net), "arith": args.arith, "host_path": host_path(),
                        "voxels_per_gpu": int(vc.shape[0]),
                        "frames_in_flight": 1 if (args.train or args.in_flight <= 1) else args.in_flight,
+                       "streams": None if (args.train or args.in_flight <= 1) else (
+                           "one HIP stream per frame in flight, each on a hardware queue of its own (mssvt_amd/pipeline.py)"
+                           if pipe.own_queues else "one pooled HIP stream per frame in flight"),
                        "frames_rotated": len(frames), "voxels_per_frame": [int(f[2].shape[0]) for f in frames],
                        "output_voxels": int(sp_out.features.shape[0]) if sp_out is not None else None,
                        "detector": None if det is None else {

@@ -4,22 +4,58 @@ Consecutive frames do not depend on each other, and one 160k-point frame does no
 serial chain of latency- and issue-bound kernels with ramp-up, tail and a dependent-launch gap each.  `FramePipeline`
 deals the frames round-robin to `depth` HIP streams; the whole-frame call keeps one frame object (persistent workspace,
 pinned status words, events) per stream (mssvt_amd/frame.py), so frames in flight share nothing they write and the
-hardware interleaves their kernels.  Measured on one MI355X (tools/two_streams.py, one scene per step): 1 583 -> 1 778
-(two streams) -> 1 850 frames/s (three); at four scenes per step +1 % -- those launches fill the chip by themselves.
+hardware interleaves their kernels.  Measured on one MI355X (tools/two_streams.py, one scene per step, each stream on a
+hardware queue of its own): 1 573 -> 1 779 (two frames in flight) -> 1 860 (three) -> 1 894 frames/s (four) -> 1 797 (six);
+at four scenes per step +1 % -- those launches fill the chip by themselves.
 Every frame computes exactly what `net(batch_dict)` computes (tests/test_pipeline_gpu.py: bit-identical outputs).
 
 The reference runs its frames one by one on the legacy default stream ("Threading / streams"); this is the
 MI355X-side answer to the same loop (a detector's data loader hands over frame i + 1 while frame i is still running).
 """
+import ctypes
+
 import torch
 
 
+def _own_queue_streams(n, device):
+    """n HIP streams with a hardware queue of their own each, as torch streams -- or None when the runtime cannot make them.
+
+    The runtime multiplexes ordinary streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two
+    streams that land on the same queue serialise: with the framework's pooled streams three frames in flight ran
+    anywhere between 1 633 and 1 858 frames/s and two frames in flight at the single-stream rate when the two shared a
+    queue (tools/two_streams.py with GPU_MAX_HW_QUEUES = 2).  A stream created with a CU mask is given its own queue;
+    the mask used here enables EVERY compute unit, so nothing is partitioned (quarter-of-the-chip masks measured the
+    same: 1 884 against 1 894 frames/s at four frames in flight)."""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        fn = hip.hipExtStreamCreateWithCUMask
+    except (OSError, AttributeError):
+        return None
+    cus = int(torch.cuda.get_device_properties(device).multi_processor_count)
+    words = (cus + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for cu in range(cus):
+        mask[cu // 32] |= 1 << (cu % 32)
+    out = []
+    with torch.cuda.device(device):
+        for _ in range(n):
+            s = ctypes.c_void_p()
+            if fn(ctypes.byref(s), ctypes.c_uint32(words), mask) != 0 or not s.value:
+                return None
+            out.append(torch.cuda.ExternalStream(s.value, device=device))
+    return out
+
+
 class FramePipeline(object):
-    def __init__(self, net, depth=2, device=None):
+    def __init__(self, net, depth=4, device=None):
         assert depth >= 1
         self.net = net
-        self.device = device if device is not None else next(net.parameters()).device
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
+        self.device = torch.device(device if device is not None else next(net.parameters()).device)
+        self.own_queues = True
+        self.streams = _own_queue_streams(depth, self.device)
+        if self.streams is None:
+            self.own_queues = False
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
         self.turn = 0
 
     @property

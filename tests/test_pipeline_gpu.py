@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("depth", [2, 3])
+@pytest.mark.parametrize("depth", [2, 4])
 def test_pipelined_frames_are_bit_identical_to_frames_run_alone(depth):
     from mssvt_amd import config, frame
     from mssvt_amd.pipeline import FramePipeline
@@ -27,6 +27,7 @@ def test_pipelined_frames_are_bit_identical_to_frames_run_alone(depth):
             alone.append((sp.features.clone(), sp.indices.clone()))
     torch.cuda.synchronize()
     pipe = FramePipeline(net, depth=depth)
+    assert pipe.own_queues and len({s.cuda_stream for s in pipe.streams}) == depth  # a hardware queue of its own per stream
     outs = [pipe(dict(scenes[i % len(scenes)])) for i in range(4 * len(scenes))]  # several rounds: workspaces are reused
     pipe.synchronize()
     for i, out in enumerate(outs):

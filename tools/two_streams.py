@@ -70,5 +70,53 @@ def main():
                   (n, "wait_stream" if wait else "no wait_stream", t * 1e3, a.batch / t))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--cu-mask" not in sys.argv:
     main()
+
+
+def cu_masked_streams(n, cus=256, full=False):
+    """n HIP streams, each confined to its own 1/n of the CUs (hipExtStreamCreateWithCUMask), as torch ExternalStreams."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = []
+    words = (cus + 31) // 32
+    per = cus // n
+    for k in range(n):
+        mask = (ctypes.c_uint32 * words)()
+        # CUs are numbered across shader engines / XCDs: interleave so that every XCD contributes to every partition
+        for cu in range(cus):
+            if full or cu % n == k:
+                mask[cu // 32] |= 1 << (cu % 32)
+        s = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(s), ctypes.c_uint32(words), mask)
+        assert rc == 0, rc
+        out.append(torch.cuda.ExternalStream(s.value))
+    return out
+
+
+def main_cu():
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    cfg = config.load_yaml(config.DEFAULT_CFG)
+    net = config.build_backbone_from_cfg(cfg).to(dev).eval()
+    frames = [bench.make_inputs(160000, 1, 0, dev, frame=f) for f in range(4)]
+    for n, masked in ((1, False), (2, "full"), (3, "full"), (4, "full"), (4, True), (6, "full"), (2, True)):
+        streams = cu_masked_streams(n, full=masked == "full") if masked else [torch.cuda.Stream() for _ in range(n)]
+
+        def run(steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                f = frames[i % len(frames)]
+                with torch.cuda.stream(streams[i % n]), torch.no_grad():
+                    net(dict(voxel_features=f[3], voxel_coords=f[2], batch_size=1))
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
+        run(20)
+        t = min(run(100) for _ in range(3))
+        print("%d stream(s), one network, %s: %.3f ms per step, %.0f frames/s" %
+              (n, "own hardware queue, all CUs each" if masked == "full" else "1/%d of the CUs each" % n if masked else "all CUs each", t * 1e3, 1 / t))
+
+
+if __name__ == "__main__" and "--cu-mask" in sys.argv:
+    main_cu()
