@@ -356,10 +356,11 @@ def main():
             def step():
                 vc_, feats_ = next_frame()
                 # (the frames are resident and complete before the timed region: nothing on this stream to wait for)
-                return pipe(dict(voxel_features=feats_, voxel_coords=vc_, batch_size=args.batch), inputs_ready=True)
+                # (deferred: the frame's one host wait happens when its stream comes round again, not between two submissions)
+                return pipe(dict(voxel_features=feats_, voxel_coords=vc_, batch_size=args.batch), inputs_ready=True, defer=True)
             for _ in range(args.in_flight):  # every stream's frame object and workspace exist before anything is timed
                 step()
-            torch.cuda.synchronize()
+            pipe.synchronize()
     points_line = None
     if args.from_points and not args.train:
         import numpy as np
@@ -410,7 +411,11 @@ def main():
         _frame.forward = _real_frame_forward  # (nothing extra inside the timed region; without warm-up steps the spy stays: ~1 us)
     host_path = lambda: ("mssvt_frame_forward: one C call per frame, persistent workspace (mssvt_amd/frame.py)"  # noqa: E731
                          if host_calls and all(host_calls) else "Python-driven entry points (mssvt_amd/fused.py)")
-    elapsed, out = mdist.timed_steps(step, args.steps, dist, dev)
+    # (with frames in flight a "sync" also finishes the host side of every submitted frame: the K steps are complete frames)
+    full_sync = (lambda: (pipe.synchronize(), torch.cuda.synchronize())) if pipe is not None else None
+    if pipe is not None:
+        pipe.synchronize()
+    elapsed, out = mdist.timed_steps(step, args.steps, dist, dev, sync=full_sync)
     # SURVEY 8(d) protocol beside the driver's K-step clock: every step between two HIP events
     # (a training step is collective -- every rank takes part; the forward is not, rank 0 measures alone)
     # (one frame at a time on one stream: a step's duration = its latency; the pipelined steps overlap)

@@ -234,9 +234,25 @@ def invalidate(net):
     net.__dict__.pop("_frame_state", None)
 
 
-def forward(net, feats, coords, batch_size):
+class Pending(object):
+    """A frame that has been enqueued but whose host wait (status words + output row count) has not happened yet:
+    `finish()` waits for the early device-to-host copy and returns the output SparseTensor (or raises what `forward` raises).
+    The frame object's pinned words are overwritten by the NEXT forward on the same stream: finish before that."""
+
+    def __init__(self, net, fr, outs, batch_size, H):
+        self.net, self.fr, self.outs, self.batch_size, self.H = net, fr, outs, batch_size, H
+
+    def finish(self):
+        sp = _finish(self.net, self.fr, self.outs, self.batch_size, self.H)
+        self.outs = None
+        return sp
+
+
+def forward(net, feats, coords, batch_size, defer=False):
     """The output SparseTensor of `net` on (feats, coords), or None: not eligible, run the Python path.  Raises
-    fused.UnsortedVoxels when the voxel list is not (b,x,y,z)-sorted (the caller redoes the frame order-agnostically)."""
+    fused.UnsortedVoxels when the voxel list is not (b,x,y,z)-sorted (the caller redoes the frame order-agnostically).
+    `defer`: return a `Pending` right behind the enqueue instead -- its `finish()` does the frame's one host wait
+    (mssvt_amd/pipeline.py keeps several frames in flight that way without the host standing still in between)."""
     if not ENABLED or torch.is_grad_enabled() or fused.FFN_TIMER is not None or net.async_index:
         return None
     if not (fused.SORTED_LEVELS and fused.OCC_COLUMNS and fused.PLAN_TABLES and fused.CMP_FUSED and fused.LEVEL_SETUP):
@@ -273,6 +289,13 @@ def forward(net, feats, coords, batch_size):
     out_c = torch.empty((B,), dtype=torch.int32, device=dev)
     _lib.call("mssvt_frame_forward", fr.handle, n, feats.data_ptr(), indices.data_ptr(), ws.data_ptr(), ws.numel(),
               out_f.data_ptr(), out_i.data_ptr(), out_t.data_ptr(), out_c.data_ptr(), _lib.stream())
+    if defer:
+        return Pending(net, fr, (out_f, out_i, out_t, out_c), batch_size, H)
+    return _finish(net, fr, (out_f, out_i, out_t, out_c), batch_size, H)
+
+
+def _finish(net, fr, outs, batch_size, H):
+    out_f, out_i, out_t, out_c = outs
     # the forward's single host wait: the early device-to-host copy (status words + output row count)
     _lib.call("mssvt_frame_wait_words", fr.handle, fr.words, _WORDS)
     w = fr.words

@@ -13,6 +13,7 @@ The reference runs its frames one by one on the legacy default stream (SURVEY 8b
 MI355X-side answer to the same loop (a detector's data loader hands over frame i + 1 while frame i is still running).
 """
 import ctypes
+import os
 
 import torch
 
@@ -52,31 +53,82 @@ class FramePipeline(object):
         self.net = net
         self.device = torch.device(device if device is not None else next(net.parameters()).device)
         self.own_queues = True
-        self.streams = _own_queue_streams(depth, self.device)
+        self.streams = None if os.environ.get("MSSVT_PIPE_POOLED") == "1" else _own_queue_streams(depth, self.device)
         if self.streams is None:
             self.own_queues = False
             self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
         self.turn = 0
+        self.pending = [None] * depth  # per stream: the deferred frame whose host wait has not happened yet
 
     @property
     def depth(self):
         return len(self.streams)
 
-    def __call__(self, batch_dict, inputs_ready=False):
+    def __call__(self, batch_dict, inputs_ready=False, defer=False):
         """Enqueue one forward on the next stream and return its output dict (as `net(batch_dict)`, plus "stream": the
         stream its tensors are produced on -- a consumer on another stream waits for it: `cur.wait_stream(out["stream"])`).
         The inputs may come from the caller's current stream: the frame's stream first waits for what is queued there now,
         unless `inputs_ready` says they are complete already (resident frames: the event pair on the default stream costs
-        4 % of the frame rate at two frames in flight, tools/two_streams.py)."""
-        s = self.streams[self.turn % len(self.streams)]
+        4 % of the frame rate at two frames in flight, tools/two_streams.py).
+        `defer`: return a `PendingFrame` right behind the enqueue; its `get()` does the frame's one host wait (the output
+        row count) and returns the dict.  The host then never stands still between two submissions: a frame's wait happens
+        when its result is asked for, or when its stream comes round again `depth` submissions later."""
+        k = self.turn % len(self.streams)
+        s = self.streams[k]
         self.turn += 1
+        if self.pending[k] is not None:  # this stream's frame object is about to be reused: its frame is `depth` old
+            self.pending[k].get()
         if not inputs_ready:
             s.wait_stream(torch.cuda.current_stream(self.device))
+        p = PendingFrame(self, s, batch_dict)
         with torch.cuda.stream(s), torch.no_grad():
-            out = self.net(batch_dict)
-        out["stream"] = s
-        return out
+            p._enqueue()
+        if defer and p.out is None:
+            self.pending[k] = p
+            return p
+        return p.get()
 
     def synchronize(self):
+        """Every submitted frame finished (host side and device side)."""
+        for p in self.pending:
+            if p is not None:
+                p.get()
         for s in self.streams:
             s.synchronize()
+
+
+class PendingFrame(object):
+    def __init__(self, pipe, stream, batch_dict):
+        self.pipe, self.stream, self.batch_dict = pipe, stream, batch_dict
+        self.out = self.pend = None
+
+    def _enqueue(self):
+        from . import frame, fused
+        net, bd = self.pipe.net, self.batch_dict
+        feats, coords = bd['voxel_features'], bd['voxel_coords']
+        ok = (getattr(net, "_unsorted_skip", 0) == 0 and net.assume_sorted and feats.is_cuda and
+              any(getattr(b, 'impl', None) == 'fused' for b in net.backbone))
+        self.pend = frame.forward(net, feats, coords, bd['batch_size'], defer=True) if ok else None
+        if self.pend is None:  # not the whole-frame call's case: the ordinary forward, finished here
+            self.out = net(bd)
+            self.out["stream"] = self.stream
+
+    def get(self):
+        """The output dict of this frame (the host wait happens here, once)."""
+        if self.out is None:
+            from . import fused
+            net = self.pipe.net
+            with torch.cuda.stream(self.stream), torch.no_grad():
+                try:
+                    sp = self.pend.finish()
+                    self.batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
+                    self.out = self.batch_dict
+                except fused.UnsortedVoxels:  # as MixedScaleSparseTransformer.forward: redo on the order-agnostic kernels
+                    net._unsorted_skip = net._unsorted_backoff
+                    self.out = net._forward(self.batch_dict, False)
+            self.out["stream"] = self.stream
+            self.pend = None
+            k = self.pipe.streams.index(self.stream)
+            if self.pipe.pending[k] is self:
+                self.pipe.pending[k] = None
+        return self.out

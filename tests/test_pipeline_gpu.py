@@ -30,9 +30,15 @@ def test_pipelined_frames_are_bit_identical_to_frames_run_alone(depth):
     assert pipe.own_queues and len({s.cuda_stream for s in pipe.streams}) == depth  # a hardware queue of its own per stream
     outs = [pipe(dict(scenes[i % len(scenes)])) for i in range(4 * len(scenes))]  # several rounds: workspaces are reused
     pipe.synchronize()
+    # ... and with the host wait deferred (what bench.py runs): a frame's result is fetched `depth` submissions later at the latest
+    pend = [pipe(dict(scenes[i % len(scenes)]), inputs_ready=True, defer=True) for i in range(4 * len(scenes))]
+    assert sum(p is not None for p in pipe.pending) == depth  # the last `depth` frames have not been waited for yet
+    pipe.synchronize()
+    assert all(p is None for p in pipe.pending)
+    outs += [p.get() for p in pend]
     for i, out in enumerate(outs):
         sp = out["encoded_spconv_tensor"]
-        f, idx = alone[i % len(scenes)]
+        f, idx = alone[(i % (4 * len(scenes))) % len(scenes)]
         assert torch.equal(sp.indices, idx) and torch.equal(sp.features, f), i
     # one frame object (workspace) per stream, all on the whole-frame C call
     st = net.__dict__["_frame_state"]
