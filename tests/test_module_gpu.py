@@ -695,8 +695,10 @@ def test_height_compression_matches_the_reference_run(golden_dir, tag):
 def test_backward_matches_the_reference_run(golden_dir, name, cls):
     """Row R15: gradients of a fixed linear functional of the block output w.r.t. the input features and every
     parameter, against the reference's own backward (its autograd Functions with K6 / K11 of the C oracle underneath,
-    run on the CPU: oracle/gen_golden.py::gen_gradients).  With autograd on, the module runs the differentiable
-    operator path (HIP K5 / K6 / K8 / K10 / K11 kernels + torch)."""
+    run on the CPU: oracle/gen_golden.py::gen_gradients).  With autograd on, the module runs the COMPACT training path
+    (mssvt_amd/train_path.py: deterministic segmented sums, pair attention, split-fp16 / MFMA linears; the default since
+    round 2) -- the padded operator path (HIP K5 / K6 / K8 / K10 / K11 kernels + torch) is what fused.TRAIN_COMPACT = False
+    selects, and tests/test_train_path_gpu.py compares the two."""
     from mssvt_amd.mssvt_utils import SparseTensor
     d, sd = load(golden_dir, name)
     blk = build_block(d, sd, cls)
