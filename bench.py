@@ -349,7 +349,7 @@ def main():
             with torch.no_grad():
                 return net(dict(voxel_features=feats_, voxel_coords=vc_, batch_size=args.batch))
         step = step_alone
-        if args.in_flight > 1:
+        if args.in_flight > 1 and not args.from_points:
             from mssvt_amd.pipeline import FramePipeline
             pipe = FramePipeline(net, depth=args.in_flight, device=dev)
 
@@ -382,7 +382,17 @@ def main():
                 bd = net(bd)
                 return to_bev(bd)
         step = step_alone = step_points
-        args.in_flight = 1  # (one stream: the framework ops of the PFN layers run on the current stream)
+        if args.in_flight > 1:  # the same pipeline over the whole chain: every op of a frame runs on that frame's stream
+            from mssvt_amd.pipeline import FramePipeline
+            pipe = FramePipeline(lambda bd: to_bev(net(vfe(bd))), depth=args.in_flight, device=dev)
+
+            def step():
+                pts = clouds[turn[0] % len(clouds)]
+                turn[0] += 1
+                return pipe(dict(points=pts, batch_size=args.batch), inputs_ready=True)
+            for _ in range(args.in_flight):
+                step()
+            pipe.synchronize()
         with torch.no_grad():
             bd0 = vfe(dict(points=clouds[0], batch_size=args.batch))
         n_vox, n_pts = int(bd0["voxel_coords"].shape[0]), int(clouds[0].shape[0])

@@ -50,7 +50,7 @@ def _own_queue_streams(n, device):
 class FramePipeline(object):
     def __init__(self, net, depth=4, device=None):
         assert depth >= 1
-        self.net = net
+        self.net = net  # the backbone, or any callable batch_dict -> batch_dict (then pass `device`)
         self.device = torch.device(device if device is not None else next(net.parameters()).device)
         self.own_queues = True
         self.streams = None if os.environ.get("MSSVT_PIPE_POOLED") == "1" else _own_queue_streams(depth, self.device)
@@ -105,11 +105,11 @@ class PendingFrame(object):
     def _enqueue(self):
         from . import frame, fused
         net, bd = self.pipe.net, self.batch_dict
-        feats, coords = bd['voxel_features'], bd['voxel_coords']
-        ok = (getattr(net, "_unsorted_skip", 0) == 0 and net.assume_sorted and feats.is_cuda and
-              any(getattr(b, 'impl', None) == 'fused' for b in net.backbone))
+        feats, coords = bd.get('voxel_features'), bd.get('voxel_coords')
+        ok = (hasattr(net, "backbone") and getattr(net, "_unsorted_skip", 0) == 0 and getattr(net, "assume_sorted", False) and
+              feats is not None and feats.is_cuda and any(getattr(b, 'impl', None) == 'fused' for b in net.backbone))
         self.pend = frame.forward(net, feats, coords, bd['batch_size'], defer=True) if ok else None
-        if self.pend is None:  # not the whole-frame call's case: the ordinary forward, finished here
+        if self.pend is None:  # not the whole-frame call's case (or any other callable, e.g. VFE -> backbone -> BEV): run it here
             self.out = net(bd)
             self.out["stream"] = self.stream
 
