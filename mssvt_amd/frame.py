@@ -216,7 +216,7 @@ def _state(net, feats, batch_size, stream=0):
         st["frames"] = {}
         st["key"] = key
     if stream not in st["frames"]:
-        if len(st["frames"]) >= 8:  # streams come and go: do not keep a workspace for each one ever seen
+        if len(st["frames"]) >= 16:  # streams come and go: do not keep a workspace for each one ever seen
             st["frames"].pop(next(iter(st["frames"])))
         with torch.no_grad():
             try:
@@ -232,6 +232,13 @@ def _state(net, feats, batch_size, stream=0):
 
 def invalidate(net):
     net.__dict__.pop("_frame_state", None)
+
+
+def forget_stream(net, stream):
+    """Drop the frame object (workspace, pinned words) kept for `stream` (a raw handle): the stream is going away."""
+    st = net.__dict__.get("_frame_state")
+    if st is not None:
+        st["frames"].pop(stream or 0, None)
 
 
 class Pending(object):

@@ -96,6 +96,30 @@ class FramePipeline(object):
         for s in self.streams:
             s.synchronize()
 
+    def close(self):
+        """Finish everything, give the per-stream frame objects (workspaces) back and destroy the streams made here."""
+        if not self.streams:
+            return
+        try:
+            self.synchronize()
+            from . import frame
+            for s in self.streams:
+                if hasattr(self.net, "backbone"):
+                    frame.forget_stream(self.net, s.cuda_stream)
+            if self.own_queues:
+                hip = ctypes.CDLL("libamdhip64.so")
+                for s in self.streams:
+                    hip.hipStreamDestroy(ctypes.c_void_p(s.cuda_stream))
+        finally:
+            self.streams = []
+            self.pending = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 (interpreter shutdown: the runtime may be gone already)
+            pass
+
 
 class PendingFrame(object):
     def __init__(self, pipe, stream, batch_dict):
