@@ -20,13 +20,18 @@ __global__ void __launch_bounds__(DB_WPB *MSSVT_WAVE)
                 int hash_size, float *out) {
     __shared__ float tile[DB_WPB][DB_CH][MSSVT_WAVE + 1];
     const int wv = threadIdx.x / MSSVT_WAVE, lane = lane_id();
-    const int xblocks = (X + MSSVT_WAVE - 1) / MSSVT_WAVE;
-    const long long lines = (long long)B * Z * Y * xblocks;
-    for (long long item = (long long)blockIdx.x * DB_WPB + wv; item < lines; item += (long long)gridDim.x * DB_WPB) {
-        const int xb = (int)(item % xblocks);
-        const int y = (int)((item / xblocks) % Y);
-        const int z = (int)((item / ((long long)xblocks * Y)) % Z);
-        const int b = (int)(item / ((long long)xblocks * Y * Z));
+    const int xblocks = (X + MSSVT_WAVE - 1) / MSSVT_WAVE, cgroups = (C + DB_CH - 1) / DB_CH;
+    const long long lines = (long long)B * Z * Y * xblocks, items = lines * cgroups;
+    // one work item = (64 cells of a line, 32 channels): the gather of a line's occupied cells is a chain of dependent loads
+    // (a cell pair per step), so the channel groups of a line go to DIFFERENT waves -- 4 x the waves in flight at C = 128, each
+    // with a quarter of the chain (68 -> 30 us at the detector's BEV grid); the hash probe is repeated per group (cache hits)
+    for (long long item = (long long)blockIdx.x * DB_WPB + wv; item < items; item += (long long)gridDim.x * DB_WPB) {
+        const int c0 = (int)(item % cgroups) * DB_CH;
+        const long long line = item / cgroups;
+        const int xb = (int)(line % xblocks);
+        const int y = (int)((line / xblocks) % Y);
+        const int z = (int)((line / ((long long)xblocks * Y)) % Z);
+        const int b = (int)(line / ((long long)xblocks * Y * Z));
         const int x = xb * MSSVT_WAVE + lane;
         int vstart = 0;
         for (int k = 0; k < b; ++k) vstart += v_bs_cnt[k];
@@ -38,32 +43,30 @@ __global__ void __launch_bounds__(DB_WPB *MSSVT_WAVE)
         const unsigned long long occ = __ballot(row >= 0);
         float *dst = out + ((size_t)b * C * Z + z) * Y * X + (size_t)y * X + x;  // + c * Z*Y*X
         const size_t cstride = (size_t)Z * Y * X;
-        for (int c0 = 0; c0 < C; c0 += DB_CH) {
-            // occupied cells' rows -> tile[channel][cell]: two cells per step (32 channels each, 128-byte reads)
-            unsigned long long m = occ;
-            while (m) {
-                const int l0 = __ffsll((long long)m) - 1;
+        // occupied cells' rows -> tile[channel][cell]: two cells per step (32 channels each, 128-byte reads)
+        unsigned long long m = occ;
+        while (m) {
+            const int l0 = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int l1 = l0;
+            if (m) {
+                l1 = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                int l1 = l0;
-                if (m) {
-                    l1 = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                }
-                const int src_lane = lane < DB_CH ? l0 : l1;
-                const int r = __shfl(row, src_lane);
-                const int c = c0 + (lane & (DB_CH - 1));
-                if (c < C && (lane < DB_CH || l1 != l0)) tile[wv][lane & (DB_CH - 1)][src_lane] = features[(size_t)r * C + c];
             }
-            wave_lds_sync();
-            if (x < X) {
-#pragma unroll 8
-                for (int cc = 0; cc < DB_CH; ++cc) {
-                    if (c0 + cc >= C) break;
-                    dst[(size_t)(c0 + cc) * cstride] = row >= 0 ? tile[wv][cc][lane] : 0.0f;
-                }
-            }
-            wave_lds_sync();
+            const int src_lane = lane < DB_CH ? l0 : l1;
+            const int r = __shfl(row, src_lane);
+            const int c = c0 + (lane & (DB_CH - 1));
+            if (c < C && (lane < DB_CH || l1 != l0)) tile[wv][lane & (DB_CH - 1)][src_lane] = features[(size_t)r * C + c];
         }
+        wave_lds_sync();
+        if (x < X) {
+#pragma unroll 8
+            for (int cc = 0; cc < DB_CH; ++cc) {
+                if (c0 + cc >= C) break;
+                dst[(size_t)(c0 + cc) * cstride] = row >= 0 ? tile[wv][cc][lane] : 0.0f;
+            }
+        }
+        wave_lds_sync();
     }
 }
 
@@ -73,7 +76,7 @@ extern "C" int mssvt_dense_bev(const float *features, int C, const int *map_tabl
     if (!features || !map_table || !v_bs_cnt || !out || C <= 0 || hash_size <= 0 || batch_size <= 0 || x_max <= 0 ||
         y_max <= 0 || z_max <= 0)
         return MSSVT_E_BADARG;
-    const long long lines = (long long)batch_size * z_max * y_max * ((x_max + MSSVT_WAVE - 1) / MSSVT_WAVE);
+    const long long lines = (long long)batch_size * z_max * y_max * ((x_max + MSSVT_WAVE - 1) / MSSVT_WAVE) * ((C + DB_CH - 1) / DB_CH);
     long long grid = (lines + DB_WPB - 1) / DB_WPB;
     if (grid > 65536) grid = 65536;
     k_dense_bev<<<(int)grid, DB_WPB * MSSVT_WAVE, 0, (hipStream_t)stream>>>(

@@ -13,6 +13,7 @@ per-voxel max a ``scatter_reduce('amax')`` (gradient to the maximal rows; pinned
 module by tests/golden/dynamic_vfe_train_*.npz: output, every parameter gradient, the BatchNorm buffers).
 """
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -20,6 +21,7 @@ from torch import nn
 from . import _lib, voxelize
 
 _i = ctypes.c_int
+FUSED_PFN = os.environ.get("MSSVT_FUSED_PFN", "1") != "0"  # csrc/pfn_fused.hip for the default DynamicVFE configuration
 
 
 def voxel_mean_xyz(points, point_voxel, num_voxels):
@@ -127,12 +129,41 @@ class DynamicVFE(nn.Module):
         batch_dict['voxel_coords'] = coords.contiguous()
         return batch_dict
 
+    def _fused_pfn_ok(self, points):
+        """The two PFN layers as two HIP launches (csrc/pfn_fused.hip): the default configuration only."""
+        if not FUSED_PFN or self.num_point_features_in != 5 or not self.with_cluster_center or not self.with_voxel_center or \
+                self.with_distance or len(self.pfn) != 2 or points.dtype != torch.float32 or points.shape[1] < 6:
+            return False
+        shapes = [(blk[0].in_features, blk[0].out_features) for blk in self.pfn]
+        return shapes == [(11, 64), (128, 128)] and all(
+            blk[0].bias is not None and blk[1].affine and blk[1].track_running_stats and blk[0].weight.dtype == torch.float32
+            for blk in self.pfn)
+
     def _forward_eval(self, batch_dict):
         points = batch_dict['points'].contiguous()  # (P, 1 + F) rows [b, x, y, z, intensity, ...]
         batch_size = batch_dict['batch_size']
         voxel_coords, pv = voxelize.voxelize(points, self.point_cloud_range_l, self.voxel_size_l, self.grid_size_l,
                                              batch_size)
         N = voxel_coords.shape[0]
+        if N and self._fused_pfn_ok(points):
+            xyz_mean, _ = voxel_mean_xyz(points, pv, N)
+            P, dev = points.shape[0], points.device
+            x1 = torch.empty((P, 64), dtype=torch.float32, device=dev)
+            m1 = torch.empty((N, 64), dtype=torch.float32, device=dev)
+            out = torch.empty((N, 128), dtype=torch.float32, device=dev)
+            (l1, n1), (l2, n2) = (self.pfn[0][0], self.pfn[0][1]), (self.pfn[1][0], self.pfn[1][1])
+            f3 = lambda xs: (ctypes.c_float * 3)(*[float(v) for v in xs])  # noqa: E731
+            vc = voxel_coords.contiguous()
+            _lib.call("mssvt_pfn_fused_64_128", _lib.ptr(points), _i(points.shape[1]), ctypes.c_longlong(P), _lib.ptr(pv), _i(N),
+                      _lib.ptr(xyz_mean), _lib.ptr(vc), f3(self.voxel_size_l),
+                      f3([self.voxel_size_l[k] / 2 + self.point_cloud_range_l[k] for k in range(3)]),
+                      _lib.ptr(l1.weight), _lib.ptr(l1.bias), _lib.ptr(n1.weight), _lib.ptr(n1.bias), _lib.ptr(n1.running_mean),
+                      _lib.ptr(n1.running_var), ctypes.c_float(n1.eps), _lib.ptr(l2.weight), _lib.ptr(l2.bias), _lib.ptr(n2.weight),
+                      _lib.ptr(n2.bias), _lib.ptr(n2.running_mean), _lib.ptr(n2.running_var), ctypes.c_float(n2.eps),
+                      _lib.ptr(x1), _lib.ptr(m1), _lib.ptr(out), _lib.stream())
+            batch_dict['voxel_features'] = out
+            batch_dict['voxel_coords'] = vc
+            return batch_dict
         gather = pv.clamp(min=0).long()  # points outside the grid read voxel 0; their rows are never reduced
         xyz = points[:, 1:4]
         feats = [points[:, 1:self.num_point_features_in + 1]]

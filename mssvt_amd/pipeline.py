@@ -114,11 +114,8 @@ class FramePipeline(object):
             self.streams = []
             self.pending = []
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:  # noqa: BLE001 (interpreter shutdown: the runtime may be gone already)
-            pass
+    # (no __del__: at interpreter exit the HIP runtime may be torn down before this object -- a hipStreamDestroy then
+    # crashes the process after its work is done; streams of a pipeline that is dropped without close() live until exit)
 
 
 class PendingFrame(object):
