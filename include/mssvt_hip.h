@@ -823,14 +823,14 @@ int mssvt_linear_rows_h(int M, int K, int N, const float *X, int ldx, const floa
  * point_voxel (P) int32, -1 outside the grid; mean3 (N, 3) = mssvt_voxel_mean_xyz; voxel_coords (N, 4) int32 [b, z, y, x];
  * host_voxel_size3 / host_offset3: HOST float[3] (offset = voxel_size / 2 + range_min); layer parameters as the state dict holds
  * them (pfn.{0,1}.0.weight / .bias, pfn.{0,1}.1.weight / .bias / .running_mean / .running_var, eps); x1_scratch (P, 64),
- * m1_scratch (max(N,1), 64): caller-owned; out (N, 128) = the voxel features.                                          */
+ * m1_scratch (max(N,1), 64), x2_scratch (P, 128): caller-owned; out (N, 128) = the voxel features.                                       */
 int mssvt_pfn_fused_64_128(const float *points, int point_stride, long long num_points, const int *point_voxel,
                            int num_voxels, const float *mean3, const int *voxel_coords, const float *host_voxel_size3,
                            const float *host_offset3, const float *W1, const float *b1, const float *bn1_w,
                            const float *bn1_b, const float *bn1_mean, const float *bn1_var, float bn1_eps, const float *W2,
                            const float *b2, const float *bn2_w, const float *bn2_b, const float *bn2_mean,
-                           const float *bn2_var, float bn2_eps, float *x1_scratch, float *m1_scratch, float *out,
-                           void *stream);
+                           const float *bn2_var, float bn2_eps, float *x1_scratch, float *m1_scratch, float *x2_scratch,
+                           float *out, void *stream);
 
 /* ======================================================================== *
  * Part 6 -- timing-only launches (csrc/ceiling.hip; no reference counterpart, nothing reads their output): the byte and

@@ -29,7 +29,7 @@ __device__ __forceinline__ float valu_filler(float seed, float c) {
 }
 
 // ---- the FFN tail's mix: per 16-row tile and wave 48 v_mfma_f32_16x16x32_f16 on 128 resident fragment registers,
-// ~260 vector instructions, per row 512 B in + 3 gathered 512-B rows + 32 B of table + 2 x 512 B out ------------------
+// ~260 vector instructions (filler sized so that SQ_INSTS_VALU / SQ_INSTS_MFMA of a launch match k_ffn_ws's: tools/pmc_ceiling.sh), per row 512 B in + 3 gathered 512-B rows + 32 B of table + 2 x 512 B out ------------------
 __global__ void __launch_bounds__(512, 2) k_ceiling_ffn_ws(int n_rows, const float4 *x_in, const int4 *tab_row, const float4 *tab_w,
                                                            const float4 *attn, const h16x8 *frags, float4 *y, float4 *yn) {
     const int lane = lane_id(), wv = threadIdx.x / MSSVT_WAVE;
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(512, 2) k_ceiling_ffn_ws(int n_rows, const flo
         for (int k = 0; k < 48; ++k)
             acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[k % 32], bfrag, acc[k % 6], 0, 0, 0);
         const float in = ((x.x + a0.x * tw.x) + (a1.y * tw.y + a2.z * tw.z)) + (x.w + x.y);
-        const float f = valu_filler<248>(in, 0.999f);
+        const float f = valu_filler<144>(in, 0.999f);  // + the loop's own ~115 vector instructions = k_ffn_ws's 262 per wave and tile (PMC)
         sink += f;
         y[(size_t)row * 32 + piece] = make_float4(f, in, x.z, a0.w);
         yn[(size_t)row * 32 + piece] = make_float4(in, f, a1.w, a2.w);
@@ -87,8 +87,9 @@ extern "C" int mssvt_ceiling_ffn_ws(int n_rows, const float *x_in, const int *ta
 }
 
 // ---- the window attention's mix (k_attn_kvh<64, 16, 4, 2, true>): one wave per (window, head group) of the real work
-// order; per window 32 key rows x 256 B gathered through the real metadata, 8 fp32 + 48 split-fp16 matrix instructions
-// and ~200 vector instructions per pass of 4 queries (+ ~250 per window), 16 B of Q' in and 4 x 16 B of Xbar out per lane
+// order; per window 32 key rows x 256 B gathered through the real metadata, 8 fp32 + 42 split-fp16 matrix instructions
+// and ~190 vector instructions per pass of 4 queries (+ ~210 per window; sized so that the launch's SQ_INSTS_VALU /
+// SQ_INSTS_MFMA match k_attn_kvh's over both query patterns: tools/pmc_ceiling.sh), 16 B of Q' in and 4 x 16 B of Xbar out per lane
 // and pass ------------------------------------------------------------------------------------------------------------
 struct CeilKvh {
     const float *xhat;
@@ -136,14 +137,14 @@ __global__ void __launch_bounds__(256, 3) k_ceiling_attn_kvh(CeilKvh a) {
             for (int S = 0; S < 4; ++S) tok += rows[t][S].x + rows[t][S].w;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x4f32(tok, 1.0f, acc[k % 6], 0, 0, 0);
-        sink += valu_filler<240>(tok, 0.999f);
+        sink += valu_filler<176>(tok, 0.999f);
         for (int q0 = 0; q0 < nqv; q0 += 4) {
             const int q = min(q0 + la / 4, nqv - 1);
             float4 *xrow = reinterpret_cast<float4 *>(a.qbuf + (size_t)g * a.row_capacity * 256 + (qbase + q) * 256 + (la % 4) * 64) + gq;
             const float4 qp = xrow[0];
 #pragma unroll
-            for (int k = 0; k < 48; ++k) acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(one, one, acc[k % 6], 0, 0, 0);
-            const float f = valu_filler<200>(qp.x + qp.w, 0.999f);
+            for (int k = 0; k < 42; ++k) acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(one, one, acc[k % 6], 0, 0, 0);
+            const float f = valu_filler<160>(qp.x + qp.w, 0.999f);
             sink += f;
             if (q0 + la / 4 < nqv) {
 #pragma unroll

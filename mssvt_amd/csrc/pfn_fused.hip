@@ -12,12 +12,13 @@
 // library GEMM, batch-norm transform, clamp, scatter-max: 0.6 ms at 160k points -- as much as the whole backbone).  Here:
 //   k_pfn1    16 lanes per point (4 output channels each): builds the 11 inputs on the fly from the point row, the voxel's
 //             mean and its integer coordinate (the reference's expressions, multiply and add rounded separately), 44 FMAs per
-//             lane, BatchNorm (eval: running statistics) + ReLU, writes x1 and max-reduces it into m1 (order-preserving
-//             integer atomics: order independent, deterministic);
+//             lane, BatchNorm (eval: running statistics) + ReLU, writes x1;
+//   k_pfn_rowmax  the per-voxel max of x1 / x2 (order-preserving integer atomics: order independent, deterministic; one
+//             wavefront per point so that an atomic instruction covers 256 contiguous bytes of one voxel row);
 //   k_pfn2_h  the 128 -> 128 layer on split-fp16 matrix operands (the arithmetic and tile structure of csrc/linear_rows_h.hip:
 //             the weight matrix as hi / lo MFMA fragments in LDS, 16-point tiles, rows normalised by a power of two): a tile's
-//             rows are gathered as [x1[p] ; m1[voxel[p]]], and the epilogue -- BatchNorm + ReLU -- max-reduces straight into
-//             `out` from the accumulators: x2 is never written.
+//             rows are gathered as [x1[p] ; m1[voxel[p]]], the epilogue is BatchNorm + ReLU, x2 leaves as 16-byte stores.
+// Five launches (fill, k_pfn1, max, k_pfn2_h, max) instead of ~25.
 // Points outside the grid (voxel < 0) are skipped.  Parity: tests/test_vfe_gpu.py (the reference-run goldens and the numpy
 // restatement at full size, 1e-4 of scale: products re-associated, BatchNorm applied in torch's operation order).
 #include "common.hip.h"
@@ -84,7 +85,6 @@ __global__ void __launch_bounds__(256) k_pfn1(Pfn1Args a) {
         s += bl[c];
         s = (s - tl[c]) * sl[c] * a.bn_w[c] + a.bn_b[c];
         o[i] = fmaxf(s, 0.f);
-        pf_atomic_max(a.m1 + (size_t)v * 64 + c, o[i]);
     }
     *reinterpret_cast<float4 *>(a.x1 + p * 64 + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -107,7 +107,7 @@ struct Pfn2Args {
     const float *x1, *m1;  // (P, 64), (N, 64)
     const float *W, *b, *bn_w, *bn_b, *bn_mean, *bn_var;  // W (128, 128): columns [0, 64) <-> x1, [64, 128) <-> m1[voxel]
     float eps;
-    float *out;  // (N, 128) pre-filled with -inf
+    float *out;  // x2 (P, 128)
 };
 
 #define PF2_WAVES 16
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(PF2_WAVES *MSSVT_WAVE, 1) k_pfn2_h(Pfn2Args a)
         h16x8 ah[KS], al[KS];
 #pragma unroll
         for (int P = 0; P < KS; ++P) pf_split8(xr[P][0], xr[P][1], s_in, ah[P], al[P]);
-        float *orow = a.out + (size_t)vs * N + 4 * g;
+        float *orow = a.out + (size_t)p * N + 4 * g;  // x2[p]: reduced per voxel by k_pfn_rowmax (256 contiguous bytes per atomic instruction)
 #pragma unroll 2
         for (int t = 0; t < NT; ++t) {
             f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
@@ -204,14 +204,22 @@ __global__ void __launch_bounds__(PF2_WAVES *MSSVT_WAVE, 1) k_pfn2_h(Pfn2Args a)
             for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(cr[i], PF_INV, mm[i]) * un;
             const float o0 = fmaxf(((r[0] + b4.x) - m4.x) * s4.x * w4.x + c4.x, 0.f), o1 = fmaxf(((r[1] + b4.y) - m4.y) * s4.y * w4.y + c4.y, 0.f),
                         o2 = fmaxf(((r[2] + b4.z) - m4.z) * s4.z * w4.z + c4.z, 0.f), o3 = fmaxf(((r[3] + b4.w) - m4.w) * s4.w * w4.w + c4.w, 0.f);
-            if (v >= 0) {
-                pf_atomic_max(orow + 16 * t + 0, o0);
-                pf_atomic_max(orow + 16 * t + 1, o1);
-                pf_atomic_max(orow + 16 * t + 2, o2);
-                pf_atomic_max(orow + 16 * t + 3, o3);
-            }
+            if (v >= 0) *reinterpret_cast<float4 *>(orow + 16 * t) = make_float4(o0, o1, o2, o3);
         }
     }
+}
+
+// scatter-max of rows into their voxels: one wavefront per point, lanes over channels -- every atomic instruction covers 256
+// contiguous bytes of ONE voxel row (the memory-side atomic units run those at full rate; the accumulator layout of the product
+// would scatter a wave's 64 dwords over 16 rows: 235 us for this reduction instead of 45)
+template <int F>
+__global__ void __launch_bounds__(256) k_pfn_rowmax(const float *x, long long P, const int *voxel, float *out) {
+    const long long p = (long long)blockIdx.x * 4 + threadIdx.x / MSSVT_WAVE;
+    if (p >= P) return;
+    const int v = voxel[p];
+    if (v < 0) return;
+#pragma unroll
+    for (int c = lane_id(); c < F; c += MSSVT_WAVE) pf_atomic_max(out + (size_t)v * F + c, x[p * F + c]);
 }
 
 __global__ void __launch_bounds__(256) k_pfn_fill2(float *a, long long na, float *b, long long nb) {
@@ -225,17 +233,17 @@ __global__ void __launch_bounds__(256) k_pfn_fill2(float *a, long long na, float
 // int32 (-1: outside the grid); mean3 (N, 3) f32 = scatter_mean of xyz (mssvt_voxel_mean_xyz); voxel_coords (N, 4) int32
 // [b, z, y, x]; host_voxel_size3 / host_offset3: HOST float[3] (offset = voxel_size / 2 + range_min); layer parameters as the
 // state dict holds them (pfn.{0,1}.0.weight / .bias, pfn.{0,1}.1.weight / .bias / .running_mean / .running_var);
-// x1_scratch (P, 64), m1_scratch (max(N, 1), 64): caller-owned; out (N, 128): the voxel features.
+// x1_scratch (P, 64), m1_scratch (max(N, 1), 64), x2_scratch (P, 128): caller-owned; out (N, 128): the voxel features.
 extern "C" int mssvt_pfn_fused_64_128(const float *points, int point_stride, long long num_points, const int *point_voxel,
                                       int num_voxels, const float *mean3, const int *voxel_coords, const float *host_voxel_size3,
                                       const float *host_offset3, const float *W1, const float *b1, const float *bn1_w,
                                       const float *bn1_b, const float *bn1_mean, const float *bn1_var, float bn1_eps, const float *W2,
                                       const float *b2, const float *bn2_w, const float *bn2_b, const float *bn2_mean,
-                                      const float *bn2_var, float bn2_eps, float *x1_scratch, float *m1_scratch, float *out,
-                                      void *stream_) {
+                                      const float *bn2_var, float bn2_eps, float *x1_scratch, float *m1_scratch, float *x2_scratch,
+                                      float *out, void *stream_) {
     if (num_points < 0 || num_voxels < 0 || point_stride < 6 || (num_points > 0 && (!points || !point_voxel)) || !mean3 || !voxel_coords ||
         !host_voxel_size3 || !host_offset3 || !W1 || !b1 || !bn1_w || !bn1_b || !bn1_mean || !bn1_var || !W2 || !b2 || !bn2_w || !bn2_b ||
-        !bn2_mean || !bn2_var || !x1_scratch || !m1_scratch || !out)
+        !bn2_mean || !bn2_var || !x1_scratch || !m1_scratch || !x2_scratch || !out)
         return MSSVT_E_BADARG;
     if (num_voxels == 0) return MSSVT_OK;
     hipStream_t stream = (hipStream_t)stream_;
@@ -248,9 +256,10 @@ extern "C" int mssvt_pfn_fused_64_128(const float *points, int point_stride, lon
     a1.W = W1; a1.b = b1; a1.bn_w = bn1_w; a1.bn_b = bn1_b; a1.bn_mean = bn1_mean; a1.bn_var = bn1_var; a1.eps = bn1_eps;
     a1.x1 = x1_scratch; a1.m1 = m1_scratch;
     k_pfn1<<<divup(num_points, 16), 256, 0, stream>>>(a1);
+    k_pfn_rowmax<64><<<divup(num_points, 4), 256, 0, stream>>>(x1_scratch, num_points, point_voxel, m1_scratch);
     Pfn2Args a2;
     a2.P = num_points; a2.voxel = point_voxel; a2.x1 = x1_scratch; a2.m1 = m1_scratch;
-    a2.W = W2; a2.b = b2; a2.bn_w = bn2_w; a2.bn_b = bn2_b; a2.bn_mean = bn2_mean; a2.bn_var = bn2_var; a2.eps = bn2_eps; a2.out = out;
+    a2.W = W2; a2.b = b2; a2.bn_w = bn2_w; a2.bn_b = bn2_b; a2.bn_mean = bn2_mean; a2.bn_var = bn2_var; a2.eps = bn2_eps; a2.out = x2_scratch;
     const size_t lds = (size_t)128 * 128 * 4;
     static bool attr = false;
     if (!attr) {
@@ -262,5 +271,6 @@ extern "C" int mssvt_pfn_fused_64_128(const float *points, int point_stride, lon
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const int grid = min((long long)cus, (long long)divup(num_points, 16 * PF2_WAVES));
     k_pfn2_h<<<grid, PF2_WAVES * MSSVT_WAVE, lds, stream>>>(a2);
+    k_pfn_rowmax<128><<<divup(num_points, 4), 256, 0, stream>>>(x2_scratch, num_points, point_voxel, out);
     return mssvt_launch_status();
 }

@@ -150,6 +150,7 @@ class DynamicVFE(nn.Module):
             P, dev = points.shape[0], points.device
             x1 = torch.empty((P, 64), dtype=torch.float32, device=dev)
             m1 = torch.empty((N, 64), dtype=torch.float32, device=dev)
+            x2 = torch.empty((P, 128), dtype=torch.float32, device=dev)
             out = torch.empty((N, 128), dtype=torch.float32, device=dev)
             (l1, n1), (l2, n2) = (self.pfn[0][0], self.pfn[0][1]), (self.pfn[1][0], self.pfn[1][1])
             f3 = lambda xs: (ctypes.c_float * 3)(*[float(v) for v in xs])  # noqa: E731
@@ -160,7 +161,7 @@ class DynamicVFE(nn.Module):
                       _lib.ptr(l1.weight), _lib.ptr(l1.bias), _lib.ptr(n1.weight), _lib.ptr(n1.bias), _lib.ptr(n1.running_mean),
                       _lib.ptr(n1.running_var), ctypes.c_float(n1.eps), _lib.ptr(l2.weight), _lib.ptr(l2.bias), _lib.ptr(n2.weight),
                       _lib.ptr(n2.bias), _lib.ptr(n2.running_mean), _lib.ptr(n2.running_var), ctypes.c_float(n2.eps),
-                      _lib.ptr(x1), _lib.ptr(m1), _lib.ptr(out), _lib.stream())
+                      _lib.ptr(x1), _lib.ptr(m1), _lib.ptr(x2), _lib.ptr(out), _lib.stream())
             batch_dict['voxel_features'] = out
             batch_dict['voxel_coords'] = vc
             return batch_dict
