@@ -24,7 +24,8 @@ __global__ void __launch_bounds__(DB_WPB *MSSVT_WAVE)
     const long long lines = (long long)B * Z * Y * xblocks, items = lines * cgroups;
     // one work item = (64 cells of a line, 32 channels): the gather of a line's occupied cells is a chain of dependent loads
     // (a cell pair per step), so the channel groups of a line go to DIFFERENT waves -- 4 x the waves in flight at C = 128, each
-    // with a quarter of the chain (68 -> 30 us at the detector's BEV grid); the hash probe is repeated per group (cache hits)
+    // with a quarter of the chain (68 -> 56.6 us at the detector's BEV grid: the 113 MB of line stores now set the time); the hash
+    // probe is repeated per group (cache hits)
     for (long long item = (long long)blockIdx.x * DB_WPB + wv; item < items; item += (long long)gridDim.x * DB_WPB) {
         const int c0 = (int)(item % cgroups) * DB_CH;
         const long long line = item / cgroups;
