@@ -3,6 +3,7 @@
 out=gpurun_out/r05final; mkdir -p $out
 line() { python -c "import json,sys;d=json.loads([l for l in open('$1') if l.startswith('{')][-1]);print('$1',round(d['value'],1),d['unit'],round(d['ms_per_step'],3),'ms', d['n_gpus'], d.get('timing',{}).get('median_ms'), (d.get('one_frame_in_flight') or {}).get('value'))"; }
 timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err; echo "bench rc $?"; line $out/bench_line.json
+timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_driver_steps20_line.json 2>> $out/bench.err; line $out/bench_driver_steps20_line.json
 timeout 400 python bench.py --in-flight 1 --no-cpu-baseline > $out/bench_one_in_flight_line.json 2>> $out/bench.err; line $out/bench_one_in_flight_line.json
 timeout 400 python bench.py --arith f32 --no-cpu-baseline > $out/bench_arith_f32_line.json 2>> $out/bench.err; line $out/bench_arith_f32_line.json
 timeout 400 python bench.py --arith f32 --in-flight 1 --no-cpu-baseline --no-roofline > $out/bench_arith_f32_one_in_flight_line.json 2>> $out/bench.err; line $out/bench_arith_f32_one_in_flight_line.json
