@@ -44,3 +44,32 @@ def test_pipelined_frames_are_bit_identical_to_frames_run_alone(depth):
     st = net.__dict__["_frame_state"]
     assert len(st["frames"]) == depth + 1 and all(fr is not None for fr in st["frames"].values())
     assert len({fr.workspace.data_ptr() for fr in st["frames"].values()}) == depth + 1
+
+
+def test_pipeline_over_any_callable_and_close():
+    """The pipeline also takes a whole chain (bench.py --from-points: VFE -> backbone -> BEV): every frame's ops run on that
+    frame's stream, results equal the chain run alone; close() gives the per-stream frame objects back."""
+    from mssvt_amd import config
+    from mssvt_amd.dynamic_vfe import DynamicVFE
+    from mssvt_amd.pipeline import FramePipeline
+    torch.manual_seed(0)
+    cfg = config.load_yaml(config.DEFAULT_CFG)
+    net = config.build_backbone_from_cfg(cfg).to(DEV).eval()
+    vfe = DynamicVFE(cfg.MODEL.VFE, 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.POINT_CLOUD_RANGE).to(DEV).eval()
+    clouds = [torch.from_numpy(synthetic.make_batch_points(20000, 1, 40 + f)).to(DEV) for f in range(3)]
+
+    def chain(bd):
+        with torch.no_grad():
+            bd = net(vfe(bd))
+        bd["bev"] = bd["encoded_spconv_tensor"].dense()
+        return bd
+    alone = [chain(dict(points=c, batch_size=1))["bev"].clone() for c in clouds]
+    torch.cuda.synchronize()
+    pipe = FramePipeline(chain, depth=3, device=torch.device(DEV, 0))
+    outs = [pipe(dict(points=clouds[i % 3], batch_size=1)) for i in range(9)]
+    pipe.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o["bev"], alone[i % 3]), i
+    n_before = len(net.__dict__["_frame_state"]["frames"])
+    pipe.close()
+    assert pipe.streams == [] and len(net.__dict__["_frame_state"]["frames"]) <= n_before
