@@ -516,7 +516,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(net, cfg, vc_np, feats_np, args.batch, gpu_out=sp_out)
         print(json.dumps(res), flush=True)
     if pipe is not None:
-        pipe.close()  # the streams made here are destroyed while the runtime is alive (a profiler's exit hooks met them otherwise)
+        pipe.close()  # (workspaces back; the streams live until the process ends)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -97,7 +97,7 @@ class FramePipeline(object):
             s.synchronize()
 
     def close(self):
-        """Finish everything, give the per-stream frame objects (workspaces) back and destroy the streams made here."""
+        """Finish everything and give the per-stream frame objects (workspaces) back."""
         if not self.streams:
             return
         try:
@@ -106,16 +106,14 @@ class FramePipeline(object):
             for s in self.streams:
                 if hasattr(self.net, "backbone"):
                     frame.forget_stream(self.net, s.cuda_stream)
-            if self.own_queues:
-                hip = ctypes.CDLL("libamdhip64.so")
-                for s in self.streams:
-                    hip.hipStreamDestroy(ctypes.c_void_p(s.cuda_stream))
+            # (the streams themselves are NOT destroyed: the framework's caching allocator keeps blocks and events tied to
+            # every stream a tensor was allocated on -- destroying one under it crashed the process at exit; they live until
+            # the process ends, as the framework's own pooled streams do)
         finally:
             self.streams = []
             self.pending = []
 
-    # (no __del__: at interpreter exit the HIP runtime may be torn down before this object -- a hipStreamDestroy then
-    # crashes the process after its work is done; streams of a pipeline that is dropped without close() live until exit)
+    # (no __del__: at interpreter exit the HIP runtime may be torn down before this object)
 
 
 class PendingFrame(object):
