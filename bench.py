@@ -70,12 +70,17 @@ def parse(argv=None):
                     help="a step = points -> voxelizer + DynamicVFE -> backbone -> dense() / HeightCompression view (SURVEY 8 f1, "
                          "f2: the neighbours either side of the path), with its own algorithmic bytes; not the BASELINE metric")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
-    ap.add_argument("--in-flight", type=int, default=4,
+    ap.add_argument("--in-flight", type=int, default=None,
                     help="frames in flight (mssvt_amd/pipeline.py: consecutive frames are independent; each runs on its own HIP "
-                         "stream with its own workspace); 1: one frame at a time on one stream, as every round before round 5")
+                         "stream with its own workspace); 1: one frame at a time on one stream, as every round before round 5; "
+                         "default: pipeline.auto_depth(batch) -- 4 below four scenes per step, 1 from there on")
     ap.add_argument("--frames", type=int, default=4,
                     help="distinct resident frames the steps rotate over (1: the same frame from the same addresses every step)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.in_flight is None:
+        from mssvt_amd.pipeline import auto_depth
+        args.in_flight = auto_depth(args.batch)
+    return args
 
 
 def spawn_ranks(args):

@@ -29,8 +29,24 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=o
 # sources under another optimisation level / without the post-RA scheduler.  A result that is "right by the luck of the
 # schedule" (a sum read before its last matrix instruction has landed) differs between them; every
 # variant must reproduce the default library's outputs.  Only the listed files are recompiled, the rest is re-linked.
-MFMA_SOURCES = ("block_attn.hip", "block_attn_bf16.hip", "compress_fused.hip", "compress_ws.hip", "ffn.hip",
-                "linear_rows.hip", "linear_wgrad.hip")
+# The list is DERIVED (every csrc/*.hip whose text names a matrix instruction), so a new MFMA translation unit cannot be
+# left out; ceiling.hip holds timing-only launches that no output depends on.
+MFMA_EXCLUDED = ("ceiling.hip",)
+
+
+def mfma_sources():
+    out = []
+    for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+        base = os.path.basename(src)
+        if base in MFMA_EXCLUDED:
+            continue
+        with open(src) as f:
+            if "mfma" in f.read():
+                out.append(base)
+    return tuple(out)
+
+
+MFMA_SOURCES = mfma_sources()
 VARIANTS = {"O2": ["-O2"], "nopost": ["-mllvm", "-enable-post-misched=false"]}
 VARIANT_DIR = os.path.join(LIB_DIR, "variants")
 

@@ -102,13 +102,9 @@ extern "C" int mssvt_linear_rows(int M, int K, int N, const float *X, int ldx, c
     const size_t lds = (size_t)N * (K + 4) * 4;
 #define LR_GO(KK, NN)                                                                                                       \
     if (K == KK && N == NN) {                                                                                               \
-        static bool attr = false;                                                                                           \
-        if (!attr) {                                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_rows<KK, NN / 16>),                   \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_rows<KK, NN / 16>),                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-            if (e != hipSuccess) return (int)e;                                                                             \
-            attr = true;                                                                                                    \
-        }                                                                                                                   \
+        if (e != hipSuccess) return (int)e;                                                                                 \
         k_linear_rows<KK, NN / 16><<<grid, LR_WAVES * MSSVT_WAVE, lds, st>>>(M, X, ldx, W, transpose_w, bias, relu, out_scale, Y, ldy); \
         return mssvt_launch_status();                                                                                       \
     }

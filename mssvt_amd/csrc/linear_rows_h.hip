@@ -221,13 +221,9 @@ extern "C" int mssvt_linear_rows_h(int M, int K, int N, const float *X, int ldx,
     const size_t lds = (size_t)K * N * 4;  // two fp16 images
 #define LH_GO(KK, NN)                                                                                                    \
     if (K == KK && N == NN) {                                                                                            \
-        static bool attr = false;                                                                                        \
-        if (!attr) {                                                                                                     \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_rows_h<KK, NN>),                   \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_rows_h<KK, NN>),                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-            if (e != hipSuccess) return (int)e;                                                                          \
-            attr = true;                                                                                                 \
-        }                                                                                                                \
+        if (e != hipSuccess) return (int)e;                                                                              \
         k_linear_rows_h<KK, NN><<<grid, LH_WAVES_OF(KK) * MSSVT_WAVE, lds, st>>>(M, X, ldx, W, transpose_w, bias, relu, out_scale, Y, ldy); \
         return mssvt_launch_status();                                                                                    \
     }

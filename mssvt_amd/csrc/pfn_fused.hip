@@ -261,11 +261,9 @@ extern "C" int mssvt_pfn_fused_64_128(const float *points, int point_stride, lon
     a2.P = num_points; a2.voxel = point_voxel; a2.x1 = x1_scratch; a2.m1 = m1_scratch;
     a2.W = W2; a2.b = b2; a2.bn_w = bn2_w; a2.bn_b = bn2_b; a2.bn_mean = bn2_mean; a2.bn_var = bn2_var; a2.eps = bn2_eps; a2.out = x2_scratch;
     const size_t lds = (size_t)128 * 128 * 4;
-    static bool attr = false;
-    if (!attr) {
+    {   // (per device and cheap next to the launches: set on every call, as the other launchers do)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pfn2_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr = true;
     }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;

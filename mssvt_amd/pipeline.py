@@ -1,21 +1,42 @@
 """Several frames of a stream of scenes in flight on one GPU.
 
-Consecutive frames do not depend on each other, and one 160k-point frame does not fill an MI355X: its 27 launches are a
+Consecutive frames do not depend on each other, and one 160k-point frame does not fill an MI355X: its launches are a
 serial chain of latency- and issue-bound kernels with ramp-up, tail and a dependent-launch gap each.  `FramePipeline`
 deals the frames round-robin to `depth` HIP streams; the whole-frame call keeps one frame object (persistent workspace,
 pinned status words, events) per stream (mssvt_amd/frame.py), so frames in flight share nothing they write and the
-hardware interleaves their kernels.  Measured on one MI355X (tools/two_streams.py, one scene per step, each stream on a
-hardware queue of its own): 1 573 -> 1 779 (two frames in flight) -> 1 860 (three) -> 1 894 frames/s (four) -> 1 797 (six);
-at four scenes per step +1 % -- those launches fill the chip by themselves.
-Every frame computes exactly what `net(batch_dict)` computes (tests/test_pipeline_gpu.py: bit-identical outputs).
+hardware interleaves their kernels.  Every frame computes exactly what `net(batch_dict)` computes
+(tests/test_pipeline_gpu.py: bit-identical outputs, at the benchmark size too).
+
+    pipe = FramePipeline(net)                 # depth from the batch size (auto_depth)
+    for bd in loader:
+        frame = pipe(bd)                      # returns right behind the enqueue: nothing waits here
+        ...
+        out = frame.get()                     # the frame's one host wait; the CURRENT stream now waits for the frame's
+        head(out["encoded_spconv_tensor"])    # stream and the outputs are recorded for it: use them like any tensor
 
 The reference runs its frames one by one on the legacy default stream ("Threading / streams"); this is the
 MI355X-side answer to the same loop (a detector's data loader hands over frame i + 1 while frame i is still running).
+
+Streams and the legacy default stream.  The pipeline's streams are created with a full CU mask, which gives each a
+hardware queue of its own (below) -- and such streams are BLOCKING streams in the legacy sense: an operation on the NULL
+(default) stream waits for everything queued on them before it, and their later operations wait for it.  Two consequences,
+both measured ("Frames in flight"):
+* inputs produced on the default stream need NO event: the implicit ordering covers them (and an event RECORDED on the
+  default stream is itself a NULL-stream operation that joins every frame in flight -- round 5's `wait_stream` default ran
+  673 / 1 129 / 914 frames/s at depth 1 / 2 / 3 for that reason);
+* work a caller launches on the default stream between two frames serialises with the frames in flight.  Run the
+  surrounding stages on a non-default stream (`torch.cuda.stream(side)`), or inside the pipeline (`FramePipeline(chain)`).
 """
 import ctypes
 import os
 
 import torch
+
+
+def auto_depth(batch_size):
+    """Frames in flight that pay at `batch_size` scenes per step (measured, DESIGN 5: one scene per step +15 - 20 % at four
+    in flight; from four scenes per step the launches fill the chip by themselves and more depth only adds workspaces)."""
+    return 4 if int(batch_size) < 4 else 1
 
 
 def _own_queue_streams(n, device):
@@ -47,8 +68,26 @@ def _own_queue_streams(n, device):
     return out
 
 
+def _tensors_of(out):
+    """The device tensors of an output dict that a consumer may read (what `record_stream` has to cover)."""
+    seen = []
+    for v in out.values():
+        if isinstance(v, torch.Tensor):
+            if v.is_cuda:
+                seen.append(v)
+        elif v is not None and hasattr(v, "features") and hasattr(v, "indices"):  # SparseTensor
+            for name in ("features", "indices", "map_table", "v_bs_cnt"):
+                t = getattr(v, name, None)
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    seen.append(t)
+    return seen
+
+
 class FramePipeline(object):
-    def __init__(self, net, depth=4, device=None):
+    def __init__(self, net, depth=None, device=None, batch_size=1):
+        """`depth`: frames in flight; None = `auto_depth(batch_size)`."""
+        if depth is None:
+            depth = auto_depth(batch_size)
         assert depth >= 1
         self.net = net  # the backbone, or any callable batch_dict -> batch_dict (then pass `device`)
         self.device = torch.device(device if device is not None else next(net.parameters()).device)
@@ -58,43 +97,60 @@ class FramePipeline(object):
             self.own_queues = False
             self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
         self.turn = 0
-        self.pending = [None] * depth  # per stream: the deferred frame whose host wait has not happened yet
+        self.pending = [None] * depth  # per stream: the frame whose host wait has not happened yet
 
     @property
     def depth(self):
         return len(self.streams)
 
-    def __call__(self, batch_dict, inputs_ready=False, defer=False):
-        """Enqueue one forward on the next stream and return its output dict (as `net(batch_dict)`, plus "stream": the
-        stream its tensors are produced on -- a consumer on another stream waits for it: `cur.wait_stream(out["stream"])`).
-        The inputs may come from the caller's current stream: the frame's stream first waits for what is queued there now,
-        unless `inputs_ready` says they are complete already (resident frames: the event pair on the default stream costs
-        4 % of the frame rate at two frames in flight, tools/two_streams.py).
-        `defer`: return a `PendingFrame` right behind the enqueue; its `get()` does the frame's one host wait (the output
-        row count) and returns the dict.  The host then never stands still between two submissions: a frame's wait happens
-        when its result is asked for, or when its stream comes round again `depth` submissions later."""
+    def __call__(self, batch_dict, inputs_ready=None, defer=True):
+        """Enqueue one forward on the next stream and return its `PendingFrame` right behind the enqueue; `get()` (or
+        indexing it like the output dict) does the frame's one host wait -- the output row count -- and hands the outputs
+        over to the caller's current stream.  The host never stands still between two submissions: a frame's wait happens
+        when its result is asked for, or when its stream comes round again `depth` submissions later.
+
+        The inputs may come from the caller's current stream: the frame's stream is ordered behind what is queued there
+        now (`inputs_ready=None`), by an event -- or by nothing at all when that stream is the legacy default stream and the
+        pipeline's streams are blocking streams (module docstring) -- unless `inputs_ready=True` says they are complete
+        already.  The input tensors are recorded for the frame's stream (the caller may drop them right away).
+        `defer=False`: return the output dict itself (= `pipe(bd).get()`)."""
         k = self.turn % len(self.streams)
         s = self.streams[k]
         self.turn += 1
         if self.pending[k] is not None:  # this stream's frame object is about to be reused: its frame is `depth` old
-            self.pending[k].get()
-        if not inputs_ready:
-            s.wait_stream(torch.cuda.current_stream(self.device))
+            self.pending[k]._finish()
+        cur = torch.cuda.current_stream(self.device)
+        if not inputs_ready and cur.cuda_stream != s.cuda_stream:
+            if not (self.own_queues and cur.cuda_stream == 0):  # (implicit ordering, see above)
+                s.wait_stream(cur)
+        for v in batch_dict.values():  # allocated on the caller's stream, read on `s` for the whole frame
+            if isinstance(v, torch.Tensor) and v.is_cuda and cur.cuda_stream != s.cuda_stream:
+                v.record_stream(s)
         p = PendingFrame(self, s, batch_dict)
         with torch.cuda.stream(s), torch.no_grad():
             p._enqueue()
-        if defer and p.out is None:
+        if p.out is None:
             self.pending[k] = p
-            return p
-        return p.get()
+        return p if defer else p.get()
+
+    @staticmethod
+    def result(frame):
+        """The output dict of what `__call__` returned (a `PendingFrame`, or already a dict)."""
+        return frame.get() if isinstance(frame, PendingFrame) else frame
 
     def synchronize(self):
         """Every submitted frame finished (host side and device side)."""
-        for p in self.pending:
+        err = None
+        for p in list(self.pending):
             if p is not None:
-                p.get()
+                try:
+                    p._finish()
+                except Exception as e:  # noqa: BLE001 -- finish the others, then report the first
+                    err = err or e
         for s in self.streams:
             s.synchronize()
+        if err is not None:
+            raise err
 
     def close(self):
         """Finish everything and give the per-stream frame objects (workspaces) back."""
@@ -102,6 +158,7 @@ class FramePipeline(object):
             return
         try:
             self.synchronize()
+        finally:
             from . import frame
             for s in self.streams:
                 if hasattr(self.net, "backbone"):
@@ -109,7 +166,6 @@ class FramePipeline(object):
             # (the streams themselves are NOT destroyed: the framework's caching allocator keeps blocks and events tied to
             # every stream a tensor was allocated on -- destroying one under it crashed the process at exit; they live until
             # the process ends, as the framework's own pooled streams do)
-        finally:
             self.streams = []
             self.pending = []
 
@@ -117,12 +173,16 @@ class FramePipeline(object):
 
 
 class PendingFrame(object):
+    """One submitted frame.  `get()` -> the output dict (as `net(batch_dict)`, plus "stream": the stream its tensors were
+    produced on).  Also readable like that dict: `frame["encoded_spconv_tensor"]`."""
+
     def __init__(self, pipe, stream, batch_dict):
         self.pipe, self.stream, self.batch_dict = pipe, stream, batch_dict
-        self.out = self.pend = None
+        self.out = self.pend = self.error = None
+        self._handed = set()
 
     def _enqueue(self):
-        from . import frame, fused
+        from . import frame
         net, bd = self.pipe.net, self.batch_dict
         feats, coords = bd.get('voxel_features'), bd.get('voxel_coords')
         ok = (hasattr(net, "backbone") and getattr(net, "_unsorted_skip", 0) == 0 and getattr(net, "assume_sorted", False) and
@@ -132,22 +192,56 @@ class PendingFrame(object):
             self.out = net(bd)
             self.out["stream"] = self.stream
 
-    def get(self):
-        """The output dict of this frame (the host wait happens here, once)."""
+    def _finish(self):
+        """The frame's host wait, once; whatever it raises is raised again by every later call (and the pipeline's slot is
+        free either way: one bad frame does not wedge its stream)."""
+        if self.error is not None:
+            raise self.error
         if self.out is None:
             from . import fused
             net = self.pipe.net
-            with torch.cuda.stream(self.stream), torch.no_grad():
-                try:
-                    sp = self.pend.finish()
-                    self.batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
-                    self.out = self.batch_dict
-                except fused.UnsortedVoxels:  # as MixedScaleSparseTransformer.forward: redo on the order-agnostic kernels
-                    net._unsorted_skip = net._unsorted_backoff
-                    self.out = net._forward(self.batch_dict, False)
-            self.out["stream"] = self.stream
-            self.pend = None
-            k = self.pipe.streams.index(self.stream)
-            if self.pipe.pending[k] is self:
-                self.pipe.pending[k] = None
+            try:
+                with torch.cuda.stream(self.stream), torch.no_grad():
+                    try:
+                        sp = self.pend.finish()
+                        self.batch_dict.update({'encoded_spconv_tensor': sp, 'encoded_spconv_tensor_stride': 1})
+                        self.out = self.batch_dict
+                    except fused.UnsortedVoxels:  # as MixedScaleSparseTransformer.forward: redo on the order-agnostic kernels
+                        net._unsorted_skip = net._unsorted_backoff
+                        self.out = net._forward(self.batch_dict, False)
+                self.out["stream"] = self.stream
+            except Exception as e:  # noqa: BLE001
+                self.error = e
+                raise
+            finally:
+                self.pend = None
+                pend = self.pipe.pending
+                for k in range(len(pend)):
+                    if pend[k] is self:
+                        pend[k] = None
         return self.out
+
+    def get(self, sync=True):
+        """The output dict.  `sync`: the caller's CURRENT stream waits for the frame's stream (device side; the host does
+        not) and the outputs are recorded for it, so that they can be used -- and dropped -- there like any tensor; the
+        framework's allocator would otherwise hand a dropped block back to the frame's stream while the consumer still
+        reads it.  `sync=False`: the caller orders and records by hand (`cur.wait_stream(out["stream"])`,
+        `t.record_stream(cur)`), or only wants host-side metadata."""
+        out = self._finish()
+        if sync:
+            cur = torch.cuda.current_stream(self.pipe.device)
+            if cur.cuda_stream != self.stream.cuda_stream and cur.cuda_stream not in self._handed:
+                self._handed.add(cur.cuda_stream)
+                cur.wait_stream(self.stream)
+                for t in _tensors_of(out):
+                    t.record_stream(cur)
+        return out
+
+    def __getitem__(self, key):
+        return self.get()[key]
+
+    def __contains__(self, key):
+        return key in self.get()
+
+    def keys(self):
+        return self.get().keys()

@@ -95,3 +95,16 @@ def test_library_has_no_mfma_result_hazard():
     assert kernels > 300 and mfmas > 10000  # the code objects were found and read
     assert not v, "\n".join("%s: %s @%x -> %s @%x: %d of %d wait states" %
                             (x.func, x.mfma, x.mfma_addr, x.consumer, x.consumer_addr, x.have, x.need) for x in v[:20])
+
+
+def test_schedule_variants_cover_every_matrix_instruction_source():
+    """build.MFMA_SOURCES is derived from the sources, so a new MFMA translation unit is rebuilt under every schedule
+    variant (round 5 left linear_rows_h.hip / pfn_fused.hip out of a hand-kept list), and the probe exercises them."""
+    import glob
+    from mssvt_amd import build
+    want = {os.path.basename(p) for p in glob.glob(os.path.join(build.CSRC, "*.hip")) if "mfma" in open(p).read()}
+    assert want - set(build.MFMA_EXCLUDED) == set(build.MFMA_SOURCES)
+    assert {"linear_rows_h.hip", "pfn_fused.hip", "ffn.hip", "block_attn.hip", "compress_ws.hip"} <= set(build.MFMA_SOURCES)
+    assert set(build.MFMA_EXCLUDED) == {"ceiling.hip"}  # timing-only launches: no output depends on them
+    probe = open(os.path.join(os.path.dirname(build.HERE), "tools", "schedule_probe.py")).read()
+    assert "vfe_fused" in probe and "linear_rows_h_%d_%d" in probe and "(256, 128)" in probe

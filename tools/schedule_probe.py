@@ -81,6 +81,29 @@ def main(out_path):
                                         synthetic.GRID_SIZE, synthetic.VOXEL_SIZE, synthetic.POINT_CLOUD_RANGE).eval().to(DEV)
     f64 = torch.randn(vc.shape[0], 64, generator=torch.Generator().manual_seed(6)).to(DEV)
     out["c64_default"] = _frame(net64, f64, coords, B)
+    # --- csrc/linear_rows_h.hip directly: K = 256 (the 8-wave form) and K = 128 (16 waves), forward and dX forms
+    from mssvt_amd import train_path
+    g = torch.Generator().manual_seed(11)
+    for K, N in ((256, 128), (128, 256), (64, 128)):
+        xr = (torch.randn(5000, K, generator=g) * torch.exp2(torch.randint(-20, 20, (5000, 1), generator=g).float())).to(DEV)
+        wr = torch.randn(N, K, generator=g).to(DEV)
+        br = torch.randn(N, generator=g).to(DEV)
+        out["linear_rows_h_%d_%d" % (K, N)] = train_path._linear_rows(xr, wr, False, br, True, N, split16=True).cpu().numpy()
+        dy = torch.randn(5000, N, generator=g).to(DEV)
+        out["linear_rows_h_%d_%d_dx" % (K, N)] = train_path._linear_rows(dy, wr, True, None, False, K, split16=True).cpu().numpy()
+    # --- csrc/pfn_fused.hip: the DynamicVFE eval forward on the default configuration (k_pfn1, k_pfn2_h, k_pfn_rowmax)
+    from mssvt_amd import dynamic_vfe
+    pts = synthetic.make_batch_points(20000, B, 78)
+    torch.manual_seed(2)
+    vfe = dynamic_vfe.DynamicVFE(config.Config.wrap({}), 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE,
+                                 synthetic.POINT_CLOUD_RANGE).eval()
+    with torch.no_grad():
+        for m in vfe.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+        assert dynamic_vfe.FUSED_PFN
+        out["vfe_fused"] = vfe.to(DEV)(dict(points=torch.from_numpy(pts).to(DEV), batch_size=B))["voxel_features"].cpu().numpy()
     np.savez(out_path, **out)
     print("schedule probe: %d arrays from %s -> %s" % (len(out) - 1, _lib.LIB_PATH, out_path))
 

@@ -46,28 +46,36 @@ def main():
         t = min(run(n, a.steps) for _ in range(3))
         print("%d stream(s), one network copy each: %.3f ms per step, %.0f frames/s" % (n, t * 1e3, a.batch / t))
     from mssvt_amd.pipeline import FramePipeline
+    side = torch.cuda.Stream()
 
-    def run_pipe(pipe, steps, wait=True):
+    def run_pipe(pipe, steps, mode):
+        """mode: default = pipe(bd) from the default stream; side = the caller works on a non-default stream (an event orders
+        the frame behind it); ready = inputs_ready=True; consume_default / consume_side = every frame's output is read by a
+        small kernel on the default / a side stream `depth` submissions later (get(): wait_stream + record_stream)."""
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            f = frames[i % len(frames)]
-            if wait:
-                pipe(dict(voxel_features=f[3], voxel_coords=f[2], batch_size=a.batch))
-            else:
-                s = pipe.streams[i % pipe.depth]
-                with torch.cuda.stream(s), torch.no_grad():
-                    net(dict(voxel_features=f[3], voxel_coords=f[2], batch_size=a.batch))
+        held = []
+        ctx = torch.cuda.stream(side) if mode in ("side", "consume_side") else torch.cuda.stream(torch.cuda.default_stream())
+        with ctx:
+            for i in range(steps):
+                f = frames[i % len(frames)]
+                bd = dict(voxel_features=f[3], voxel_coords=f[2], batch_size=a.batch)
+                held.append(pipe(bd, inputs_ready=True) if mode == "ready" else pipe(bd))
+                if mode.startswith("consume") and len(held) > pipe.depth:
+                    out = held.pop(0).get()
+                    out["encoded_spconv_tensor"].features.sum()
+        pipe.synchronize()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
     for n in range(1, a.streams + 1):
         pipe = FramePipeline(net, depth=n)
-        for wait in (True, False):
-            run_pipe(pipe, 20, wait)
-            t = min(run_pipe(pipe, a.steps, wait) for _ in range(3))
-            print("FramePipeline depth %d (%s): %.3f ms per step, %.0f frames/s" %
-                  (n, "wait_stream" if wait else "no wait_stream", t * 1e3, a.batch / t))
+        for mode in ("default", "side", "ready", "consume_default", "consume_side"):
+            run_pipe(pipe, 20, mode)
+            t = min(run_pipe(pipe, a.steps, mode) for _ in range(3))
+            print("FramePipeline depth %d (%s, %s): %.3f ms per step, %.0f frames/s" %
+                  (n, "own queues" if pipe.own_queues else "pooled streams", mode, t * 1e3, a.batch / t))
+        pipe.close()
 
 
 if __name__ == "__main__" and "--cu-mask" not in sys.argv:
