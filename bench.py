@@ -214,29 +214,24 @@ def cpu_baseline(net, cfg, vc_np, feats_np, batch, gpu_out=None):
     return res
 
 
-def ffn_arith_name(net):
-    """How the FFN / CompressBlock matrix products are computed (mssvt_amd/fused.py FFN_ARITH)."""
-    from mssvt_amd import fused
-    if net.backbone[0].impl != "fused":
-        return "library GEMM (fp32)"
-    if getattr(net.backbone[0], "ffn_arith", fused.FFN_ARITH) == "f16x3":
-        return ("fp32 operands split into two fp16 halves (hi + 2^-11 lo: 22 of 24 mantissa bits, the lo x lo term dropped), "
-                "3 x v_mfma_f32_16x16x32_f16, fp32 accumulate (max error vs float64 within 1.3x of the fp32 MFMA's)")
-    return "v_mfma_f32_16x16x4_f32"
+_ARITH_TEXT = {
+    "split16": "fp32 operands as two fp16 halves (hi + 2^-11 lo: 22 of 24 mantissa bits, the lo x lo term dropped), 3 x "
+               "v_mfma_f32_16x16x32_f16, fp32 accumulate",
+    "f32": "v_mfma_f32_16x16x4_f32", "bf16": "bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16), one launch"}
 
 
-def attn_arith_name(net, attn_dtype):
-    """How the window attention's matrix products are computed (mssvt_amd/fused.py ATTN_KV16 / attn_dtype)."""
+def arith_of(net):
+    """(attn_arith, ffn_arith, per-block list): the arithmetic the blocks RAN on -- the outcome of the fp16-range guards on
+    the parameters as they are (mssvt_amd/fused.py::arith_report), not the policy."""
     from mssvt_amd import fused
-    blk = net.backbone[0]
-    if getattr(blk, "impl", None) != "fused":
-        return "operator path (fp32)"
-    if attn_dtype == "bf16" and fused.attn_uses_bf16(blk):
-        return "bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16), one launch"
-    if getattr(blk, "attn_kv16", fused.ATTN_KV16):
-        return ("fp32 operands as two fp16 halves (as ffn_arith) in all three launches when the parameters keep them inside "
-                "the fp16 range (checked per parameter version), else v_mfma_f32_16x16x4_f32")
-    return "v_mfma_f32_16x16x4_f32"
+    rep = fused.arith_report(net)
+
+    def name(key, blocks):
+        kinds = sorted({b[key].split(" (")[0] for b in blocks})
+        txt = " + ".join(_ARITH_TEXT.get(k, k) for k in kinds)
+        return "%s: %s" % (" / ".join(kinds), txt) if kinds else None
+    body = [b for b in rep[:-1]] if len(rep) > 1 else rep
+    return name("attn", body), name("ffn", rep), rep
 
 
 def workload_name(args, cfg_given):
@@ -462,6 +457,7 @@ def main():
             torch.cuda.synchronize()
         sp_out = out["encoded_spconv_tensor"]
         ms = 1e3 * elapsed / args.steps
+        arith = arith_of(net)
         n_bn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in det.modules()) if det is not None else 0
         n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in det.modules()) if det is not None else 0
         res = {
@@ -474,13 +470,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.attn_dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": workload_name(args, bool(args.cfg)),
-                       "impl": impl, "attn_dtype": args.attn_dtype, "attn_arith": attn_arith_name(net, args.attn_dtype),
-                       "ffn_arith": ffn_arith_name(net), "arith": args.arith, "host_path": host_path(),
+                       "impl": impl, "attn_dtype": args.attn_dtype, "attn_arith": arith[0], "ffn_arith": arith[1],
+                       "arith_per_block": arith[2], "arith": args.arith, "host_path": host_path(),
                        "voxels_per_gpu": int(vc.shape[0]),
                        "frames_in_flight": 1 if (args.train or args.in_flight <= 1) else args.in_flight,
-                       "streams": None if (args.train or args.in_flight <= 1) else (
-                           "one HIP stream per frame in flight, each on a hardware queue of its own (mssvt_amd/pipeline.py)"
-                           if pipe.own_queues else "one pooled HIP stream per frame in flight"),
+                       "streams": None if (args.train or args.in_flight <= 1) else {
+                           "priority": "one high-priority framework stream per frame in flight (a hardware-queue pool of their own; "
+                                       "mssvt_amd/pipeline.py)",
+                           "cumask": "one HIP stream per frame in flight, each on a hardware queue of its own (CU-mask streams)",
+                           "pooled": "one pooled HIP stream per frame in flight"}[pipe.stream_kind],
                        "frames_rotated": len(frames), "voxels_per_frame": [int(f[2].shape[0]) for f in frames],
                        "output_voxels": int(sp_out.features.shape[0]) if sp_out is not None else None,
                        "detector": None if det is None else {

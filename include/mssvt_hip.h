@@ -839,6 +839,11 @@ int mssvt_pfn_fused_64_128(const float *points, int point_stride, long long num_
  * ======================================================================== */
 int mssvt_ceiling_ffn_ws(int n_rows, const float *x_in, const int *tab_row, const float *tab_w, const float *attn,
                          const void *fragments_256k, float *y, float *y_norm, void *stream);
+/* round 6: the same launch with the mix as a parameter -- variant = 100 * mode + filler index; mode 0 no matrix instructions,
+ * 1 = 48 v_mfma_f32_16x16x32_f16 per wave and 16-row tile (the product's), 2 = 48 v_mfma_f32_32x32x16_f16 per wave and
+ * 32-row tile (the same FLOP per row); filler index -> {0, 72, 144, 216, 288, 400} vector instructions per wave and tile. */
+int mssvt_ceiling_ffn_mix(int variant, int n_rows, const float *x_in, const int *tab_row, const float *tab_w,
+                          const float *attn, const void *fragments_256k, float *y, float *y_norm, void *stream);
 int mssvt_ceiling_attn_kvh(int C, int c0_group0, int c0_group1, int K, const float *xhat, const float *kmeta0,
                            const float *kmeta1, const int *perm, const int *num_active_dev, const int *q_off,
                            const int *nq_valid, int row_capacity, int win_capacity, float *qbuf, void *stream);

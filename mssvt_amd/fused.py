@@ -1304,6 +1304,43 @@ CMP_WS = os.environ.get("MSSVT_CMP_WS", "1") != "0"  # csrc/compress_ws.hip (sor
 
 
 @_no_grad
+def arith_report(net):
+    """Which arithmetic every block of `net` RUNS on with its parameters as they are now: the outcome of the fp16-range
+    guards per block (not the policy) -- bench.py prints it as config.arith_per_block, so a checkpoint whose weights send a
+    block to the fp32-instruction kernels shows in the line.  One small host sync per block and parameter version."""
+    from .frame import _Stub
+    from .mssvt_backbone import MixedScaleSparseTransformerCompressBlock as Cmp
+    stub = _Stub(net.point_cloud_range)
+    out = []
+    for i, blk in enumerate(net.backbone):
+        if getattr(blk, "impl", None) != "fused":
+            out.append({"block": i, "attn": "operator path (fp32)", "ffn": "library GEMM (fp32)"})
+            continue
+        want16 = getattr(blk, "ffn_arith", FFN_ARITH) == "f16x3"
+        ffn = "split16" if want16 and _ffn_f16_weights(_ffn_refs(blk)) is not None else "f32"
+        if isinstance(blk, Cmp):
+            C = blk.linear1.in_features
+            if not _compress_fused_ok(blk, None, C):
+                attn = "operator path (fp32)"
+            elif CMP_WS and _compress_ws_weights(blk, stub) is not None:
+                attn = "split16 (k_cmp_ws, one launch)"
+            elif want16 and _compress_f16_ok(blk, stub):
+                attn = "split16 (three launches)"
+            else:
+                attn = "f32"
+        elif not _supported_static(blk):
+            attn = "operator path (fp32)"
+        elif attn_uses_bf16(blk):
+            attn = "bf16"
+        else:
+            r = _attn_refs(blk, None)
+            ok = getattr(blk, "attn_kv16", ATTN_KV16) and _attn_kv16_ok(blk, r, stub)
+            attn = ("split16" if getattr(blk, "attn_qo16", ATTN_QO16) and r.get("kv16_packed") is not None else
+                    "split16 (window launch only)") if ok else "f32"
+        out.append({"block": i, "attn": attn, "ffn": ffn})
+    return out
+
+
 def _compress_ws_weights(block, sp):
     """The split-fp16 fragments of pos_proj.2 / to_q / to_kv / proj for mssvt_compress_ws (once per parameter version), or
     None: shape not covered (C = 128, one head group of 16-channel heads), fp32 arithmetic asked for, or operands that may

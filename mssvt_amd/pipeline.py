@@ -17,15 +17,27 @@ hardware interleaves their kernels.  Every frame computes exactly what `net(batc
 The reference runs its frames one by one on the legacy default stream ("Threading / streams"); this is the
 MI355X-side answer to the same loop (a detector's data loader hands over frame i + 1 while frame i is still running).
 
-Streams and the legacy default stream.  The pipeline's streams are created with a full CU mask, which gives each a
-hardware queue of its own (below) -- and such streams are BLOCKING streams in the legacy sense: an operation on the NULL
-(default) stream waits for everything queued on them before it, and their later operations wait for it.  Two consequences,
-both measured ("Frames in flight"):
-* inputs produced on the default stream need NO event: the implicit ordering covers them (and an event RECORDED on the
-  default stream is itself a NULL-stream operation that joins every frame in flight -- round 5's `wait_stream` default ran
-  673 / 1 129 / 914 frames/s at depth 1 / 2 / 3 for that reason);
-* work a caller launches on the default stream between two frames serialises with the frames in flight.  Run the
-  surrounding stages on a non-default stream (`torch.cuda.stream(side)`), or inside the pipeline (`FramePipeline(chain)`).
+Which streams (`STREAMS`, or MSSVT_PIPE_STREAMS=priority|cumask|pooled).  Measured on one MI355X, one 160k-point scene per
+step, four frames in flight, 100 steps (tools/two_streams.py, profiles/r06_*_two_streams.txt; one frame at a time: 1 555):
+
+                                             producer only   + a consumer kernel per frame on the DEFAULT stream / a side stream
+    priority  (framework pool, priority -1)      1 865              1 609 / 1 608
+    cumask    (own hardware queue each)          1 878                592 / 1 646
+    pooled    (framework pool, priority 0)       1 765              1 746 / 1 749     (GPU_MAX_HW_QUEUES=8: 1 863, 1 637 / 1 636)
+
+* The runtime multiplexes ordinary streams onto GPU_MAX_HW_QUEUES = 4 hardware queues and two streams on one queue
+  serialise: the normal-priority pool shares its queues with the default stream (1 765; three frames in flight ran anywhere
+  between 1 633 and 1 858 in round 5).  High-priority streams draw from a queue pool of their own -> `priority`, the default.
+* A stream created with a CU mask (`cumask`: hipExtStreamCreateWithCUMask, every CU enabled) gets a hardware queue of its
+  own -- and is a BLOCKING stream in the legacy sense (the call takes no flags): every operation on the NULL (default)
+  stream, an event record included, waits for everything queued on it and holds back whatever follows.  Round 5's default
+  call recorded an event on the default stream per frame (`wait_stream`) and ran 673 / 1 129 / 914 frames/s at depth 1 / 2 /
+  3 for that reason (1.485 ms per frame at depth 1 against 0.641); a detector whose other stages run on the default stream
+  loses the overlap altogether (592).  With `cumask` inputs from the default stream therefore take NO event (the implicit
+  ordering covers them) and the surrounding stages belong on a side stream; it stays selectable for producer-only loops.
+* A consumer waits for ITS frame (an event recorded right behind the frame), not for the frame's stream: `wait_stream`
+  would also wait for the next frame already queued there, and the next submission would wait for the consumer -- the
+  pipeline then runs at depth ~1.5 (measured: 995 frames/s).
 """
 import ctypes
 import os
@@ -33,10 +45,16 @@ import os
 import torch
 
 
+STREAMS = "priority"  # "priority": the framework's high-priority pool; "cumask": a hardware queue of its own per stream; "pooled"
+
+
 def auto_depth(batch_size):
     """Frames in flight that pay at `batch_size` scenes per step (measured, DESIGN 5: one scene per step +15 - 20 % at four
-    in flight; from four scenes per step the launches fill the chip by themselves and more depth only adds workspaces)."""
-    return 4 if int(batch_size) < 4 else 1
+    in flight, two scenes per step +3 % at two; from four scenes per step the launches fill the chip by themselves -- batch 4:
+    1 875 / 1 881 / 1 856 frames/s at depth 1 / 2 / 4, batch 8: 1 894 / 1 931 / 1 909, profiles/r06_a_depth_by_batch.txt -- and more
+    depth only adds workspaces)."""
+    b = int(batch_size)
+    return 4 if b < 2 else (2 if b < 4 else 1)
 
 
 def _own_queue_streams(n, device):
@@ -91,12 +109,15 @@ class FramePipeline(object):
         assert depth >= 1
         self.net = net  # the backbone, or any callable batch_dict -> batch_dict (then pass `device`)
         self.device = torch.device(device if device is not None else next(net.parameters()).device)
-        self.own_queues = True
-        self.streams = None if os.environ.get("MSSVT_PIPE_POOLED") == "1" else _own_queue_streams(depth, self.device)
+        kind = os.environ.get("MSSVT_PIPE_STREAMS", "pooled" if os.environ.get("MSSVT_PIPE_POOLED") == "1" else STREAMS)
+        self.streams = _own_queue_streams(depth, self.device) if kind == "cumask" else None
+        self.own_queues = self.streams is not None  # (blocking streams in the legacy sense: module docstring)
         if self.streams is None:
-            self.own_queues = False
-            self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
+            prio = -1 if kind == "priority" else 0
+            self.streams = [torch.cuda.Stream(self.device, priority=prio) for _ in range(depth)]
+        self.stream_kind = "cumask" if self.own_queues else ("priority" if kind == "priority" else "pooled")
         self.turn = 0
+        self.frame_events = True
         self.pending = [None] * depth  # per stream: the frame whose host wait has not happened yet
 
     @property
@@ -129,6 +150,9 @@ class FramePipeline(object):
         p = PendingFrame(self, s, batch_dict)
         with torch.cuda.stream(s), torch.no_grad():
             p._enqueue()
+            if self.frame_events:  # what a consumer on another stream waits for: THIS frame, not whatever follows it on `s`
+                p.done = torch.cuda.Event()
+                p.done.record(s)
         if p.out is None:
             self.pending[k] = p
         return p if defer else p.get()
@@ -178,7 +202,7 @@ class PendingFrame(object):
 
     def __init__(self, pipe, stream, batch_dict):
         self.pipe, self.stream, self.batch_dict = pipe, stream, batch_dict
-        self.out = self.pend = self.error = None
+        self.out = self.pend = self.error = self.done = None
         self._handed = set()
 
     def _enqueue(self):
@@ -232,7 +256,10 @@ class PendingFrame(object):
             cur = torch.cuda.current_stream(self.pipe.device)
             if cur.cuda_stream != self.stream.cuda_stream and cur.cuda_stream not in self._handed:
                 self._handed.add(cur.cuda_stream)
-                cur.wait_stream(self.stream)
+                if self.done is not None:
+                    cur.wait_event(self.done)
+                else:
+                    cur.wait_stream(self.stream)
                 for t in _tensors_of(out):
                     t.record_stream(cur)
         return out

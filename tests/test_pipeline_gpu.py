@@ -27,7 +27,7 @@ def test_pipelined_frames_are_bit_identical_to_frames_run_alone(depth):
             alone.append((sp.features.clone(), sp.indices.clone()))
     torch.cuda.synchronize()
     pipe = FramePipeline(net, depth=depth)
-    assert pipe.own_queues and len({s.cuda_stream for s in pipe.streams}) == depth  # a hardware queue of its own per stream
+    assert pipe.stream_kind == "priority" and len({s.cuda_stream for s in pipe.streams}) == depth
     outs = [pipe(dict(scenes[i % len(scenes)])) for i in range(4 * len(scenes))]  # several rounds: workspaces are reused
     pipe.synchronize()
     # ... and with the host wait deferred (what bench.py runs): a frame's result is fetched `depth` submissions later at the latest
@@ -104,7 +104,6 @@ def test_four_full_size_frames_in_flight_match_frames_run_alone_and_the_oracle()
             alone.append((sp.features.clone(), sp.indices.clone()))
     torch.cuda.synchronize()
     pipe = FramePipeline(net, depth=4)
-    assert pipe.own_queues
     pend = [pipe(dict(scenes[i % 4]), inputs_ready=True, defer=True) for i in range(24)]  # six rounds, all four in flight
     pipe.synchronize()
     outs = [p.get() for p in pend]
@@ -134,7 +133,7 @@ def test_default_call_is_the_fast_path():
     import time
     from mssvt_amd import config
     from mssvt_amd.pipeline import FramePipeline, auto_depth
-    assert auto_depth(1) == 4 and auto_depth(4) == 1
+    assert auto_depth(1) == 4 and auto_depth(2) == 2 and auto_depth(4) == 1
     torch.manual_seed(0)
     net = config.build_backbone_from_cfg(config.load_yaml(config.DEFAULT_CFG)).to(DEV).eval()
     scenes = []

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--kinds", default="cumask,priority,pooled", help="FramePipeline stream kinds to compare (MSSVT_PIPE_STREAMS)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -68,14 +69,16 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
-    for n in range(1, a.streams + 1):
-        pipe = FramePipeline(net, depth=n)
-        for mode in ("default", "side", "ready", "consume_default", "consume_side"):
-            run_pipe(pipe, 20, mode)
-            t = min(run_pipe(pipe, a.steps, mode) for _ in range(3))
-            print("FramePipeline depth %d (%s, %s): %.3f ms per step, %.0f frames/s" %
-                  (n, "own queues" if pipe.own_queues else "pooled streams", mode, t * 1e3, a.batch / t))
-        pipe.close()
+    for kind in a.kinds.split(","):
+        os.environ["MSSVT_PIPE_STREAMS"] = kind
+        for n in ([1, a.streams] if kind == "cumask" else [a.streams]):
+            pipe = FramePipeline(net, depth=n)
+            for mode in ("default", "side", "ready", "consume_default", "consume_side"):
+                run_pipe(pipe, 20, mode)
+                t = min(run_pipe(pipe, a.steps, mode) for _ in range(3))
+                print("FramePipeline depth %d (%s streams, %s): %.3f ms per step, %.0f frames/s" %
+                      (n, pipe.stream_kind, mode, t * 1e3, a.batch / t))
+            pipe.close()
 
 
 if __name__ == "__main__" and "--cu-mask" not in sys.argv:
