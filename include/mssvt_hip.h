@@ -832,6 +832,20 @@ int mssvt_pfn_fused_64_128(const float *points, int point_stride, long long num_
                            const float *bn2_var, float bn2_eps, float *x1_scratch, float *m1_scratch, float *x2_scratch,
                            float *out, void *stream);
 
+/* Round 6: the same two layers AND the cluster-centre mean over points grouped by voxel (csrc/pfn_sorted.hip): a counting
+ * sort on point_voxel, then every reduction is a loop over a voxel's run of rows -- no atomics on feature rows, no -inf
+ * fills, the per-point layer-2 output never reaches memory.  Results bit-identical to mssvt_voxel_mean_xyz +
+ * mssvt_pfn_fused_64_128.  workspace: mssvt_pfn_sorted_workspace_ints(P, N) int32; x1_scratch (P, 64), m1_scratch (N, 64):
+ * caller-owned; out (N, 128).  Every voxel must hold at least one point (mssvt_voxelize's output does).                  */
+long long mssvt_pfn_sorted_workspace_ints(long long num_points, int num_voxels);
+int mssvt_pfn_sorted_64_128(const float *points, int point_stride, long long num_points, const int *point_voxel,
+                            int num_voxels, const int *voxel_coords, const float *host_voxel_size3,
+                            const float *host_offset3, const float *W1, const float *b1, const float *bn1_w,
+                            const float *bn1_b, const float *bn1_mean, const float *bn1_var, float bn1_eps, const float *W2,
+                            const float *b2, const float *bn2_w, const float *bn2_b, const float *bn2_mean,
+                            const float *bn2_var, float bn2_eps, int *workspace, float *x1_scratch, float *m1_scratch,
+                            float *out, void *stream);
+
 /* ======================================================================== *
  * Part 6 -- timing-only launches (csrc/ceiling.hip; no reference counterpart, nothing reads their output): the byte and
  *           instruction mix of k_ffn_ws / k_attn_kvh on the frame's real tables with every dependency between the
@@ -847,6 +861,13 @@ int mssvt_ceiling_ffn_mix(int variant, int n_rows, const float *x_in, const int 
 int mssvt_ceiling_attn_kvh(int C, int c0_group0, int c0_group1, int K, const float *xhat, const float *kmeta0,
                            const float *kmeta1, const int *perm, const int *num_active_dev, const int *q_off,
                            const int *nq_valid, int row_capacity, int win_capacity, float *qbuf, void *stream);
+
+/* round 6: variant 1 = the mix of "Wv applied at the end of the window launch" (24 more matrix + ~40 more vector
+ * instructions per pass of 4 queries, the hand-off a quarter of the bytes); variant 0 = mssvt_ceiling_attn_kvh.          */
+int mssvt_ceiling_attn_kvh_variant(int variant, int C, int c0_group0, int c0_group1, int K, const float *xhat,
+                                   const float *kmeta0, const float *kmeta1, const int *perm, const int *num_active_dev,
+                                   const int *q_off, const int *nq_valid, int row_capacity, int win_capacity, float *qbuf,
+                                   void *stream);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,7 @@ struct AttnArgs {
     float *attn;
     int row_capacity;  // rows of qbuf / the compact row arrays
     const void *packed;  // split-fp16 weight fragments of this group (mssvt_attn_pack_weights) or null
+    int xcd;  // deal the work order so that an XCD owns a contiguous run per round (common.hip.h, xcd_contiguous_block)
 };
 
 // head groups of equal shape run in ONE launch: blockIdx.y = group (their work is independent: channel
@@ -1062,7 +1063,21 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     const int n_act = __builtin_amdgcn_readfirstlane(*a.num_wins);
     const int wstep = gridDim.x * ATTN_ROW_WAVES;
     const int K = a.K;
-    int wi = __builtin_amdgcn_readfirstlane(blockIdx.x * ATTN_ROW_WAVES + wv);
+    // XCD-aware deal of the work order (MSSVT_XCD_REMAP=2; off by default until measured faster): neighbours in the order are
+    // neighbours in space inside a weight class and share key rows, and every XCD has an L2 of its own.  Whole contiguous runs
+    // per XCD (common.hip.h, xcd_contiguous_block) cut the HBM traffic 114.1 -> 106.3 MB per launch but cost 106k -> 116k cycles:
+    // the order is heaviest-first, and a contiguous eighth of a round hands one XCD the heaviest windows of every round.  So:
+    // CHUNKS of 24 consecutive entries, dealt round-robin to the XCDs -- every XCD sees the whole weight range of a round.
+    int wi;
+    {
+        const int per_xcd = (int)(gridDim.x >> 3) * ATTN_ROW_WAVES;
+        if (a.xcd > 1 && (gridDim.x & 7) == 0 && per_xcd % 24 == 0) {
+            const int x = blockIdx.x & 7, idx = (int)(blockIdx.x >> 3) * ATTN_ROW_WAVES + wv;
+            wi = __builtin_amdgcn_readfirstlane(((idx / 24) * 8 + x) * 24 + idx % 24);
+        } else {
+            wi = __builtin_amdgcn_readfirstlane(blockIdx.x * ATTN_ROW_WAVES + wv);
+        }
+    }
     if (wi >= n_act) return;
     const __amdgpu_buffer_rsrc_t xr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.xhat), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t km_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(a.kmeta), 0, -1, 0x00020000);
@@ -1459,6 +1474,7 @@ static int block_attention_impl(
         a.attn = attn;
         a.row_capacity = row_capacity;
         a.packed = host_packed ? host_packed[g] : nullptr;
+        a.xcd = mssvt_xcd_remap();
         qoff += (size_t)row_capacity * (((heads + 3) / 4) * 4) * Cg;
         if (same) {
             pack.g[g] = a;

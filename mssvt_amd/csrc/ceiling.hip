@@ -193,6 +193,13 @@ struct CeilKvh {
     float *qbuf;
     int C, c0[2], K, row_capacity;
 };
+// VAR 0: the product's mix.  VAR 1 (round 6): "Wv at the end of the window launch" -- per pass 24 more
+// split-fp16 matrix instructions (4 heads x 2 k-steps x 3 products: V^T = Wv_h Xbar_h on the pass's 16 (query, head) columns)
+// and ~40 more vector instructions (the operand split of Xbar), and the hand-off shrinks from 4 x 16 B per lane (Xbar: 64 floats
+// per query and head) to 16 B (V: 16 floats per query and head).  Round 6 also removed what made this ceiling SLOWER than the
+// product (114k against 104k cycles): the first pass's Q' was a dependent load inside the pass loop; it now travels with the
+// next window's rows, one window ahead, like everything else.
+template <int VAR>
 __global__ void __launch_bounds__(256, 3) k_ceiling_attn_kvh(CeilKvh a) {
     const int g = blockIdx.y, lane = lane_id(), la = lane & 15, gq = lane >> 4, wv = threadIdx.x / MSSVT_WAVE;
     const int n_act = *a.num_act, wstep = gridDim.x * 4;
@@ -201,9 +208,11 @@ __global__ void __launch_bounds__(256, 3) k_ceiling_attn_kvh(CeilKvh a) {
     for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float sink = 0.f;
     const h16x8 one = h16x8{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
-    // the next window's key rows are requested before this window's work (k_attn_kvh runs its rows one window ahead too)
-    float4 rows_n[2][4];
-    int w_n = 0;
+    // the next window's key rows, counts and first Q' piece are requested before this window's work
+    float4 rows_n[2][4], qp_n;
+    int w_n = 0, nqv_n = 0;
+    size_t qbase_n = 0;
+#define CEIL_QROW(qbase_, q_) (reinterpret_cast<float4 *>(a.qbuf + (size_t)g * a.row_capacity * 256 + ((qbase_) + (q_)) * 256 + (la % 4) * 64) + gq)
 #define CEIL_ROWS(wi_)                                                                                   \
     {                                                                                                    \
         w_n = a.perm[min((wi_), n_act - 1)];                                                             \
@@ -213,13 +222,16 @@ __global__ void __launch_bounds__(256, 3) k_ceiling_attn_kvh(CeilKvh a) {
             const float4 *src = reinterpret_cast<const float4 *>(a.xhat + (size_t)r * a.C + a.c0[g]) + gq; \
             _Pragma("unroll") for (int S = 0; S < 4; ++S) rows_n[t][S] = src[4 * S];                     \
         }                                                                                                \
+        const int qo_ = a.q_off[w_n], nv_ = a.nq_valid[w_n];                                             \
+        nqv_n = qo_ + nv_ <= a.row_capacity ? nv_ : 0;                                                   \
+        qbase_n = (size_t)qo_;                                                                           \
+        qp_n = CEIL_QROW(qbase_n, min(la / 4, max(nqv_n - 1, 0)))[0];                                    \
     }
     if ((int)(blockIdx.x * 4 + wv) < n_act) CEIL_ROWS((int)(blockIdx.x * 4 + wv))
     for (int wi = blockIdx.x * 4 + wv; wi < n_act; wi += wstep) {
-        const int w = w_n;
-        const int nqv = a.q_off[w] + a.nq_valid[w] <= a.row_capacity ? a.nq_valid[w] : 0;
-        const size_t qbase = (size_t)a.q_off[w];
-        float4 rows[2][4];
+        const int nqv = nqv_n;
+        const size_t qbase = qbase_n;
+        float4 rows[2][4], qp = qp_n;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -235,27 +247,29 @@ __global__ void __launch_bounds__(256, 3) k_ceiling_attn_kvh(CeilKvh a) {
         sink += valu_filler<176>(tok, 0.999f);
         for (int q0 = 0; q0 < nqv; q0 += 4) {
             const int q = min(q0 + la / 4, nqv - 1);
-            float4 *xrow = reinterpret_cast<float4 *>(a.qbuf + (size_t)g * a.row_capacity * 256 + (qbase + q) * 256 + (la % 4) * 64) + gq;
-            const float4 qp = xrow[0];
+            float4 *xrow = CEIL_QROW(qbase, q);
+            if (q0 > 0) qp = xrow[0];
 #pragma unroll
-            for (int k = 0; k < 42; ++k) acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(one, one, acc[k % 6], 0, 0, 0);
-            const float f = valu_filler<160>(qp.x + qp.w, 0.999f);
+            for (int k = 0; k < (VAR == 1 ? 66 : 42); ++k) acc[k % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(one, one, acc[k % 6], 0, 0, 0);
+            const float f = valu_filler<(VAR == 1 ? 200 : 160)>(qp.x + qp.w, 0.999f);
             sink += f;
             if (q0 + la / 4 < nqv) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xrow[4 * u] = make_float4(f, qp.y, qp.z, qp.x);
+                for (int u = 0; u < (VAR == 1 ? 1 : 4); ++u) xrow[4 * u] = make_float4(f, qp.y, qp.z, qp.x);
             }
         }
     }
+#undef CEIL_ROWS
+#undef CEIL_QROW
     float s = sink;
 #pragma unroll
     for (int i = 0; i < 6; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 123.456f) a.qbuf[0] = s;
 }
 
-extern "C" int mssvt_ceiling_attn_kvh(int C, int c0_group0, int c0_group1, int K, const float *xhat, const float *kmeta0,
-                                      const float *kmeta1, const int *perm, const int *num_active_dev, const int *q_off,
-                                      const int *nq_valid, int row_capacity, int win_capacity, float *qbuf, void *stream) {
+static int ceiling_attn_kvh_launch(int variant, int C, int c0_group0, int c0_group1, int K, const float *xhat, const float *kmeta0,
+                                   const float *kmeta1, const int *perm, const int *num_active_dev, const int *q_off,
+                                   const int *nq_valid, int row_capacity, int win_capacity, float *qbuf, void *stream) {
     if (C <= 0 || K <= 0 || !xhat || !kmeta0 || !kmeta1 || !perm || !num_active_dev || !q_off || !nq_valid || !qbuf || win_capacity <= 0)
         return MSSVT_E_BADARG;
     CeilKvh a;
@@ -263,6 +277,24 @@ extern "C" int mssvt_ceiling_attn_kvh(int C, int c0_group0, int c0_group1, int K
     a.perm = perm; a.num_act = num_active_dev; a.q_off = q_off; a.nq_valid = nq_valid; a.qbuf = qbuf;
     a.C = C; a.c0[0] = c0_group0; a.c0[1] = c0_group1; a.K = K; a.row_capacity = row_capacity;
     const int grid = min(divup(win_capacity, 4), 512);  // the product launch: (256 CUs x 4 workgroups / 2 groups, 2) at 3 waves per SIMD
-    k_ceiling_attn_kvh<<<dim3(grid, 2), 256, 0, (hipStream_t)stream>>>(a);
+    if (variant == 1) k_ceiling_attn_kvh<1><<<dim3(grid, 2), 256, 0, (hipStream_t)stream>>>(a);
+    else k_ceiling_attn_kvh<0><<<dim3(grid, 2), 256, 0, (hipStream_t)stream>>>(a);
     return mssvt_launch_status();
+}
+
+extern "C" int mssvt_ceiling_attn_kvh(int C, int c0_group0, int c0_group1, int K, const float *xhat, const float *kmeta0,
+                                      const float *kmeta1, const int *perm, const int *num_active_dev, const int *q_off,
+                                      const int *nq_valid, int row_capacity, int win_capacity, float *qbuf, void *stream) {
+    return ceiling_attn_kvh_launch(0, C, c0_group0, c0_group1, K, xhat, kmeta0, kmeta1, perm, num_active_dev, q_off, nq_valid,
+                                   row_capacity, win_capacity, qbuf, stream);
+}
+
+// variant 1: the mix of "Wv applied at the end of the window launch" (24 more matrix instructions, ~40 more vector instructions
+// per pass, a quarter of the hand-off bytes) -- the timing-only answer to "would that fusion pay?"
+extern "C" int mssvt_ceiling_attn_kvh_variant(int variant, int C, int c0_group0, int c0_group1, int K, const float *xhat,
+                                              const float *kmeta0, const float *kmeta1, const int *perm, const int *num_active_dev,
+                                              const int *q_off, const int *nq_valid, int row_capacity, int win_capacity, float *qbuf,
+                                              void *stream) {
+    return ceiling_attn_kvh_launch(variant, C, c0_group0, c0_group1, K, xhat, kmeta0, kmeta1, perm, num_active_dev, q_off, nq_valid,
+                                   row_capacity, win_capacity, qbuf, stream);
 }

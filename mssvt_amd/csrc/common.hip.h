@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mssvt_hip.h"
 
@@ -33,6 +34,19 @@ int mssvt_occupancy_columns_launch(const int *indices, int num_voxels, int batch
                                    unsigned long long *columns, hipStream_t stream);
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (MSSVT_WAVE - 1); }
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one -- observed, MI355X_MICROARCH.md; used for
+// speed only, never for correctness), and every XCD has an L2 of its own.  Work whose neighbours in the work order read the same
+// rows (voxel tiles that gather the attention rows of shared windows, windows that gather the key rows of shared cells)
+// should be dealt so that an XCD's workgroups own a CONTIGUOUS run of it each round: logical block = (b % 8) (n / 8) + b / 8,
+// a permutation of [0, n) when 8 divides n (else the identity).  MSSVT_XCD_REMAP=0 turns it off (A / B runs).
+__device__ __forceinline__ int xcd_contiguous_block(int b, int n, int on) {
+    return (on && (n & 7) == 0) ? (b & 7) * (n >> 3) + (b >> 3) : b;
+}
+static inline int mssvt_xcd_remap() {
+    static const int on = getenv("MSSVT_XCD_REMAP") ? atoi(getenv("MSSVT_XCD_REMAP")) : 1;
+    return on;
+}
 
 // Ordering point for LDS traffic between lanes of ONE wave (LDS operations of a
 // wave complete in order; this only stops the compiler from moving them).

@@ -38,6 +38,7 @@ struct FfnArgs {
     const float *ln2_w, *ln2_b;  // optional second LayerNorm applied to y (next block's norm1)
     float eps2;
     float *y_norm;
+    int xcd;  // deal the tiles so that an XCD owns a contiguous run per round (common.hip.h, xcd_contiguous_block)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -602,12 +603,25 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     const int r = wv * RPW + lane / LPR, q = lane % LPR;  // row-wise view: row of the tile, channels [4 q, 4 q + 4)
     const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
     const int tiles = (n + 15) >> 4;
-    if (n <= 0 || (int)blockIdx.x >= tiles) return;
+    // Tiles are dealt so that an XCD owns ONE contiguous eighth of the rows and its gridDim / 8 workgroups walk it side by side
+    // (workgroups are dispatched round-robin over the XCDs: block b runs on XCD b % 8 -- observed, used for speed only): the
+    // voxels of a window lie in three x-slabs ~160 rows apart in the (b, x, y, z) order and gather the SAME attention rows, so
+    // the rows a workgroup gathers were mostly fetched into ITS XCD's L2 by a neighbour a moment ago.  Round-robin tiles put
+    // consecutive tiles on different XCDs (each with an L2 of its own): 146 MB of HBM traffic per launch against 114 MB
+    // algorithmic.  MSSVT_XCD_REMAP=0 restores the round-robin deal.
+    int tstep = gridDim.x, tend = tiles, tile0 = blockIdx.x;
+    if (a.xcd && (gridDim.x & 7) == 0 && tiles >= 8 * (int)gridDim.x) {
+        const int x = blockIdx.x & 7, per_xcd = (tiles + 7) >> 3;
+        tstep = gridDim.x >> 3;
+        tile0 = x * per_xcd + (int)(blockIdx.x >> 3);
+        tend = min((x + 1) * per_xcd, tiles);
+    }
+    if (n <= 0 || tile0 >= tend) return;
 
     // Rows past the end are CLAMPED to row n - 1 everywhere (table, gathers, stores): such lanes compute exactly what the
     // lanes of row n - 1 compute and store the same values to the same place -- no predication, hence no branches
     // inside the barrier intervals (the scheduler interleaves MFMA and VALU only within one basic block).
-    int tile = blockIdx.x;
+    int tile = tile0;
     int4 tr = make_int4(0, 0, 0, 0);
     float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
     int own = 0;
@@ -717,7 +731,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     int4 trn = tr;
     float4 twn = tw;
     int ownn = own;
-    FFW_TAB(min(tile + (int)gridDim.x, tiles - 1), trn, twn, ownn)
+    FFW_TAB(min(tile + tstep, tend - 1), trn, twn, ownn)
 
     // ---- this wave's weight slices as A fragments: pre-split by k_ffn_pack, or split here ---------------------
     h16x8 W1h[2][NP], W1l[2][NP], W2h[NW], W2l[NW];
@@ -772,9 +786,9 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     float4 xc;
     FFW_COMBINE(xc)
     {
-        const int t1 = min(tile + (int)gridDim.x, tiles - 1);
+        const int t1 = min(tile + tstep, tend - 1);
         FFW_ISSUE(t1, trn, twn, ownn)
-        FFW_TAB(min(t1 + (int)gridDim.x, tiles - 1), trn, twn, ownn)
+        FFW_TAB(min(t1 + tstep, tend - 1), trn, twn, ownn)
     }
     FFW_NORM_TO_BFRAG(xc)
     __syncthreads();
@@ -787,8 +801,8 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     // every vector instruction: both waves of a SIMD then want the same pipe at the same time) or hoists every LDS read to
     // the top (spills at 256 registers); sched_group_barrier patterns were tried and are not stable from build to build.
     for (;;) {
-        const int tile_next = tile + gridDim.x;
-        const bool has_next = tile_next < tiles;
+        const int tile_next = tile + tstep;
+        const bool has_next = tile_next < tend;
         const int t1 = has_next ? tile_next : tile;  // the tile whose A / GEMM1 run in this iteration
         WSTAMP(1)
         // ---- I2: GEMM2(t): this wave's 16 output channels over all k-slices | A(t1) ------------------------------
@@ -815,9 +829,9 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                     if (pc == 0) {
                         FFW_COMBINE(xn)
                     } else if (pc == 1) {
-                        const int t2 = min(t1 + (int)gridDim.x, tiles - 1);
+                        const int t2 = min(t1 + tstep, tend - 1);
                         FFW_ISSUE(t2, trn, twn, ownn)
-                        FFW_TAB(min(t2 + (int)gridDim.x, tiles - 1), trn, twn, ownn)
+                        FFW_TAB(min(t2 + tstep, tend - 1), trn, twn, ownn)
                     } else if (pc == 2) {
                         mean_ = ffw_row_sum<LPR>((xn.x + xn.y) + (xn.z + xn.w)) * (1.0f / C);
                         d01_ = pk2(xn.x, xn.y) - pk1(mean_);
@@ -1044,7 +1058,7 @@ extern "C" int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, co
     a.tab_row = nullptr; a.tab_w = nullptr; a.attn = nullptr;
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
-    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm;
+    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm; a.xcd = mssvt_xcd_remap();
     return dispatch_ffn(C, FF, a, hidden, phases, (hipStream_t)stream);
 }
 
@@ -1070,6 +1084,6 @@ extern "C" int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_
     a.attn = attn;
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
-    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm;
+    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm; a.xcd = mssvt_xcd_remap();
     return dispatch_ffn(C, FF, a, hidden, phases, (hipStream_t)stream);
 }

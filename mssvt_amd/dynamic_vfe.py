@@ -22,6 +22,9 @@ from . import _lib, voxelize
 
 _i = ctypes.c_int
 FUSED_PFN = os.environ.get("MSSVT_FUSED_PFN", "1") != "0"  # csrc/pfn_fused.hip for the default DynamicVFE configuration
+# ... over points grouped by voxel (csrc/pfn_sorted.hip: no atomics on feature rows, no fills, x2 never stored); "0": the
+# atomic reductions of round 5 (kept: the comparator of tests/test_vfe_gpu.py)
+SORTED_PFN = os.environ.get("MSSVT_PFN_SORTED", "1") != "0"
 
 
 def voxel_mean_xyz(points, point_voxel, num_voxels):
@@ -145,6 +148,27 @@ class DynamicVFE(nn.Module):
         voxel_coords, pv = voxelize.voxelize(points, self.point_cloud_range_l, self.voxel_size_l, self.grid_size_l,
                                              batch_size)
         N = voxel_coords.shape[0]
+        if N and self._fused_pfn_ok(points) and SORTED_PFN:
+            P, dev = points.shape[0], points.device
+            lib = _lib.lib()
+            lib.mssvt_pfn_sorted_workspace_ints.restype = ctypes.c_longlong
+            ws = torch.empty(int(lib.mssvt_pfn_sorted_workspace_ints(ctypes.c_longlong(P), _i(N))), dtype=torch.int32, device=dev)
+            x1 = torch.empty((P, 64), dtype=torch.float32, device=dev)
+            m1 = torch.empty((N, 64), dtype=torch.float32, device=dev)
+            out = torch.empty((N, 128), dtype=torch.float32, device=dev)
+            (l1, n1), (l2, n2) = (self.pfn[0][0], self.pfn[0][1]), (self.pfn[1][0], self.pfn[1][1])
+            f3 = lambda xs: (ctypes.c_float * 3)(*[float(v) for v in xs])  # noqa: E731
+            vc = voxel_coords.contiguous()
+            _lib.call("mssvt_pfn_sorted_64_128", _lib.ptr(points), _i(points.shape[1]), ctypes.c_longlong(P), _lib.ptr(pv), _i(N),
+                      _lib.ptr(vc), f3(self.voxel_size_l),
+                      f3([self.voxel_size_l[k] / 2 + self.point_cloud_range_l[k] for k in range(3)]),
+                      _lib.ptr(l1.weight), _lib.ptr(l1.bias), _lib.ptr(n1.weight), _lib.ptr(n1.bias), _lib.ptr(n1.running_mean),
+                      _lib.ptr(n1.running_var), ctypes.c_float(n1.eps), _lib.ptr(l2.weight), _lib.ptr(l2.bias), _lib.ptr(n2.weight),
+                      _lib.ptr(n2.bias), _lib.ptr(n2.running_mean), _lib.ptr(n2.running_var), ctypes.c_float(n2.eps),
+                      _lib.ptr(ws), _lib.ptr(x1), _lib.ptr(m1), _lib.ptr(out), _lib.stream())
+            batch_dict['voxel_features'] = out
+            batch_dict['voxel_coords'] = vc
+            return batch_dict
         if N and self._fused_pfn_ok(points):
             xyz_mean, _ = voxel_mean_xyz(points, pv, N)
             P, dev = points.shape[0], points.device

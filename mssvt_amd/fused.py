@@ -1532,7 +1532,7 @@ def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
     ma = blk.ms_attn
     qbuf = _query_scratch(p, od["row_cap"], ma, x_in.device)
     ms = event_time_ms(lambda: _attention_call(blk, p, od, C, nq, xhat, qbuf, attn), 20)
-    ms_ceil = None
+    ms_ceil = ms_ceil_wv = None
     r_ = _attn_refs(blk, None)
     if r_["n"] == 2 and tuple(ma.scale_dims) == (64, 64) and blk.key_num_sample == 32 and ma.per_head_dim == 16:
         # csrc/ceiling.hip: k_attn_kvh's bytes through the real work order and key metadata, its instruction counts per
@@ -1540,6 +1540,11 @@ def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
         ms_ceil = event_time_ms(lambda: _lib.call(
             "mssvt_ceiling_attn_kvh", _i(C), _i(0), _i(64), _i(32), _P(xhat), _P(p.kmeta[0]), _P(p.kmeta[1]), _P(od["perm"]),
             _P(od["n_act"]), _P(od["q_off"]), _P(od["nq_valid"]), _i(od["row_cap"]), _i(p.cap), _P(qbuf), _lib.stream()), 20)
+        # ... and the mix of "Wv applied at the end of the window launch" (round 6: measured instead of argued)
+        ms_ceil_wv = event_time_ms(lambda: _lib.call(
+            "mssvt_ceiling_attn_kvh_variant", _i(1), _i(C), _i(0), _i(64), _i(32), _P(xhat), _P(p.kmeta[0]), _P(p.kmeta[1]),
+            _P(od["perm"]), _P(od["n_act"]), _P(od["q_off"]), _P(od["nq_valid"]), _i(od["row_cap"]), _i(p.cap), _P(qbuf),
+            _lib.stream()), 20)
     nw = int(p.num_wins.item())
     K = blk.key_num_sample
     keys = [int((p.k_mask[g][:nw] == 0).sum()) for g in range(2)]
@@ -1575,6 +1580,7 @@ def _attention_roofline(net, blk, sp, xhat, event_time_ms, peak_gbs, pmc):
                                    "against the 16-bit matrix peak (the pipe it runs on); frac_vs_f32_matrix_peak = the same FLOP "
                                    "against the fp32 instruction's peak (what rounds 3-4 reported as frac)" if kv16 else "f32"},
             "ceiling_us_window_launch": None if ms_ceil is None else ms_ceil * 1e3,
+            "ceiling_us_window_launch_wv_fused": None if ms_ceil_wv is None else ms_ceil_wv * 1e3,
             "pmc": counters or None,
             "note": "ceiling_us_window_launch = k_ceiling_attn_kvh (csrc/ceiling.hip, timing only): the bytes and instruction "
                     "counts of the per-window launch k_attn_kvh (its own time: profiles/r05_*_kernel_stats.csv) with no dependency "

@@ -17,35 +17,41 @@ hardware interleaves their kernels.  Every frame computes exactly what `net(batc
 The reference runs its frames one by one on the legacy default stream ("Threading / streams"); this is the
 MI355X-side answer to the same loop (a detector's data loader hands over frame i + 1 while frame i is still running).
 
-Which streams (`STREAMS`, or MSSVT_PIPE_STREAMS=priority|cumask|pooled).  Measured on one MI355X, one 160k-point scene per
-step, four frames in flight, 100 steps (tools/two_streams.py, profiles/r06_*_two_streams.txt; one frame at a time: 1 555):
+Which streams (`STREAMS`, or MSSVT_PIPE_STREAMS=cumask|priority|pooled).  Measured on one MI355X, one 160k-point scene per
+step, four frames in flight (one frame at a time: 1 555 - 1 575 frames/s; profiles/r06_*_two_streams.txt, r06_*_pipe_trace.txt):
 
-                                             producer only   + a consumer kernel per frame on the DEFAULT stream / a side stream
-    priority  (framework pool, priority -1)      1 865              1 609 / 1 608
-    cumask    (own hardware queue each)          1 878                592 / 1 646
-    pooled    (framework pool, priority 0)       1 765              1 746 / 1 749     (GPU_MAX_HW_QUEUES=8: 1 863, 1 637 / 1 636)
+                                             bench.py loop, 20 / 50 steps      + a consumer kernel per frame on the DEFAULT / a side stream
+    cumask    (own hardware queue each)          1 680 / 1 784                      592 / 1 646     (100-step loop: 1 878)
+    priority  (framework pool, priority -1)      1 527 / 1 609                    1 609 / 1 608     (100-step loop: 1 865 in a process
+    pooled    (framework pool, priority 0)             -                          1 746 / 1 749      that had made cumask streams first)
 
-* The runtime multiplexes ordinary streams onto GPU_MAX_HW_QUEUES = 4 hardware queues and two streams on one queue
-  serialise: the normal-priority pool shares its queues with the default stream (1 765; three frames in flight ran anywhere
-  between 1 633 and 1 858 in round 5).  High-priority streams draw from a queue pool of their own -> `priority`, the default.
-* A stream created with a CU mask (`cumask`: hipExtStreamCreateWithCUMask, every CU enabled) gets a hardware queue of its
-  own -- and is a BLOCKING stream in the legacy sense (the call takes no flags): every operation on the NULL (default)
-  stream, an event record included, waits for everything queued on it and holds back whatever follows.  Round 5's default
-  call recorded an event on the default stream per frame (`wait_stream`) and ran 673 / 1 129 / 914 frames/s at depth 1 / 2 /
-  3 for that reason (1.485 ms per frame at depth 1 against 0.641); a detector whose other stages run on the default stream
-  loses the overlap altogether (592).  With `cumask` inputs from the default stream therefore take NO event (the implicit
-  ordering covers them) and the surrounding stages belong on a side stream; it stays selectable for producer-only loops.
+* The runtime multiplexes ordinary streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4 for normal priority) and two
+  streams on one queue serialise.  Which streams collide is the luck of the process's stream-creation history: in a fresh
+  process the four high-priority framework streams share TWO queues -- the completion times of tools/pipe_trace.py come in
+  pairs 1.3 ms apart, i.e. no gain over one frame at a time -- while the same streams made after four CU-mask streams ran at
+  the own-queue rate.  Only a stream created with a CU mask (`cumask`: hipExtStreamCreateWithCUMask, every CU enabled, nothing
+  partitioned) is GIVEN a queue of its own: the default.
+* Such a stream is a BLOCKING stream in the legacy sense (the call takes no flags): every operation on the NULL (default)
+  stream -- an event record included -- waits for everything queued on it and holds back whatever follows.  Round 5's default
+  call recorded an event on the default stream per frame (`wait_stream`) and ran 673 / 1 129 / 914 frames/s at depth 1 / 2 / 3
+  for that reason (1.485 ms per frame at depth 1 against 0.641).  Now inputs that come from the default stream take NO event
+  (the implicit ordering already covers them), and the default call runs at the deferred rate (1 552 / 1 850 at depth 1 / 4).
+  What remains is the consumer side: kernels a caller launches on the DEFAULT stream join every frame in flight (592 frames/s).
+  Run the stages around the backbone on a side stream (`with torch.cuda.stream(side):` -- 1 646), inside the pipeline
+  (`FramePipeline(chain)`), or select `priority` / `pooled` streams (no legacy coupling, 1 6xx - 1 7xx either way); `get()`
+  logs a warning once when it is called with the default stream current on `cumask` streams.
 * A consumer waits for ITS frame (an event recorded right behind the frame), not for the frame's stream: `wait_stream`
   would also wait for the next frame already queued there, and the next submission would wait for the consumer -- the
   pipeline then runs at depth ~1.5 (measured: 995 frames/s).
 """
 import ctypes
+import logging
 import os
 
 import torch
 
 
-STREAMS = "priority"  # "priority": the framework's high-priority pool; "cumask": a hardware queue of its own per stream; "pooled"
+STREAMS = "cumask"  # "cumask": a hardware queue of its own per stream (blocking w.r.t. the default stream); "priority"; "pooled"
 
 
 def auto_depth(batch_size):
@@ -256,6 +262,11 @@ class PendingFrame(object):
             cur = torch.cuda.current_stream(self.pipe.device)
             if cur.cuda_stream != self.stream.cuda_stream and cur.cuda_stream not in self._handed:
                 self._handed.add(cur.cuda_stream)
+                if cur.cuda_stream == 0 and self.pipe.own_queues and not self.pipe.__dict__.get("_warned"):
+                    self.pipe._warned = True
+                    logging.getLogger("mssvt_amd.pipeline").warning(
+                        "FramePipeline: the consumer runs on the legacy default stream, which joins every frame in flight on the "
+                        "pipeline's (blocking) streams -- run it under torch.cuda.stream(side) or set MSSVT_PIPE_STREAMS=priority")
                 if self.done is not None:
                     cur.wait_event(self.done)
                 else:

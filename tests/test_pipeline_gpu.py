@@ -27,7 +27,7 @@ def test_pipelined_frames_are_bit_identical_to_frames_run_alone(depth):
             alone.append((sp.features.clone(), sp.indices.clone()))
     torch.cuda.synchronize()
     pipe = FramePipeline(net, depth=depth)
-    assert pipe.stream_kind == "priority" and len({s.cuda_stream for s in pipe.streams}) == depth
+    assert pipe.stream_kind == "cumask" and pipe.own_queues and len({s.cuda_stream for s in pipe.streams}) == depth  # a hardware queue of its own each
     outs = [pipe(dict(scenes[i % len(scenes)])) for i in range(4 * len(scenes))]  # several rounds: workspaces are reused
     pipe.synchronize()
     # ... and with the host wait deferred (what bench.py runs): a frame's result is fetched `depth` submissions later at the latest

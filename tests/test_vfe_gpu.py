@@ -90,3 +90,41 @@ def test_dynamic_vfe_matches_the_reference_run(name):
     np.testing.assert_array_equal(out["voxel_coords"].cpu().numpy(), d["voxel_coords"])
     got, want = out["voxel_features"].cpu().numpy(), d["voxel_features"]
     assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("pts,B", [(160000, 1), (20000, 2), (700, 3), (65, 1)])
+def test_sorted_pfn_path_equals_the_atomic_path(pts, B):
+    """csrc/pfn_sorted.hip (points grouped by voxel: no atomics on feature rows, x2 never stored) against round 5's atomic
+    reductions (csrc/pfn_fused.hip + csrc/vfe.hip): the same arithmetic per row and order-independent reductions -- the voxel
+    features must be BIT-identical, whatever the arrival order inside a voxel; voxels of 1 .. ~300 points (runs longer than a
+    16-row tile and than a 64-row task window), points outside the grid, row counts that are no multiple of anything."""
+    from mssvt_amd import dynamic_vfe
+    p = synthetic.make_batch_points(pts, B, 11)
+    p[::53, 1] += 500.0  # outside the range
+    n_dense = min(300, pts // 3)
+    p[5:5 + n_dense, 1:4] = p[5, 1:4] + np.random.default_rng(0).uniform(-0.02, 0.02, (n_dense, 3)).astype(np.float32)  # one crowded voxel
+    p[5:5 + n_dense, 0] = p[5, 0]
+    torch.manual_seed(3)
+    vfe = dynamic_vfe.DynamicVFE(_Cfg(NUM_FILTERS=[64, 128]), 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE,
+                                 synthetic.POINT_CLOUD_RANGE).eval()
+    with torch.no_grad():
+        for m in vfe.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.normal_(0, 1.0)  # negative scales too
+                m.bias.normal_(0, 0.2)
+    vfe = vfe.to(DEV)
+    pt = torch.from_numpy(p).to(DEV)
+    assert dynamic_vfe.SORTED_PFN and dynamic_vfe.FUSED_PFN
+    a = vfe(dict(points=pt, batch_size=B))
+    a2 = vfe(dict(points=pt, batch_size=B))
+    dynamic_vfe.SORTED_PFN = False
+    try:
+        b = vfe(dict(points=pt, batch_size=B))
+    finally:
+        dynamic_vfe.SORTED_PFN = True
+    assert torch.equal(a["voxel_coords"], b["voxel_coords"])
+    assert torch.equal(a["voxel_features"], a2["voxel_features"])  # run to run
+    assert torch.equal(a["voxel_features"], b["voxel_features"])
+    assert bool(torch.isfinite(a["voxel_features"]).all()) and a["voxel_features"].shape[1] == 128
