@@ -382,9 +382,9 @@ def main():
                 bd = net(bd)
                 return to_bev(bd)
         step = step_alone = step_points
-        if args.in_flight > 1:  # the same pipeline over the whole chain: every op of a frame runs on that frame's stream
+        if args.in_flight > 1:  # the pipeline around the whole chain: VFE and BEV on the frame's stream, the backbone's host wait deferred
             from mssvt_amd.pipeline import FramePipeline
-            pipe = FramePipeline(lambda bd: to_bev(net(vfe(bd))), depth=args.in_flight, device=dev)
+            pipe = FramePipeline(net, depth=args.in_flight, device=dev, pre=vfe, post=to_bev)
 
             def step():
                 pts = clouds[turn[0] % len(clouds)]

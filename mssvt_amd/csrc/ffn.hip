@@ -673,9 +673,14 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         x_ = make_float4(a_[0], a_[1], b_[0], b_[1]);                                                       \
     }
     // LayerNorm (norm2) over the row's LPR lanes, split, B fragments of GEMM1.  channel 4 q = 32 P + 8 gq + j0: fragment
-    // P, lane (la = r, g = gq), halves j0 .. j0 + 3.  Slot of lane (la, g) inside a fragment: 16 g + ((la + 4 g + P) & 15)
-    // -- the 16 (P, gq) writers of a row hit 16 different 16-byte bank groups (plain 16 g + la: all of them the same
-    // one), the readers of a 16-lane phase still 16 different
+    // P, lane (la = r, g = gq), halves j0 .. j0 + 3.  Slot of lane (la, g) inside a fragment: 16 g + ((la + rot(g) + P) & 15)
+    // with rot = 0, 0, 4, 4.  ds_read_b128 serves a wave in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32):
+    // a group takes la in {0..3, 12..15} from g and la in {4..11} from g + 1 -- complementary sets, so g and g + 1 must carry the
+    // SAME rotation for its 16 slots to differ mod 16 (rounds 3 - 5 rotated by 4 g, which is conflict free for 16 CONTIGUOUS
+    // lanes but made lanes 12-15 and 24-27 of every read collide: 22 % of the kernel's LDS cycles were bank conflicts); the
+    // writers of a row (16 (P, gq) lanes, 8 bytes each) stay at the two-way level of the old form through the 4-slot step
+    // between the g pairs (plain 16 g + la: four-way)
+#define FFW_ROT(g_) (((g_) >> 1) << 2)
 #define FFW_NORM_TO_BFRAG(x_)                                                                               \
     {                                                                                                       \
         const float mean_ = ffw_row_sum<LPR>((x_.x + x_.y) + (x_.z + x_.w)) * (1.0f / C);                   \
@@ -688,7 +693,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         ffw_split4(d01_ * pk1(rstd_) * pk2(lnw.x, lnw.y) + pk2(lnb.x, lnb.y),                               \
                    d23_ * pk1(rstd_) * pk2(lnw.z, lnw.w) + pk2(lnb.z, lnb.w), hi_, lo_);                     \
         const int P_ = q >> 3, gq_ = (q >> 1) & 3, j0_ = (q & 1) * 4;                                       \
-        h16x4 *dst_ = reinterpret_cast<h16x4 *>(bfrag + (P_ * 2) * 64 + 16 * gq_ + ((r + 4 * gq_ + P_) & 15)) + (j0_ >> 2); \
+        h16x4 *dst_ = reinterpret_cast<h16x4 *>(bfrag + (P_ * 2) * 64 + 16 * gq_ + ((r + FFW_ROT(gq_) + P_) & 15)) + (j0_ >> 2); \
         dst_[0] = hi_;                                                                                      \
         dst_[64 * 2] = lo_; /* the lo fragment follows the hi fragment: 64 slots x 2 h16x4 */               \
     }
@@ -704,7 +709,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
         f32x4 um_[2], ul_[2], uk_[2]; /* hi hi | hi lo | lo hi: six independent accumulation chains */      \
         h16x8 bh_[NP], bl_[NP];                                                                             \
         _Pragma("unroll") for (int P = 0; P < NP; ++P) {                                                   \
-            const int slot_ = 16 * g + ((la + 4 * g + P) & 15);                                             \
+            const int slot_ = 16 * g + ((la + FFW_ROT(g) + P) & 15);                                             \
             bh_[P] = bfrag[(P * 2) * 64 + slot_];                                                           \
             bl_[P] = bfrag[(P * 2 + 1) * 64 + slot_];                                                       \
         }                                                                                                   \
@@ -848,7 +853,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                         h16x4 hi_, lo_;
                         ffw_split4(n01_, n23_, hi_, lo_);
                         const int P_ = q >> 3, gq_ = (q >> 1) & 3, j0_ = (q & 1) * 4;
-                        h16x4 *dst_ = reinterpret_cast<h16x4 *>(bfrag + (P_ * 2) * 64 + 16 * gq_ + ((r + 4 * gq_ + P_) & 15)) + (j0_ >> 2);
+                        h16x4 *dst_ = reinterpret_cast<h16x4 *>(bfrag + (P_ * 2) * 64 + 16 * gq_ + ((r + FFW_ROT(gq_) + P_) & 15)) + (j0_ >> 2);
                         dst_[0] = hi_;
                         dst_[64 * 2] = lo_;
                     }
@@ -878,8 +883,8 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                 ul_[T] = f32x4{0.f, 0.f, 0.f, 0.f};
                 uk_[T] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            bh_[0] = bfrag[16 * g + ((la + 4 * g) & 15)];
-            bl_[0] = bfrag[64 + 16 * g + ((la + 4 * g) & 15)];
+            bh_[0] = bfrag[16 * g + ((la + FFW_ROT(g)) & 15)];
+            bl_[0] = bfrag[64 + 16 * g + ((la + FFW_ROT(g)) & 15)];
             const float4 yt = *reinterpret_cast<const float4 *>(ytile + r * PS + 4 * q);
             f32x2 y01 = pk1(0.f), y23 = y01, d01 = y01, d23 = y01;
             float var = 0.f;
@@ -888,7 +893,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
             for (int st = 0; st < NS1; ++st) {
                 const int T = st / NP, P = st % NP;
                 if (T == 0 && P + 1 < NP) {
-                    const int slot_ = 16 * g + ((la + 4 * g + P + 1) & 15);
+                    const int slot_ = 16 * g + ((la + FFW_ROT(g) + P + 1) & 15);
                     bh_[P + 1] = bfrag[((P + 1) * 2) * 64 + slot_];
                     bl_[P + 1] = bfrag[((P + 1) * 2 + 1) * 64 + slot_];
                 }

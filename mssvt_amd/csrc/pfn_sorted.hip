@@ -20,7 +20,7 @@
 //                (one kernel with 16 lanes per VOXEL doing all three was measured first: 81 us -- a chain of dependent loads per
 //                point of the run; split like this every load of a thread is independent of its others)
 //   k_ps_pfn2    the 128 -> 128 layer on split-fp16 matrix operands (the tile arithmetic of k_pfn2_h, csrc/pfn_fused.hip), a
-//                wave owns a fixed 64-row window of the sorted order: its 16-row tiles go through a per-wave LDS tile, lane =
+//                wave owns fixed 16-row windows (one tile) of the sorted order: its 16-row tiles go through a per-wave LDS tile, lane =
 //                channel walks the rows with a running max that is flushed (one 256-byte store) whenever the voxel changes;
 //                only the voxels a window boundary cuts (a few per cent) take integer atomic max, on rows k_ps_place zeroed.
 //                (Voxel-aligned tasks were measured first: 51 us -- the crowded voxels next to the sensor, hundreds of points
@@ -38,7 +38,7 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 #define PS_MFMA(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16((av), (bv), acc, 0, 0, 0)
 #define PS_FIX 1048576.0  // 2^20 steps per metre (csrc/vfe.hip)
 #define PS_SCAN 1024      // counts per scan block
-#define PS_TASK 64        // sorted rows per task window
+#define PS_TASK_DEFAULT 16  // sorted rows per task window of k_ps_pfn2 (MSSVT_PFN_TASK = 16 | 32 | 64: 37.3 / 45.9 / 45.1 us at 160k points)
 
 __global__ void __launch_bounds__(256) k_ps_rank(const int *voxel, long long P, int *count, int *slot) {
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -104,11 +104,11 @@ __global__ void __launch_bounds__(1024) k_ps_scan2(int *block_sum, int nblocks, 
 }
 
 // thread i: point i -> its place in the sorted order; voxel i (i <= N) -> start[i].  k_ps_pfn2 deals the sorted rows in
-// fixed windows of PS_TASK rows; a voxel whose run is CUT by a window boundary gets its maximum from two or more waves through
+// fixed windows of task_rows rows; a voxel whose run is CUT by a window boundary gets its maximum from two or more waves through
 // integer atomic max on the (non-negative) float bits -- its output row is zeroed here, ahead of them (a few per cent of the voxels)
 __global__ void __launch_bounds__(256)
     k_ps_place(const int *voxel, long long P, const int *slot, const int *local, const int *block_sum, const int *total, int N,
-               int *order, int *row_voxel, int *start, float *out) {
+               int task_rows, int *order, int *row_voxel, int *start, float *out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < P) {
         const int v = voxel[i];
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256)
         start[v] = s;
         if (v < N) {
             const int e = v + 1 < N ? local[v + 1] + block_sum[(v + 1) / PS_SCAN] : *total;
-            if (s / PS_TASK != (e - 1) / PS_TASK) {
+            if (s / task_rows != (e - 1) / task_rows) {
                 float4 *o = reinterpret_cast<float4 *>(out + (size_t)v * 128);
 #pragma unroll 8
                 for (int k = 0; k < 32; ++k) o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -249,7 +249,7 @@ __device__ __forceinline__ void ps_split8(const float4 v0, const float4 v1, floa
 }
 
 struct Ps2Args {
-    int N;
+    int N, task_rows;
     const int *total, *start, *row_voxel;
     const float *x1, *m1;  // (rows, 64) sorted, (N, 64)
     const float *W, *b, *bn_w, *bn_b, *bn_mean, *bn_var;  // W (128, 128): columns [0, 64) <-> x1, [64, 128) <-> m1[voxel]
@@ -308,11 +308,11 @@ __global__ void __launch_bounds__(PS2_WAVES *MSSVT_WAVE, 1) k_ps_pfn2(Ps2Args a)
     float *tile = tiles + wv * 16 * PS2_TS;
     __syncthreads();
     const int total = *a.total;
-    const int ntasks = (total + PS_TASK - 1) / PS_TASK, step = gridDim.x * PS2_WAVES;
+    const int ntasks = (total + a.task_rows - 1) / a.task_rows, step = gridDim.x * PS2_WAVES;
     for (int task = blockIdx.x * PS2_WAVES + wv; task < ntasks; task += step) {
         // a fixed window of the sorted order (perfect balance, whatever the voxels' sizes); its first / last voxel may be cut
         // by the window: those two take integer atomic max on zeroed rows (k_ps_place), every other voxel a plain store
-        const int rs = task * PS_TASK, re = min(rs + PS_TASK, total);
+        const int rs = task * a.task_rows, re = min(rs + a.task_rows, total);
         const int v_first = __builtin_amdgcn_readfirstlane(a.row_voxel[rs]), v_last = __builtin_amdgcn_readfirstlane(a.row_voxel[re - 1]);
         const bool cut_first = __builtin_amdgcn_readfirstlane(a.start[v_first]) < rs;
         const bool cut_last = __builtin_amdgcn_readfirstlane(a.start[v_last + 1]) > re;
@@ -436,9 +436,11 @@ extern "C" int mssvt_pfn_sorted_64_128(const float *points, int point_stride, lo
     k_ps_rank<<<divup(num_points, 256), 256, 0, stream>>>(point_voxel, num_points, count, slot);
     k_ps_scan1<<<nb, 256, 0, stream>>>(count, N, local, block_sum);
     k_ps_scan2<<<1, 1024, 0, stream>>>(block_sum, nb, total);
+    static const int task_env = getenv("MSSVT_PFN_TASK") ? atoi(getenv("MSSVT_PFN_TASK")) : 0;
+    const int task_rows = task_env == 16 || task_env == 32 || task_env == 64 ? task_env : PS_TASK_DEFAULT;
     const long long nthreads = num_points > N + 1 ? num_points : N + 1;
-    k_ps_place<<<divup(nthreads, 256), 256, 0, stream>>>(point_voxel, num_points, slot, local, block_sum, total, N, order, row_voxel,
-                                                         start, out);
+    k_ps_place<<<divup(nthreads, 256), 256, 0, stream>>>(point_voxel, num_points, slot, local, block_sum, total, N, task_rows, order,
+                                                         row_voxel, start, out);
     k_ps_mean<<<divup(N, 16), 256, 0, stream>>>(points, point_stride, N, order, start, mean3);
     Ps1Args a1;
     a1.points = points; a1.stride = point_stride; a1.total = total; a1.order = order; a1.row_voxel = row_voxel; a1.mean3 = mean3;
@@ -449,7 +451,7 @@ extern "C" int mssvt_pfn_sorted_64_128(const float *points, int point_stride, lo
     k_ps_pfn1<<<divup(num_points, 16), 256, 0, stream>>>(a1);
     k_ps_max1<<<divup(N, 16), 256, 0, stream>>>(x1_scratch, N, start, m1_scratch);
     Ps2Args a2;
-    a2.N = N; a2.total = total; a2.start = start; a2.row_voxel = row_voxel;
+    a2.N = N; a2.task_rows = task_rows; a2.total = total; a2.start = start; a2.row_voxel = row_voxel;
     a2.x1 = x1_scratch; a2.m1 = m1_scratch;
     a2.W = W2; a2.b = b2; a2.bn_w = bn2_w; a2.bn_b = bn2_b; a2.bn_mean = bn2_mean; a2.bn_var = bn2_var; a2.eps = bn2_eps; a2.out = out;
     const size_t lds = (size_t)128 * 128 * 4 + (size_t)PS2_WAVES * 16 * PS2_TS * 4;
@@ -457,7 +459,7 @@ extern "C" int mssvt_pfn_sorted_64_128(const float *points, int point_stride, lo
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const int grid = min((long long)cus, (long long)divup(num_points / PS_TASK + 1, PS2_WAVES));
+    const int grid = min((long long)cus, (long long)divup(num_points / task_rows + 1, PS2_WAVES));
     k_ps_pfn2<<<grid, PS2_WAVES * MSSVT_WAVE, lds, stream>>>(a2);
     return mssvt_launch_status();
 }

@@ -108,12 +108,18 @@ def _tensors_of(out):
 
 
 class FramePipeline(object):
-    def __init__(self, net, depth=None, device=None, batch_size=1):
-        """`depth`: frames in flight; None = `auto_depth(batch_size)`."""
+    def __init__(self, net, depth=None, device=None, batch_size=1, pre=None, post=None):
+        """`depth`: frames in flight; None = `auto_depth(batch_size)`.
+        `pre` / `post`: stages either side of the backbone that run ON THE FRAME'S STREAM -- `pre(batch_dict) -> batch_dict`
+        right before the backbone is enqueued (e.g. the DynamicVFE: points -> voxels), `post(batch_dict) -> batch_dict` right
+        behind the frame's host wait (e.g. dense() / HeightCompression, which need the output row count).  Unlike a chain
+        passed as `net`, this keeps the backbone's host wait DEFERRED: the host is held per frame only by what `pre` itself
+        waits for (the voxelizer's voxel count), not until the backbone's level set-up has run."""
         if depth is None:
             depth = auto_depth(batch_size)
         assert depth >= 1
         self.net = net  # the backbone, or any callable batch_dict -> batch_dict (then pass `device`)
+        self.pre, self.post = pre, post
         self.device = torch.device(device if device is not None else next(net.parameters()).device)
         kind = os.environ.get("MSSVT_PIPE_STREAMS", "pooled" if os.environ.get("MSSVT_PIPE_POOLED") == "1" else STREAMS)
         self.streams = _own_queue_streams(depth, self.device) if kind == "cumask" else None
@@ -153,8 +159,10 @@ class FramePipeline(object):
         for v in batch_dict.values():  # allocated on the caller's stream, read on `s` for the whole frame
             if isinstance(v, torch.Tensor) and v.is_cuda and cur.cuda_stream != s.cuda_stream:
                 v.record_stream(s)
-        p = PendingFrame(self, s, batch_dict)
         with torch.cuda.stream(s), torch.no_grad():
+            if self.pre is not None:
+                batch_dict = self.pre(batch_dict)
+            p = PendingFrame(self, s, batch_dict)
             p._enqueue()
             if self.frame_events:  # what a consumer on another stream waits for: THIS frame, not whatever follows it on `s`
                 p.done = torch.cuda.Event()
@@ -220,6 +228,8 @@ class PendingFrame(object):
         self.pend = frame.forward(net, feats, coords, bd['batch_size'], defer=True) if ok else None
         if self.pend is None:  # not the whole-frame call's case (or any other callable, e.g. VFE -> backbone -> BEV): run it here
             self.out = net(bd)
+            if self.pipe.post is not None:
+                self.out = self.pipe.post(self.out)
             self.out["stream"] = self.stream
 
     def _finish(self):
@@ -239,6 +249,11 @@ class PendingFrame(object):
                     except fused.UnsortedVoxels:  # as MixedScaleSparseTransformer.forward: redo on the order-agnostic kernels
                         net._unsorted_skip = net._unsorted_backoff
                         self.out = net._forward(self.batch_dict, False)
+                    if self.pipe.post is not None:  # enqueued behind the frame on its stream; what a consumer waits for moves with it
+                        self.out = self.pipe.post(self.out)
+                        if self.done is not None:
+                            self.done = torch.cuda.Event()
+                            self.done.record(self.stream)
                 self.out["stream"] = self.stream
             except Exception as e:  # noqa: BLE001
                 self.error = e

@@ -57,8 +57,12 @@ def test_bench_ffn_arith_flag_and_roofline_object():
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, env=e, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert "split into two fp16 halves" in res["config"]["ffn_arith"]
+    assert res["config"]["ffn_arith"].startswith("split16") and "two fp16 halves" in res["config"]["ffn_arith"]
+    # the arithmetic that RAN, per block (the outcome of the fp16-range guards on these parameters): 4 Blocks + the CompressBlock
+    per = res["config"]["arith_per_block"]
+    assert len(per) == 5 and all(b["ffn"] == "split16" and b["attn"].startswith("split16") for b in per)
     rf = res["roofline"]
+    assert 0 < rf["frame"]["frac_design"] <= rf["frame"]["frac"]  # the design's own floor is the stricter figure
     assert rf["bound"] == "hbm" and "k_ffn_ws" in rf["kernel"] and 0 < rf["frac"] < 1 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["frame"]["frac"] > 0
     assert any("mssvt_block_attention" in o["kernel"] for o in rf["other_kernels"])
@@ -80,7 +84,8 @@ def test_bench_detector_training_two_ranks_and_sync_bn():
 def test_bench_arith_f32_in_flight_and_from_points():
     res = _bench("--arith", "f32", "--in-flight", "1")
     assert res["config"]["arith"] == "f32" and "v_mfma_f32_16x16x4_f32" in res["config"]["ffn_arith"]
-    assert res["config"]["attn_arith"] == "v_mfma_f32_16x16x4_f32" and res["config"]["frames_in_flight"] == 1
+    assert res["config"]["attn_arith"] == "f32: v_mfma_f32_16x16x4_f32" and res["config"]["frames_in_flight"] == 1
+    assert all(b["ffn"] == "f32" and b["attn"] == "f32" for b in res["config"]["arith_per_block"])
     res = _bench("--in-flight", "3")
     assert res["config"]["frames_in_flight"] == 3 and res["one_frame_in_flight"]["value"] > 0
     assert "mssvt_frame_forward" in res["config"]["host_path"]

@@ -73,6 +73,14 @@ def test_pipeline_over_any_callable_and_close():
     n_before = len(net.__dict__["_frame_state"]["frames"])
     pipe.close()
     assert pipe.streams == [] and len(net.__dict__["_frame_state"]["frames"]) <= n_before
+    # the same chain as stages around the backbone (`pre` / `post` run on the frame's stream, the backbone's host wait stays
+    # deferred -- what bench.py --from-points runs): identical BEV maps, fetched out of order
+    pipe = FramePipeline(net, depth=3, pre=vfe, post=lambda bd: dict(bd, bev=bd["encoded_spconv_tensor"].dense()))
+    frames = [pipe(dict(points=clouds[i % 3], batch_size=1)) for i in range(9)]
+    assert any(p is not None for p in pipe.pending)  # deferred: the last frames have not been waited for
+    for i in reversed(range(9)):
+        assert torch.equal(frames[i].get()["bev"], alone[i % 3]), i
+    pipe.close()
 
 
 def test_four_full_size_frames_in_flight_match_frames_run_alone_and_the_oracle():
