@@ -1,6 +1,7 @@
 #!/bin/bash
 # end-of-round measurements (round 6): bench lines, rocprofv3 kernel stats of the bench commands, PMC counters of the frame
 out=gpurun_out/r06final; mkdir -p $out
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1; tail -1 $out/smoke.txt
 line() { python -c "import json,sys;d=json.loads([l for l in open('$1') if l.startswith('{')][-1]);print('$1',round(d['value'],1),d['unit'],round(d['ms_per_step'],3),'ms', d['n_gpus'], d.get('timing',{}).get('median_ms'), (d.get('one_frame_in_flight') or {}).get('value'))"; }
 timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err; echo "bench rc $?"; line $out/bench_line.json
 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_driver_steps20_line.json 2>> $out/bench.err; line $out/bench_driver_steps20_line.json

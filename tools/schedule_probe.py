@@ -91,7 +91,7 @@ def main(out_path):
         out["linear_rows_h_%d_%d" % (K, N)] = train_path._linear_rows(xr, wr, False, br, True, N, split16=True).cpu().numpy()
         dy = torch.randn(5000, N, generator=g).to(DEV)
         out["linear_rows_h_%d_%d_dx" % (K, N)] = train_path._linear_rows(dy, wr, True, None, False, K, split16=True).cpu().numpy()
-    # --- csrc/pfn_fused.hip: the DynamicVFE eval forward on the default configuration (k_pfn1, k_pfn2_h, k_pfn_rowmax)
+    # --- csrc/pfn_sorted.hip (k_ps_pfn2) and csrc/pfn_fused.hip (k_pfn2_h): the DynamicVFE eval forward on the default configuration
     from mssvt_amd import dynamic_vfe
     pts = synthetic.make_batch_points(20000, B, 78)
     torch.manual_seed(2)
@@ -102,8 +102,14 @@ def main(out_path):
             if isinstance(m, torch.nn.BatchNorm1d):
                 m.running_mean.normal_(0, 0.3)
                 m.running_var.uniform_(0.5, 1.5)
-        assert dynamic_vfe.FUSED_PFN
-        out["vfe_fused"] = vfe.to(DEV)(dict(points=torch.from_numpy(pts).to(DEV), batch_size=B))["voxel_features"].cpu().numpy()
+        assert dynamic_vfe.FUSED_PFN and dynamic_vfe.SORTED_PFN
+        vfe = vfe.to(DEV)
+        out["vfe_fused"] = vfe(dict(points=torch.from_numpy(pts).to(DEV), batch_size=B))["voxel_features"].cpu().numpy()  # pfn_sorted.hip
+        dynamic_vfe.SORTED_PFN = False
+        try:
+            out["vfe_atomic"] = vfe(dict(points=torch.from_numpy(pts).to(DEV), batch_size=B))["voxel_features"].cpu().numpy()  # pfn_fused.hip
+        finally:
+            dynamic_vfe.SORTED_PFN = True
     np.savez(out_path, **out)
     print("schedule probe: %d arrays from %s -> %s" % (len(out) - 1, _lib.LIB_PATH, out_path))
 
