@@ -13,7 +13,8 @@
 // 160k points), after which every reduction is a loop over a run:
 //   k_ps_rank    per point: slot = atomicAdd(count[voxel], 1)                  (one returning integer atomic per point)
 //   k_ps_scan1/2 exclusive scan of the counts (two levels)
-//   k_ps_place   order[start[voxel] + slot] = point, row_voxel[...] = voxel; start[]; zero rows for the voxels a 64-row window cuts
+//   k_ps_place   the point's row moves to place start[voxel] + slot of the sorted order, row_voxel[...] = voxel; start[]; zero rows
+//                for the voxels a layer-2 tile boundary cuts
 //   k_ps_mean    16 lanes per voxel: the cluster centre from exact 64-bit fixed-point sums (the arithmetic of csrc/vfe.hip)
 //   k_ps_pfn1    16 lanes per SORTED ROW: layer 1 (x1 rows written in sorted order: a voxel's rows are contiguous)
 //   k_ps_max1    16 lanes per voxel: m1 = max over the voxel's run of x1 rows
@@ -108,13 +109,17 @@ __global__ void __launch_bounds__(1024) k_ps_scan2(int *block_sum, int nblocks, 
 // integer atomic max on the (non-negative) float bits -- its output row is zeroed here, ahead of them (a few per cent of the voxels)
 __global__ void __launch_bounds__(256)
     k_ps_place(const int *voxel, long long P, const int *slot, const int *local, const int *block_sum, const int *total, int N,
-               int task_rows, int *order, int *row_voxel, int *start, float *out) {
+               int task_rows, const float *points, int stride, float4 *pts8, int *row_voxel, int *start, float *out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < P) {
         const int v = voxel[i];
         if (v >= 0) {
             const int r = local[v] + block_sum[v / PS_SCAN] + slot[i];
-            order[r] = (int)i;
+            // the point's row moves to its place in the sorted order ([x, y, z, f4 | f5, 0, 0, 0]: 32 bytes): the per-voxel
+            // loops below then read contiguous rows instead of chasing an index into the scan order
+            const float *pr = points + i * stride;
+            pts8[2 * (size_t)r] = make_float4(pr[1], pr[2], pr[3], pr[4]);
+            pts8[2 * (size_t)r + 1] = make_float4(pr[5], 0.f, 0.f, 0.f);
             row_voxel[r] = v;
         }
     }
@@ -145,17 +150,16 @@ __device__ __forceinline__ long long ps_row_sum_ll(long long v) {  // all-reduce
     }
     return v;
 }
-__global__ void __launch_bounds__(256)
-    k_ps_mean(const float *points, int stride, int N, const int *order, const int *start, float *mean3) {
+__global__ void __launch_bounds__(256) k_ps_mean(const float4 *pts8, int N, const int *start, float *mean3) {
     const int q = threadIdx.x & 15;
-    const int v = min(blockIdx.x * 16 + (threadIdx.x >> 4), N - 1);  // (clamped: every lane takes part in the DPP sums)
+    const int v = min(blockIdx.x * 16 + (threadIdx.x >> 4), N - 1);  // (clamped: every lane takes part in the lane sums)
     const int s = start[v], e = start[v + 1];
     long long sx = 0, sy = 0, sz = 0;
     for (int i = s + q; i < e; i += 16) {
-        const float *pr = points + (size_t)order[i] * stride;
-        sx += __double2ll_rn((double)pr[1] * PS_FIX);
-        sy += __double2ll_rn((double)pr[2] * PS_FIX);
-        sz += __double2ll_rn((double)pr[3] * PS_FIX);
+        const float4 p = pts8[2 * (size_t)i];
+        sx += __double2ll_rn((double)p.x * PS_FIX);
+        sy += __double2ll_rn((double)p.y * PS_FIX);
+        sz += __double2ll_rn((double)p.z * PS_FIX);
     }
     sx = ps_row_sum_ll(sx); sy = ps_row_sum_ll(sy); sz = ps_row_sum_ll(sz);
     if (q < 3 && blockIdx.x * 16 + (threadIdx.x >> 4) < N) {
@@ -165,10 +169,9 @@ __global__ void __launch_bounds__(256)
 }
 
 struct Ps1Args {
-    const float *points;  // (P, stride) rows [b, x, y, z, f4, f5]
-    int stride;
+    const float4 *pts8;               // sorted point rows [x, y, z, f4 | f5, 0, 0, 0]
     const int *total;                 // rows of the sorted order (points inside the grid)
-    const int *order, *row_voxel;     // sorted row -> point, voxel
+    const int *row_voxel;             // sorted row -> voxel
     const float *mean3;               // (N, 3)
     const int *coords;                // (N, 4) [b, z, y, x]
     float vs[3], off[3];              // voxel size, voxel_size / 2 + range_min
@@ -194,11 +197,11 @@ __global__ void __launch_bounds__(256) k_ps_pfn1(Ps1Args a) {
     const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (r >= *a.total) return;
     const int v = a.row_voxel[r];
-    const float *pr = a.points + (size_t)a.order[r] * a.stride;
-    const float x = pr[1], y = pr[2], z = pr[3];
+    const float4 p0 = a.pts8[2 * (size_t)r], p1 = a.pts8[2 * (size_t)r + 1];
+    const float x = p0.x, y = p0.y, z = p0.z;
     const int4 c4 = reinterpret_cast<const int4 *>(a.coords)[v];
     float f[11];
-    f[0] = x; f[1] = y; f[2] = z; f[3] = pr[4]; f[4] = pr[5];
+    f[0] = x; f[1] = y; f[2] = z; f[3] = p0.w; f[4] = p1.x;
     f[5] = x - a.mean3[(size_t)v * 3 + 0]; f[6] = y - a.mean3[(size_t)v * 3 + 1]; f[7] = z - a.mean3[(size_t)v * 3 + 2];
     f[8] = x - __fadd_rn(__fmul_rn((float)c4.w, a.vs[0]), a.off[0]);  // ref :107-109: coord * voxel_size + offset
     f[9] = y - __fadd_rn(__fmul_rn((float)c4.z, a.vs[1]), a.off[1]);
@@ -309,27 +312,43 @@ __global__ void __launch_bounds__(PS2_WAVES *MSSVT_WAVE, 1) k_ps_pfn2(Ps2Args a)
     __syncthreads();
     const int total = *a.total;
     const int ntasks = (total + a.task_rows - 1) / a.task_rows, step = gridDim.x * PS2_WAVES;
-    for (int task = blockIdx.x * PS2_WAVES + wv; task < ntasks; task += step) {
+    // the voxels of a task's rows are requested one task ahead: with them in hand the x1 rows, the m1 gather and the two
+    // start[] probes of a task all leave together (one round trip in front of the products instead of two)
+    int pf_first = 0, pf_last = 0, pf_lane = 0;
+#define PS2_PREFETCH(t_)                                                              \
+    {                                                                                 \
+        const int rs_ = (t_) * a.task_rows, re_ = min(rs_ + a.task_rows, total);      \
+        pf_first = a.row_voxel[rs_];                                                  \
+        pf_last = a.row_voxel[re_ - 1];                                               \
+        pf_lane = a.row_voxel[min(rs_ + la, re_ - 1)];                                \
+    }
+    int task = blockIdx.x * PS2_WAVES + wv;
+    if (task < ntasks) PS2_PREFETCH(task)
+    for (; task < ntasks; task += step) {
         // a fixed window of the sorted order (perfect balance, whatever the voxels' sizes); its first / last voxel may be cut
         // by the window: those two take integer atomic max on zeroed rows (k_ps_place), every other voxel a plain store
         const int rs = task * a.task_rows, re = min(rs + a.task_rows, total);
-        const int v_first = __builtin_amdgcn_readfirstlane(a.row_voxel[rs]), v_last = __builtin_amdgcn_readfirstlane(a.row_voxel[re - 1]);
-        const bool cut_first = __builtin_amdgcn_readfirstlane(a.start[v_first]) < rs;
-        const bool cut_last = __builtin_amdgcn_readfirstlane(a.start[v_last + 1]) > re;
+        const int v_first = __builtin_amdgcn_readfirstlane(pf_first), v_last = __builtin_amdgcn_readfirstlane(pf_last);
+        const int lane_v0 = pf_lane;
+        if (task + step < ntasks) PS2_PREFETCH(task + step)
+        // (raw loads: they are first READ at a flush, behind the tile's products -- a readfirstlane here would wait for them
+        // in front of the row loads)
+        const int sf_raw = a.start[v_first], sl_raw = a.start[v_last + 1];
         int cur[2] = {-1, -1};      // the voxel whose running max a half holds (wave uniform)
         float run[2] = {0.f, 0.f};  // lane = channel 64 h + lane
 #define PS2_FLUSH(h_)                                                                                              \
         if (cur[h_] >= 0) {                                                                                        \
             float *dst_ = a.out + (size_t)cur[h_] * N + 64 * (h_) + lane;                                          \
-            if ((cur[h_] == v_first && cut_first) || (cur[h_] == v_last && cut_last))                              \
+            if ((cur[h_] == v_first && __builtin_amdgcn_readfirstlane(sf_raw) < rs) ||                             \
+                (cur[h_] == v_last && __builtin_amdgcn_readfirstlane(sl_raw) > re))                                \
                 atomicMax(reinterpret_cast<int *>(dst_), __builtin_bit_cast(int, run[h_])); /* run >= 0: ordered as ints */ \
             else                                                                                                   \
                 *dst_ = run[h_];                                                                                   \
         }
         for (int r0 = rs; r0 < re; r0 += 16) {
             const int row = min(r0 + la, re - 1);
-            const int v = r0 + la < re ? a.row_voxel[row] : -2;
-            const int vs = a.row_voxel[row];
+            const int vs = r0 == rs ? lane_v0 : a.row_voxel[row];
+            const int v = r0 + la < re ? vs : -2;
             // lane (row = la, g) reads its row's k slots 32 P + 8 g ..: P = 0, 1 from x1[row], P = 2, 3 from m1[voxel]
             float4 xr[KS][2];
 #pragma unroll
@@ -399,12 +418,13 @@ __global__ void __launch_bounds__(PS2_WAVES *MSSVT_WAVE, 1) k_ps_pfn2(Ps2Args a)
         PS2_FLUSH(1)
 #undef PS2_FLUSH
     }
+#undef PS2_PREFETCH
 }
 
 extern "C" long long mssvt_pfn_sorted_workspace_ints(long long num_points, int num_voxels) {
     const long long nb = (num_voxels + PS_SCAN - 1) / PS_SCAN;
-    // count | local | block_sum | total | start (N + 1) | slot | order | row_voxel (P each) | mean3 (3 N floats)
-    return 2LL * num_voxels + nb + 1 + 16 + (num_voxels + 1) + 3 * num_points + 3LL * num_voxels;
+    // count | local | block_sum | total | start (N + 1) | slot | row_voxel (P each) | mean3 (3 N floats) | sorted point rows (8 P floats)
+    return 2LL * num_voxels + nb + 1 + 16 + (num_voxels + 1) + 2 * num_points + 3LL * num_voxels + 8 + 8 * num_points;
 }
 
 // DynamicVFE's cluster-centre mean and two PFN layers in eval mode (ref dynamic_vfe.py:96-131), default configuration:
@@ -429,8 +449,10 @@ extern "C" int mssvt_pfn_sorted_64_128(const float *points, int point_stride, lo
     hipStream_t stream = (hipStream_t)stream_;
     const int N = num_voxels, nb = (N + PS_SCAN - 1) / PS_SCAN;
     int *count = workspace, *local = count + N, *block_sum = local + N, *total = block_sum + nb + 1;
-    int *start = total + 16, *slot = start + N + 1, *order = slot + num_points, *row_voxel = order + num_points;
+    int *start = total + 16, *slot = start + N + 1, *row_voxel = slot + num_points;
     float *mean3 = reinterpret_cast<float *>(row_voxel + num_points);
+    // (16-byte aligned: the workspace is, and every region before this one is a whole number of ints)
+    float4 *pts8 = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(mean3 + 3 * (size_t)N) + 15) & ~(uintptr_t)15);
     hipError_t e = hipMemsetAsync(count, 0, (size_t)N * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     k_ps_rank<<<divup(num_points, 256), 256, 0, stream>>>(point_voxel, num_points, count, slot);
@@ -439,11 +461,11 @@ extern "C" int mssvt_pfn_sorted_64_128(const float *points, int point_stride, lo
     static const int task_env = getenv("MSSVT_PFN_TASK") ? atoi(getenv("MSSVT_PFN_TASK")) : 0;
     const int task_rows = task_env == 16 || task_env == 32 || task_env == 64 ? task_env : PS_TASK_DEFAULT;
     const long long nthreads = num_points > N + 1 ? num_points : N + 1;
-    k_ps_place<<<divup(nthreads, 256), 256, 0, stream>>>(point_voxel, num_points, slot, local, block_sum, total, N, task_rows, order,
-                                                         row_voxel, start, out);
-    k_ps_mean<<<divup(N, 16), 256, 0, stream>>>(points, point_stride, N, order, start, mean3);
+    k_ps_place<<<divup(nthreads, 256), 256, 0, stream>>>(point_voxel, num_points, slot, local, block_sum, total, N, task_rows, points,
+                                                         point_stride, pts8, row_voxel, start, out);
+    k_ps_mean<<<divup(N, 16), 256, 0, stream>>>(pts8, N, start, mean3);
     Ps1Args a1;
-    a1.points = points; a1.stride = point_stride; a1.total = total; a1.order = order; a1.row_voxel = row_voxel; a1.mean3 = mean3;
+    a1.pts8 = pts8; a1.total = total; a1.row_voxel = row_voxel; a1.mean3 = mean3;
     a1.coords = voxel_coords;
     for (int k = 0; k < 3; ++k) { a1.vs[k] = host_voxel_size3[k]; a1.off[k] = host_offset3[k]; }
     a1.W = W1; a1.b = b1; a1.bn_w = bn1_w; a1.bn_b = bn1_b; a1.bn_mean = bn1_mean; a1.bn_var = bn1_var; a1.eps = bn1_eps;

@@ -43,6 +43,8 @@ __global__ void __launch_bounds__(VX_TPB)
     const long long i = (long long)blockIdx.x * VX_TPB + threadIdx.x;
     if (i >= n) return;
     long long cell;
+    // (a plain read of the word first, to skip the atomic when the bit already shows -- the columns next to the sensor take
+    // hundreds of points each -- was measured: 15.5 -> 46 us; the fire-and-forget atomic does not wait, the read does)
     if (point_cell(points, stride, i, minx, miny, minz, vsx, vsy, vsz, X, Y, Z, B, cell))
         atomicOr(bitmap + (cell >> 5), 1u << (cell & 31));
 }
