@@ -434,7 +434,10 @@ template <int CG>
 struct AttnBlob {
     static constexpr int NT = CG / 16, NP = CG / 32;
     static constexpr int WQ = 0, WK = WQ + NT * NP * 2 * 64 * 16, WV = WK + NT * NT * 2 * 64 * 8, WO = WV + NT * NP * 2 * 64 * 16,
-                         WK2 = WO + NT * NP * 2 * 64 * 16, BYTES = WK2 + (NT / 2) * NT * 2 * 64 * 16;
+                         WK2 = WO + NT * NP * 2 * 64 * 16, WV2 = WK2 + (NT / 2) * NT * 2 * 64 * 16,
+                         BYTES = WV2 + NT * NP * 2 * 64 * 16;
+    // WvF2 [t][P][hi | lo][lane] x 16 B (round 6): Wv for the window launch -- A rows o = 16 t + m, k slot (g, j) <-> channel
+    // 32 P + 16 (g % 2) + 8 (j / 4) + 4 (g / 2) + j % 4 = the order in which k_attn_kvh's Xbar accumulators sit in its lanes
 };
 
 template <int CG>
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(MSSVT_WAVE) k_attn_pack(const float *Wq, const
     using L = AttnBlob<CG>;
     constexpr int NT = L::NT, NP = L::NP;
     const int lane = lane_id(), m = lane & 15, g = lane >> 4, f = blockIdx.x;  // fragment index within its matrix
-    const int which = blockIdx.y;                                              // 0 Wq, 1 Wk, 2 Wv, 3 Wo, 4 Wk head pairs
+    const int which = blockIdx.y;                                              // 0 Wq, 1 Wk, 2 Wv, 3 Wo, 4 Wk head pairs, 5 Wv (window launch)
     if (which == 1) {
         if (f >= NT * NT) return;
         const int h = f / NT, u = f % NT;
@@ -475,6 +478,16 @@ __global__ void __launch_bounds__(MSSVT_WAVE) k_attn_pack(const float *Wq, const
     }
     if (f >= NT * NP) return;
     const int t = f / NP, P = f % NP;
+    if (which == 5) {  // Wv in the lane order of k_attn_kvh's Xbar tiles (AttnBlob::WV2)
+        const float *rowp = Wkv + (size_t)(CG + 16 * t + m) * CG + 32 * P + 16 * (g & 1) + 4 * (g >> 1);
+        const float4 w0 = *reinterpret_cast<const float4 *>(rowp), w1 = *reinterpret_cast<const float4 *>(rowp + 8);
+        h16x8 hi, lo;
+        h16_split8(f32x4{w0.x, w0.y, w0.z, w0.w}, f32x4{w1.x, w1.y, w1.z, w1.w}, hi, lo);
+        h16x8 *dst = reinterpret_cast<h16x8 *>(blob + L::WV2) + (size_t)f * 2 * 64 + lane;
+        dst[0] = hi;
+        dst[64] = lo;
+        return;
+    }
     // 8 k slots of a lane = two runs of 4 consecutive columns, 16 apart (kv16 operand order)
     const float *rowp = (which == 0 ? Wq + (size_t)(16 * t + m) * CG : which == 2 ? Wkv + (size_t)(CG + 16 * t + m) * CG
                                                                                   : Wo + (size_t)(16 * t + m) * CG) + 32 * P + 4 * g;
@@ -634,7 +647,8 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_q16(Att
 }
 
 // ---- C, kv16 form: Xbar -> attention output rows
-template <int CG, int HP>
+// VIN (round 6): the hand-off rows hold V (k_attn_kvh<.., VOUT>): only the output projection is left
+template <int CG, int HP, bool VIN = false>
 __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_o16(AttnPack pack) {
     const AttnArgs &a = pack.g[blockIdx.y];
     using L = AttnBlob<CG>;
@@ -657,7 +671,7 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_o16(Att
             dst_[S] = f32x4{t4_.x, t4_.y, t4_.z, t4_.w};                                                  \
         }                                                                                                 \
     }
-    ATTN_O16_ROWS(x, min(tile * 16 + r, rows - 1), 0)
+    if (!VIN) ATTN_O16_ROWS(x, min(tile * 16 + r, rows - 1), 0)
     attn_stage16<(L::WK2 - L::WV) / 16, ATTN_QO16_WAVES * MSSVT_WAVE>(
         lds4, reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.packed) + L::WV));
     if (threadIdx.x < CG) {
@@ -669,11 +683,18 @@ __global__ void __launch_bounds__(ATTN_QO16_WAVES *MSSVT_WAVE, 4) k_attn_o16(Att
         const int row = min(tile * 16 + r, rows - 1);
         const bool row_ok = tile * 16 + r < rows;
         const int dest = a.qrow_src[row].y;
-        if (!first) ATTN_O16_ROWS(x, row, 0)
+        if (!first && !VIN) ATTN_O16_ROWS(x, row, 0)
         // GEMM3^T: V^T[o][row] = sum_c Wv[o][c] Xbar_{head(o)}[row][c] + bv[o]  (head of tile t = t)
         f32x4 v[NT];
+        if (VIN) {  // V of head t: 16 floats at the start of the (row, head) slot, this lane's o = 16 t + 4 g + i
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NT; ++t) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(a.qbuf + (size_t)row * QROW + t * CG + 4 * g);
+                v[t] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT && !VIN; ++t) {
             if (t + 1 < NT) ATTN_O16_ROWS(xn, row, t + 1)  // the next head's row pieces under this head's products
             const float4 b = *reinterpret_cast<const float4 *>(bv_l + 16 * t + 4 * g);
             f32x4 mm = f32x4{b.x, b.y, b.z, b.w}, cr = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1032,9 +1053,15 @@ __device__ __forceinline__ h16x4 lds_read_tr16(const char *p) {
 // QP: the hand-off rows hold Q' fragments (k_attn_q16<.., 2>) and Qt_h = (scale Wk_h)^T q'_h is formed here, per pass, from the
 // Wk fragments of the pack blob staged into the LDS: one product per head with the columns of the other heads zeroed in
 // the B operand, all accumulated into one tile -- NH x NT x 3 K = 16 instructions for 1 instead of 4 row loads per lane
-template <int CG, int HD, int HP, int KT, bool QP>
-__global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_AHEAD || QP ? 3 : 4) : 2) k_attn_kvh(AttnPack pack) {
+// VOUT (round 6, MSSVT_ATTN_VFUSE=1): V_h = Wv_h Xbar_h + bv_h is formed HERE, per pass, and the hand-off row holds V (16 floats per
+// query and head) instead of Xbar (Cg floats): every output tile of Wv (= one head, HD = 16) times the pass's Xbar columns, a
+// lane keeps the tile of ITS column's head -- NT x NP x 3 more instructions and one operand split per pass for a quarter of
+// the hand-off bytes; k_attn_o16<.., VIN> then only applies Wo.  The Wv fragments (16 KiB per group) join the Wk pair
+// fragments in the LDS, so the workgroup becomes NWV = 12 waves sharing one copy: 32 + 12 x 9 KiB, still 3 waves per SIMD.
+template <int CG, int HD, int HP, int KT, bool QP, bool VOUT = false, int NWV = ATTN_ROW_WAVES>
+__global__ void __launch_bounds__(NWV *MSSVT_WAVE, KT <= 2 ? (KVH_QT_AHEAD || QP ? 3 : 4) : 2) k_attn_kvh(AttnPack pack) {
     static_assert(!QP || (HD == 16 && (CG / HD) % 2 == 0 && !KVH_QT_AHEAD), "Q' hand-off: head = one 16-row tile, heads in pairs");
+    static_assert(!VOUT || (QP && HP * HD == CG), "V hand-off: Q' mode, one output tile of Wv per head");
     static_assert(CG % 32 == 0 && KT % 2 == 0, "32-channel and 32-key steps");
     const AttnArgs &a = pack.g[blockIdx.y];
     constexpr int NT = CG / 16, NP = CG / 32, NS = KT / 2, NH = CG / HD, QROW = HP * CG, QPP = 16 / HP;
@@ -1042,11 +1069,14 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     extern __shared__ float4 lds4[];
     const int lane = lane_id(), la = lane & 15, g = lane >> 4;
     const int wv = threadIdx.x / MSSVT_WAVE;
-    constexpr int WKB = QP ? AttnBlob<CG>::BYTES - AttnBlob<CG>::WK2 : 0;  // bytes of Wk pair fragments in front of the images
+    // bytes of fragments in front of the images: the Wk pair fragments (+ the Wv fragments of the V hand-off)
+    constexpr int WKB = QP ? (VOUT ? AttnBlob<CG>::BYTES : AttnBlob<CG>::WV2) - AttnBlob<CG>::WK2 : 0;
+    const h16x8 *WvF2 = reinterpret_cast<const h16x8 *>(reinterpret_cast<const char *>(lds4) + (AttnBlob<CG>::WV2 - AttnBlob<CG>::WK2));
+    (void)WvF2;
     char *Ti = reinterpret_cast<char *>(lds4) + WKB + (size_t)wv * 2 * IMG;
     const h16x8 *WkF2 = reinterpret_cast<const h16x8 *>(lds4);
     if (QP) {  // before any wave can leave: every wave of the workgroup meets at the barrier
-        attn_stage16<(WKB > 0 ? WKB : 16) / 16, ATTN_ROW_WAVES * MSSVT_WAVE>(
+        attn_stage16<(WKB > 0 ? WKB : 16) / 16, NWV * MSSVT_WAVE>(
             lds4, reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.packed) + AttnBlob<CG>::WK2));
         __syncthreads();
     }
@@ -1061,7 +1091,7 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
         wctr[u] = g < 3 ? wp[3 + g] : 0.f;
     }
     const int n_act = __builtin_amdgcn_readfirstlane(*a.num_wins);
-    const int wstep = gridDim.x * ATTN_ROW_WAVES;
+    const int wstep = gridDim.x * NWV;
     const int K = a.K;
     // XCD-aware deal of the work order (MSSVT_XCD_REMAP=2; off by default until measured faster): neighbours in the order are
     // neighbours in space inside a weight class and share key rows, and every XCD has an L2 of its own.  Whole contiguous runs
@@ -1070,12 +1100,12 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     // CHUNKS of 24 consecutive entries, dealt round-robin to the XCDs -- every XCD sees the whole weight range of a round.
     int wi;
     {
-        const int per_xcd = (int)(gridDim.x >> 3) * ATTN_ROW_WAVES;
+        const int per_xcd = (int)(gridDim.x >> 3) * NWV;
         if (a.xcd > 1 && (gridDim.x & 7) == 0 && per_xcd % 24 == 0) {
-            const int x = blockIdx.x & 7, idx = (int)(blockIdx.x >> 3) * ATTN_ROW_WAVES + wv;
+            const int x = blockIdx.x & 7, idx = (int)(blockIdx.x >> 3) * NWV + wv;
             wi = __builtin_amdgcn_readfirstlane(((idx / 24) * 8 + x) * 24 + idx % 24);
         } else {
-            wi = __builtin_amdgcn_readfirstlane(blockIdx.x * ATTN_ROW_WAVES + wv);
+            wi = __builtin_amdgcn_readfirstlane(blockIdx.x * NWV + wv);
         }
     }
     if (wi >= n_act) return;
@@ -1123,6 +1153,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
     w_p = a.perm[min(wi + wstep, w_last)];
     const int hh = la % HP;
     const bool head_ok = hh < NH;
+    // V hand-off: this lane's four outputs of its column's head, o = 16 hh + 4 g + i
+    const float4 bv4 = VOUT ? *reinterpret_cast<const float4 *>(a.bkv + CG + 16 * (head_ok ? hh : 0) + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
     // first-pass Qt fragments of a window travel one window ahead as well (stage R): issued before the previous window's
     // Xbar stores, so that waiting for them never waits for those stores (vmcnt retires in order)
     h16x8 qh_r[NP], ql_r[NP];
@@ -1300,6 +1332,8 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
             h16x8 ph[NS], pl[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) h16_split8(sc[2 * s] * inv, sc[2 * s + 1] * inv, ph[s], pl[s]);
+            f32x4 xb[VOUT ? NT : 1];  // V hand-off: the pass's Xbar tiles stay in registers
+            (void)xb;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
@@ -1312,10 +1346,43 @@ __global__ void __launch_bounds__(ATTN_ROW_WAVES *MSSVT_WAVE, KT <= 2 ? (KVH_QT_
                     MFMA_H(cr, ah, pl[s]);
                     MFMA_H(cr, al, ph[s]);
                 }
-                if (q_ok)  // xbar replaces qt in place (this lane's own bytes of the row)
+                const f32x4 xt = f32x4{__builtin_fmaf(cr[0], H16_INV, mm[0]), __builtin_fmaf(cr[1], H16_INV, mm[1]),
+                                       __builtin_fmaf(cr[2], H16_INV, mm[2]), __builtin_fmaf(cr[3], H16_INV, mm[3])};
+                if (VOUT) {
+                    xb[VOUT ? u : 0] = xt;
+                } else if (q_ok) {  // xbar replaces qt in place (this lane's own bytes of the row)
                     // image column 16 u + 4 g + i is k slot (2 (u % 2) + g / 2, 4 (g % 2) + i) of step u / 2 (see above)
-                    store_handoff(xrow + 32 * (u >> 1) + 16 * (g & 1) + 8 * (u & 1) + 4 * (g >> 1), f32x4{__builtin_fmaf(cr[0], H16_INV, mm[0]), __builtin_fmaf(cr[1], H16_INV, mm[1]),
-                                                               __builtin_fmaf(cr[2], H16_INV, mm[2]), __builtin_fmaf(cr[3], H16_INV, mm[3])});
+                    store_handoff(xrow + 32 * (u >> 1) + 16 * (g & 1) + 8 * (u & 1) + 4 * (g >> 1), xt);
+                }
+            }
+            if (VOUT) {
+                // V^T[o][col] = sum_c Wv[o][c] Xbar[c][col] for every head tile t; the lane keeps t = head(col).  Tiles 2 P,
+                // 2 P + 1 of Xbar are the two halves of k step P as they stand (AttnBlob::WV2 holds Wv in that order)
+                h16x8 xh[NP], xl[NP];
+#pragma unroll
+                for (int P = 0; P < NP; ++P) h16_split8(xb[VOUT ? 2 * P : 0], xb[VOUT ? 2 * P + 1 : 0], xh[P], xl[P]);
+                f32x4 vsel = f32x4{0.f, 0.f, 0.f, 0.f};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
+#pragma unroll
+                    for (int P = 0; P < NP; ++P) {
+                        const h16x8 wh = WvF2[((t * NP + P) * 2) * 64 + lane], wl = WvF2[((t * NP + P) * 2 + 1) * 64 + lane];
+                        MFMA_H(mm, wh, xh[P]);
+                        MFMA_H(cr, wh, xl[P]);
+                        MFMA_H(cr, wl, xh[P]);
+                    }
+                    const bool mine = hh == t;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float vt = __builtin_fmaf(cr[i], H16_INV, mm[i]);
+                        vsel[i] = mine ? vt : vsel[i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const f32x4 vout = f32x4{vsel[0] + bv4.x, vsel[1] + bv4.y, vsel[2] + bv4.z, vsel[3] + bv4.w};
+                if (q_ok) store_handoff(xrow + 4 * g, vout);  // V of (query, head): the first 16 floats of its slot
             }
         }
         wave_lds_sync();  // the next window rewrites the image
@@ -1355,12 +1422,33 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, boo
             if (grid16 < 1) grid16 = 1;
             static const int qo16 = getenv("MSSVT_ATTN_QO16_MASK") ? atoi(getenv("MSSVT_ATTN_QO16_MASK")) : 7;  // 1: A, 2: C, 4: Q' hand-off
             const bool q16 = packed && (qo16 & 1), o16 = packed && (qo16 & 2), qp = q16 && (qo16 & 4) && K <= 32;
+            static const int vfuse_env = getenv("MSSVT_ATTN_VFUSE") ? atoi(getenv("MSSVT_ATTN_VFUSE")) : 0;
+            const bool vfuse = (vfuse_env == 1 || vfuse_env == 2) && qp && o16 && HP * HD == CG;  // V formed in the window launch (round 6)
             if constexpr (HD == 16 && !KVH_QT_AHEAD) {
                 if (qp) {
                     using L = AttnBlob<CG>;
                     const dim3 qp_grid(cus * 3 / ng > 0 ? cus * 3 / ng : 1, ng);
                     k_attn_q16<CG, HP, 2><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, L::WK + CG * 4, stream>>>(pack);
-                    k_attn_kvh<CG, HD, HP, 2, true><<<qp_grid, ATTN_ROW_WAVES * MSSVT_WAVE, (L::BYTES - L::WK2) + 2 * img, stream>>>(pack);
+                    if constexpr (HP * HD == CG) {
+#define KVH_V_LAUNCH(VOUT_, NWV_)                                                                                              \
+    {                                                                                                                          \
+        const size_t lds_v = (size_t)((VOUT_ ? L::BYTES : L::WV2) - L::WK2) + (size_t)(NWV_) * 2 * 2 * 16 * RS;               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_kvh<CG, HD, HP, 2, true, VOUT_, NWV_>),       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v);                           \
+        if (e != hipSuccess) return (int)e;                                                                                    \
+        const int per_cu = 12 / (NWV_);                                                                                        \
+        const dim3 v_grid(cus * per_cu / ng > 0 ? cus * per_cu / ng : 1, ng);                                                  \
+        k_attn_kvh<CG, HD, HP, 2, true, VOUT_, NWV_><<<v_grid, (NWV_) * MSSVT_WAVE, lds_v, stream>>>(pack);                    \
+    }
+                        // V hand-off (experiments): 1 = one 12-wave workgroup per CU and group half (the
+                        // fragments are shared), 2 = 4-wave workgroups (68 KB each: two per CU), 3 = X-bar hand-off on 12-wave workgroups
+                        if (vfuse && vfuse_env == 1) KVH_V_LAUNCH(true, 12)
+                        else if (vfuse && vfuse_env == 2) KVH_V_LAUNCH(true, 4)
+                        else if (vfuse_env == 3) KVH_V_LAUNCH(false, 12)
+#undef KVH_V_LAUNCH
+                    }
+                    if (!((vfuse || vfuse_env == 3) && HP * HD == CG))
+                        k_attn_kvh<CG, HD, HP, 2, true><<<qp_grid, ATTN_ROW_WAVES * MSSVT_WAVE, (L::WV2 - L::WK2) + 2 * img, stream>>>(pack);
                 }
             }
             if constexpr (HD == 16) {
@@ -1379,7 +1467,9 @@ static int launch_block_attn(const AttnPack &pack, int ng, int row_capacity, boo
                 k_attn_kvh<CG, HD, HP, 4, false><<<kv_grid, ATTN_ROW_WAVES * MSSVT_WAVE, 4 * img, stream>>>(pack);
             }
             if constexpr (HD == 16) {
-                if (o16)
+                if (o16 && vfuse)
+                    k_attn_o16<CG, HP, true><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, AttnBlob<CG>::WK2 - AttnBlob<CG>::WV + 2 * CG * 4, stream>>>(pack);
+                else if (o16)
                     k_attn_o16<CG, HP><<<dim3(grid16, ng), ATTN_QO16_WAVES * MSSVT_WAVE, AttnBlob<CG>::WK2 - AttnBlob<CG>::WV + 2 * CG * 4, stream>>>(pack);
             }
             if (!o16)
@@ -1528,8 +1618,8 @@ extern "C" int mssvt_attn_pack_weights(int Cg, int head_dim, float scale, const 
     if (!Wq || !Wkv || !Wo || !packed) return MSSVT_E_BADARG;
     if (head_dim != 16) return MSSVT_E_TOOLARGE;
     hipStream_t st = (hipStream_t)stream;
-    if (Cg == 64) k_attn_pack<64><<<dim3(16, 5), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
-    else if (Cg == 32) k_attn_pack<32><<<dim3(4, 5), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
+    if (Cg == 64) k_attn_pack<64><<<dim3(16, 6), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
+    else if (Cg == 32) k_attn_pack<32><<<dim3(4, 6), MSSVT_WAVE, 0, st>>>(Wq, Wkv, Wo, scale, reinterpret_cast<char *>(packed));
     else return MSSVT_E_TOOLARGE;
     return mssvt_launch_status();
 }

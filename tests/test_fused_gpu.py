@@ -256,6 +256,28 @@ def test_dense_bev_matches_scatter(pts, B, C):
     assert got.shape == want.shape and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("grid,B,C", [([8, 9, 5], 3, 40), ([7, 9, 5], 2, 40), ([16, 4, 1], 1, 8), ([470, 470, 1], 2, 128)])
+def test_dense_bev_small_grids_and_partial_channel_groups(grid, B, C):
+    """k_dense_bev4 (16-byte stores, four cells per lane) and its fallback: planes that are / are not a multiple of four cells,
+    channel counts that end inside a 32-channel group, several samples, the detector's one-cell-high BEV grid."""
+    from mssvt_amd.mssvt_utils import SparseTensor, scatter_nd
+    g = torch.Generator().manual_seed(sum(grid) + C)
+    X, Y, Z = grid
+    rows = []
+    for b in range(B):
+        n = max(1, int(0.3 * X * Y * Z) if X * Y * Z < 5000 else 30000)
+        cells = torch.randperm(X * Y * Z, generator=g)[:n].sort().values  # x-major order: (b, x, y, z) ascending
+        x, y, z = cells // (Y * Z), (cells // Z) % Y, cells % Z
+        rows.append(torch.stack([torch.full_like(x, b), z, y, x], dim=1))
+    vc = torch.cat(rows).int()
+    feats = torch.randn(vc.shape[0], C, generator=g).to(DEV)
+    sp = SparseTensor(features=feats, indices=vc.to(DEV), spatial_shape=grid, voxel_size=[0.3, 0.3, 0.2],
+                      point_cloud_range=[0, 0, 0, 0.3 * X, 0.3 * Y, 0.2 * Z], batch_size=B, hash_size=100003)
+    got = sp.dense()
+    want = scatter_nd(sp.indices.long(), feats, [B, Z, Y, X, C]).permute(0, 4, 1, 2, 3).contiguous()
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("pts,B", [(20000, 2), (160000, 1), (0, 1)])
 def test_occupancy_columns_bit_exact(pts, B):
     """One 64-bit word per (b, x, y) column, bit z = occupied (input of the K3 hit test)."""
