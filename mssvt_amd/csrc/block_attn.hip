@@ -1132,6 +1132,8 @@ __global__ void __launch_bounds__(NWV *MSSVT_WAVE, KT <= 2 ? (KVH_QT_AHEAD || QP
     float rel_r[KT];
     unsigned vmask_r, used_r;
     f32x4 T1n[KT][NT];
+    // (round 6 measured the first pass's Q' piece travelling with the rows, one window ahead -- the load that cost the CEILING
+    // kernel 6 us per odd launch -- in this kernel: 52.1 / 26.0 against 51.4 / 25.6 us, no gain: three waves per SIMD hide it)
 #define KVH_ISSUE_ROWS()                                                                   \
     {                                                                                      \
         wc_r = wc_m; nqv_r = nqv_m; qbase_r = qbase_m;                                     \
