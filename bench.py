@@ -458,7 +458,9 @@ def main():
             torch.cuda.synchronize()
         sp_out = out["encoded_spconv_tensor"]
         ms = 1e3 * elapsed / args.steps
-        arith = arith_of(net)
+        arith = arith_of(net) if not args.train else (
+            "compact training path (mssvt_amd/train_path.py): pair attention on fp32 vector FMAs, linears on split-fp16 operands",
+            "compact training path: split-fp16 linears (mssvt_linear_rows_h), fp32 MFMA weight gradients", None)
         n_bn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in det.modules()) if det is not None else 0
         n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in det.modules()) if det is not None else 0
         res = {
