@@ -16,7 +16,7 @@
 //   k_ps_place   the point's row moves to place start[voxel] + slot of the sorted order, row_voxel[...] = voxel; start[]; zero rows
 //                for the voxels a layer-2 tile boundary cuts
 //   k_ps_mean    16 lanes per voxel: the cluster centre from exact 64-bit fixed-point sums (the arithmetic of csrc/vfe.hip)
-//   k_ps_pfn1    16 lanes per SORTED ROW: layer 1 (x1 rows written in sorted order: a voxel's rows are contiguous)
+//   k_ps_pfn1    8 lanes per SORTED ROW: layer 1 (x1 rows written in sorted order: a voxel's rows are contiguous)
 //   k_ps_max1    16 lanes per voxel: m1 = max over the voxel's run of x1 rows
 //                (one kernel with 16 lanes per VOXEL doing all three was measured first: 81 us -- a chain of dependent loads per
 //                point of the run; split like this every load of a thread is independent of its others)
@@ -180,21 +180,26 @@ struct Ps1Args {
     float *x1;  // (rows, 64) in sorted order
 };
 
-// layer 1 of every point, 16 lanes per SORTED row (4 output channels each): the 11 inputs built on the fly (the
-// reference's expressions, multiply and add rounded separately), 44 FMAs per lane, BatchNorm (running statistics) + ReLU;
-// x1 rows leave in sorted order -- contiguous runs per voxel for k_ps_max1 / k_ps_pfn2
+// layer 1 of every point, 8 lanes per SORTED row (8 output channels each: the per-row part -- five loads, the 11 inputs -- is
+// paid once per 8 channels): the 11 inputs built on the fly (the reference's expressions, multiply and add rounded separately),
+// 88 FMAs per lane, BatchNorm (running statistics) + ReLU; x1 rows leave in sorted order -- contiguous runs per voxel for
+// k_ps_max1 / k_ps_pfn2
 __global__ void __launch_bounds__(256) k_ps_pfn1(Ps1Args a) {
-    __shared__ float Wl[64 * 12], bl[64], sl[64], tl[64];
-    for (int e = threadIdx.x; e < 64 * 11; e += 256) Wl[(e / 11) * 12 + e % 11] = a.W[e];
+    __shared__ float Wl[11 * 64], bl[64], sl[64], tl[64], gl[64], hl[64];
+    // input-major in the LDS: the 8 lanes of a row read channels 8 q + i of ONE input -- 8 different banks (channel-major
+    // rows of 12 floats put all of them on one bank)
+    for (int e = threadIdx.x; e < 64 * 11; e += 256) Wl[(e % 11) * 64 + e / 11] = a.W[e];
     if (threadIdx.x < 64) {
         const int c = threadIdx.x;
         bl[c] = a.b[c];
         sl[c] = 1.0f / sqrtf(a.bn_var[c] + a.eps);  // torch's eval batch norm: (z - mean) * invstd * weight + bias
         tl[c] = a.bn_mean[c];
+        gl[c] = a.bn_w[c];
+        hl[c] = a.bn_b[c];
     }
     __syncthreads();
-    const int q = threadIdx.x & 15;  // channels [4 q, 4 q + 4) of the row
-    const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int q = threadIdx.x & 7;  // channels [8 q, 8 q + 8) of the row
+    const long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
     if (r >= *a.total) return;
     const int v = a.row_voxel[r];
     const float4 p0 = a.pts8[2 * (size_t)r], p1 = a.pts8[2 * (size_t)r + 1];
@@ -206,18 +211,20 @@ __global__ void __launch_bounds__(256) k_ps_pfn1(Ps1Args a) {
     f[8] = x - __fadd_rn(__fmul_rn((float)c4.w, a.vs[0]), a.off[0]);  // ref :107-109: coord * voxel_size + offset
     f[9] = y - __fadd_rn(__fmul_rn((float)c4.z, a.vs[1]), a.off[1]);
     f[10] = z - __fadd_rn(__fmul_rn((float)c4.y, a.vs[2]), a.off[2]);
-    float o[4];
+    float o[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = 4 * q + i;
+    for (int i = 0; i < 8; ++i) {
+        const int c = 8 * q + i;
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) acc = __builtin_fmaf(f[k], Wl[c * 12 + k], acc);
+        for (int k = 0; k < 11; ++k) acc = __builtin_fmaf(f[k], Wl[k * 64 + c], acc);
         acc += bl[c];
-        acc = (acc - tl[c]) * sl[c] * a.bn_w[c] + a.bn_b[c];
+        acc = (acc - tl[c]) * sl[c] * gl[c] + hl[c];
         o[i] = fmaxf(acc, 0.f);
     }
-    *reinterpret_cast<float4 *>(a.x1 + (size_t)r * 64 + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    float4 *dst = reinterpret_cast<float4 *>(a.x1 + (size_t)r * 64 + 8 * q);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
 // m1 = channel-wise max over a voxel's run of x1 rows: 16 lanes per voxel, eight rows in flight
@@ -470,7 +477,7 @@ extern "C" int mssvt_pfn_sorted_64_128(const float *points, int point_stride, lo
     for (int k = 0; k < 3; ++k) { a1.vs[k] = host_voxel_size3[k]; a1.off[k] = host_offset3[k]; }
     a1.W = W1; a1.b = b1; a1.bn_w = bn1_w; a1.bn_b = bn1_b; a1.bn_mean = bn1_mean; a1.bn_var = bn1_var; a1.eps = bn1_eps;
     a1.x1 = x1_scratch;
-    k_ps_pfn1<<<divup(num_points, 16), 256, 0, stream>>>(a1);
+    k_ps_pfn1<<<divup(num_points, 32), 256, 0, stream>>>(a1);
     k_ps_max1<<<divup(N, 16), 256, 0, stream>>>(x1_scratch, N, start, m1_scratch);
     Ps2Args a2;
     a2.N = N; a2.task_rows = task_rows; a2.total = total; a2.start = start; a2.row_voxel = row_voxel;

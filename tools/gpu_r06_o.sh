@@ -1,0 +1,9 @@
+#!/bin/bash
+out=gpurun_out/r06o; mkdir -p $out
+line() { python -c "import json,sys;d=json.loads([l for l in open('$1') if l.startswith('{')][-1]);print('$1',round(d['value'],1),d['unit'],round(d['ms_per_step'],3),'ms', (d.get('one_frame_in_flight') or {}).get('value'))"; }
+b() { name=$1; shift; timeout 400 python bench.py --no-cpu-baseline --no-roofline "$@" > $out/$name.json 2>> $out/bench.err; line $out/$name.json; }
+timeout 900 python -m pytest tests/test_vfe_gpu.py tests/test_mfma_schedules_gpu.py -q > $out/pytest.txt 2>&1; echo "pytest rc $?"; tail -3 $out/pytest.txt
+ROWS=60 bash tools/prof.sh r06o_pts_one --steps 20 --in-flight 1 --from-points > $out/prof_pts_one.txt; grep "k_ps_" $out/prof_pts_one.txt | cut -c1-100
+b pts --from-points
+b pts2 --from-points
+b pts_one --from-points --in-flight 1
