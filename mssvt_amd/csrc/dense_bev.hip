@@ -78,7 +78,9 @@ __global__ void __launch_bounds__(DB_WPB *MSSVT_WAVE)
 // and one global_store_dwordx4 per channel -- zeros included, so no fill pass and
 // every store instruction writes 1 KB of one plane.  The next chunk's loads are issued before this chunk's stores (vmcnt
 // retires in order).  56.6 -> see DESIGN (113 MB grid: the write stream is the floor, 113 MB / 6.3 TB/s = 18 us).
+#ifndef DB4_CH
 #define DB4_CH 32
+#endif
 #define DB4_CK 8
 __global__ void __launch_bounds__(256)
     k_dense_bev4(const float *features, const slot_t *table, const int *v_bs_cnt, int B, int X, int Y, int Z, int C,

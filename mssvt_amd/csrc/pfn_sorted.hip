@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(PS2_WAVES *MSSVT_WAVE, 1) k_ps_pfn2(Ps2Args a)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int tt = 0; tt < NT / 2; ++tt) {
+                for (int tt = 0; tt < NT / 2; ++tt) {  // (the four tiles of a half as interleaved chains, k step outermost: 41.6 against 38.4 us)
                     const int t = h * (NT / 2) + tt;
                     f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f}, cr = mm;
 #pragma unroll
