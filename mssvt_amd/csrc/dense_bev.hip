@@ -98,14 +98,29 @@ __global__ void __launch_bounds__(256)
         int vstart = 0;
         for (int k = 0; k < b; ++k) vstart += v_bs_cnt[k];
         const slot_t *tab = table + (size_t)b * hash_size;
-        int row[4];
+        // the four probes of a lane: their FIRST slots leave together (one round trip; a table at load 0.1 answers nearly every
+        // probe there), only a collision walks on through table_find
+        int row[4], key[4];
+        slot_t first[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long long cell = cell0 + j;
-            row[j] = -1;
+            key[j] = -1;
+            first[j] = SLOT_EMPTY;
             if (cell < plane) {
                 const int x = (int)(cell % X), y = (int)((cell / X) % Y), z = (int)(cell / ((long long)X * Y));
-                const int sv = table_find(x * Y * Z + y * Z + z, hash_size, tab);  // x-major key
+                key[j] = x * Y * Z + y * Z + z;  // x-major key
+                first[j] = tab[key[j] % hash_size];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            row[j] = -1;
+            if (key[j] >= 0) {
+                const int k0 = slot_key(first[j]);
+                int sv = MSSVT_EMPTY;
+                if (k0 == key[j]) sv = slot_val(first[j]);
+                else if (k0 != MSSVT_EMPTY) sv = table_find(key[j], hash_size, tab);
                 if (sv != MSSVT_EMPTY) row[j] = vstart + sv;
             }
         }
