@@ -8,11 +8,12 @@ hardware interleaves their kernels.  Every frame computes exactly what `net(batc
 (tests/test_pipeline_gpu.py: bit-identical outputs, at the benchmark size too).
 
     pipe = FramePipeline(net)                 # depth from the batch size (auto_depth)
-    for bd in loader:
-        frame = pipe(bd)                      # returns right behind the enqueue: nothing waits here
-        ...
-        out = frame.get()                     # the frame's one host wait; the CURRENT stream now waits for the frame's
-        head(out["encoded_spconv_tensor"])    # stream and the outputs are recorded for it: use them like any tensor
+    with torch.cuda.stream(side):             # (consumers off the legacy default stream: "Which streams" below)
+        for bd in loader:
+            frame = pipe(bd)                  # returns right behind the enqueue: nothing waits here
+            ...
+            out = frame.get()                 # the frame's one host wait; the CURRENT stream now waits for that frame
+            head(out["encoded_spconv_tensor"])  # and the outputs are recorded for it: use them like any tensor
 
 The reference runs its frames one by one on the legacy default stream ("Threading / streams"); this is the
 MI355X-side answer to the same loop (a detector's data loader hands over frame i + 1 while frame i is still running).
