@@ -536,7 +536,9 @@ int mssvt_block_interp_table_multi(int num_sets, const int *host_nq, const int *
                                    const float *host_range_min3, const int *host_zero_row,
                                    int *const *host_tab_row, float *const *host_tab_w, void *stream);
 /* mssvt_ffn_fused fed by that table: x = tab_row[v][0] < 0 ? 2*x_in[v]
- *                                      : x_in[v] + sum_i tab_w[v][i] * attn[tab_row[v][i]].   */
+ *                                      : x_in[v] + sum_i tab_w[v][i] * attn[tab_row[v][i]].
+ * y may be NULL when phases == 4 and y_norm is given (round 6): only the next LayerNorm's output is stored -- the last
+ * Block in front of a CompressBlock, which has no input residual (ref mssvt_backbone.py:370-385).                    */
 int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_in, const int *tab_row,
                            const float *tab_w, const float *attn, const float *norm_w,
                            const float *norm_b, float eps, const float *W1, const float *b1,

@@ -583,7 +583,10 @@ extern "C" int mssvt_debug_read_ffn_ws_spans(unsigned long long *host) {
 #define WSTAMP(k_)
 #endif
 
-template <int C, int FF, bool TABBED, bool NORM2>
+// STOREY = false (round 6): y itself has no reader -- the last Block in front of a CompressBlock, which takes only the
+// LayerNorm output (it has no input residual, ref mssvt_backbone.py:370-385) -- and is not stored: 4 C of the launch's 12 C
+// bytes per row
+template <int C, int FF, bool TABBED, bool NORM2, bool STOREY = true>
 __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a, const h16x8 *packed) {
 #ifdef MSSVT_STAMPS
     unsigned long long ws_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ws_t = __builtin_readcyclecounter();
@@ -907,7 +910,7 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
                     if (pc == 0) {
                         y01 = pk2(yt.x, yt.y) + pk2(xc.x, xc.y);
                         y23 = pk2(yt.z, yt.w) + pk2(xc.z, xc.w);
-                        *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = make_float4(y01[0], y01[1], y23[0], y23[1]);
+                        if (STOREY) *reinterpret_cast<float4 *>(a.y + row * C + 4 * q) = make_float4(y01[0], y01[1], y23[0], y23[1]);
                     } else if (pc == 1 && NORM2) {
                         const float mean = ffw_row_sum<LPR>((y01[0] + y01[1]) + (y23[0] + y23[1])) * (1.0f / C);
                         d01 = y01 - pk1(mean);
@@ -973,7 +976,11 @@ static int launch_ffn_ws(const FfnArgs &a, const void *packed, hipStream_t strea
     if (grid < 1) return MSSVT_OK;
     const h16x8 *pk = reinterpret_cast<const h16x8 *>(packed);
     const dim3 block(NW * MSSVT_WAVE);
-    if (a.tab_row) {
+    if (a.tab_row && a.y_norm && !a.y) {
+        k_ffn_ws<C, FF, true, true, false><<<grid, block, lds, stream>>>(a, pk);
+    } else if (!a.y) {
+        return MSSVT_E_BADARG;
+    } else if (a.tab_row) {
         if (a.y_norm) k_ffn_ws<C, FF, true, true><<<grid, block, lds, stream>>>(a, pk);
         else k_ffn_ws<C, FF, true, false><<<grid, block, lds, stream>>>(a, pk);
     } else {
@@ -1077,9 +1084,9 @@ extern "C" int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_
                                       const float *next_norm_w, const float *next_norm_b, float next_eps,
                                       float *y_norm, float *hidden, const int *num_rows_dev, int phases,
                                       void *stream) {
-    if (n_rows < 0 || !x_in || !tab_row || !tab_w || !attn || !norm_w || !norm_b || !W1 || !b1 || !W2 ||
-        !b2 || !y)
+    if (n_rows < 0 || !x_in || !tab_row || !tab_w || !attn || !norm_w || !norm_b || !W1 || !b1 || !W2 || !b2)
         return MSSVT_E_BADARG;
+    if (!y && !(phases == 4 && y_norm)) return MSSVT_E_BADARG;  // y may be NULL only for the single launch with a LayerNorm output
     if (y_norm && (!next_norm_w || !next_norm_b)) return MSSVT_E_BADARG;
     if (n_rows == 0) return MSSVT_OK;
     FfnArgs a;

@@ -624,7 +624,8 @@ extern "C" int mssvt_frame_forward(void *frame, int num_voxels, const float *fea
         // the FFN tail emits the NEXT block's norm1 (the CompressBlock's after the last Block)
         const float *nw = i + 1 < nb ? f->blocks[i + 1].n1w : c.n1w, *nbias = i + 1 < nb ? f->blocks[i + 1].n1b : c.n1b;
         const float neps = i + 1 < nb ? f->blocks[i + 1].n1eps : c.n1eps;
-        float *y = L.x[i & 1], *yn = L.xh[i & 1];
+        // (the last Block's y has no reader: the CompressBlock takes the LayerNorm output only -- not stored)
+        float *y = i + 1 < nb ? L.x[i & 1] : nullptr, *yn = L.xh[i & 1];
         FR_TRY(mssvt_ffn_fused_interp(n, C, FF, x, L.tab_rows + (size_t)t * n * 4, L.tab_w + (size_t)t * n * 4, L.attn[s], k.n2w,
                                       k.n2b, k.n2eps, k.W1, k.b1, k.W2, k.b2, y, nw, nbias, neps, yn,
                                       const_cast<float *>(reinterpret_cast<const float *>(k.ffn_packed)), nullptr, 4, stream));
