@@ -39,6 +39,7 @@ struct FfnArgs {
     float eps2;
     float *y_norm;
     int xcd;  // deal the tiles so that an XCD owns a contiguous run per round (common.hip.h, xcd_contiguous_block)
+    int prio;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -808,6 +809,9 @@ __global__ void __launch_bounds__((FF / 32) * MSSVT_WAVE, 1) k_ffn_ws(FfnArgs a,
     // row-wise work of the other tile.  Left to itself the scheduler either serialises the two phases (every MFMA, then
     // every vector instruction: both waves of a SIMD then want the same pipe at the same time) or hoists every LDS read to
     // the top (spills at 256 registers); sched_group_barrier patterns were tried and are not stable from build to build.
+    // the later-dispatched half of the workgroup -- the loser of every issue arbitration on its SIMD, MI355X_MICROARCH.md "Two
+    // waves per SIMD" item 4 -- runs at static priority 1: 46.4 -> 46.0 and 47.4 -> 46.5 us on two boxes (MSSVT_FFN_PRIO=0: off)
+    if (a.prio && wv >= NW / 2) __builtin_amdgcn_s_setprio(1);
     for (;;) {
         const int tile_next = tile + tstep;
         const bool has_next = tile_next < tend;
@@ -1070,7 +1074,7 @@ extern "C" int mssvt_ffn_fused(int n_rows, int C, int FF, const float *x_new, co
     a.tab_row = nullptr; a.tab_w = nullptr; a.attn = nullptr;
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
-    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm; a.xcd = mssvt_xcd_remap();
+    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm; a.xcd = mssvt_xcd_remap(); a.prio = getenv("MSSVT_FFN_PRIO") ? atoi(getenv("MSSVT_FFN_PRIO")) : 1;
     return dispatch_ffn(C, FF, a, hidden, phases, (hipStream_t)stream);
 }
 
@@ -1096,6 +1100,6 @@ extern "C" int mssvt_ffn_fused_interp(int n_rows, int C, int FF, const float *x_
     a.attn = attn;
     a.ln_w = norm_w; a.ln_b = norm_b; a.eps = eps;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.y = y;
-    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm; a.xcd = mssvt_xcd_remap();
+    a.ln2_w = next_norm_w; a.ln2_b = next_norm_b; a.eps2 = next_eps; a.y_norm = y_norm; a.xcd = mssvt_xcd_remap(); a.prio = getenv("MSSVT_FFN_PRIO") ? atoi(getenv("MSSVT_FFN_PRIO")) : 1;
     return dispatch_ffn(C, FF, a, hidden, phases, (hipStream_t)stream);
 }
